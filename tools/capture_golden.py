@@ -1,0 +1,387 @@
+"""Generate tests/golden/* by RUNNING THE REFERENCE'S OWN PYTHON (container only).
+
+    python tools/capture_golden.py
+
+Imports /root/reference's Stitcher / ImageFusion / ImageUtility under the shims of tools/refshim.py and
+records inputs + outputs of every pure-numpy function on the hot path (SURVEY.md section 8c list):
+ROI slicing, mode vote, the incremental-ROI / direction state machines (with scripted fake operators),
+getStitchByOffset layout + paste + fuse dispatch, fuseByFadeInAndFadeOut / getWeightsMatrix, and the
+segment-restart driver.  Also extracts the only numeric ground truth in the reference (the 89-offset list
+in the comment at Stitcher.py:87) and crops a few real demo strips whose expected offsets that list gives.
+
+Fixtures are DATA (arrays in, arrays out).  No reference source text is stored.
+"""
+import ast
+import json
+import os
+import sys
+import tempfile
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, HERE)
+import refshim  # noqa: E402
+
+_phase_script = {}
+
+
+def _phase_stub(a, b):
+    _phase_script["calls"].append((a.shape, b.shape, str(a.dtype)))
+    k = len(_phase_script["calls"])
+    if k == _phase_script["success_at"]:
+        return _phase_script["value"], 0.5
+    return _phase_script["value"], 0.1
+
+
+cv2, RS, RF, RU = refshim.install(phase_correlate=_phase_stub)
+rng = np.random.default_rng(20190158)
+
+
+# ------------------------------------------------------------------------------------------ ROI
+def cap_roi():
+    m = RU.Method()
+    cases = []
+    for shape in [(1936, 2584), (2048, 2048), (1024, 1280), (97, 131)]:
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        base = img.__array_interface__["data"][0]
+        for direction in (1, 2, 3, 4):
+            for order in ("first", "second"):
+                for ratio in (0.1, 0.2, 2 * 0.2, 3 * 0.2, 3 * 0.1, 6 * 0.1):
+                    r = m.getROIRegionForIncreMethod(img, direction=direction, order=order, searchRatio=ratio)
+                    off = r.__array_interface__["data"][0] - base
+                    cases.append(dict(shape=list(shape), direction=direction, order=order, ratio=ratio,
+                                      out_shape=list(r.shape), row0=int(off // shape[1]), col0=int(off % shape[1])))
+    json.dump(cases, open(os.path.join(OUT, "roi_cases.json"), "w"))
+    print("roi cases", len(cases))
+
+
+# ------------------------------------------------------------------------------------------ mode
+def cap_mode():
+    m = RU.Method()
+    m.isPrintLog = False
+    store = {}
+    exp = []
+    ncase = 0
+    for case in range(240):
+        na, nb = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+        kind = case % 8
+        kA = (rng.random((na, 2)) * 400).astype(np.float32)
+        kB = (rng.random((nb, 2)) * 400).astype(np.float32)
+        M = int(rng.integers(0, 80)) if kind != 7 else 0
+        pairs = np.stack([rng.integers(0, nb, M), rng.integers(0, na, M)], 1).astype(np.int32) if M else np.zeros((0, 2), np.int32)
+        if kind in (1, 2, 3) and M:
+            # plant a true shift so several matches agree (and near-integer / negative fractions occur)
+            shift = np.array([rng.integers(-30, 30) + rng.choice([0.0, 0.999, -0.999, 0.5]), rng.integers(-30, 30) + 0.25], np.float32)
+            for k in range(0, M, 2):
+                kA[pairs[k, 1]] = kB[pairs[k, 0]] + shift
+        if kind == 4 and M:   # everything identical -> all (0,0) votes dropped
+            for k in range(M):
+                kA[pairs[k, 1]] = kB[pairs[k, 0]] + np.float32(0.4)
+        if kind == 5 and M > 4:  # engineered tie: two offsets with equal counts, order decides
+            kB[:] = 100
+            q = pairs[:, 1]
+            for k in range(M):
+                pairs[k, 1] = k % na
+            kA[:] = 100
+            for k in range(min(M, na)):
+                kA[k] = 100 + (3 if k % 2 == 0 else 7)
+        ev = int(rng.choice([1, 3, 3, 10]))
+        (st, off) = m.getOffsetByMode(kA, kB, [tuple(int(v) for v in p) for p in pairs], offsetEvaluate=ev)
+        store["c%d_kpsA" % ncase] = kA; store["c%d_kpsB" % ncase] = kB; store["c%d_pairs" % ncase] = pairs
+        exp.append([int(ev), int(bool(st)), int(off[0]), int(off[1])])
+        ncase += 1
+    store["expected"] = np.array(exp, np.int32)
+    np.savez_compressed(os.path.join(OUT, "mode_cases.npz"), **store)
+    print("mode cases", ncase)
+
+
+# ------------------------------------------------------------------------------------------ state machines
+class ScriptedStitcher(RS.Stitcher):
+    """Reference Stitcher with the three operators replaced by scripted fakes (control flow only)."""
+
+    def __init__(self, success_at, raw):
+        self.trace = []
+        self.success_at = success_at
+        self.raw = raw
+        self.pending = []
+
+    def detectAndDescribe(self, image, featureMethod):
+        self.pending.append(list(image.shape))
+        return (np.zeros((1, 2), np.float32), np.zeros((1, 64), np.float32))
+
+    def matchDescriptors(self, featuresA, featuresB):
+        return [(0, 0)]
+
+    def getOffsetByMode(self, kpsA, kpsB, matches, offsetEvaluate=10):
+        self.trace.append(self.pending[-2:])
+        ok = len(self.trace) == self.success_at
+        return (ok, list(self.raw))
+
+
+def cap_state_machine():
+    cases = []
+    for shape in [(1936, 2584), (2048, 2048), (1024, 1280)]:
+        imgA = np.zeros(shape, np.uint8); imgB = np.zeros(shape, np.uint8)
+        for roiRatio in (0.1, 0.2):
+            for ini in (1, 2, 3, 4):
+                for incre in (-1, 0, 1):
+                    maxI = int(np.floor(0.5 / roiRatio) + 1) + 1
+                    max_att = (maxI - 1) * (1 if incre == 0 else 4)
+                    for success_at in list(range(1, max_att + 1)) + [0]:
+                        if shape != (1936, 2584) and success_at not in (0, 1, 2, 5, max_att):
+                            continue
+                        raw = [7, -3]
+                        s = ScriptedStitcher(success_at, raw)
+                        s.isPrintLog = False
+                        s.roiRatio = roiRatio; s.direction = ini; s.directIncre = incre
+                        s.featureMethod = "surf"; s.offsetCaculate = "mode"; s.isEnhance = False
+                        st, off = s.calculateOffsetForFeatureSearchIncre([imgA, imgB])
+                        rec = dict(kind="feature", shape=list(shape), roiRatio=roiRatio, ini=ini, incre=incre,
+                                   success_at=success_at, raw=raw, trace=s.trace, status=bool(st),
+                                   offset=(list(map(int, off)) if st else off), final_direction=int(s.direction))
+                        cases.append(rec)
+                        # phase variant: cv2.phaseCorrelate stub returns ((x, y), response)
+                        _phase_script.update(calls=[], success_at=success_at, value=(-3.7, 7.9))
+                        p = RS.Stitcher()
+                        p.isPrintLog = False
+                        p.roiRatio = roiRatio; p.direction = ini; p.directIncre = incre
+                        st, off = p.calculateOffsetForPhaseCorrleateIncre([imgA, imgB])
+                        cases.append(dict(kind="phase", shape=list(shape), roiRatio=roiRatio, ini=ini, incre=incre,
+                                          success_at=success_at, raw=[-3.7, 7.9],
+                                          trace=[[list(c[0]), list(c[1])] for c in _phase_script["calls"]],
+                                          dtype=_phase_script["calls"][0][2], status=bool(st),
+                                          offset=(list(map(int, off)) if st else off), final_direction=int(p.direction)))
+    json.dump(cases, open(os.path.join(OUT, "state_machine.json"), "w"))
+    print("state machine cases", len(cases))
+
+
+def cap_feature_search_cache():
+    """calculateOffsetForFeatureSearch (Stitcher.py:260-304): which images get described, cache reuse/invalidate."""
+    class S(RS.Stitcher):
+        def __init__(self, script):
+            self.script = list(script); self.described = []; self.k = 0
+
+        def detectAndDescribe(self, image, featureMethod):
+            self.described.append(int(image[0, 0]))
+            return (np.full((1, 2), image[0, 0], np.float32), np.full((1, 64), image[0, 0], np.float32))
+
+        def matchDescriptors(self, fa, fb):
+            self.matched = (int(fa[0, 0]), int(fb[0, 0]))
+            return [(0, 0)]
+
+        def getOffsetByMode(self, kpsA, kpsB, matches, offsetEvaluate=10):
+            ok = self.script[self.k]; self.k += 1
+            return (ok, [5, -6])
+    out = []
+    for script in ([True, True, True], [True, False, True, True], [False, True]):
+        RS.Stitcher.tempImageFeature.isBreak = True
+        s = S(script); s.isPrintLog = False; s.isEnhance = False; s.offsetCaculate = "mode"
+        steps = []
+        for k, _ in enumerate(script):
+            A = np.full((8, 8), 10 + k, np.uint8); B = np.full((8, 8), 11 + k, np.uint8)
+            n0 = len(s.described)
+            st, off = s.calculateOffsetForFeatureSearch([A, B])
+            steps.append(dict(described=s.described[n0:], matched=list(s.matched), status=bool(st),
+                              offset=(list(off) if st else off), isBreak=bool(s.tempImageFeature.isBreak)))
+        out.append(dict(script=script, steps=steps))
+    RS.Stitcher.tempImageFeature.isBreak = True
+    json.dump(out, open(os.path.join(OUT, "feature_search_cache.json"), "w"))
+    print("feature-search cache cases", len(out))
+
+
+# ------------------------------------------------------------------------------------------ fuse
+def _mk_corner(r, c, ch, which, rng, t_r, t_c, black=False):
+    """int64 canvas ROI with an L-shaped occupied region: `which` = empty corner quadrant id as in getWeightsMatrix."""
+    shape = (r, c) if ch == 1 else (r, c, ch)
+    A = rng.integers(1 if not black else 0, 256, shape).astype(np.int64)
+    if which == 2:   # bottom-right empty: A occupies top strip (t_r rows) and left strip (t_c cols)
+        A[t_r:, t_c:] = -1
+    elif which == 3:  # top-right empty
+        A[:r - t_r, t_c:] = -1
+    elif which == 0:  # top-left empty
+        A[:r - t_r, :c - t_c] = -1
+    elif which == 1:  # bottom-left empty
+        A[t_r:, :c - t_c] = -1
+    return A
+
+
+def cap_fuse():
+    f = RF.ImageFusion()
+    f.isPrintLog = False
+    store = {}
+    meta = []
+    n = 0
+
+    def add(A, B, dx, dy, color):
+        nonlocal n
+        f.isColorMode = color
+        try:
+            out = f.fuseByFadeInAndFadeOut([A.copy(), B.copy()], dx, dy)
+        except (IndexError, ZeroDivisionError):
+            return
+        store["f%d_A" % n] = A; store["f%d_B" % n] = B; store["f%d_out" % n] = out
+        meta.append([int(dx), int(dy), int(color)])
+        n += 1
+
+    # strip mode: full or >65 % occupied, both aspect classes, all sign combinations, gray + colour
+    for (r, c) in [(6, 4), (4, 6), (5, 5), (40, 13), (13, 40), (64, 48), (1, 9), (9, 1)]:
+        for ch in (1, 3):
+            shape = (r, c) if ch == 1 else (r, c, ch)
+            for dx, dy in [(5, 3), (-5, -3), (0, 0), (7, -2), (-7, 2)]:
+                A = rng.integers(0, 256, shape).astype(np.int64)
+                B = rng.integers(0, 256, shape).astype(np.int64)
+                if r * c >= 25:   # sprinkle < 35 % empties into A
+                    mask = rng.random((r, c)) < 0.2
+                    A[mask] = -1
+                add(A, B, dx, dy, ch == 3)
+    A = np.full((6, 4), 100, np.int64); B = np.full((6, 4), 200, np.int64)
+    for dx, dy in [(1, 1), (1, -1)]:
+        add(A, B, dx, dy, False)
+    A = np.full((4, 6), 100, np.int64); B = np.full((4, 6), 200, np.int64)
+    for dx, dy in [(1, 1), (-1, 1), (0, 1)]:
+        add(A, B, dx, dy, False)
+    # corner mode: the four L-shapes, several thicknesses incl. degenerate 1-2 px strips, gray + colour
+    for (r, c) in [(24, 30), (31, 23), (48, 64), (12, 12)]:
+        for which in (0, 1, 2, 3):
+            for (t_r, t_c) in [(3, 4), (1, 1), (2, 1), (1, 3), (5, 2)]:
+                for ch in (1, 3):
+                    A = _mk_corner(r, c, ch, which, rng, t_r, t_c)
+                    shape = A.shape
+                    B = rng.integers(0, 256, shape).astype(np.int64)
+                    add(A, B, int(rng.integers(-9, 9)), int(rng.integers(-9, 9)), ch == 3)
+    # corner mode with black (0) valid pixels (quadrant test uses > 0) and an all-empty A
+    for which in (0, 1, 2, 3):
+        A = _mk_corner(20, 26, 1, which, rng, 4, 5, black=True)
+        A[A > 0] = np.where(rng.random(np.count_nonzero(A > 0)) < 0.5, 0, A[A > 0])
+        add(A, rng.integers(0, 256, A.shape).astype(np.int64), 3, 3, False)
+    store["meta"] = np.array(meta, np.int32)
+    np.savez_compressed(os.path.join(OUT, "fuse_cases.npz"), **store)
+    print("fuse cases", n)
+
+
+# ------------------------------------------------------------------------------------------ getStitchByOffset
+def _write_png(path, arr):
+    from PIL import Image
+    if arr.ndim == 3:
+        Image.fromarray(arr[:, :, ::-1]).save(path)   # stored RGB so the stub's BGR flip restores arr
+    else:
+        Image.fromarray(arr).save(path)
+
+
+def cap_stitch():
+    store = {}
+    meta = []
+    n = 0
+    tmp = tempfile.mkdtemp()
+    th, tw = 64, 80
+    # column-major serpentine 3x3 with jitter; plus a line scan to the left (direction 4) and negative sums
+    serp = [[52, 2], [50, -1], [3, 66], [-51, 1], [-49, -2], [-2, 65], [50, 2], [52, -3]]
+    line4 = [[1, -60], [-2, -58], [0, -61]]
+    mixed = [[-30, 40], [60, -70], [-50, -20], [20, 75]]
+    for name, offs in (("serp", serp), ("line4", line4), ("mixed", mixed)):
+        ntile = len(offs) + 1
+        for color in (False, True):
+            tiles = [rng.integers(0, 256, (th, tw, 3) if color else (th, tw), dtype=np.uint8) for _ in range(ntile)]
+            tiles[1][:7, :9] = 0   # some true black pixels: matters for average/max/min (0 treated as empty)
+            files = []
+            for k, t in enumerate(tiles):
+                p = os.path.join(tmp, "%s_%d_%d.png" % (name, color, k)); _write_png(p, t); files.append(p)
+            for fm in ("notFuse", "average", "maximum", "minimum", "fadeInAndFadeOut", "trigonometric"):
+                s = RS.Stitcher()
+                msgs = []
+                s.printAndWrite = lambda c, msgs=msgs: msgs.append(c)
+                RS.Stitcher.isColorMode = color   # getStitchByOffset reads both self.isColorMode and Stitcher.isColorMode
+                s.fuseMethod = fm
+                ol = [list(o) for o in offs]
+                res = s.getStitchByOffset(files, ol)
+                rect = [m for m in msgs if "rectified" in m][0]
+                rect = ast.literal_eval(rect[rect.index("["):])
+                store["s%d_tiles" % n] = np.stack(tiles)
+                store["s%d_offsets" % n] = np.array(offs, np.int32)
+                store["s%d_rect" % n] = np.array(rect, np.int32)
+                store["s%d_out" % n] = res
+                meta.append([int(color), ["notFuse", "average", "maximum", "minimum", "fadeInAndFadeOut", "trigonometric"].index(fm), int(len(ol) == ntile)])
+                n += 1
+    RS.Stitcher.isColorMode = True
+    store["meta"] = np.array(meta, np.int32)
+    np.savez_compressed(os.path.join(OUT, "stitch_cases.npz"), **store)
+    print("stitch cases", n)
+
+
+def cap_flow():
+    """flowStitchWithMutiple segmenting (Stitcher.py:96-127) with a scripted offset method; notFuse, gray."""
+    tmp = tempfile.mkdtemp()
+    th, tw = 20, 24
+    out = []
+    store = {}
+    n = 0
+    for script in ([1, 1, 1, 1], [1, 0, 1, 1], [0, 1, 1], [1, 1, 0], [0, 0, 0], [1, 0, 0, 1, 1]):
+        ntile = len(script) + 1
+        tiles = [np.full((th, tw), 10 * (k + 1), np.uint8) for k in range(ntile)]
+        files = []
+        for k, t in enumerate(tiles):
+            p = os.path.join(tmp, "flow_%d_%d.png" % (n, k)); _write_png(p, t); files.append(p)
+        s = RS.Stitcher()
+        msgs = []
+        s.printAndWrite = lambda c, msgs=msgs: msgs.append(c)
+        RS.Stitcher.isColorMode = False
+        s.fuseMethod = "notFuse"
+
+        def method(images, script=script):
+            a = int(images[0][0, 0]) // 10 - 1   # pair index from the tile's fill value
+            return (True, [15, 3]) if script[a] else (False, "  The two images can not match")
+        res = s.flowStitchWithMutiple(files, method)
+        for k, r in enumerate(res):
+            store["w%d_res%d" % (n, k)] = r
+        out.append(dict(script=script, nres=len(res), shapes=[list(r.shape) for r in res],
+                        breaks=[m for m in msgs if "stitching Break" in m or "can not be stitched" in m].__len__()))
+        n += 1
+    RS.Stitcher.isColorMode = True
+    json.dump(out, open(os.path.join(OUT, "flow_cases.json"), "w"))
+    np.savez_compressed(os.path.join(OUT, "flow_cases.npz"), **store)
+    print("flow cases", n)
+
+
+# ------------------------------------------------------------------------------------------ real data pins
+def cap_real():
+    src = open(os.path.join(refshim.REF, "Stitcher.py"), encoding="utf-8-sig").read().splitlines()[86]
+    gold = ast.literal_eval(src[src.index("["):])
+    assert len(gold) == 89
+    json.dump(dict(source="Stitcher.py:87 (commented-out offsetList; entry k = offset of tile k+2 relative to tile k+1)",
+                   offsets=gold), open(os.path.join(OUT, "dendritic_offsets.json"), "w"))
+    from PIL import Image
+
+    def load(path):
+        im = Image.open(path); im.draft("L", im.size)
+        return np.asarray(im.convert("L"))
+    m = RU.Method()
+    store = {}
+    meta = []
+    d = os.path.join(refshim.REF, "demoImages", "dendriticCrystal", "1")
+    # (tile a, tile b, direction, column/row crop) ; expected = gold[a-1]
+    for n, (a, b, direction, lo, hi) in enumerate([(4, 5, 1, 600, 1900), (16, 17, 3, 0, 1300), (15, 16, 2, 300, 1500)]):
+        A = load(os.path.join(d, "1-%03d.jpg" % a)); B = load(os.path.join(d, "1-%03d.jpg" % b))
+        ra = m.getROIRegionForIncreMethod(A, direction=direction, order="first", searchRatio=0.2)
+        rb = m.getROIRegionForIncreMethod(B, direction=direction, order="second", searchRatio=0.2)
+        if direction in (1, 3):
+            ra, rb = ra[:, lo:hi], rb[:, lo:hi]
+        else:
+            ra, rb = ra[lo:hi, :], rb[lo:hi, :]
+        store["r%d_roiA" % n] = np.ascontiguousarray(ra); store["r%d_roiB" % n] = np.ascontiguousarray(rb)
+        meta.append([a, b, direction, A.shape[0], A.shape[1]] + gold[a - 1])
+    store["meta"] = np.array(meta, np.int32)
+    np.savez_compressed(os.path.join(OUT, "real_strips.npz"), **store)
+    print("real strips", len(meta), os.path.getsize(os.path.join(OUT, "real_strips.npz")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["roi", "mode", "sm", "cache", "fuse", "stitch", "flow", "real"]
+    fns = dict(roi=cap_roi, mode=cap_mode, sm=cap_state_machine, cache=cap_feature_search_cache,
+               fuse=cap_fuse, stitch=cap_stitch, flow=cap_flow, real=cap_real)
+    for w in which:
+        fns[w]()
