@@ -1,0 +1,348 @@
+"""ctypes binding of libvfsms.so (include/vfsms.h) -- the only compute backend of this package.
+
+There is deliberately NO CPU fallback: if the shared library is missing or no MI355X is visible, every
+operator raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvfsms.so")
+
+VFSMS_OK = 0
+ATTEMPT_INTS = 8
+
+
+class VfsmsError(RuntimeError):
+    pass
+
+
+class SurfParams(C.Structure):
+    _fields_ = [("hessian_threshold", C.c_float), ("n_octaves", C.c_int32), ("n_octave_layers", C.c_int32),
+                ("extended", C.c_int32), ("upright", C.c_int32)]
+
+
+class RoiPair(C.Structure):
+    _fields_ = [("tile_a", C.c_int64), ("tile_b", C.c_int64),
+                ("ay0", C.c_int32), ("ax0", C.c_int32), ("by0", C.c_int32), ("bx0", C.c_int32),
+                ("h", C.c_int32), ("w", C.c_int32)]
+
+
+KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"),
+                     ("response", "f4"), ("octave", "i4"), ("class_id", "i4")])
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "vfsms_version": (C.c_int, []),
+    "vfsms_device_count": (C.c_int, []),
+    "vfsms_last_error": (C.c_int, [C.c_char_p, C.c_int]),
+    "vfsms_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "vfsms_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "vfsms_ctx_sync": (C.c_int, [C.c_void_p]),
+    "vfsms_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "vfsms_ctx_set_keypoint_capacity": (C.c_int, [C.c_void_p, C.c_int]),
+    "vfsms_tile_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "vfsms_tile_wrap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "vfsms_tile_free": (C.c_int, [C.c_void_p, C.c_int64]),
+    "vfsms_integral_u8_i32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vfsms_surf_detect_describe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(SurfParams),
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "vfsms_surf_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(SurfParams),
+                                    C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "vfsms_bf_l2_knn2_ratio": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double,
+                                         C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "vfsms_bf_l2_knn2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vfsms_bf_hamming_nn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "vfsms_mode_offset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_int, C.c_void_p]),
+    "vfsms_phase_correlate_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p]),
+    "vfsms_fuse_fade_i64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p]),
+    "vfsms_fuse_ramps_i64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p]),
+    "vfsms_attempt_surf_batch": (C.c_int, [C.c_void_p, C.POINTER(RoiPair), C.c_int, C.POINTER(SurfParams), C.c_double,
+                                           C.c_int, C.c_void_p]),
+    "vfsms_attempt_phase_batch": (C.c_int, [C.c_void_p, C.POINTER(RoiPair), C.c_int, C.c_void_p]),
+    "vfsms_canvas_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "vfsms_canvas_free": (C.c_int, [C.c_void_p, C.c_int64]),
+    "vfsms_canvas_paste": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vfsms_canvas_fuse_tile": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vfsms_canvas_download": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libvfsms.so and bind every declared entry point.  Raises if the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VfsmsError("libvfsms.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(make -C imagestitch_amd/csrc).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError here == header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_names():
+    return sorted(_SIGNATURES)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _u8_2d(img):
+    img = np.asarray(img)
+    if img.dtype != np.uint8 or img.ndim != 2:
+        raise ValueError("expected a 2-D uint8 image, got %s %s" % (img.dtype, img.shape))
+    if img.shape[1] > 1 and img.strides[1] != 1:
+        img = np.ascontiguousarray(img)
+    if img.strides[0] < img.shape[1]:
+        img = np.ascontiguousarray(img)
+    return img
+
+
+class Engine:
+    """One HIP context (one GPU, one stream).  All methods are synchronous."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.vfsms_ctx_create(int(device), C.byref(h))
+        self.ctx = h
+        self._check(rc)
+        self.device = device
+
+    # -- plumbing ---------------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != VFSMS_OK:
+            buf = C.create_string_buffer(512)
+            self.lib.vfsms_last_error(buf, 512)
+            raise VfsmsError("libvfsms error %d: %s" % (rc, buf.value.decode(errors="replace")))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.vfsms_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(self.lib.vfsms_ctx_sync(self.ctx))
+
+    def stream_handle(self):
+        return self.lib.vfsms_ctx_stream(self.ctx)
+
+    def set_keypoint_capacity(self, cap):
+        self._check(self.lib.vfsms_ctx_set_keypoint_capacity(self.ctx, int(cap)))
+
+    # -- tiles ---------------------------------------------------------------------------------------------
+    def tile_upload(self, img):
+        img = _u8_2d(img)
+        h = C.c_int64()
+        self._check(self.lib.vfsms_tile_upload(self.ctx, _ptr(img), img.shape[0], img.shape[1], img.strides[0], C.byref(h)))
+        return h.value
+
+    def tile_wrap(self, device_ptr, h, w, stride):
+        hd = C.c_int64()
+        self._check(self.lib.vfsms_tile_wrap(self.ctx, C.c_void_p(int(device_ptr)), int(h), int(w), int(stride), C.byref(hd)))
+        return hd.value
+
+    def tile_free(self, handle):
+        self._check(self.lib.vfsms_tile_free(self.ctx, C.c_int64(handle)))
+
+    # -- operators -------------------------------------------------------------------------------------------
+    def integral(self, img):
+        img = _u8_2d(img)
+        h, w = img.shape
+        out = np.empty((h + 1, w + 1), np.int32)
+        self._check(self.lib.vfsms_integral_u8_i32(self.ctx, _ptr(img), h, w, img.strides[0], _ptr(out)))
+        return out
+
+    @staticmethod
+    def surf_params(hessian=100.0, n_octaves=4, n_layers=3, extended=False, upright=False):
+        return SurfParams(float(hessian), int(n_octaves), int(n_layers), int(bool(extended)), int(bool(upright)))
+
+    def surf_detect_describe(self, img, params=None, cap=None, full=False):
+        img = _u8_2d(img)
+        h, w = img.shape
+        params = params or self.surf_params()
+        cap = cap or (h * w // 24 + 4096)
+        d = 128 if params.extended else 64
+        kxy = np.empty((cap, 2), np.float32)
+        desc = np.empty((cap, d), np.float32)
+        kfull = np.empty(cap, KP_DTYPE) if full else None
+        n = C.c_int()
+        self._check(self.lib.vfsms_surf_detect_describe(self.ctx, _ptr(img), h, w, img.strides[0], C.byref(params),
+                                                        _ptr(kxy), _ptr(desc), _ptr(kfull), cap, C.byref(n)))
+        n = n.value
+        if full:
+            return kxy[:n].copy(), desc[:n].copy(), kfull[:n].copy()
+        return kxy[:n].copy(), desc[:n].copy()
+
+    def surf_detect(self, img, params=None, cap=None):
+        img = _u8_2d(img)
+        h, w = img.shape
+        params = params or self.surf_params()
+        cap = cap or (h * w // 24 + 4096)
+        kfull = np.empty(cap, KP_DTYPE)
+        n = C.c_int()
+        self._check(self.lib.vfsms_surf_detect(self.ctx, _ptr(img), h, w, img.strides[0], C.byref(params),
+                                               _ptr(kfull), cap, C.byref(n)))
+        return kfull[:n.value].copy()
+
+    def bf_l2_ratio_matches(self, q, t, ratio=0.75):
+        q = np.ascontiguousarray(q, np.float32); t = np.ascontiguousarray(t, np.float32)
+        nq, nt = len(q), len(t)
+        if nq == 0 or nt == 0:
+            return np.zeros((0, 2), np.int32)
+        dim = q.shape[1]
+        pairs = np.empty((nq, 2), np.int32)
+        m = C.c_int()
+        self._check(self.lib.vfsms_bf_l2_knn2_ratio(self.ctx, _ptr(q), nq, _ptr(t), nt, dim, float(ratio), _ptr(pairs), nq, C.byref(m)))
+        return pairs[:m.value].copy()
+
+    def bf_l2_knn2(self, q, t):
+        q = np.ascontiguousarray(q, np.float32); t = np.ascontiguousarray(t, np.float32)
+        nq, nt = len(q), len(t)
+        dim = q.shape[1] if nq else (t.shape[1] if nt else 64)
+        i1 = np.empty(nq, np.int32); d1 = np.empty(nq, np.float32); d2 = np.empty(nq, np.float32)
+        self._check(self.lib.vfsms_bf_l2_knn2(self.ctx, _ptr(q), nq, _ptr(t), nt, dim, _ptr(i1), _ptr(d1), _ptr(d2)))
+        return i1, d1, d2
+
+    def bf_hamming_matches(self, q, t, max_dist=-1):
+        q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+        nq, nt = len(q), len(t)
+        if nq == 0 or nt == 0:
+            return np.zeros((0, 2), np.int32)
+        pairs = np.empty((nq, 2), np.int32)
+        m = C.c_int()
+        self._check(self.lib.vfsms_bf_hamming_nn(self.ctx, _ptr(q), nq, _ptr(t), nt, q.shape[1], int(max_dist), _ptr(pairs), nq, C.byref(m)))
+        return pairs[:m.value].copy()
+
+    def mode_offset(self, kpsA, kpsB, pairs, offset_evaluate=3):
+        kpsA = np.ascontiguousarray(kpsA, np.float32).reshape(-1, 2)
+        kpsB = np.ascontiguousarray(kpsB, np.float32).reshape(-1, 2)
+        pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        out = np.zeros(4, np.int32)
+        self._check(self.lib.vfsms_mode_offset(self.ctx, _ptr(kpsA), len(kpsA), _ptr(kpsB), len(kpsB), _ptr(pairs), len(pairs),
+                                               int(offset_evaluate), _ptr(out)))
+        return bool(out[0]), [int(out[1]), int(out[2])], int(out[3])
+
+    def phase_correlate(self, a, b):
+        a = _u8_2d(a); b = _u8_2d(b)
+        if a.shape != b.shape:
+            raise ValueError("phase_correlate: shapes differ")
+        out = np.zeros(3, np.float64)
+        self._check(self.lib.vfsms_phase_correlate_u8(self.ctx, _ptr(a), _ptr(b), a.shape[0], a.shape[1], a.strides[0], b.strides[0], _ptr(out)))
+        return (float(out[0]), float(out[1])), float(out[2])
+
+    def fuse_fade_i64(self, A, B, dx, dy, return_info=False):
+        A = np.ascontiguousarray(A, np.int64); B = np.ascontiguousarray(B, np.int64)
+        if A.shape != B.shape:
+            raise ValueError("fuse: shapes differ")
+        r, c = A.shape[:2]
+        ch = 1 if A.ndim == 2 else A.shape[2]
+        out = np.empty(A.shape, np.uint8)
+        info = np.zeros(4, np.int32)
+        self._check(self.lib.vfsms_fuse_fade_i64(self.ctx, _ptr(A), _ptr(B), r, c, ch, int(dx), int(dy), _ptr(out), _ptr(info)))
+        return (out, info) if return_info else out
+
+    def fuse_ramps_i64(self, A, dx, dy, force_corner=False):
+        """-> ((wA_r, wB_r, wA_c, wB_c), info): the separable float32 ramps of the fade blend / getWeightsMatrix."""
+        A = np.ascontiguousarray(A, np.int64)
+        r, c = A.shape[:2]
+        ch = 1 if A.ndim == 2 else A.shape[2]
+        ramps = np.empty(2 * (r + c), np.float32)
+        info = np.zeros(4, np.int32)
+        self._check(self.lib.vfsms_fuse_ramps_i64(self.ctx, _ptr(A), r, c, ch, int(dx), int(dy), int(bool(force_corner)),
+                                                  _ptr(ramps), _ptr(info)))
+        return (ramps[:r].copy(), ramps[r:2 * r].copy(), ramps[2 * r:2 * r + c].copy(), ramps[2 * r + c:].copy()), info
+
+    # -- fused fast path ----------------------------------------------------------------------------------------
+    @staticmethod
+    def make_jobs(jobs):
+        arr = (RoiPair * len(jobs))()
+        for k, j in enumerate(jobs):
+            arr[k] = RoiPair(*[int(v) for v in j])
+        return arr
+
+    def attempt_surf_batch(self, jobs, params=None, ratio=0.75, offset_evaluate=3):
+        """jobs: sequence of (tile_a, tile_b, ay0, ax0, by0, bx0, h, w) -> int32[n, 8]
+        columns: status, dx, dy, votes, nA, nB, nMatches, 0   (raw vote, before the stitch-axis correction)."""
+        n = len(jobs)
+        out = np.zeros((n, ATTEMPT_INTS), np.int32)
+        if n == 0:
+            return out
+        arr = jobs if isinstance(jobs, C.Array) else self.make_jobs(jobs)
+        params = params or self.surf_params()
+        self._check(self.lib.vfsms_attempt_surf_batch(self.ctx, arr, n, C.byref(params), float(ratio), int(offset_evaluate), _ptr(out)))
+        return out
+
+    def attempt_phase_batch(self, jobs):
+        n = len(jobs)
+        out = np.zeros((n, 3), np.float64)
+        if n == 0:
+            return out
+        arr = jobs if isinstance(jobs, C.Array) else self.make_jobs(jobs)
+        self._check(self.lib.vfsms_attempt_phase_batch(self.ctx, arr, n, _ptr(out)))
+        return out
+
+    # -- canvas ----------------------------------------------------------------------------------------------------
+    def canvas_create(self, rows, cols, ch):
+        h = C.c_int64()
+        self._check(self.lib.vfsms_canvas_create(self.ctx, int(rows), int(cols), int(ch), C.byref(h)))
+        return h.value
+
+    def canvas_free(self, handle):
+        self._check(self.lib.vfsms_canvas_free(self.ctx, C.c_int64(handle)))
+
+    def canvas_paste(self, handle, tile, y0, x0):
+        tile = np.ascontiguousarray(tile, np.uint8)
+        self._check(self.lib.vfsms_canvas_paste(self.ctx, C.c_int64(handle), _ptr(tile), tile.shape[0], tile.shape[1], int(y0), int(x0)))
+
+    def canvas_fuse_tile(self, handle, tile, y0, x0, roi, dx, dy):
+        tile = np.ascontiguousarray(tile, np.uint8)
+        info = np.zeros(4, np.int32)
+        ry0, rx0, ry1, rx1 = [int(v) for v in roi]
+        self._check(self.lib.vfsms_canvas_fuse_tile(self.ctx, C.c_int64(handle), _ptr(tile), tile.shape[0], tile.shape[1],
+                                                    int(y0), int(x0), ry0, rx0, ry1, rx1, int(dx), int(dy), _ptr(info)))
+        return info
+
+    def canvas_download(self, handle, rows, cols, ch):
+        out = np.empty((rows, cols, ch) if ch > 1 else (rows, cols), np.uint8)
+        self._check(self.lib.vfsms_canvas_download(self.ctx, C.c_int64(handle), _ptr(out)))
+        return out
+
+
+_default_engine = None
+
+
+def default_engine():
+    """Process-wide engine on the GPU selected by LOCAL_RANK (one process per GPU) or device 0."""
+    global _default_engine
+    if _default_engine is None:
+        dev = int(os.environ.get("VFSMS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        lib = load_library()
+        n = lib.vfsms_device_count()
+        if n <= 0:
+            raise VfsmsError("no HIP device visible: imagestitch_amd needs an MI355X (there is no CPU fallback)")
+        _default_engine = Engine(dev % n)
+    return _default_engine

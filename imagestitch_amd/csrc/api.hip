@@ -1,0 +1,668 @@
+// api.hip -- context management and the extern "C" entry points declared in include/vfsms.h.
+#include "common.h"
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+
+size_t phase_bytes(int h, int w);
+int fuse_i64_device(vfsms_ctx *ctx, const long long *dA, const long long *dB, int r, int c, int ch, int dx, int dy,
+                    uint8_t *d_out, int32_t *info);
+
+// ---- errors -------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void vfsms_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" int vfsms_last_error(char *buf, int buflen)
+{
+    if (!buf || buflen <= 0) return VFSMS_ERR_BAD_ARG;
+    snprintf(buf, (size_t)buflen, "%s", g_err);
+    return VFSMS_OK;
+}
+extern "C" int vfsms_version(void) { return 100; }
+extern "C" int vfsms_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- arena ----------------------------------------------------------------------------------------------
+int ctx_arena_reserve(vfsms_ctx *ctx, size_t bytes)
+{
+    bytes += 1 << 20;
+    if (bytes > ctx->arena_size) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->arena) HIP_TRY(hipFree(ctx->arena));
+        ctx->arena = nullptr; ctx->arena_size = 0;
+        size_t want = bytes + bytes / 4;
+        HIP_TRY(hipMalloc((void **)&ctx->arena, want));
+        ctx->arena_size = want;
+    }
+    ctx->arena_off = 0;
+    return VFSMS_OK;
+}
+void *ctx_arena_alloc(vfsms_ctx *ctx, size_t bytes, size_t align)
+{
+    size_t off = (ctx->arena_off + align - 1) & ~(align - 1);
+    if (off + bytes > ctx->arena_size) return nullptr;
+    ctx->arena_off = off + bytes;
+    return ctx->arena + off;
+}
+
+// ---- SURF tables (resizeHaarPattern for every layer; SURFInvoker constructor tables) -------------------
+static void gaussian_kernel_f32(int n, double sigma, float *cf)   // cv::getGaussianKernel(n, sigma, CV_32F)
+{
+    const double scale2X = -0.5 / (sigma * sigma);
+    double sum = 0;
+    for (int i = 0; i < n; i++) {
+        const double x = i - (n - 1) * 0.5;
+        cf[i] = (float)exp(scale2X * x * x);
+        sum += cf[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) cf[i] = (float)(cf[i] * sum);
+}
+
+int ctx_prepare_surf(vfsms_ctx *ctx, const vfsms_surf_params *p)
+{
+    if (!p || p->n_octaves < 1 || p->n_octave_layers < 1 || (p->n_octave_layers + 2) * p->n_octaves > VFSMS_MAX_LAYERS ||
+        p->hessian_threshold < 0 || p->n_octaves > 8) {
+        vfsms_set_error("bad SURF parameters");
+        return VFSMS_ERR_BAD_ARG;
+    }
+    // largest keypoint size = largest middle-layer size + its scale step -> descriptor window side
+    {
+        const int lpo = p->n_octave_layers + 2;
+        const int top = (9 + 6 * (lpo - 1)) << (p->n_octaves - 1);
+        const float s = (float)top * 1.2f / 9.0f;
+        if ((int)(21 * s) > VFSMS_MAX_WIN) {
+            vfsms_set_error("SURF parameters give descriptor windows > %d px (unsupported)", VFSMS_MAX_WIN);
+            return VFSMS_ERR_UNSUPPORTED;
+        }
+    }
+    if (ctx->tables_valid && memcmp(&ctx->cur_params, p, sizeof(*p)) == 0) return VFSMS_OK;
+    static const int dx_s[3][5] = { {0, 2, 3, 7, 1}, {3, 2, 6, 7, -2}, {6, 2, 9, 7, 1} };
+    static const int dy_s[3][5] = { {2, 0, 7, 3, 1}, {2, 3, 7, 6, -2}, {2, 6, 7, 9, 1} };
+    static const int dxy_s[4][5] = { {1, 1, 4, 4, 1}, {5, 1, 8, 4, -1}, {1, 5, 4, 8, -1}, {5, 5, 8, 8, 1} };
+    const int lpo = p->n_octave_layers + 2;
+    const int nl = lpo * p->n_octaves;
+    std::vector<LayerPat> L(nl);
+    int step = 1, idx = 0;
+    for (int o = 0; o < p->n_octaves; o++) {
+        for (int l = 0; l < lpo; l++, idx++) {
+            LayerPat &P = L[idx];
+            P.size = (9 + 6 * l) << o; P.step = step; P.margin = (P.size / 2) / step; P.octave = o;
+            const float ratio = (float)P.size / 9;
+            for (int k = 0; k < 10; k++) {
+                const int *src = k < 3 ? dx_s[k] : k < 6 ? dy_s[k - 3] : dxy_s[k - 6];
+                const int x1 = (int)lrintf(ratio * src[0]), y1 = (int)lrintf(ratio * src[1]);
+                const int x2 = (int)lrintf(ratio * src[2]), y2 = (int)lrintf(ratio * src[3]);
+                P.box[k][0] = x1; P.box[k][1] = y1; P.box[k][2] = x2; P.box[k][3] = y2;
+                P.w[k] = src[4] / ((float)(x2 - x1) * (y2 - y1));
+            }
+        }
+        step *= 2;
+    }
+    SurfTables T;
+    memset(&T, 0, sizeof(T));
+    float G_ori[13], G_desc[20];
+    gaussian_kernel_f32(13, 2.5f, G_ori);
+    for (int i = -6; i <= 6; i++)
+        for (int j = -6; j <= 6; j++)
+            if (i * i + j * j <= 36) {
+                T.aptx[T.nOriSamples] = i; T.apty[T.nOriSamples] = j;
+                T.aptw[T.nOriSamples++] = G_ori[i + 6] * G_ori[j + 6];
+            }
+    gaussian_kernel_f32(20, 3.3f, G_desc);
+    for (int i = 0; i < 20; i++)
+        for (int j = 0; j < 20; j++) T.DW[i * 20 + j] = G_desc[i] * G_desc[j];
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (!ctx->d_layers) HIP_TRY(hipMalloc((void **)&ctx->d_layers, sizeof(LayerPat) * VFSMS_MAX_LAYERS));
+    if (!ctx->d_tables) HIP_TRY(hipMalloc((void **)&ctx->d_tables, sizeof(SurfTables)));
+    HIP_TRY(hipMemcpy(ctx->d_layers, L.data(), sizeof(LayerPat) * nl, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_tables, &T, sizeof(T), hipMemcpyHostToDevice));
+    ctx->n_layers = nl;
+    ctx->cur_params = *p;
+    ctx->tables_valid = true;
+    return VFSMS_OK;
+}
+
+// ---- context ---------------------------------------------------------------------------------------------
+extern "C" int vfsms_ctx_create(int device, vfsms_ctx **out)
+{
+    if (!out) return VFSMS_ERR_BAD_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { vfsms_set_error("no HIP device visible"); return VFSMS_ERR_NO_DEVICE; }
+    if (device < 0 || device >= n) { vfsms_set_error("device %d out of range (%d visible)", device, n); return VFSMS_ERR_BAD_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    vfsms_ctx *c = new vfsms_ctx();
+    c->device = device; c->arena = nullptr; c->arena_size = 0; c->arena_off = 0;
+    c->pinned = nullptr; c->pinned_size = 0; c->kp_cap_override = 0;
+    c->tables_valid = false; c->d_layers = nullptr; c->d_tables = nullptr; c->n_layers = 0; c->next_handle = 1;
+    memset(&c->cur_params, 0, sizeof(c->cur_params));
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { vfsms_set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete c; return VFSMS_ERR_HIP; }
+    *out = c;
+    return VFSMS_OK;
+}
+
+int phase_destroy_plans(vfsms_ctx *ctx);
+
+extern "C" int vfsms_ctx_destroy(vfsms_ctx *ctx)
+{
+    if (!ctx) return VFSMS_ERR_BAD_ARG;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    phase_destroy_plans(ctx);
+    for (auto &kv : ctx->tiles) if (kv.second.owned) hipFree(kv.second.ptr);
+    for (auto &kv : ctx->canvases) { hipFree(kv.second.pix); hipFree(kv.second.mask); }
+    if (ctx->arena) hipFree(ctx->arena);
+    if (ctx->d_layers) hipFree(ctx->d_layers);
+    if (ctx->d_tables) hipFree(ctx->d_tables);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return VFSMS_OK;
+}
+extern "C" int vfsms_ctx_sync(vfsms_ctx *ctx)
+{
+    if (!ctx) return VFSMS_ERR_BAD_ARG;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VFSMS_OK;
+}
+extern "C" void *vfsms_ctx_stream(vfsms_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+extern "C" int vfsms_ctx_set_keypoint_capacity(vfsms_ctx *ctx, int cap)
+{
+    if (!ctx || cap < 0) return VFSMS_ERR_BAD_ARG;
+    ctx->kp_cap_override = cap;
+    return VFSMS_OK;
+}
+static int kp_capacity(vfsms_ctx *ctx, int h, int w)
+{
+    if (ctx->kp_cap_override > 0) return ctx->kp_cap_override;
+    return (int)((long long)h * w / 24) + 4096;
+}
+#define CTX_ENTER(ctx)                                                     \
+    do {                                                                   \
+        if (!(ctx)) { vfsms_set_error("null context"); return VFSMS_ERR_BAD_ARG; } \
+        HIP_TRY(hipSetDevice((ctx)->device));                              \
+    } while (0)
+
+// ---- tiles -------------------------------------------------------------------------------------------------
+extern "C" int vfsms_tile_upload(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int64_t *handle)
+{
+    CTX_ENTER(ctx);
+    if (!img || !handle || h <= 0 || w <= 0 || stride < w) { vfsms_set_error("tile_upload: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    TileRec t; t.h = h; t.w = w; t.stride = w; t.owned = true;
+    HIP_TRY(hipMalloc((void **)&t.ptr, (size_t)h * w));
+    HIP_TRY(hipMemcpy2DAsync(t.ptr, w, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *handle = ctx->next_handle++;
+    ctx->tiles[*handle] = t;
+    return VFSMS_OK;
+}
+extern "C" int vfsms_tile_wrap(vfsms_ctx *ctx, const void *device_ptr, int h, int w, int stride, int64_t *handle)
+{
+    CTX_ENTER(ctx);
+    if (!device_ptr || !handle || h <= 0 || w <= 0 || stride < w) { vfsms_set_error("tile_wrap: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    TileRec t; t.ptr = (uint8_t *)device_ptr; t.h = h; t.w = w; t.stride = stride; t.owned = false;
+    *handle = ctx->next_handle++;
+    ctx->tiles[*handle] = t;
+    return VFSMS_OK;
+}
+extern "C" int vfsms_tile_free(vfsms_ctx *ctx, int64_t handle)
+{
+    CTX_ENTER(ctx);
+    auto it = ctx->tiles.find(handle);
+    if (it == ctx->tiles.end()) { vfsms_set_error("tile_free: unknown handle"); return VFSMS_ERR_BAD_ARG; }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (it->second.owned) HIP_TRY(hipFree(it->second.ptr));
+    ctx->tiles.erase(it);
+    return VFSMS_OK;
+}
+
+// ---- helpers ---------------------------------------------------------------------------------------------------
+static int upload_image(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, uint8_t **d)
+{
+    *d = (uint8_t *)ctx_arena_alloc(ctx, (size_t)h * w);
+    if (!*d) { vfsms_set_error("arena exhausted (image upload)"); return VFSMS_ERR_CAPACITY; }
+    HIP_TRY(hipMemcpy2DAsync(*d, w, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+    return VFSMS_OK;
+}
+template <typename T>
+static int upload_array(vfsms_ctx *ctx, const T *src, size_t n, T **d)
+{
+    *d = (T *)ctx_arena_alloc(ctx, sizeof(T) * (n ? n : 1));
+    if (!*d) { vfsms_set_error("arena exhausted (array upload)"); return VFSMS_ERR_CAPACITY; }
+    if (n) HIP_TRY(hipMemcpyAsync(*d, src, sizeof(T) * n, hipMemcpyHostToDevice, ctx->stream));
+    return VFSMS_OK;
+}
+
+// ---- integral ----------------------------------------------------------------------------------------------------
+extern "C" int vfsms_integral_u8_i32(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int32_t *sum_out)
+{
+    CTX_ENTER(ctx);
+    if (!img || !sum_out || h <= 0 || w <= 0 || stride < w) { vfsms_set_error("integral: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    const size_t sbytes = sizeof(int32_t) * (size_t)(h + 1) * (w + 1);
+    TRY(ctx_arena_reserve(ctx, (size_t)h * w + sbytes + 8192));
+    RoiDev R; memset(&R, 0, sizeof(R));
+    uint8_t *d_img;
+    TRY(upload_image(ctx, img, h, w, stride, &d_img));
+    R.img = d_img; R.stride = w; R.h = h; R.w = w;
+    R.sum = (int32_t *)ctx_arena_alloc(ctx, sbytes);
+    RoiDev *d_R;
+    TRY(upload_array(ctx, &R, 1, &d_R));
+    TRY(launch_integral(ctx, d_R, 1, h, w));
+    HIP_TRY(hipMemcpyAsync(sum_out, R.sum, sbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VFSMS_OK;
+}
+
+// ---- SURF (host buffers) ------------------------------------------------------------------------------------------
+static int surf_host(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, const vfsms_surf_params *params,
+                     float *kps_xy, float *desc, vfsms_keypoint *kps_full, int cap, int *n_out, bool describe)
+{
+    CTX_ENTER(ctx);
+    if (!img || !params || !n_out || h <= 0 || w <= 0 || stride < w || cap < 0) { vfsms_set_error("surf: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    TRY(ctx_prepare_surf(ctx, params));
+    const int dim = params->extended ? 128 : 64;
+    const int dcap = kp_capacity(ctx, h, w);
+    TRY(ctx_arena_reserve(ctx, (size_t)h * w + surf_roi_bytes(h, w, dcap, ctx->n_layers, params->n_octaves, dim) + 65536));
+    uint8_t *d_img;
+    TRY(upload_image(ctx, img, h, w, stride, &d_img));
+    RoiDev R;
+    TRY(surf_roi_carve(ctx, &R, d_img, w, h, w, dcap, params));
+    RoiDev *d_R;
+    TRY(upload_array(ctx, &R, 1, &d_R));
+    TRY(launch_surf_detect(ctx, d_R, &R, 1, params));
+    int counters[16];
+    if (describe) {
+        TRY(launch_surf_describe(ctx, d_R, &R, 1, params));
+    }
+    HIP_TRY(hipMemcpyAsync(counters, R.counters, sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (counters[2] || counters[0] > dcap) {
+        vfsms_set_error("surf: more than %d keypoint candidates (raise with vfsms_ctx_set_keypoint_capacity)", dcap);
+        return VFSMS_ERR_CAPACITY;
+    }
+    const int n = describe ? counters[1] : counters[0];
+    *n_out = n;
+    if (n > cap) { vfsms_set_error("surf: %d keypoints exceed the caller's capacity %d", n, cap); return VFSMS_ERR_CAPACITY; }
+    if (n > 0) {
+        if (describe) {
+            if (kps_xy) HIP_TRY(hipMemcpyAsync(kps_xy, R.kps_xy, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+            if (desc) HIP_TRY(hipMemcpyAsync(desc, R.desc, sizeof(float) * (size_t)n * dim, hipMemcpyDeviceToHost, ctx->stream));
+            if (kps_full) HIP_TRY(hipMemcpyAsync(kps_full, R.kps_out, sizeof(vfsms_keypoint) * n, hipMemcpyDeviceToHost, ctx->stream));
+        } else if (kps_full) {
+            HIP_TRY(hipMemcpyAsync(kps_full, R.kps, sizeof(vfsms_keypoint) * n, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return VFSMS_OK;
+}
+extern "C" int vfsms_surf_detect_describe(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride,
+                                          const vfsms_surf_params *params, float *kps_xy, float *desc,
+                                          vfsms_keypoint *kps_full, int cap, int *n_out)
+{
+    return surf_host(ctx, img, h, w, stride, params, kps_xy, desc, kps_full, cap, n_out, true);
+}
+extern "C" int vfsms_surf_detect(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride,
+                                 const vfsms_surf_params *params, vfsms_keypoint *kps_full, int cap, int *n_out)
+{
+    return surf_host(ctx, img, h, w, stride, params, nullptr, nullptr, kps_full, cap, n_out, false);
+}
+
+// ---- matching (host buffers) -----------------------------------------------------------------------------------------
+static int pick_nsplit(int nq, int nt, int njobs, int dim)
+{
+    const int qpw = dim == 64 ? 128 : 64;                 // queries per wave
+    const long long waves = (long long)((nq + qpw - 1) / qpw) * njobs;
+    int ns = (int)((2048 + waves - 1) / (waves > 0 ? waves : 1));
+    ns = std::max(1, std::min(ns, 64));
+    ns = std::min(ns, std::max(1, nt / 64));
+    return ns;
+}
+
+static int bf_l2_host(vfsms_ctx *ctx, const float *q, int nq, const float *t, int nt, int dim, MatchDev *M, bool with_ratio, double ratio)
+{
+    const int capq = std::max(nq, 1);
+    const int ns = pick_nsplit(nq, nt, 1, dim);
+    TRY(ctx_arena_reserve(ctx, sizeof(float) * ((size_t)nq + nt) * dim + match_bytes(capq, ns) + 65536));
+    memset(M, 0, sizeof(*M));
+    float *dq, *dt;
+    TRY(upload_array(ctx, q, (size_t)nq * dim, &dq));
+    TRY(upload_array(ctx, t, (size_t)nt * dim, &dt));
+    int cnt[2] = {nq, nt}; int *dcnt;
+    TRY(upload_array(ctx, cnt, 2, &dcnt));
+    TRY(match_carve(ctx, M, capq, dim, ns));
+    M->q = dq; M->t = dt; M->nq_ptr = dcnt; M->nt_ptr = dcnt + 1; M->kq = nullptr; M->kt = nullptr;
+    MatchDev *dM;
+    TRY(upload_array(ctx, M, 1, &dM));
+    TRY(launch_bf_l2(ctx, dM, 1, capq, ns, dim));
+    if (with_ratio) {
+        TRY(launch_ratio_only(ctx, dM, 1, capq, ratio));
+    } else {
+        TRY(launch_merge_only(ctx, dM, 1, capq));
+    }
+    return VFSMS_OK;
+}
+
+extern "C" int vfsms_bf_l2_knn2_ratio(vfsms_ctx *ctx, const float *q, int nq, const float *t, int nt, int dim,
+                                      double ratio, int32_t *pairs, int cap, int *m_out)
+{
+    CTX_ENTER(ctx);
+    if (!m_out || nq < 0 || nt < 0 || (nq && !q) || (nt && !t)) { vfsms_set_error("bf_l2: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    *m_out = 0;
+    if (nq == 0 || nt == 0) return VFSMS_OK;
+    MatchDev M;
+    TRY(bf_l2_host(ctx, q, nq, t, nt, dim, &M, true, ratio));
+    int mc[4];
+    HIP_TRY(hipMemcpyAsync(mc, M.mcount, sizeof(mc), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *m_out = mc[0];
+    if (mc[0] > cap) { vfsms_set_error("bf_l2: %d matches exceed capacity %d", mc[0], cap); return VFSMS_ERR_CAPACITY; }
+    if (mc[0] > 0 && pairs) {
+        HIP_TRY(hipMemcpyAsync(pairs, M.pairs, sizeof(int32_t) * 2 * mc[0], hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return VFSMS_OK;
+}
+
+extern "C" int vfsms_bf_l2_knn2(vfsms_ctx *ctx, const float *q, int nq, const float *t, int nt, int dim,
+                                int32_t *idx1, float *d1, float *d2)
+{
+    CTX_ENTER(ctx);
+    if (nq < 0 || nt < 0 || (nq && !q) || (nt && !t)) { vfsms_set_error("bf_l2_knn2: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    if (nq == 0) return VFSMS_OK;
+    if (nt == 0) {
+        for (int i = 0; i < nq; i++) { if (idx1) idx1[i] = -1; if (d1) d1[i] = INFINITY; if (d2) d2[i] = INFINITY; }
+        return VFSMS_OK;
+    }
+    MatchDev M;
+    TRY(bf_l2_host(ctx, q, nq, t, nt, dim, &M, false, 0.0));
+    if (idx1) HIP_TRY(hipMemcpyAsync(idx1, M.i1, sizeof(int) * nq, hipMemcpyDeviceToHost, ctx->stream));
+    if (d1) HIP_TRY(hipMemcpyAsync(d1, M.d1, sizeof(float) * nq, hipMemcpyDeviceToHost, ctx->stream));
+    if (d2) HIP_TRY(hipMemcpyAsync(d2, M.d2, sizeof(float) * nq, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VFSMS_OK;
+}
+
+extern "C" int vfsms_bf_hamming_nn(vfsms_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int nbytes,
+                                   int max_dist, int32_t *pairs, int cap, int *m_out)
+{
+    CTX_ENTER(ctx);
+    if (!m_out || nq < 0 || nt < 0 || (nq && !q) || (nt && !t)) { vfsms_set_error("bf_hamming: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    *m_out = 0;
+    if (nq == 0 || nt == 0) return VFSMS_OK;
+    TRY(ctx_arena_reserve(ctx, ((size_t)nq + nt) * nbytes + sizeof(int) * 2 * (size_t)nq + 65536));
+    uint8_t *dq, *dt;
+    TRY(upload_array(ctx, q, (size_t)nq * nbytes, &dq));
+    TRY(upload_array(ctx, t, (size_t)nt * nbytes, &dt));
+    int *bi = (int *)ctx_arena_alloc(ctx, sizeof(int) * nq), *bd = (int *)ctx_arena_alloc(ctx, sizeof(int) * nq);
+    TRY(launch_bf_hamming(ctx, dq, nq, dt, nt, nbytes, bi, bd));
+    std::vector<int> hi(nq), hd(nq);
+    HIP_TRY(hipMemcpyAsync(hi.data(), bi, sizeof(int) * nq, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(hd.data(), bd, sizeof(int) * nq, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int m = 0;
+    for (int i = 0; i < nq; i++) {
+        if (hi[i] < 0) continue;
+        if (max_dist >= 0 && !(hd[i] < max_dist)) continue;
+        if (m < cap && pairs) { pairs[2 * m] = hi[i]; pairs[2 * m + 1] = i; }
+        m++;
+    }
+    *m_out = m;
+    if (m > cap) { vfsms_set_error("bf_hamming: %d matches exceed capacity %d", m, cap); return VFSMS_ERR_CAPACITY; }
+    return VFSMS_OK;
+}
+
+extern "C" int vfsms_mode_offset(vfsms_ctx *ctx, const float *kpsA, int nA, const float *kpsB, int nB,
+                                 const int32_t *pairs, int m, int offset_evaluate, int32_t *out4)
+{
+    CTX_ENTER(ctx);
+    if (!out4 || m < 0 || nA < 0 || nB < 0) { vfsms_set_error("mode_offset: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    if (m == 0) return VFSMS_OK;
+    for (int k = 0; k < m; k++)
+        if (pairs[2 * k] < 0 || pairs[2 * k] >= nB || pairs[2 * k + 1] < 0 || pairs[2 * k + 1] >= nA) {
+            vfsms_set_error("mode_offset: match index out of range"); return VFSMS_ERR_BAD_ARG;
+        }
+    TRY(ctx_arena_reserve(ctx, sizeof(float) * 2 * ((size_t)nA + nB) + match_bytes(m, 1) + 65536));
+    MatchDev M; memset(&M, 0, sizeof(M));
+    float *dA, *dB;
+    TRY(upload_array(ctx, kpsA, (size_t)2 * nA, &dA));
+    TRY(upload_array(ctx, kpsB, (size_t)2 * nB, &dB));
+    int cnt[2] = {m, m}; int *dcnt;
+    TRY(upload_array(ctx, cnt, 2, &dcnt));
+    TRY(match_carve(ctx, &M, m, 64, 1));
+    M.kq = dA; M.kt = dB; M.nq_ptr = dcnt; M.nt_ptr = dcnt + 1; M.pairs_given = 1;
+    HIP_TRY(hipMemcpyAsync(M.pairs, pairs, sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice, ctx->stream));
+    MatchDev *dM;
+    TRY(upload_array(ctx, &M, 1, &dM));
+    TRY(launch_mode_only(ctx, dM, 1, m, offset_evaluate));
+    int32_t res[VFSMS_ATTEMPT_INTS];
+    HIP_TRY(hipMemcpyAsync(res, M.result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 4; k++) out4[k] = res[k];
+    return VFSMS_OK;
+}
+
+// ---- phase correlation ---------------------------------------------------------------------------------------------------
+extern "C" int vfsms_phase_correlate_u8(vfsms_ctx *ctx, const uint8_t *a, const uint8_t *b, int h, int w,
+                                        int stride_a, int stride_b, double *out3)
+{
+    CTX_ENTER(ctx);
+    if (!a || !b || !out3 || h <= 0 || w <= 0 || stride_a < w || stride_b < w) { vfsms_set_error("phase: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    TRY(ctx_arena_reserve(ctx, 2 * (size_t)h * w + phase_bytes(h, w) + 65536));
+    uint8_t *da, *db;
+    TRY(upload_image(ctx, a, h, w, stride_a, &da));
+    TRY(upload_image(ctx, b, h, w, stride_b, &db));
+    double *d_out = (double *)ctx_arena_alloc(ctx, 3 * sizeof(double));
+    TRY(phase_correlate_device(ctx, da, w, db, w, h, w, d_out));
+    HIP_TRY(hipMemcpyAsync(out3, d_out, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VFSMS_OK;
+}
+
+static int resolve_job(vfsms_ctx *ctx, const vfsms_roi_pair &j, const uint8_t **pa, int *sa, const uint8_t **pb, int *sb)
+{
+    auto ia = ctx->tiles.find(j.tile_a), ib = ctx->tiles.find(j.tile_b);
+    if (ia == ctx->tiles.end() || ib == ctx->tiles.end()) { vfsms_set_error("attempt: unknown tile handle"); return VFSMS_ERR_BAD_ARG; }
+    const TileRec &A = ia->second, &B = ib->second;
+    if (j.h <= 0 || j.w <= 0 || j.ay0 < 0 || j.ax0 < 0 || j.by0 < 0 || j.bx0 < 0 || j.ay0 + j.h > A.h || j.ax0 + j.w > A.w ||
+        j.by0 + j.h > B.h || j.bx0 + j.w > B.w) { vfsms_set_error("attempt: ROI outside its tile"); return VFSMS_ERR_BAD_ARG; }
+    *pa = A.ptr + (size_t)j.ay0 * A.stride + j.ax0; *sa = A.stride;
+    *pb = B.ptr + (size_t)j.by0 * B.stride + j.bx0; *sb = B.stride;
+    return VFSMS_OK;
+}
+
+extern "C" int vfsms_attempt_phase_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, double *out)
+{
+    CTX_ENTER(ctx);
+    if (n < 0 || (n && (!jobs || !out))) { vfsms_set_error("attempt_phase: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    if (n == 0) return VFSMS_OK;
+    size_t need = 0;
+    for (int k = 0; k < n; k++) need = std::max(need, phase_bytes(jobs[k].h, jobs[k].w));
+    TRY(ctx_arena_reserve(ctx, need + sizeof(double) * 3 * n + 65536));
+    double *d_out = (double *)ctx_arena_alloc(ctx, sizeof(double) * 3 * n);
+    const size_t mark = ctx->arena_off;
+    for (int k = 0; k < n; k++) {
+        const uint8_t *pa, *pb; int sa, sb;
+        TRY(resolve_job(ctx, jobs[k], &pa, &sa, &pb, &sb));
+        ctx->arena_off = mark;                               // stream order makes scratch reuse safe
+        TRY(phase_correlate_device(ctx, pa, sa, pb, sb, jobs[k].h, jobs[k].w, d_out + 3 * k));
+    }
+    HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VFSMS_OK;
+}
+
+// ---- fused SURF + BF + ratio + mode attempts --------------------------------------------------------------------------------
+extern "C" int vfsms_attempt_surf_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n,
+                                        const vfsms_surf_params *params, double ratio, int offset_evaluate, int32_t *out)
+{
+    CTX_ENTER(ctx);
+    if (n < 0 || (n && (!jobs || !out)) || !params) { vfsms_set_error("attempt_surf: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    if (n == 0) return VFSMS_OK;
+    TRY(ctx_prepare_surf(ctx, params));
+    const int dim = params->extended ? 128 : 64;
+    size_t need = 0; int maxcap = 0;
+    std::vector<int> caps(n);
+    for (int k = 0; k < n; k++) {
+        caps[k] = kp_capacity(ctx, jobs[k].h, jobs[k].w);
+        maxcap = std::max(maxcap, caps[k]);
+    }
+    const int ns = pick_nsplit(maxcap / 3, maxcap / 3, n, dim);   // typical occupancy of the capacity
+    for (int k = 0; k < n; k++)
+        need += 2 * surf_roi_bytes(jobs[k].h, jobs[k].w, caps[k], ctx->n_layers, params->n_octaves, dim) + match_bytes(caps[k], ns);
+    need += (sizeof(RoiDev) * 2 + sizeof(MatchDev)) * n + 64 * 3 * n + 65536;
+    TRY(ctx_arena_reserve(ctx, need));
+    std::vector<RoiDev> R(2 * n);
+    std::vector<MatchDev> M(n);
+    for (int k = 0; k < n; k++) {
+        const uint8_t *pa, *pb; int sa, sb;
+        TRY(resolve_job(ctx, jobs[k], &pa, &sa, &pb, &sb));
+        TRY(surf_roi_carve(ctx, &R[2 * k], pa, sa, jobs[k].h, jobs[k].w, caps[k], params));
+        TRY(surf_roi_carve(ctx, &R[2 * k + 1], pb, sb, jobs[k].h, jobs[k].w, caps[k], params));
+        memset(&M[k], 0, sizeof(MatchDev));
+        TRY(match_carve(ctx, &M[k], caps[k], dim, ns));
+        M[k].q = R[2 * k].desc; M[k].t = R[2 * k + 1].desc;
+        M[k].nq_ptr = R[2 * k].counters + 1; M[k].nt_ptr = R[2 * k + 1].counters + 1;
+        M[k].kq = R[2 * k].kps_xy; M[k].kt = R[2 * k + 1].kps_xy;
+    }
+    RoiDev *dR; MatchDev *dM;
+    TRY(upload_array(ctx, R.data(), (size_t)2 * n, &dR));
+    TRY(upload_array(ctx, M.data(), (size_t)n, &dM));
+    TRY(launch_surf_detect(ctx, dR, R.data(), 2 * n, params));
+    TRY(launch_surf_describe(ctx, dR, R.data(), 2 * n, params));
+    TRY(launch_bf_l2(ctx, dM, n, maxcap, ns, dim));
+    TRY(launch_ratio_mode(ctx, dM, n, maxcap, ratio, offset_evaluate));
+    std::vector<int> counters((size_t)16 * 2 * n);
+    for (int k = 0; k < 2 * n; k++)
+        HIP_TRY(hipMemcpyAsync(&counters[(size_t)16 * k], R[k].counters, 16 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    for (int k = 0; k < n; k++)
+        HIP_TRY(hipMemcpyAsync(out + (size_t)VFSMS_ATTEMPT_INTS * k, M[k].result, VFSMS_ATTEMPT_INTS * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 2 * n; k++)
+        if (counters[(size_t)16 * k + 2] || counters[(size_t)16 * k] > R[k].cap) {
+            vfsms_set_error("attempt_surf: ROI %d exceeded %d keypoint candidates (vfsms_ctx_set_keypoint_capacity)", k, R[k].cap);
+            return VFSMS_ERR_CAPACITY;
+        }
+    return VFSMS_OK;
+}
+
+// ---- fuse ----------------------------------------------------------------------------------------------------------------------
+extern "C" int vfsms_fuse_fade_i64(vfsms_ctx *ctx, const int64_t *A, const int64_t *B, int r, int c, int ch,
+                                   int dx, int dy, uint8_t *out, int32_t *info)
+{
+    CTX_ENTER(ctx);
+    if (!A || !B || !out || r <= 0 || c <= 0 || ch < 1 || ch > 4) { vfsms_set_error("fuse_i64: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    const size_t nel = (size_t)r * c * ch;
+    TRY(ctx_arena_reserve(ctx, nel * 17 + sizeof(float) * 4 * ((size_t)r + c) + sizeof(int) * 4 * ((size_t)r + c) + 65536));
+    long long *dA, *dB;
+    TRY(upload_array(ctx, (const long long *)A, nel, &dA));
+    TRY(upload_array(ctx, (const long long *)B, nel, &dB));
+    uint8_t *d_out = (uint8_t *)ctx_arena_alloc(ctx, nel);
+    TRY(fuse_i64_device(ctx, dA, dB, r, c, ch, dx, dy, d_out, info));
+    HIP_TRY(hipMemcpyAsync(out, d_out, nel, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VFSMS_OK;
+}
+
+int fuse_i64_ramps(vfsms_ctx *ctx, const long long *dA, int r, int c, int ch, int dx, int dy, int force_corner,
+                   float *h_ramps, int32_t *info);
+
+extern "C" int vfsms_fuse_ramps_i64(vfsms_ctx *ctx, const int64_t *A, int r, int c, int ch, int dx, int dy,
+                                    int force_corner, float *ramps, int32_t *info)
+{
+    CTX_ENTER(ctx);
+    if (!A || !ramps || r <= 0 || c <= 0 || ch < 1 || ch > 4) { vfsms_set_error("fuse_ramps: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    const size_t nel = (size_t)r * c * ch;
+    TRY(ctx_arena_reserve(ctx, nel * 8 + sizeof(float) * 8 * ((size_t)r + c) + 65536));
+    long long *dA;
+    TRY(upload_array(ctx, (const long long *)A, nel, &dA));
+    TRY(fuse_i64_ramps(ctx, dA, r, c, ch, dx, dy, force_corner, ramps, info));
+    return VFSMS_OK;
+}
+
+extern "C" int vfsms_canvas_create(vfsms_ctx *ctx, int rows, int cols, int ch, int64_t *handle)
+{
+    CTX_ENTER(ctx);
+    if (!handle || rows <= 0 || cols <= 0 || ch < 1 || ch > 4) { vfsms_set_error("canvas_create: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    CanvasRec cv; cv.rows = rows; cv.cols = cols; cv.ch = ch;
+    HIP_TRY(hipMalloc((void **)&cv.pix, (size_t)rows * cols * ch));
+    HIP_TRY(hipMalloc((void **)&cv.mask, (size_t)rows * cols));
+    HIP_TRY(hipMemsetAsync(cv.pix, 0, (size_t)rows * cols * ch, ctx->stream));
+    HIP_TRY(hipMemsetAsync(cv.mask, 0, (size_t)rows * cols, ctx->stream));
+    *handle = ctx->next_handle++;
+    ctx->canvases[*handle] = cv;
+    return VFSMS_OK;
+}
+extern "C" int vfsms_canvas_free(vfsms_ctx *ctx, int64_t handle)
+{
+    CTX_ENTER(ctx);
+    auto it = ctx->canvases.find(handle);
+    if (it == ctx->canvases.end()) { vfsms_set_error("canvas_free: unknown handle"); return VFSMS_ERR_BAD_ARG; }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(it->second.pix)); HIP_TRY(hipFree(it->second.mask));
+    ctx->canvases.erase(it);
+    return VFSMS_OK;
+}
+static int canvas_tile_args(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w, int y0, int x0, CanvasRec **cv)
+{
+    auto it = ctx->canvases.find(canvas);
+    if (it == ctx->canvases.end()) { vfsms_set_error("canvas: unknown handle"); return VFSMS_ERR_BAD_ARG; }
+    *cv = &it->second;
+    if (!tile || h <= 0 || w <= 0 || y0 < 0 || x0 < 0 || y0 + h > (*cv)->rows || x0 + w > (*cv)->cols) {
+        vfsms_set_error("canvas: tile rectangle outside the canvas"); return VFSMS_ERR_BAD_ARG;
+    }
+    return VFSMS_OK;
+}
+extern "C" int vfsms_canvas_paste(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w, int y0, int x0)
+{
+    CTX_ENTER(ctx);
+    CanvasRec *cv;
+    TRY(canvas_tile_args(ctx, canvas, tile, h, w, y0, x0, &cv));
+    const size_t nb = (size_t)h * w * cv->ch;
+    TRY(ctx_arena_reserve(ctx, nb + 65536));
+    uint8_t *d_tile;
+    TRY(upload_array(ctx, tile, nb, &d_tile));
+    TRY(canvas_paste_device(ctx, cv, d_tile, h, w, y0, x0));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VFSMS_OK;
+}
+extern "C" int vfsms_canvas_fuse_tile(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w,
+                                      int y0, int x0, int ry0, int rx0, int ry1, int rx1, int dx, int dy, int32_t *info)
+{
+    CTX_ENTER(ctx);
+    CanvasRec *cv;
+    TRY(canvas_tile_args(ctx, canvas, tile, h, w, y0, x0, &cv));
+    if (ry1 > ry0 && rx1 > rx0 && (ry0 < y0 || rx0 < x0 || ry1 > y0 + h || rx1 > x0 + w)) {
+        vfsms_set_error("canvas_fuse_tile: fuse ROI must lie inside the tile rectangle"); return VFSMS_ERR_BAD_ARG;
+    }
+    const size_t nb = (size_t)h * w * cv->ch;
+    const int r = std::max(ry1 - ry0, 0), c = std::max(rx1 - rx0, 0);
+    TRY(ctx_arena_reserve(ctx, nb + sizeof(float) * 8 * ((size_t)r + c) + 65536));
+    uint8_t *d_tile;
+    TRY(upload_array(ctx, tile, nb, &d_tile));
+    TRY(canvas_fuse_device(ctx, cv, d_tile, h, w, y0, x0, ry0, rx0, ry1, rx1, dx, dy, info));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VFSMS_OK;
+}
+extern "C" int vfsms_canvas_download(vfsms_ctx *ctx, int64_t canvas, uint8_t *out)
+{
+    CTX_ENTER(ctx);
+    auto it = ctx->canvases.find(canvas);
+    if (it == ctx->canvases.end() || !out) { vfsms_set_error("canvas_download: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    const CanvasRec &cv = it->second;
+    // never-written pixels are still 0 (the canvas is zero-initialised), exactly Stitcher.py:485
+    HIP_TRY(hipMemcpyAsync(out, cv.pix, (size_t)cv.rows * cv.cols * cv.ch, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VFSMS_OK;
+}

@@ -1,0 +1,139 @@
+// common.h -- internal declarations shared by the libvfsms translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "../../include/vfsms.h"
+
+#define VFSMS_MAX_LAYERS 32      // (nOctaveLayers + 2) * nOctaves
+#define VFSMS_MAX_WIN 768        // SURF descriptor window side upper bound (size <= 264 -> 739)
+
+// ---- error plumbing ------------------------------------------------------------------------------
+void vfsms_set_error(const char *fmt, ...);
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            vfsms_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return VFSMS_ERR_HIP;                                                             \
+        }                                                                                     \
+    } while (0)
+#define TRY(expr)                  \
+    do {                           \
+        int _r = (expr);           \
+        if (_r != VFSMS_OK) return _r; \
+    } while (0)
+
+// ---- fast-Hessian layer description (host-built, device-resident table) ---------------------------
+struct LayerPat {
+    int size, step, margin, octave;   // margin = (size/2)/step
+    int box[10][4];                   // dx1, dy1, dx2, dy2 for Dx[3], Dy[3], Dxy[4]  (resizeHaarPattern)
+    float w[10];
+};
+
+struct SurfTables {                   // orientation lattice + descriptor Gaussian (SURFInvoker ctor)
+    int nOriSamples;
+    int aptx[128], apty[128];
+    float aptw[128];
+    float DW[400];
+};
+
+struct Cand {                         // NMS survivor before sorting
+    float x, y, size, response;
+    int octave, class_id;
+    int layer, i, j;
+};
+
+// ---- one ROI's device working set; arrays of these drive every batched kernel ---------------------
+struct RoiDev {
+    const uint8_t *img;
+    int stride, h, w;
+    int32_t *sum;                     // (h+1) x (w+1)
+    float *det[VFSMS_MAX_LAYERS];
+    float *trace[VFSMS_MAX_LAYERS];
+    int cap;
+    int *counters;                    // [0] n candidates, [1] n kept after deletion, [2] overflow flag
+    Cand *cand;
+    vfsms_keypoint *kps;              // sorted (KeypointGreater), angle filled by orientation; size=-1 -> deleted
+    float *desc_raw;                  // cap x D, rows aligned with kps
+    int *keep_pos;                    // exclusive scan of keep flags
+    float *kps_xy;                    // compacted [n][2]
+    float *desc;                      // compacted [n][D]
+    vfsms_keypoint *kps_out;          // compacted
+};
+
+// ---- one (query ROI, train ROI) matching job --------------------------------------------------------
+struct MatchDev {
+    const float *q; const float *t;   // descriptors
+    const int *nq_ptr; const int *nt_ptr;   // device-side counts (RoiDev.counters+1) or host-filled
+    const float *kq; const float *kt; // keypoints xy (may be null for raw matching)
+    int capq;
+    int dim;
+    // partial 2-NN per (split, query)
+    float *p_d1; float *p_d2; int *p_i1; int nsplit;
+    // merged
+    float *d1; float *d2; int *i1;
+    int *match_flag; int *match_pos;
+    int32_t *pairs;                   // [capq][2] (train, query)
+    int32_t *votes;                   // [capq][2] (dx, dy) after dropping (0,0)
+    int *mcount;                      // [0] n matches, [1] n votes
+    int32_t *result;                  // VFSMS_ATTEMPT_INTS
+    int pairs_given;                  // pairs[] supplied by the caller (vfsms_mode_offset): do not rewrite
+};
+
+// ---- context ------------------------------------------------------------------------------------------
+struct TileRec { uint8_t *ptr; int h, w, stride; bool owned; };
+struct CanvasRec { uint8_t *pix; uint8_t *mask; int rows, cols, ch; };
+struct FftPlan { int M, N; void *fwd; void *inv; };   // hipfftHandle stored as void* (int in practice)
+
+struct vfsms_ctx {
+    int device;
+    hipStream_t stream;
+    // bump arena for per-call scratch
+    char *arena; size_t arena_size; size_t arena_off;
+    // pinned staging for small results
+    char *pinned; size_t pinned_size;
+    int kp_cap_override;
+    // SURF tables
+    vfsms_surf_params cur_params; bool tables_valid;
+    LayerPat *d_layers; int n_layers;
+    SurfTables *d_tables;
+    std::unordered_map<int64_t, TileRec> tiles;
+    std::unordered_map<int64_t, CanvasRec> canvases;
+    int64_t next_handle;
+    std::vector<FftPlan> plans;
+};
+
+int ctx_arena_reserve(vfsms_ctx *ctx, size_t bytes);             // ensure capacity (may sync + realloc), reset offset
+void *ctx_arena_alloc(vfsms_ctx *ctx, size_t bytes, size_t align = 256);
+int ctx_prepare_surf(vfsms_ctx *ctx, const vfsms_surf_params *p);
+
+// ---- kernel launchers (each is stream-ordered, no host sync) --------------------------------------------
+// surf_kernels.hip
+size_t surf_roi_bytes(int h, int w, int cap, int nlayers_total, int noctaves, int dim);
+int surf_roi_carve(vfsms_ctx *ctx, RoiDev *r, const uint8_t *img, int stride, int h, int w, int cap,
+                   const vfsms_surf_params *p);
+int launch_integral(vfsms_ctx *ctx, const RoiDev *d_rois, int nrois, int maxh, int maxw);
+int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_rois, int nrois,
+                       const vfsms_surf_params *p);
+int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_rois, int nrois,
+                         const vfsms_surf_params *p);
+// match_kernels.hip
+size_t match_bytes(int capq, int nsplit);
+int match_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int dim, int nsplit);
+int launch_bf_l2(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int nsplit, int dim);
+int launch_merge_only(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq);
+int launch_ratio_only(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, double ratio);
+int launch_ratio_mode(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, double ratio, int offset_evaluate);
+int launch_mode_only(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capm, int offset_evaluate);
+int launch_bf_hamming(vfsms_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int nbytes,
+                      int *best_idx, int *best_dist);
+// phase_kernels.hip
+int phase_correlate_device(vfsms_ctx *ctx, const uint8_t *a, int stride_a, const uint8_t *b, int stride_b,
+                           int h, int w, double *d_out3);
+// fuse_kernels.hip
+int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0,
+                       int ry0, int rx0, int ry1, int rx1, int dx, int dy, int32_t *info);
+int canvas_paste_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0);

@@ -1,0 +1,380 @@
+// match_kernels.hip -- brute-force matchers + ratio test + mode vote for gfx950.
+//
+// Replaces BFMatcher("BruteForce").knnMatch(k=2) + ratio filter (ImageUtility.py:288-296; DLL twin
+// appendix/myGpuFeatures.cpp:160-173), BFMatcher("BruteForce-Hamming").match (ImageUtility.py:297-302)
+// and Method.getOffsetByMode (ImageUtility.py:139-178).
+//
+// BF-L2 layout (CDNA4-native, not a warp-tiled GEMM): every lane OWNS two query descriptors in VGPRs
+// (2 x 64 floats, packed so the inner loop is v_pk_add/v_pk_mul on both queries at once); train
+// descriptors are wave-uniform and stream through the scalar data path (s_load) -- no LDS traffic, no
+// cross-lane reduction in the hot loop: each lane keeps its own running best / second best.  Trains are
+// split across blockIdx.y so that a single ROI pair still fills 256 CUs; the partial 2-NN lists are
+// merged (ascending train order, ties keep the lower index) by k_merge_ratio.
+// Distances: float accumulation in the 4-wide order of normL2Sqr_, sqrt per candidate exactly when the
+// squared distance can still change the top-2 (comparisons happen in the sqrt domain like OpenCV's).
+#include "common.h"
+#include <math.h>
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef const float __attribute__((address_space(4))) cfloat;   // AMDGPU constant address space
+
+__device__ __forceinline__ void knn_update(float dsq, int j, float &b1, float &b2, int &i1, float &b1sq, float &b2sq)
+{
+    if (dsq < b2sq) {
+        float d = sqrtf(dsq);
+        if (d < b1) { b2 = b1; b2sq = b1sq; b1 = d; b1sq = dsq; i1 = j; }
+        else if (d < b2) { b2 = d; b2sq = dsq; }
+    }
+}
+
+// DIM = 64: two queries per lane (packed).  block = 256 threads = 4 waves x 128 queries.
+__global__ __launch_bounds__(256) void k_bf_l2_d64(const MatchDev *jobs)
+{
+    const MatchDev &J = jobs[blockIdx.z];
+    // device-side counts are wave-uniform: pin them to SGPRs so loop bounds and train addresses stay scalar
+    const int nq = __builtin_amdgcn_readfirstlane(*J.nq_ptr), nt = __builtin_amdgcn_readfirstlane(*J.nt_ptr);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q0 = blockIdx.x * 512 + wave * 128;
+    if (q0 >= nq) return;
+    const int nsplit = gridDim.y, sp = blockIdx.y;
+    const int chunk = (nt + nsplit - 1) / nsplit;
+    const int t0 = sp * chunk, t1 = min(nt, t0 + chunk);
+    const int qa = q0 + lane, qb = q0 + 64 + lane;
+    const float *__restrict__ pa = J.q + (size_t)min(qa, nq - 1) * 64;
+    const float *__restrict__ pb = J.q + (size_t)min(qb, nq - 1) * 64;
+    float2v qv[64];
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) {
+        float4 va = *reinterpret_cast<const float4 *>(pa + d);
+        float4 vb = *reinterpret_cast<const float4 *>(pb + d);
+        qv[d + 0] = (float2v){va.x, vb.x}; qv[d + 1] = (float2v){va.y, vb.y};
+        qv[d + 2] = (float2v){va.z, vb.z}; qv[d + 3] = (float2v){va.w, vb.w};
+    }
+    float b1a = INFINITY, b2a = INFINITY, b1sa = INFINITY, b2sa = INFINITY; int i1a = -1;
+    float b1b = INFINITY, b2b = INFINITY, b1sb = INFINITY, b2sb = INFINITY; int i1b = -1;
+    // Train descriptors were written by an earlier kernel and are read-only here: address them through the
+    // constant address space so the wave-uniform loads are issued on the scalar unit (s_load_dwordx16).
+    const cfloat *T = (const cfloat *)(uintptr_t)J.t;
+    for (int j = t0; j < t1; j++) {
+        const cfloat *tr = T + (size_t)j * 64;
+        float2v acc = (float2v){0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 64; d += 4) {
+            float2v e0 = qv[d + 0] - tr[d + 0];
+            float2v e1 = qv[d + 1] - tr[d + 1];
+            float2v e2 = qv[d + 2] - tr[d + 2];
+            float2v e3 = qv[d + 3] - tr[d + 3];
+            acc += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+        }
+        knn_update(acc.x, j, b1a, b2a, i1a, b1sa, b2sa);
+        knn_update(acc.y, j, b1b, b2b, i1b, b1sb, b2sb);
+    }
+    const size_t o = (size_t)sp * J.capq;
+    if (qa < nq) { J.p_d1[o + qa] = b1a; J.p_d2[o + qa] = b2a; J.p_i1[o + qa] = i1a; }
+    if (qb < nq) { J.p_d1[o + qb] = b1b; J.p_d2[o + qb] = b2b; J.p_i1[o + qb] = i1b; }
+}
+
+// generic DIM (multiple of 4, <= 128): one query per lane.  block = 256 threads = 256 queries.
+template <int DIM>
+__global__ __launch_bounds__(256) void k_bf_l2_gen(const MatchDev *jobs)
+{
+    const MatchDev &J = jobs[blockIdx.z];
+    // device-side counts are wave-uniform: pin them to SGPRs so loop bounds and train addresses stay scalar
+    const int nq = __builtin_amdgcn_readfirstlane(*J.nq_ptr), nt = __builtin_amdgcn_readfirstlane(*J.nt_ptr);
+    const int q0 = blockIdx.x * 256;
+    if (q0 >= nq) return;
+    const int nsplit = gridDim.y, sp = blockIdx.y;
+    const int chunk = (nt + nsplit - 1) / nsplit;
+    const int t0 = sp * chunk, t1 = min(nt, t0 + chunk);
+    const int qa = q0 + threadIdx.x;
+    const float *__restrict__ pa = J.q + (size_t)min(qa, nq - 1) * DIM;
+    float qv[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) qv[d] = pa[d];
+    float b1 = INFINITY, b2 = INFINITY, b1s = INFINITY, b2s = INFINITY; int i1 = -1;
+    const float *__restrict__ T = J.t;
+    for (int j = t0; j < t1; j++) {
+        const float *__restrict__ tr = T + (size_t)j * DIM;
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < DIM; d += 4) {
+            float e0 = qv[d] - tr[d], e1 = qv[d + 1] - tr[d + 1], e2 = qv[d + 2] - tr[d + 2], e3 = qv[d + 3] - tr[d + 3];
+            acc += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+        }
+        knn_update(acc, j, b1, b2, i1, b1s, b2s);
+    }
+    const size_t o = (size_t)sp * J.capq;
+    if (qa < nq) { J.p_d1[o + qa] = b1; J.p_d2[o + qa] = b2; J.p_i1[o + qa] = i1; }
+}
+
+// merge the per-split 2-NN lists, apply the ratio test (Python double arithmetic on float32 distances,
+// ImageUtility.py:294) and compute the vote of ImageUtility.py:153-161 for surviving matches.
+__global__ __launch_bounds__(256) void k_merge_ratio(const MatchDev *jobs, double ratio, int do_ratio)
+{
+    const MatchDev &J = jobs[blockIdx.y];
+    // device-side counts are wave-uniform: pin them to SGPRs so loop bounds and train addresses stay scalar
+    const int nq = __builtin_amdgcn_readfirstlane(*J.nq_ptr), nt = __builtin_amdgcn_readfirstlane(*J.nt_ptr);
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    float B1 = INFINITY, B2 = INFINITY; int I1 = -1;
+    for (int s = 0; s < J.nsplit; s++) {
+        const size_t o = (size_t)s * J.capq + q;
+        float d = J.p_d1[o]; int i = J.p_i1[o];
+        if (i >= 0) {
+            if (d < B1) { B2 = B1; B1 = d; I1 = i; } else if (d < B2) { B2 = d; }
+            float e = J.p_d2[o];
+            if (e < B1) { B2 = B1; B1 = e; } else if (e < B2) { B2 = e; }
+        }
+    }
+    J.d1[q] = B1; J.d2[q] = B2; J.i1[q] = I1;
+    if (!do_ratio) return;
+    int ok = (I1 >= 0) && (nt >= 2) && ((double)B1 < (double)B2 * ratio);
+    int vote = 0;
+    if (ok && J.kq) {
+        // ptA = (kpsA[q][1], kpsA[q][0]); dx = int(ptA[0]-ptB[0]) (float32 subtract, trunc toward zero)
+        float ay = J.kq[2 * q + 1], ax = J.kq[2 * q];
+        float by = J.kt[2 * I1 + 1], bx = J.kt[2 * I1];
+        int dx = (int)(ay - by), dy = (int)(ax - bx);
+        vote = !(dx == 0 && dy == 0);
+        J.votes[2 * (size_t)(J.capq + q)] = dx;             // staging area: second half of the votes buffer
+        J.votes[2 * (size_t)(J.capq + q) + 1] = dy;
+    }
+    J.match_flag[q] = ok | (vote << 1);
+}
+
+__device__ __forceinline__ int wave_incl_scan_i(int v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int n = __shfl_up(v, d, 64);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+
+// order-preserving compaction of matches and of non-(0,0) votes: one 1024-thread workgroup per job
+__global__ __launch_bounds__(1024) void k_match_scan(const MatchDev *jobs)
+{
+    const MatchDev &J = jobs[blockIdx.x];
+    const int nq = *J.nq_ptr;
+    __shared__ int wsum_m[16], wsum_v[16];
+    __shared__ int carry_m, carry_v;
+    if (threadIdx.x == 0) { carry_m = 0; carry_v = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int base = 0; base < nq; base += 1024) {
+        const int q = base + threadIdx.x;
+        const int f = (q < nq) ? J.match_flag[q] : 0;
+        const int fm = f & 1, fv = (f >> 1) & 1;
+        const int im = wave_incl_scan_i(fm), iv = wave_incl_scan_i(fv);
+        if (lane == 63) { wsum_m[wid] = im; wsum_v[wid] = iv; }
+        __syncthreads();
+        int om = carry_m, ov = carry_v;
+        for (int k = 0; k < wid; k++) { om += wsum_m[k]; ov += wsum_v[k]; }
+        if (fm && !J.pairs_given) {
+            const int pos = om + im - 1;
+            J.pairs[2 * (size_t)pos] = J.i1[q];              // (trainIdx, queryIdx)
+            J.pairs[2 * (size_t)pos + 1] = q;
+        }
+        if (fv) {
+            const int pos = ov + iv - 1;
+            J.votes[2 * (size_t)pos] = J.votes[2 * (size_t)(J.capq + q)];
+            J.votes[2 * (size_t)pos + 1] = J.votes[2 * (size_t)(J.capq + q) + 1];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) { carry_m = om + im; carry_v = ov + iv; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { J.mcount[0] = carry_m; J.mcount[1] = carry_v; J.mcount[2] = 0; J.mcount[3] = 0; }
+}
+
+// votes from an explicit (trainIdx, queryIdx) list (per-operator entry point vfsms_mode_offset)
+__global__ __launch_bounds__(256) void k_votes_from_pairs(const MatchDev *jobs, int m)
+{
+    const MatchDev &J = jobs[blockIdx.y];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= m) return;
+    const int tr = J.pairs[2 * k], q = J.pairs[2 * k + 1];
+    float ay = J.kq[2 * q + 1], ax = J.kq[2 * q];
+    float by = J.kt[2 * tr + 1], bx = J.kt[2 * tr];
+    int dx = (int)(ay - by), dy = (int)(ax - bx);
+    J.votes[2 * (size_t)(J.capq + k)] = dx;
+    J.votes[2 * (size_t)(J.capq + k) + 1] = dy;
+    J.match_flag[k] = 1 | ((!(dx == 0 && dy == 0)) << 1);
+}
+
+// mode of the (dx,dy) tuples, ties -> first inserted: every vote counts its equals (LDS tiles) and the
+// first occurrence of each distinct tuple bids (count, -index) with one 64-bit atomicMax.
+__global__ __launch_bounds__(256) void k_mode_count(const MatchDev *jobs)
+{
+    const MatchDev &J = jobs[blockIdx.y];
+    const int n = J.mcount[1];
+    if ((int)(blockIdx.x * 256) >= n) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ long long tile[256];
+    const long long *V = reinterpret_cast<const long long *>(J.votes);
+    long long me = (i < n) ? V[i] : 0;
+    int cnt = 0; bool first = true;
+    for (int base = 0; base < n; base += 256) {
+        int t = base + threadIdx.x;
+        if (t < n) tile[threadIdx.x] = V[t];
+        __syncthreads();
+        int lim = min(256, n - base);
+        if (i < n)
+            for (int k = 0; k < lim; k++) {
+                bool eq = tile[k] == me;
+                cnt += eq ? 1 : 0;
+                if (eq && base + k < i) first = false;
+            }
+        __syncthreads();
+    }
+    if (i < n && first) {
+        unsigned long long bid = ((unsigned long long)(unsigned)cnt << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        atomicMax(reinterpret_cast<unsigned long long *>(J.mcount + 2), bid);
+    }
+}
+
+__global__ void k_mode_final(const MatchDev *jobs, int njobs, int offset_evaluate)
+{
+    const int jn = blockIdx.x * blockDim.x + threadIdx.x;
+    if (jn >= njobs) return;
+    const MatchDev &J = jobs[jn];
+    const int nm = J.mcount[0], nv = J.mcount[1];
+    int status = 0, dx = 0, dy = 0, votes = 0;
+    if (nm > 0) {
+        if (nv == 0) { votes = 1; }                          // dxList.append(0); dyList.append(0)
+        else {
+            unsigned long long bid = *reinterpret_cast<const unsigned long long *>(J.mcount + 2);
+            votes = (int)(bid >> 32);
+            unsigned idx = 0xFFFFFFFFu - (unsigned)(bid & 0xFFFFFFFFull);
+            dx = J.votes[2 * (size_t)idx]; dy = J.votes[2 * (size_t)idx + 1];
+        }
+        status = votes >= offset_evaluate;
+    }
+    J.result[0] = status; J.result[1] = dx; J.result[2] = dy; J.result[3] = votes;
+    J.result[4] = *J.nq_ptr; J.result[5] = *J.nt_ptr; J.result[6] = nm; J.result[7] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Hamming 1-NN: lanes own queries (32 bytes = 8 dwords in VGPRs), trains stream through the scalar path
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bf_hamming32(const uint32_t *__restrict__ q, int nq,
+                                                      const uint32_t *__restrict__ t, int nt,
+                                                      int *best_idx, int *best_dist)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= nq) return;
+    const uint32_t *pq = q + (size_t)min(qi, nq - 1) * 8;
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = pq[k];
+    int best = 0x7fffffff, bi = -1;
+    for (int j = 0; j < nt; j++) {
+        const uint32_t *__restrict__ tr = t + (size_t)j * 8;
+        int d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) d += __popc(v[k] ^ tr[k]);
+        if (d < best) { best = d; bi = j; }
+    }
+    if (qi < nq) { best_idx[qi] = bi; best_dist[qi] = best; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t match_bytes(int capq, int nsplit)
+{
+    size_t b = 3 * al(sizeof(float) * (size_t)capq * nsplit);
+    b += 3 * al(sizeof(float) * capq) + 2 * al(sizeof(int) * capq);
+    b += al(sizeof(int32_t) * 2 * capq) + al(sizeof(int32_t) * 4 * capq) + al(64) + al(64);
+    return b + 4096;
+}
+
+int match_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int dim, int nsplit)
+{
+    m->capq = capq; m->dim = dim; m->nsplit = nsplit;
+    m->p_d1 = (float *)ctx_arena_alloc(ctx, sizeof(float) * (size_t)capq * nsplit);
+    m->p_d2 = (float *)ctx_arena_alloc(ctx, sizeof(float) * (size_t)capq * nsplit);
+    m->p_i1 = (int *)ctx_arena_alloc(ctx, sizeof(int) * (size_t)capq * nsplit);
+    m->d1 = (float *)ctx_arena_alloc(ctx, sizeof(float) * capq);
+    m->d2 = (float *)ctx_arena_alloc(ctx, sizeof(float) * capq);
+    m->i1 = (int *)ctx_arena_alloc(ctx, sizeof(int) * capq);
+    m->match_flag = (int *)ctx_arena_alloc(ctx, sizeof(int) * capq);
+    m->match_pos = (int *)ctx_arena_alloc(ctx, sizeof(int) * capq);
+    m->pairs = (int32_t *)ctx_arena_alloc(ctx, sizeof(int32_t) * 2 * capq);
+    m->votes = (int32_t *)ctx_arena_alloc(ctx, sizeof(int32_t) * 4 * capq);
+    m->mcount = (int *)ctx_arena_alloc(ctx, 64);
+    m->result = (int32_t *)ctx_arena_alloc(ctx, 64);
+    if (!m->result) { vfsms_set_error("arena exhausted while carving a match job"); return VFSMS_ERR_CAPACITY; }
+    return VFSMS_OK;
+}
+
+int launch_bf_l2(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int nsplit, int dim)
+{
+    if (njobs <= 0 || capq <= 0) return VFSMS_OK;
+    if (dim == 64) {
+        hipLaunchKernelGGL(k_bf_l2_d64, dim3((capq + 511) / 512, nsplit, njobs), dim3(256), 0, ctx->stream, d_jobs);
+    } else if (dim == 128) {
+        hipLaunchKernelGGL(k_bf_l2_gen<128>, dim3((capq + 255) / 256, nsplit, njobs), dim3(256), 0, ctx->stream, d_jobs);
+    } else if (dim == 32) {
+        hipLaunchKernelGGL(k_bf_l2_gen<32>, dim3((capq + 255) / 256, nsplit, njobs), dim3(256), 0, ctx->stream, d_jobs);
+    } else {
+        vfsms_set_error("bf_l2: descriptor dim %d unsupported (64, 128, 32)", dim);
+        return VFSMS_ERR_UNSUPPORTED;
+    }
+    HIP_TRY(hipGetLastError());
+    return VFSMS_OK;
+}
+
+int launch_ratio_mode(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, double ratio, int offset_evaluate)
+{
+    if (njobs <= 0) return VFSMS_OK;
+    hipLaunchKernelGGL(k_merge_ratio, dim3((capq + 255) / 256, njobs), dim3(256), 0, ctx->stream, d_jobs, ratio, 1);
+    hipLaunchKernelGGL(k_match_scan, dim3(njobs), dim3(1024), 0, ctx->stream, d_jobs);
+    hipLaunchKernelGGL(k_mode_count, dim3((capq + 255) / 256, njobs), dim3(256), 0, ctx->stream, d_jobs);
+    hipLaunchKernelGGL(k_mode_final, dim3((njobs + 63) / 64), dim3(64), 0, ctx->stream, d_jobs, njobs, offset_evaluate);
+    HIP_TRY(hipGetLastError());
+    return VFSMS_OK;
+}
+
+int launch_ratio_only(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, double ratio)
+{
+    hipLaunchKernelGGL(k_merge_ratio, dim3((capq + 255) / 256, njobs), dim3(256), 0, ctx->stream, d_jobs, ratio, 1);
+    hipLaunchKernelGGL(k_match_scan, dim3(njobs), dim3(1024), 0, ctx->stream, d_jobs);
+    HIP_TRY(hipGetLastError());
+    return VFSMS_OK;
+}
+
+int launch_merge_only(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq)
+{
+    hipLaunchKernelGGL(k_merge_ratio, dim3((capq + 255) / 256, njobs), dim3(256), 0, ctx->stream, d_jobs, 0.0, 0);
+    HIP_TRY(hipGetLastError());
+    return VFSMS_OK;
+}
+
+int launch_mode_only(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capm, int offset_evaluate)
+{
+    if (njobs <= 0) return VFSMS_OK;
+    if (capm > 0)
+        hipLaunchKernelGGL(k_votes_from_pairs, dim3((capm + 255) / 256, njobs), dim3(256), 0, ctx->stream, d_jobs, capm);
+    hipLaunchKernelGGL(k_match_scan, dim3(njobs), dim3(1024), 0, ctx->stream, d_jobs);
+    if (capm > 0)
+        hipLaunchKernelGGL(k_mode_count, dim3((capm + 255) / 256, njobs), dim3(256), 0, ctx->stream, d_jobs);
+    hipLaunchKernelGGL(k_mode_final, dim3((njobs + 63) / 64), dim3(64), 0, ctx->stream, d_jobs, njobs, offset_evaluate);
+    HIP_TRY(hipGetLastError());
+    return VFSMS_OK;
+}
+
+int launch_bf_hamming(vfsms_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int nbytes,
+                      int *best_idx, int *best_dist)
+{
+    if (nbytes != 32) { vfsms_set_error("bf_hamming: only 32-byte descriptors supported"); return VFSMS_ERR_UNSUPPORTED; }
+    if (nq <= 0) return VFSMS_OK;
+    hipLaunchKernelGGL(k_bf_hamming32, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream,
+                       (const uint32_t *)q, nq, (const uint32_t *)t, nt, best_idx, best_dist);
+    HIP_TRY(hipGetLastError());
+    return VFSMS_OK;
+}

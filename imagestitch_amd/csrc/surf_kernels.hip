@@ -1,0 +1,734 @@
+// surf_kernels.hip -- integral image, fast-Hessian pyramid, NMS + sub-pixel interpolation, keypoint
+// ordering, orientation and descriptor kernels for gfx950 (wave64).
+//
+// What is computed follows the reference's SURF call (cv2.xfeatures2d.SURF_create().detectAndCompute,
+// ImageUtility.py:258,262; GPU twin appendix/myGpuFeatures.cpp:67-104) -- i.e. OpenCV 3.3.1 xfeatures2d
+// semantics as written down in SURVEY.md section 8a D1-D5 / Appendix A.2.  How it is computed is native:
+// every kernel is batched over an array of ROI working sets (blockIdx.z / .y = ROI), no host sync between
+// stages (grids are sized by capacity, blocks early-exit on device-side counts), all float/double
+// operation orders are explicit (built with -ffp-contract=off) so results are reproducible bit for bit.
+#include "common.h"
+#include <math.h>
+#include <float.h>
+#include <string.h>
+
+// ---------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cv_round_f(float v) { return (int)rintf(v); }      // round-half-even
+__device__ __forceinline__ int cv_round_d(double v) { return (int)rint(v); }
+__device__ __forceinline__ int cv_floor_d(double v) { return (int)floor(v); }
+__device__ __forceinline__ int cv_ceil_d(double v) { return (int)ceil(v); }
+
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int n = __shfl_up(v, d, 64);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1 integral image: u8 h x w -> i32 (h+1) x (w+1)            [HBM-bound; bytes = h*w + 4(h+1)(w+1)]
+//   pass 1: one workgroup per row, 16 px per lane, wave shuffle scan + LDS carry across the 4 waves
+//   pass 2: 64 columns x 16 row-segments per workgroup; segment sums through LDS, then in-place prefix
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_integral_rows(const RoiDev *rois)
+{
+    const RoiDev &R = rois[blockIdx.y];
+    const int y = blockIdx.x;
+    if (y > R.h) return;
+    const int sw = R.w + 1;
+    int32_t *out = R.sum + (size_t)y * sw;
+    if (y == 0) {                                   // row 0 of the integral is zero
+        for (int x = threadIdx.x; x < sw; x += 256) out[x] = 0;
+        return;
+    }
+    const uint8_t *src = R.img + (size_t)(y - 1) * R.stride;
+    __shared__ int wsum[4];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) { carry_s = 0; out[0] = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int base = 0; base < R.w; base += 256 * 16) {
+        const int x0 = base + threadIdx.x * 16;
+        int v[16];
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            int x = x0 + k;
+            int p = (x < R.w) ? (int)src[x] : 0;
+            s += p;
+            v[k] = s;
+        }
+        int incl = wave_incl_scan(s);
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        int off = carry_s + incl - s;
+        for (int k = 0; k < wid; k++) off += wsum[k];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            int x = x0 + k;
+            if (x < R.w) out[x + 1] = off + v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = off + s;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_integral_cols(const RoiDev *rois)
+{
+    const RoiDev &R = rois[blockIdx.y];
+    const int sw = R.w + 1;
+    const int x = blockIdx.x * 64 + threadIdx.x;     // column of the (h+1)x(w+1) array
+    const int seg = threadIdx.y;                      // 16 row segments
+    __shared__ int segsum[16][64];
+    const int L = (R.h + 15) / 16;
+    const int ya = 1 + seg * L;
+    const int yb = min(ya + L, R.h + 1);
+    int s = 0;
+    if (x < sw)
+        for (int y = ya; y < yb; y++) s += R.sum[(size_t)y * sw + x];
+    segsum[seg][threadIdx.x] = s;
+    __syncthreads();
+    if (x >= sw) return;
+    int acc = 0;
+    for (int k = 0; k < seg; k++) acc += segsum[k][threadIdx.x];
+    for (int y = ya; y < yb; y++) {
+        acc += R.sum[(size_t)y * sw + x];
+        R.sum[(size_t)y * sw + x] = acc;
+    }
+}
+
+int launch_integral(vfsms_ctx *ctx, const RoiDev *d_rois, int nrois, int maxh, int maxw)
+{
+    if (nrois <= 0) return VFSMS_OK;
+    hipLaunchKernelGGL(k_integral_rows, dim3(maxh + 1, nrois), dim3(256), 0, ctx->stream, d_rois);
+    hipLaunchKernelGGL(k_integral_cols, dim3((maxw + 1 + 63) / 64, nrois), dim3(64, 16), 0, ctx->stream, d_rois);
+    HIP_TRY(hipGetLastError());
+    return VFSMS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2 fast-Hessian det/trace, one launch per octave, blockIdx.z = roi * (nLayers+2) + layer
+//   calcLayerDetAndTrace: box sums are int, each multiplied by its float weight as float, accumulated
+//   in double, cast to float; det = dx*dy - 0.81f*dxy*dxy.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float haar_box(const int32_t *__restrict__ sp, int sw, const LayerPat &P, int k0, int n)
+{
+    double d = 0;
+    for (int k = k0; k < k0 + n; k++) {
+        const int dx1 = P.box[k][0], dy1 = P.box[k][1], dx2 = P.box[k][2], dy2 = P.box[k][3];
+        int v = sp[dy1 * sw + dx1] + sp[dy2 * sw + dx2] - sp[dy2 * sw + dx1] - sp[dy1 * sw + dx2];
+        d += (double)((float)v * P.w[k]);
+    }
+    return (float)d;
+}
+
+__global__ __launch_bounds__(256) void k_hessian(const RoiDev *rois, const LayerPat *pats, int layers_per_octave, int octave)
+{
+    const int roi = blockIdx.z / layers_per_octave;
+    const int l = blockIdx.z % layers_per_octave;
+    const int li = octave * layers_per_octave + l;
+    const RoiDev &R = rois[roi];
+    const LayerPat &P = pats[li];
+    const int step = P.step, size = P.size;
+    if (size > R.h || size > R.w) return;
+    const int samples_i = 1 + (R.h - size) / step;
+    const int samples_j = 1 + (R.w - size) / step;
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y * 4 + threadIdx.y;
+    if (i >= samples_i || j >= samples_j) return;
+    const int sw = R.w + 1;
+    const int lcols = R.w / step;
+    const int32_t *sp = R.sum + (size_t)(i * step) * sw + j * step;
+    float dx = haar_box(sp, sw, P, 0, 3);
+    float dy = haar_box(sp, sw, P, 3, 3);
+    float dxy = haar_box(sp, sw, P, 6, 4);
+    size_t o = (size_t)(i + P.margin) * lcols + (j + P.margin);
+    R.det[li][o] = dx * dy - 0.81f * dxy * dxy;
+    R.trace[li][o] = dx + dy;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3 3x3x3 non-maximum suppression + interpolateKeypoint (Cramer's rule in float, as
+//   Matx33f::solve(DECOMP_LU) does) + atomic append
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool interpolate_keypoint(const float N9[3][9], int dx, int dy, int ds, Cand &kpt)
+{
+    float b0 = -(N9[1][5] - N9[1][3]) / 2;
+    float b1 = -(N9[1][7] - N9[1][1]) / 2;
+    float b2 = -(N9[2][4] - N9[0][4]) / 2;
+    float a00 = N9[1][3] - 2 * N9[1][4] + N9[1][5];
+    float a01 = (N9[1][8] - N9[1][6] - N9[1][2] + N9[1][0]) / 4;
+    float a02 = (N9[2][5] - N9[2][3] - N9[0][5] + N9[0][3]) / 4;
+    float a10 = a01;
+    float a11 = N9[1][1] - 2 * N9[1][4] + N9[1][7];
+    float a12 = (N9[2][7] - N9[2][1] - N9[0][7] + N9[0][1]) / 4;
+    float a20 = a02;
+    float a21 = a12;
+    float a22 = N9[0][4] - 2 * N9[1][4] + N9[2][4];
+    float x0 = 0, x1 = 0, x2 = 0;
+    float det = a00 * (a11 * a22 - a21 * a12) - a01 * (a10 * a22 - a20 * a12) + a02 * (a10 * a21 - a20 * a11);
+    float d = det;
+    if (d != 0) {
+        d = 1 / d;
+        x0 = d * (b0 * (a11 * a22 - a12 * a21) - a01 * (b1 * a22 - a12 * b2) + a02 * (b1 * a21 - a11 * b2));
+        x1 = d * (a00 * (b1 * a22 - a12 * b2) - b0 * (a10 * a22 - a12 * a20) + a02 * (a10 * b2 - b1 * a20));
+        x2 = d * (a00 * (a11 * b2 - b1 * a21) - a01 * (a10 * b2 - b1 * a20) + b0 * (a10 * a21 - a11 * a20));
+    }
+    bool ok = (x0 != 0 || x1 != 0 || x2 != 0) && fabsf(x0) <= 1 && fabsf(x1) <= 1 && fabsf(x2) <= 1;
+    if (ok) {
+        kpt.x += x0 * dx;
+        kpt.y += x1 * dy;
+        kpt.size = (float)cv_round_f(kpt.size + x2 * ds);
+    }
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat *pats, int layers_per_octave,
+                                             int n_middle, int octave, float hessianThreshold)
+{
+    const int roi = blockIdx.z / n_middle;
+    const int l = 1 + blockIdx.z % n_middle;
+    const int li = octave * layers_per_octave + l;
+    const RoiDev &R = rois[roi];
+    const LayerPat &P = pats[li];
+    const int ss = P.step, size = P.size;
+    const int lrows = R.h / ss, lcols = R.w / ss;
+    const int margin = (pats[li + 1].size / 2) / ss + 1;
+    const int j = margin + blockIdx.x * 64 + threadIdx.x;
+    const int i = margin + blockIdx.y * 4 + threadIdx.y;
+    if (i >= lrows - margin || j >= lcols - margin) return;
+    if (pats[li + 1].size > R.h || pats[li + 1].size > R.w) return;   // upper layer not computed: nothing readable
+    const float *d2 = R.det[li] + (size_t)i * lcols + j;
+    float val0 = d2[0];
+    if (!(val0 > hessianThreshold)) return;
+    const float *d1 = R.det[li - 1] + (size_t)i * lcols + j;
+    const float *d3 = R.det[li + 1] + (size_t)i * lcols + j;
+    const int st = lcols;
+    float N9[3][9] = {
+        { d1[-st - 1], d1[-st], d1[-st + 1], d1[-1], d1[0], d1[1], d1[st - 1], d1[st], d1[st + 1] },
+        { d2[-st - 1], d2[-st], d2[-st + 1], d2[-1], d2[0], d2[1], d2[st - 1], d2[st], d2[st + 1] },
+        { d3[-st - 1], d3[-st], d3[-st + 1], d3[-1], d3[0], d3[1], d3[st - 1], d3[st], d3[st + 1] } };
+    bool is_max = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 9; b++)
+            if (!(a == 1 && b == 4)) is_max = is_max && (val0 > N9[a][b]);
+    if (!is_max) return;
+    const int sum_i = ss * (i - (size / 2) / ss);
+    const int sum_j = ss * (j - (size / 2) / ss);
+    Cand c;
+    c.y = sum_i + (size - 1) * 0.5f;
+    c.x = sum_j + (size - 1) * 0.5f;
+    c.size = (float)size;
+    c.response = val0;
+    c.octave = octave;
+    float tr = R.trace[li][(size_t)i * lcols + j];
+    c.class_id = (tr > 0) - (tr < 0);
+    c.layer = li; c.i = i; c.j = j;
+    const int ds = size - pats[li - 1].size;
+    if (!interpolate_keypoint(N9, ss, ss, ds, c)) return;
+    int pos = atomicAdd(&R.counters[0], 1);
+    if (pos < R.cap) R.cand[pos] = c;
+    else R.counters[2] = 1;                            // overflow: reported as VFSMS_ERR_CAPACITY by the host
+}
+
+// ---------------------------------------------------------------------------------------------------
+// keypoint ordering: std::sort(KeypointGreater) == rank by counting (N^2 compares through LDS tiles).
+//   order: response desc, size desc, octave desc, y asc, x asc, then (layer, i, j) asc to make it total.
+// ---------------------------------------------------------------------------------------------------
+struct SortKey { uint32_t resp; int32_t size_oct; uint32_t y, x; uint32_t lij_hi, lij_lo; };
+
+__device__ __forceinline__ SortKey make_key(const Cand &c)
+{
+    SortKey k;
+    k.resp = __float_as_uint(c.response);                 // response > threshold >= 0: bit order == value order
+    k.size_oct = ((int)c.size << 4) | c.octave;           // size is an integer-valued float (may be negative)
+    // y, x: map float to order-preserving uint
+    uint32_t yb = __float_as_uint(c.y), xb = __float_as_uint(c.x);
+    k.y = (yb & 0x80000000u) ? ~yb : (yb | 0x80000000u);
+    k.x = (xb & 0x80000000u) ? ~xb : (xb | 0x80000000u);
+    k.lij_hi = (uint32_t)c.layer;
+    k.lij_lo = ((uint32_t)c.i << 16) | (uint32_t)c.j;
+    return k;
+}
+__device__ __forceinline__ bool key_before(const SortKey &a, const SortKey &b)   // a sorts strictly before b
+{
+    if (a.resp != b.resp) return a.resp > b.resp;
+    if (a.size_oct != b.size_oct) return a.size_oct > b.size_oct;
+    if (a.y != b.y) return a.y < b.y;
+    if (a.x != b.x) return a.x < b.x;
+    if (a.lij_hi != b.lij_hi) return a.lij_hi < b.lij_hi;
+    return a.lij_lo < b.lij_lo;
+}
+
+__global__ __launch_bounds__(256) void k_rank_sort(const RoiDev *rois)
+{
+    const RoiDev &R = rois[blockIdx.y];
+    const int n = min(R.counters[0], R.cap);
+    if ((int)(blockIdx.x * 256) >= n) return;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    __shared__ SortKey tile[256];
+    Cand me;
+    SortKey mk;
+    if (idx < n) { me = R.cand[idx]; mk = make_key(me); }
+    int rank = 0;
+    for (int base = 0; base < n; base += 256) {
+        int t = base + threadIdx.x;
+        if (t < n) tile[threadIdx.x] = make_key(R.cand[t]);
+        __syncthreads();
+        int lim = min(256, n - base);
+        if (idx < n)
+            for (int k = 0; k < lim; k++) rank += key_before(tile[k], mk) ? 1 : 0;
+        __syncthreads();
+    }
+    if (idx < n) {
+        vfsms_keypoint kp;
+        kp.x = me.x; kp.y = me.y; kp.size = me.size; kp.angle = -1.f; kp.response = me.response;
+        kp.octave = me.octave; kp.class_id = me.class_id;
+        R.kps[rank] = kp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K4 orientation (SURFInvoker, upright == 0): 128 threads per keypoint
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)   // core atan_f32 polynomial, degrees
+{
+    const float s = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s;
+    const float p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// resizeHaarPattern for the 4-unit gradient wavelets + calcHaarPattern (2 boxes)
+__device__ __forceinline__ float grad_haar(const int32_t *__restrict__ ptr, int sw, int gws, bool is_dx)
+{
+    // dx_s = {{0,0,2,4,-1},{2,0,4,4,1}}, dy_s = {{0,0,4,2,1},{0,2,4,4,-1}}
+    const float ratio = (float)gws / 4;
+    const int r2 = cv_round_f(ratio * 2), r4 = cv_round_f(ratio * 4);
+    double d = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        int dx1, dy1, dx2, dy2, sgn;
+        if (is_dx) { dx1 = k ? r2 : 0; dy1 = 0; dx2 = k ? r4 : r2; dy2 = r4; sgn = k ? 1 : -1; }
+        else       { dx1 = 0; dy1 = k ? r2 : 0; dx2 = r4; dy2 = k ? r4 : r2; sgn = k ? -1 : 1; }
+        float w = sgn / ((float)(dx2 - dx1) * (dy2 - dy1));
+        int v = ptr[dy1 * sw + dx1] + ptr[dy2 * sw + dx2] - ptr[dy2 * sw + dx1] - ptr[dy1 * sw + dx2];
+        d += (double)((float)v * w);
+    }
+    return (float)d;
+}
+
+__global__ __launch_bounds__(128) void k_orientation(const RoiDev *rois, const SurfTables *T, int upright)
+{
+    const RoiDev &R = rois[blockIdx.y];
+    const int n = min(R.counters[0], R.cap);
+    const int k = blockIdx.x;
+    if (k >= n) return;
+    __shared__ float X[128], Y[128];
+    __shared__ int A[128];
+    __shared__ float mod_s[72], sx_s[72], sy_s[72];
+    vfsms_keypoint kp = R.kps[k];
+    const float s = kp.size * 1.2f / 9.0f;
+    const int gws = 2 * cv_round_f(2 * s);
+    const int srows = R.h + 1, scols = R.w + 1, sw = R.w + 1;
+    if (srows < gws || scols < gws) {                  // gradient wavelet larger than the image: delete
+        if (threadIdx.x == 0) R.kps[k].size = -1.f;
+        return;
+    }
+    if (upright) {
+        if (threadIdx.x == 0) R.kps[k].angle = 270.f;
+        return;
+    }
+    const int nori = T->nOriSamples;
+    const int t = threadIdx.x;
+    int valid = 0;
+    if (t < nori) {
+        int x = cv_round_f(kp.x + T->aptx[t] * s - (float)(gws - 1) / 2);
+        int y = cv_round_f(kp.y + T->apty[t] * s - (float)(gws - 1) / 2);
+        if (!(y < 0 || y >= srows - gws || x < 0 || x >= scols - gws)) {
+            const int32_t *ptr = R.sum + (size_t)y * sw + x;
+            float vx = grad_haar(ptr, sw, gws, true);
+            float vy = grad_haar(ptr, sw, gws, false);
+            float xx = vx * T->aptw[t], yy = vy * T->aptw[t];
+            X[t] = xx; Y[t] = yy;
+            A[t] = cv_round_f(fast_atan2_deg(yy, xx));     // cv::phase(X, Y, angle, true) then cvRound
+            valid = 1;
+        }
+    }
+    if (t < 128 && !valid) A[t] = -100000;
+    int nangle = __syncthreads_count(valid);
+    if (nangle == 0) {
+        if (threadIdx.x == 0) R.kps[k].size = -1.f;
+        return;
+    }
+    if (t < 72) {
+        const int i = t * 5;
+        float sumx = 0, sumy = 0;
+        for (int j = 0; j < nori; j++) {
+            int a = A[j];
+            if (a == -100000) continue;
+            int d = abs(a - i);
+            if (d < 30 || d > 330) { sumx += X[j]; sumy += Y[j]; }
+        }
+        mod_s[t] = sumx * sumx + sumy * sumy;
+        sx_s[t] = sumx; sy_s[t] = sumy;
+    }
+    __syncthreads();
+    if (t == 0) {
+        float bestx = 0, besty = 0, best = 0;
+        for (int i = 0; i < 72; i++)
+            if (mod_s[i] > best) { best = mod_s[i]; bestx = sx_s[i]; besty = sy_s[i]; }
+        R.kps[k].angle = fast_atan2_deg(-besty, bestx);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K5 descriptor: one 256-thread workgroup per keypoint.
+//   The rotated win_size^2 window is never materialised: each of the 21x21 INTER_AREA output pixels
+//   re-derives the bilinear samples of its own source cell in exactly the accumulation order of
+//   cv::resize's three area paths.  Row origins (start_x/start_y) are running float sums in the
+//   reference, so lane 0 produces them sequentially into LDS first.
+// ---------------------------------------------------------------------------------------------------
+struct WinGeom {
+    int win; float sin_dir, cos_dir;
+    int h, w, stride; const uint8_t *img;
+    int upright, usx, usy;            // upright: integer lattice origin (start_x, start_y)
+};
+
+__device__ __forceinline__ int win_sample(const WinGeom &G, const float *sx_row, const float *sy_row, int i, int j)
+{
+    if (G.upright) {                  // WIN[i][j] = img[clamp(start_y - j)][clamp(start_x + i)]
+        int x = min(max(G.usx + i, 0), G.w - 1);
+        int y = min(max(G.usy - j, 0), G.h - 1);
+        return (int)G.img[(size_t)y * G.stride + x];
+    }
+    // pixel_x = start_x(i) (+= cos_dir j times in double); pixel_y = start_y(i) (-= sin_dir j times)
+    double pixel_x = (double)sx_row[i] + (double)j * (double)G.cos_dir;
+    double pixel_y = (double)sy_row[i] - (double)j * (double)G.sin_dir;
+    int ix = cv_floor_d(pixel_x), iy = cv_floor_d(pixel_y);
+    const int ncols1 = G.w - 1, nrows1 = G.h - 1;
+    if ((unsigned)ix < (unsigned)ncols1 && (unsigned)iy < (unsigned)nrows1) {
+        float a = (float)(pixel_x - ix), b = (float)(pixel_y - iy);
+        const uint8_t *p = G.img + (size_t)iy * G.stride + ix;
+        float v = p[0] * (1.f - a) * (1.f - b) + p[1] * a * (1.f - b) + p[G.stride] * (1.f - a) * b + p[G.stride + 1] * a * b;
+        return (int)(uint8_t)cv_round_f(v);
+    }
+    int x = min(max(cv_round_d(pixel_x), 0), ncols1);
+    int y = min(max(cv_round_d(pixel_y), 0), nrows1);
+    return (int)G.img[(size_t)y * G.stride + x];
+}
+
+// one destination index of computeResizeAreaTab: up to (left partial, full cells [sx1,sx2), right partial)
+struct AreaSpan { int s_left; float a_left; int sx1, sx2; float a_full; int s_right; float a_right; };
+
+__device__ __forceinline__ AreaSpan area_span(int dx, int ssize, double scale)
+{
+    AreaSpan S;
+    double fsx1 = dx * scale;
+    double fsx2 = fsx1 + scale;
+    double cellWidth = fmin(scale, ssize - fsx1);
+    int sx1 = cv_ceil_d(fsx1), sx2 = cv_floor_d(fsx2);
+    sx2 = min(sx2, ssize - 1);
+    sx1 = min(sx1, sx2);
+    S.s_left = -1; S.s_right = -1; S.a_left = 0; S.a_right = 0;
+    if (sx1 - fsx1 > 1e-3) { S.s_left = sx1 - 1; S.a_left = (float)((sx1 - fsx1) / cellWidth); }
+    S.sx1 = sx1; S.sx2 = sx2; S.a_full = (float)(1.0 / cellWidth);
+    if (fsx2 - sx2 > 1e-3) { S.s_right = sx2; S.a_right = (float)(fmin(fmin(fsx2 - sx2, 1.), cellWidth) / cellWidth); }
+    return S;
+}
+
+__device__ __forceinline__ uint8_t sat_u8(float v)
+{
+    int iv = cv_round_f(v);
+    return (uint8_t)(iv < 0 ? 0 : iv > 255 ? 255 : iv);
+}
+
+__global__ __launch_bounds__(256) void k_describe(const RoiDev *rois, const SurfTables *T, int extended, int upright)
+{
+    const RoiDev &R = rois[blockIdx.y];
+    const int n = min(R.counters[0], R.cap);
+    const int k = blockIdx.x;
+    if (k >= n) return;
+    vfsms_keypoint kp = R.kps[k];
+    if (!(kp.size > 0)) return;                            // deleted by the orientation stage
+    const int dsize = extended ? 128 : 64;
+    __shared__ float sx_row[VFSMS_MAX_WIN], sy_row[VFSMS_MAX_WIN];
+    __shared__ uint8_t PATCH[21][21 + 3];
+    __shared__ float DX[20][20], DY[20][20];
+    __shared__ float vec_s[128];
+    __shared__ float scale_s;
+    const float s = kp.size * 1.2f / 9.0f;
+    WinGeom G;
+    G.win = (int)((20 + 1) * s);
+    G.h = R.h; G.w = R.w; G.stride = R.stride; G.img = R.img;
+    const int win = min(G.win, VFSMS_MAX_WIN);
+    float dir = kp.angle;
+    if (!upright) {
+        dir *= (float)(3.1415926535897932384626433832795 / 180);
+        // std::sin/std::cos on float in the reference; evaluated in double and rounded here (agrees with a
+        // correctly rounded sinf/cosf except in double-rounding corner cases)
+        G.sin_dir = -(float)sin((double)dir);
+        G.cos_dir = (float)cos((double)dir);
+        if (threadIdx.x == 0) {
+            float win_offset = -(float)(win - 1) / 2;
+            float start_x = kp.x + win_offset * G.cos_dir + win_offset * G.sin_dir;
+            float start_y = kp.y - win_offset * G.sin_dir + win_offset * G.cos_dir;
+            for (int i = 0; i < win; i++, start_x += G.sin_dir, start_y += G.cos_dir) { sx_row[i] = start_x; sy_row[i] = start_y; }
+        }
+    } else {
+        G.sin_dir = 0.f; G.cos_dir = 0.f;
+        float win_offset = -(float)(win - 1) / 2;
+        G.usx = cv_round_f(kp.x + win_offset);
+        G.usy = cv_round_f(kp.y - win_offset);
+    }
+    G.upright = upright;
+    __syncthreads();
+
+    const int dsz = 21;
+    const double inv_scale = (double)dsz / win;
+    const double scale = 1. / inv_scale;
+    const int iscale = cv_round_d(scale);
+    const bool is_area_fast = fabs(scale - iscale) < DBL_EPSILON;
+    for (int o = threadIdx.x; o < dsz * dsz; o += 256) {
+        const int dy = o / dsz, dx = o % dsz;
+        uint8_t outv;
+        if (is_area_fast && iscale == 2) {
+            int s00 = win_sample(G, sx_row, sy_row, dy * 2, dx * 2), s01 = win_sample(G, sx_row, sy_row, dy * 2, dx * 2 + 1);
+            int s10 = win_sample(G, sx_row, sy_row, dy * 2 + 1, dx * 2), s11 = win_sample(G, sx_row, sy_row, dy * 2 + 1, dx * 2 + 1);
+            outv = (uint8_t)((s00 + s01 + s10 + s11 + 2) >> 2);
+        } else if (is_area_fast) {
+            int sum = 0;
+            for (int sy = 0; sy < iscale; sy++)
+                for (int sx = 0; sx < iscale; sx++) sum += win_sample(G, sx_row, sy_row, dy * iscale + sy, dx * iscale + sx);
+            outv = sat_u8(sum * (1.f / (iscale * iscale)));
+        } else {
+            AreaSpan Sy = area_span(dy, win, scale), Sx = area_span(dx, win, scale);
+            float sum = 0; bool first = true;
+            for (int pass = 0; pass < 3; pass++) {
+                int r0 = pass == 0 ? Sy.s_left : pass == 1 ? Sy.sx1 : Sy.s_right;
+                int r1 = pass == 1 ? Sy.sx2 : r0 + 1;
+                float beta = pass == 0 ? Sy.a_left : pass == 1 ? Sy.a_full : Sy.a_right;
+                if (pass != 1 && r0 < 0) continue;
+                for (int sy = r0; sy < r1; sy++) {
+                    float buf = 0;
+                    if (Sx.s_left >= 0) buf += (float)win_sample(G, sx_row, sy_row, sy, Sx.s_left) * Sx.a_left;
+                    for (int sxx = Sx.sx1; sxx < Sx.sx2; sxx++) buf += (float)win_sample(G, sx_row, sy_row, sy, sxx) * Sx.a_full;
+                    if (Sx.s_right >= 0) buf += (float)win_sample(G, sx_row, sy_row, sy, Sx.s_right) * Sx.a_right;
+                    if (first) { sum = beta * buf; first = false; } else sum += beta * buf;
+                }
+            }
+            outv = sat_u8(sum);
+        }
+        PATCH[dy][dx] = outv;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 400; o += 256) {
+        const int i = o / 20, j = o % 20;
+        float dw = T->DW[o];
+        float vx = (float)(PATCH[i][j + 1] - PATCH[i][j] + PATCH[i + 1][j + 1] - PATCH[i + 1][j]) * dw;
+        float vy = (float)(PATCH[i + 1][j] - PATCH[i][j] + PATCH[i + 1][j + 1] - PATCH[i][j + 1]) * dw;
+        DX[i][j] = vx; DY[i][j] = vy;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int ci = threadIdx.x / 4, cj = threadIdx.x % 4;
+        if (extended) {
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int y = ci * 5; y < ci * 5 + 5; y++)
+                for (int x = cj * 5; x < cj * 5 + 5; x++) {
+                    float tx = DX[y][x], ty = DY[y][x];
+                    if (ty >= 0) { v[0] += tx; v[1] += fabsf(tx); } else { v[2] += tx; v[3] += fabsf(tx); }
+                    if (tx >= 0) { v[4] += ty; v[5] += fabsf(ty); } else { v[6] += ty; v[7] += fabsf(ty); }
+                }
+            for (int q = 0; q < 8; q++) vec_s[threadIdx.x * 8 + q] = v[q];
+        } else {
+            float v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+            for (int y = ci * 5; y < ci * 5 + 5; y++)
+                for (int x = cj * 5; x < cj * 5 + 5; x++) {
+                    float tx = DX[y][x], ty = DY[y][x];
+                    v0 += tx; v1 += ty; v2 += fabsf(tx); v3 += fabsf(ty);
+                }
+            vec_s[threadIdx.x * 4 + 0] = v0; vec_s[threadIdx.x * 4 + 1] = v1;
+            vec_s[threadIdx.x * 4 + 2] = v2; vec_s[threadIdx.x * 4 + 3] = v3;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double square_mag = 0;
+        for (int q = 0; q < dsize; q++) square_mag += (double)(vec_s[q] * vec_s[q]);
+        scale_s = (float)(1. / (sqrt(square_mag) + DBL_EPSILON));
+    }
+    __syncthreads();
+    if (threadIdx.x < dsize) R.desc_raw[(size_t)k * dsize + threadIdx.x] = vec_s[threadIdx.x] * scale_s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// deletion of size<=0 keypoints preserving order (SURF_Impl::detectAndCompute tail): single-workgroup
+// scan per ROI + scatter.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_keep_scan(const RoiDev *rois)
+{
+    const RoiDev &R = rois[blockIdx.x];
+    const int n = min(R.counters[0], R.cap);
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        int idx = base + threadIdx.x;
+        int keep = (idx < n) ? (R.kps[idx].size > 0 ? 1 : 0) : 0;
+        int incl = wave_incl_scan(keep);
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        int off = carry;
+        for (int k = 0; k < wid; k++) off += wsum[k];
+        if (idx < n) R.keep_pos[idx] = keep ? (off + incl - 1) : -1;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) R.counters[1] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_compact(const RoiDev *rois, int dsize)
+{
+    const RoiDev &R = rois[blockIdx.y];
+    const int n = min(R.counters[0], R.cap);
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);     // one wave per keypoint
+    if (k >= n) return;
+    const int pos = R.keep_pos[k];
+    if (pos < 0) return;
+    const int lane = threadIdx.x & 63;
+    for (int q = lane; q < dsize; q += 64) R.desc[(size_t)pos * dsize + q] = R.desc_raw[(size_t)k * dsize + q];
+    if (lane == 0) {
+        vfsms_keypoint kp = R.kps[k];
+        R.kps_out[pos] = kp;
+        R.kps_xy[2 * pos] = kp.x; R.kps_xy[2 * pos + 1] = kp.y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side: arena carving and launch sequences
+// ---------------------------------------------------------------------------------------------------
+static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t surf_roi_bytes(int h, int w, int cap, int nlayers_total, int noctaves, int dim)
+{
+    size_t b = al(sizeof(int32_t) * (size_t)(h + 1) * (w + 1));
+    int lpo = nlayers_total / noctaves;
+    for (int o = 0; o < noctaves; o++) {
+        size_t n = (size_t)(h >> o) * (w >> o);
+        b += 2 * lpo * al(sizeof(float) * (n ? n : 1));
+    }
+    b += al(16 * sizeof(int)) + al(sizeof(Cand) * cap) + al(sizeof(vfsms_keypoint) * cap) + al(sizeof(float) * (size_t)cap * dim);
+    b += al(sizeof(int) * cap) + al(sizeof(float) * 2 * cap) + al(sizeof(float) * (size_t)cap * dim) + al(sizeof(vfsms_keypoint) * cap);
+    return b + 4096;
+}
+
+int surf_roi_carve(vfsms_ctx *ctx, RoiDev *r, const uint8_t *img, int stride, int h, int w, int cap,
+                   const vfsms_surf_params *p)
+{
+    const int lpo = p->n_octave_layers + 2;
+    const int dim = p->extended ? 128 : 64;
+    memset(r, 0, sizeof(*r));
+    r->img = img; r->stride = stride; r->h = h; r->w = w; r->cap = cap;
+    r->sum = (int32_t *)ctx_arena_alloc(ctx, sizeof(int32_t) * (size_t)(h + 1) * (w + 1));
+    int step = 1;
+    for (int o = 0; o < p->n_octaves; o++) {
+        size_t n = (size_t)(h / step) * (w / step);
+        for (int l = 0; l < lpo; l++) {
+            r->det[o * lpo + l] = (float *)ctx_arena_alloc(ctx, sizeof(float) * (n ? n : 1));
+            r->trace[o * lpo + l] = (float *)ctx_arena_alloc(ctx, sizeof(float) * (n ? n : 1));
+        }
+        step *= 2;
+    }
+    r->counters = (int *)ctx_arena_alloc(ctx, 16 * sizeof(int));
+    r->cand = (Cand *)ctx_arena_alloc(ctx, sizeof(Cand) * cap);
+    r->kps = (vfsms_keypoint *)ctx_arena_alloc(ctx, sizeof(vfsms_keypoint) * cap);
+    r->desc_raw = (float *)ctx_arena_alloc(ctx, sizeof(float) * (size_t)cap * dim);
+    r->keep_pos = (int *)ctx_arena_alloc(ctx, sizeof(int) * cap);
+    r->kps_xy = (float *)ctx_arena_alloc(ctx, sizeof(float) * 2 * cap);
+    r->desc = (float *)ctx_arena_alloc(ctx, sizeof(float) * (size_t)cap * dim);
+    r->kps_out = (vfsms_keypoint *)ctx_arena_alloc(ctx, sizeof(vfsms_keypoint) * cap);
+    if (!r->kps_out) { vfsms_set_error("arena exhausted while carving a SURF ROI"); return VFSMS_ERR_CAPACITY; }
+    return VFSMS_OK;
+}
+
+int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_rois, int nrois,
+                       const vfsms_surf_params *p)
+{
+    if (nrois <= 0) return VFSMS_OK;
+    const int lpo = p->n_octave_layers + 2;
+    int maxh = 0, maxw = 0, maxcap = 0;
+    for (int r = 0; r < nrois; r++) {
+        maxh = h_rois[r].h > maxh ? h_rois[r].h : maxh;
+        maxw = h_rois[r].w > maxw ? h_rois[r].w : maxw;
+        maxcap = h_rois[r].cap > maxcap ? h_rois[r].cap : maxcap;
+        HIP_TRY(hipMemsetAsync(h_rois[r].counters, 0, 16 * sizeof(int), ctx->stream));
+        // layer arrays are contiguous in the arena: det[0] .. end of trace[last]
+        char *lo = (char *)h_rois[r].det[0];
+        char *hi = (char *)h_rois[r].counters;
+        HIP_TRY(hipMemsetAsync(lo, 0, (size_t)(hi - lo), ctx->stream));
+    }
+    TRY(launch_integral(ctx, d_rois, nrois, maxh, maxw));
+    int step = 1;
+    for (int o = 0; o < p->n_octaves; o++) {
+        int lrows = maxh / step, lcols = maxw / step;
+        if (lrows > 0 && lcols > 0) {
+            dim3 grid((lcols + 63) / 64, (lrows + 3) / 4, nrois * lpo);
+            hipLaunchKernelGGL(k_hessian, grid, dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo, o);
+        }
+        step *= 2;
+    }
+    step = 1;
+    for (int o = 0; o < p->n_octaves; o++) {
+        int lrows = maxh / step, lcols = maxw / step;
+        if (lrows > 0 && lcols > 0) {
+            dim3 grid((lcols + 63) / 64, (lrows + 3) / 4, nrois * p->n_octave_layers);
+            hipLaunchKernelGGL(k_nms, grid, dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo,
+                               p->n_octave_layers, o, p->hessian_threshold);
+        }
+        step *= 2;
+    }
+    hipLaunchKernelGGL(k_rank_sort, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
+    HIP_TRY(hipGetLastError());
+    return VFSMS_OK;
+}
+
+int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_rois, int nrois,
+                         const vfsms_surf_params *p)
+{
+    if (nrois <= 0) return VFSMS_OK;
+    int maxcap = 0;
+    for (int r = 0; r < nrois; r++) maxcap = h_rois[r].cap > maxcap ? h_rois[r].cap : maxcap;
+    const int dim = p->extended ? 128 : 64;
+    hipLaunchKernelGGL(k_orientation, dim3(maxcap, nrois), dim3(128), 0, ctx->stream, d_rois, ctx->d_tables, p->upright);
+    hipLaunchKernelGGL(k_describe, dim3(maxcap, nrois), dim3(256), 0, ctx->stream, d_rois, ctx->d_tables, p->extended, p->upright);
+    hipLaunchKernelGGL(k_keep_scan, dim3(nrois), dim3(1024), 0, ctx->stream, d_rois);
+    hipLaunchKernelGGL(k_compact, dim3((maxcap + 3) / 4, nrois), dim3(256), 0, ctx->stream, d_rois, dim);
+    HIP_TRY(hipGetLastError());
+    return VFSMS_OK;
+}

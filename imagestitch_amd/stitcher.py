@@ -1,0 +1,451 @@
+"""Sequence drivers, pair registration and mosaic assembly -- host-side mirror of the reference's
+`Stitcher.Stitcher` (/root/reference/Stitcher.py; every method cites the lines it mirrors).
+
+Drop-in for Main.py: same class attributes (direction, directIncre, fuseMethod, ...), same method names and
+return conventions (`(True, [dx, dy])` / `(False, "  The two images can not match")`), same log lines.
+What differs is where the work happens: registration attempts run as fused device-resident batches
+(SURF + BF-L2 + ratio + mode vote, or FP64 phase correlation) and the mosaic lives in a u8 + validity canvas
+in HBM; see imagestitch_amd/csrc.
+"""
+import copy
+import glob
+import os
+import time
+
+import numpy as np
+
+from . import utility as Utility
+from . import fusion as ImageFusion
+from .utility import roi_rect
+
+CANNOT_MATCH = "  The two images can not match"
+
+
+class ImageFeature():
+    """Stitcher.py:14-18: features of the second image of the previous pair (full-image line scans)."""
+    isBreak = True
+    kps = None
+    feature = None
+
+
+def _imread(path, color):
+    """cv2.imdecode(np.fromfile(path), IMREAD_COLOR | IMREAD_GRAYSCALE) stand-in (Stitcher.py:68-69,382-384).
+    Grayscale asks libjpeg for the luma plane directly like OpenCV does; colour is BGR."""
+    from PIL import Image
+    im = Image.open(path)
+    if not color:
+        im.draft("L", im.size)
+        return np.asarray(im.convert("L"))
+    return np.ascontiguousarray(np.asarray(im.convert("RGB"))[:, :, ::-1])
+
+
+def _imwrite(path, img):
+    from PIL import Image
+    img = np.asarray(img)
+    if img.ndim == 3:
+        img = img[:, :, ::-1]
+    d = os.path.dirname(path)
+    if d and not os.path.exists(d):
+        os.makedirs(d)
+    Image.fromarray(np.ascontiguousarray(img)).save(path)
+
+
+def _list_images(folder, extension):
+    """glob(folder/*.ext): the reference relies on Windows semantics (case-insensitive, name order)."""
+    ext = "." + extension.lower()
+    names = [n for n in os.listdir(folder) if n.lower().endswith(ext)] if os.path.isdir(folder) else []
+    return [os.path.join(folder, n) for n in sorted(names)]
+
+
+def _join(base, *parts):
+    return os.path.join(base.replace("\\", os.sep), *[str(p) for p in parts])
+
+
+class Stitcher(Utility.Method):
+    isColorMode = True
+    direction = 1               # 1: A above B; 2: A left of B; 3: A below B; 4: A right of B
+    directIncre = 1             # rotation step of the direction search: 1, 0 or -1
+    fuseMethod = "notFuse"
+    phaseResponseThreshold = 0.15
+    tempImageFeature = ImageFeature()
+
+    imageFusion = ImageFusion.ImageFusion()
+
+    # ------------------------------------------------------------------------------------------------
+    def directionIncrease(self, direction):
+        """Stitcher.py:36-47: rotate within [1, 4]."""
+        direction += self.directIncre
+        if direction == 5:
+            direction = 1
+        if direction == 0:
+            direction = 4
+        return direction
+
+    # ------------------------------------------------------------------------------------------------
+    def flowStitch(self, fileList, caculateOffsetMethod):
+        """Stitcher.py:49-94 -> ((status, endfileIndex), stitchImage)."""
+        self.printAndWrite("Stitching the directory which have " + str(fileList[0]))
+        fileNum = len(fileList)
+        offsetList = []
+        describtion = ""
+        startTime = time.time()
+        status = True
+        endfileIndex = 0
+        imageB = None
+        for fileIndex in range(0, fileNum - 1):
+            self.printAndWrite("stitching " + str(fileList[fileIndex]) + " and " + str(fileList[fileIndex + 1]))
+            imageA = imageB if imageB is not None else _imread(fileList[fileIndex], False)   # decoded once per tile
+            imageB = _imread(fileList[fileIndex + 1], False)
+            if caculateOffsetMethod == self.calculateOffsetForPhaseCorrleate:
+                (status, offset) = self.calculateOffsetForPhaseCorrleate([fileList[fileIndex], fileList[fileIndex + 1]])
+            else:
+                (status, offset) = caculateOffsetMethod([imageA, imageB])
+            if status == False:
+                describtion = "  " + str(fileList[fileIndex]) + " and " + str(fileList[fileIndex + 1]) + " can not be stitched"
+                break
+            else:
+                offsetList.append(offset)
+                endfileIndex = fileIndex + 1
+        endTime = time.time()
+        self.printAndWrite("The time of registering is " + str(endTime - startTime) + "s")
+        self.printAndWrite("start stitching")
+        startTime = time.time()
+        stitchImage = self.getStitchByOffset(fileList, offsetList)
+        endTime = time.time()
+        self.printAndWrite("The time of fusing is " + str(endTime - startTime) + "s")
+        if status == False:
+            self.printAndWrite(describtion)
+        return ((status, endfileIndex), stitchImage)
+
+    def flowStitchWithMutiple(self, fileList, caculateOffsetMethod):
+        """Stitcher.py:96-127: restart after every registration break; a trailing lone tile is its own result."""
+        result = []
+        totalNum = len(fileList)
+        startNum = 0
+        while 1:
+            (status, stitchResult) = self.flowStitch(fileList[startNum: totalNum], caculateOffsetMethod)
+            result.append(stitchResult)
+            self.tempImageFeature.isBreak = True
+            startNum = startNum + status[1] + 1
+            if startNum == totalNum:
+                break
+            if startNum == (totalNum - 1):
+                result.append(_imread(fileList[startNum], self.isColorMode))
+                break
+            self.printAndWrite("stitching Break, start from " + str(fileList[startNum]) + " again")
+        return result
+
+    def imageSetStitch(self, projectAddress, outputAddress, fileNum, caculateOffsetMethod, startNum=1, fileExtension="jpg", outputfileExtension="jpg"):
+        """Stitcher.py:129-151."""
+        for i in range(startNum, fileNum + 1):
+            fileList = _list_images(_join(projectAddress, i), fileExtension)
+            outDir = outputAddress.replace("\\", os.sep)
+            if not os.path.exists(outDir):
+                os.makedirs(outDir)
+            Stitcher.outputAddress = outputAddress
+            (status, result) = self.flowStitch(fileList, caculateOffsetMethod)
+            self.tempImageFeature.isBreak = True
+            _imwrite(os.path.join(outDir, "stitching_result_" + str(i) + "." + outputfileExtension), result)
+            if status == False:
+                self.printAndWrite("stitching Failed")
+
+    def imageSetStitchWithMutiple(self, projectAddress, outputAddress, fileNum, caculateOffsetMethod, startNum=1, fileExtension="jpg", outputfileExtension="jpg"):
+        """Stitcher.py:153-182 (the entry point Main.py:20-51 uses)."""
+        for i in range(startNum, fileNum + 1):
+            startTime = time.time()
+            fileAddress = _join(projectAddress, i)
+            fileList = _list_images(fileAddress, fileExtension)
+            outDir = outputAddress.replace("\\", os.sep)
+            if not os.path.exists(outDir):
+                os.makedirs(outDir)
+            Stitcher.outputAddress = outputAddress
+            result = self.flowStitchWithMutiple(fileList, caculateOffsetMethod)
+            self.tempImageFeature.isBreak = True
+            if len(result) == 1:
+                _imwrite(os.path.join(outDir, "stitching_result_" + str(i) + "." + outputfileExtension), result[0])
+            else:
+                for j in range(0, len(result)):
+                    _imwrite(os.path.join(outDir, "stitching_result_" + str(i) + "_" + str(j + 1) + "." + outputfileExtension), result[j])
+            endTime = time.time()
+            print("Time Consuming for " + fileAddress + " is " + str(endTime - startTime))
+
+    # ------------------------------------------------------------------------------------------------
+    def calculateOffsetForPhaseCorrleate(self, dirAddress):
+        """Stitcher.py:184-203 dereferences `self.phase`, which the reference never defines (dead code);
+        the same AttributeError is raised here.  Use calculateOffsetForPhaseCorrleateIncre."""
+        raise AttributeError("'Stitcher' object has no attribute 'phase'")
+
+    # -- device tile cache: consecutive pairs share a tile (B of pair k is A of pair k+1) ---------------
+    def _tileHandle(self, image):
+        cache = self.__dict__.setdefault("_tiles", [])
+        for ent in cache:
+            if ent[0] is image:
+                return ent[1]
+        h = self.engine.tile_upload(image)
+        cache.append((image, h))
+        while len(cache) > 4:
+            _old, oh = cache.pop(0)
+            self.engine.tile_free(oh)
+        return h
+
+    def _usesStockOperators(self):
+        c = type(self)
+        return (c.detectAndDescribe is Utility.Method.detectAndDescribe and c.matchDescriptors is Utility.Method.matchDescriptors
+                and c.getOffsetByMode is Utility.Method.getOffsetByMode and not self.isEnhance
+                and self.featureMethod == "surf" and self.offsetCaculate == "mode")
+
+    def _featureAttempt(self, imageA, imageB, direction, searchRatio):
+        """One pass of the loop body at Stitcher.py:322-345 -> (status, [dx, dy]) or None when an image has no features."""
+        if self._usesStockOperators():
+            ra = roi_rect(imageA.shape, direction, "first", searchRatio)
+            rb = roi_rect(imageB.shape, direction, "second", searchRatio)
+            if ra[2:] == rb[2:] and ra[2] > 0 and ra[3] > 0:
+                job = (self._tileHandle(imageA), self._tileHandle(imageB), ra[0], ra[1], rb[0], rb[1], ra[2], ra[3])
+                row = self.engine.attempt_surf_batch([job], self._surfParams(), self.searchRatio, self.offsetEvaluate)[0]
+                if row[4] == 0 or row[5] == 0:
+                    return None                      # featuresA is None or featuresB is None: status untouched
+                return (bool(row[0]), [int(row[1]), int(row[2])])
+        roiImageA = self.getROIRegionForIncreMethod(imageA, direction=direction, order="first", searchRatio=searchRatio)
+        roiImageB = self.getROIRegionForIncreMethod(imageB, direction=direction, order="second", searchRatio=searchRatio)
+        if self.isEnhance:
+            raise NotImplementedError("isEnhance (CLAHE / equalizeHist, Stitcher.py:327-334) is outside the hot-path scope")
+        kpsA, featuresA = self.detectAndDescribe(roiImageA, featureMethod=self.featureMethod)
+        kpsB, featuresB = self.detectAndDescribe(roiImageB, featureMethod=self.featureMethod)
+        if featuresA is not None and featuresB is not None:
+            matches = self.matchDescriptors(featuresA, featuresB)
+            if self.offsetCaculate == "mode":
+                return self.getOffsetByMode(kpsA, kpsB, matches, offsetEvaluate=self.offsetEvaluate)
+            (status, offset, _adjustH) = self.getOffsetByRansac(kpsA, kpsB, matches, offsetEvaluate=self.offsetEvaluate)
+            return (status, offset)
+        return None
+
+    def _phaseCorrelate(self, roiImageA, roiImageB):
+        """cv2.phaseCorrelate(np.float64(a), np.float64(b)) at Stitcher.py:230 -> ((x, y), response)."""
+        return self.engine.phase_correlate(roiImageA, roiImageB)
+
+    def _axisCorrection(self, offset, localDirection, i, imageA, imageB):
+        """Stitcher.py:244-251 / 353-360: put the ROI-relative vote back into full-tile coordinates."""
+        if localDirection == 1:
+            offset[0] = offset[0] + imageA.shape[0] - int(i * self.roiRatio * imageA.shape[0])
+        elif localDirection == 2:
+            offset[1] = offset[1] + imageA.shape[1] - int(i * self.roiRatio * imageA.shape[1])
+        elif localDirection == 3:
+            offset[0] = offset[0] - (imageB.shape[0] - int(i * self.roiRatio * imageB.shape[0]))
+        elif localDirection == 4:
+            offset[1] = offset[1] - (imageB.shape[1] - int(i * self.roiRatio * imageB.shape[1]))
+        return offset
+
+    def _maxI(self):
+        return int(np.floor(0.5 / self.roiRatio) + 1) + 1     # Stitcher.py:217,316
+
+    def calculateOffsetForPhaseCorrleateIncre(self, images):
+        """Stitcher.py:205-258: incremental ROI x direction rotation around FP64 phase correlation.
+        offset = [int(y), int(x)] (truncation), accepted when response > phaseResponseThreshold."""
+        (imageA, imageB) = images
+        offset = [0, 0]
+        status = False
+        iniDirection = self.direction
+        localDirection = iniDirection
+        for i in range(1, self._maxI()):
+            while True:
+                roiImageA = self.getROIRegionForIncreMethod(imageA, direction=localDirection, order="first", searchRatio=i * self.roiRatio)
+                roiImageB = self.getROIRegionForIncreMethod(imageB, direction=localDirection, order="second", searchRatio=i * self.roiRatio)
+                (offsetTemp, response) = self._phaseCorrelate(roiImageA, roiImageB)
+                offset[0] = int(offsetTemp[1])
+                offset[1] = int(offsetTemp[0])
+                if response > self.phaseResponseThreshold:
+                    status = True
+                if status == True:
+                    break
+                else:
+                    localDirection = self.directionIncrease(localDirection)
+                if localDirection == iniDirection:
+                    break
+            if status == True:
+                offset = self._axisCorrection(offset, localDirection, i, imageA, imageB)
+                self.direction = localDirection
+                break
+        if status == False:
+            return (status, CANNOT_MATCH)
+        self.printAndWrite("  The offset of stitching: dx is " + str(offset[0]) + " dy is " + str(offset[1]))
+        return (status, offset)
+
+    def calculateOffsetForFeatureSearch(self, images):
+        """Stitcher.py:260-304: whole-tile features; tile B's features are reused as tile A's of the next pair."""
+        (imageA, imageB) = images
+        offset = [0, 0]
+        status = False
+        if self.isEnhance == True:
+            raise NotImplementedError("isEnhance (CLAHE / equalizeHist, Stitcher.py:269-276) is outside the hot-path scope")
+        if self.tempImageFeature.isBreak == True:
+            (kpsA, featuresA) = self.detectAndDescribe(imageA, featureMethod=self.featureMethod)
+            (kpsB, featuresB) = self.detectAndDescribe(imageB, featureMethod=self.featureMethod)
+        else:
+            kpsA = self.tempImageFeature.kps
+            featuresA = self.tempImageFeature.feature
+            (kpsB, featuresB) = self.detectAndDescribe(imageB, featureMethod=self.featureMethod)
+        self.tempImageFeature.isBreak = False
+        self.tempImageFeature.kps = kpsB
+        self.tempImageFeature.feature = featuresB
+        if featuresA is not None and featuresB is not None:
+            matches = self.matchDescriptors(featuresA, featuresB)
+            if self.offsetCaculate == "mode":
+                (status, offset) = self.getOffsetByMode(kpsA, kpsB, matches, offsetEvaluate=self.offsetEvaluate)
+            elif self.offsetCaculate == "ransac":
+                (status, offset, adjustH) = self.getOffsetByRansac(kpsA, kpsB, matches, offsetEvaluate=self.offsetEvaluate)
+        if status == False:
+            self.tempImageFeature.isBreak = True
+            return (status, CANNOT_MATCH)
+        self.tempImageFeature.isBreak = False
+        self.printAndWrite("  The offset of stitching: dx is " + str(offset[0]) + " dy is " + str(offset[1]))
+        return (status, offset)
+
+    def calculateOffsetForFeatureSearchIncre(self, images):
+        """Stitcher.py:306-367: for i in 1..maxI-1 { rotate directions until one attempt votes >= offsetEvaluate }."""
+        (imageA, imageB) = images
+        offset = [0, 0]
+        status = False
+        iniDirection = self.direction
+        localDirection = iniDirection
+        for i in range(1, self._maxI()):
+            while True:
+                res = self._featureAttempt(imageA, imageB, localDirection, i * self.roiRatio)
+                if res is not None:
+                    (status, offset) = res
+                    offset = list(offset)
+                if status:
+                    break
+                else:
+                    localDirection = self.directionIncrease(localDirection)
+                if localDirection == iniDirection:
+                    break
+            if status:
+                offset = self._axisCorrection(offset, localDirection, i, imageA, imageB)
+                self.direction = localDirection
+                break
+        if status == False:
+            return (status, CANNOT_MATCH)
+        self.printAndWrite("  The offset of stitching: dx is " + str(offset[0]) + " dy is " + str(offset[1]))
+        return (status, offset)
+
+    # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _layout(shapes, originOffsetList):
+        """Stitcher.py:387-431: canvas-relative tile origins, running bounding boxes, canvas size.
+        originOffsetList already carries the leading [0, 0]."""
+        n = len(originOffsetList)
+        offsetList = copy.deepcopy(originOffsetList)
+        rangeX = [[0, 0] for _ in range(n)]
+        rangeY = [[0, 0] for _ in range(n)]
+        resultRow, resultCol = shapes[0][0], shapes[0][1]
+        rangeX[0][1] = resultRow
+        rangeY[0][1] = resultCol
+        dxSum = dySum = 0
+        for i in range(1, n):
+            th, tw = shapes[i][0], shapes[i][1]
+            dxSum += offsetList[i][0]
+            dySum += offsetList[i][1]
+            for (axis, total, ranges, tlen) in ((0, dxSum, rangeX, th), (1, dySum, rangeY, tw)):
+                size = resultRow if axis == 0 else resultCol
+                if total <= 0:
+                    shift = abs(total)
+                    for j in range(0, i):
+                        offsetList[j][axis] += shift
+                        ranges[j][0] += shift
+                        ranges[j][1] += shift
+                    size += shift
+                    ranges[i][1] = size
+                    ranges[i][0] = offsetList[i][axis] = 0
+                    if axis == 0:
+                        dxSum = 0
+                    else:
+                        dySum = 0
+                else:
+                    offsetList[i][axis] = total
+                    size = max(size, total + tlen)
+                    ranges[i][1] = size
+                if axis == 0:
+                    resultRow = size
+                else:
+                    resultCol = size
+        return offsetList, rangeX, rangeY, resultRow, resultCol
+
+    def getStitchByOffset(self, fileList, originOffsetList):
+        """Stitcher.py:369-486.  NB: like the reference this inserts [0, 0] at the head of the caller's list."""
+        color = self.isColorMode
+        originOffsetList.insert(0, [0, 0])
+        n = len(originOffsetList)
+        imageList = [_imread(fileList[0], color)]
+        for i in range(1, n):
+            imageList.append(_imread(fileList[i], Stitcher.isColorMode))
+        offsetList, rangeX, rangeY, resultRow, resultCol = self._layout([im.shape for im in imageList], originOffsetList)
+        self.printAndWrite("  The rectified offsetList is " + str(offsetList))
+        if self.fuseMethod not in ("notFuse", "fadeInAndFadeOut"):
+            return self._stitchWithHostFuse(fileList, imageList, originOffsetList, offsetList, rangeX, rangeY, resultRow, resultCol)
+        eng = self.engine
+        ch = 3 if color else 1
+        canvas = eng.canvas_create(resultRow, resultCol, ch)
+        try:
+            for i in range(0, n):
+                self.printAndWrite("  stitching " + str(fileList[i]))
+                tile = imageList[i]
+                oy, ox = offsetList[i][0], offsetList[i][1]
+                if i == 0 or self.fuseMethod == "notFuse":
+                    eng.canvas_paste(canvas, tile, oy, ox)
+                    continue
+                roi_ltx = max(oy, rangeX[i - 1][0]); roi_lty = max(ox, rangeY[i - 1][0])
+                roi_rbx = min(oy + tile.shape[0], rangeX[i - 1][1]); roi_rby = min(ox + tile.shape[1], rangeY[i - 1][1])
+                eng.canvas_fuse_tile(canvas, tile, oy, ox, (roi_ltx, roi_lty, roi_rbx, roi_rby),
+                                     originOffsetList[i][0], originOffsetList[i][1])
+            return eng.canvas_download(canvas, resultRow, resultCol, ch)
+        finally:
+            eng.canvas_free(canvas)
+
+    def _stitchWithHostFuse(self, fileList, imageList, originOffsetList, offsetList, rangeX, rangeY, resultRow, resultCol):
+        """average / maximum / minimum / trigonometric: outside the accelerated scope;
+        same int64 / -1 canvas walk as Stitcher.py:434-486, blend through self.fuseImage."""
+        color = self.isColorMode
+        shape = (resultRow, resultCol, 3) if color else (resultRow, resultCol)
+        stitchResult = np.zeros(shape, np.int64) - 1
+        for i in range(0, len(offsetList)):
+            self.printAndWrite("  stitching " + str(fileList[i]))
+            tile = imageList[i]
+            oy, ox = offsetList[i][0], offsetList[i][1]
+            if i == 0:
+                stitchResult[oy:oy + tile.shape[0], ox:ox + tile.shape[1]] = tile
+                continue
+            roi_ltx = max(oy, rangeX[i - 1][0]); roi_lty = max(ox, rangeY[i - 1][0])
+            roi_rbx = min(oy + tile.shape[0], rangeX[i - 1][1]); roi_rby = min(ox + tile.shape[1], rangeY[i - 1][1])
+            roiImageRegionA = stitchResult[roi_ltx:roi_rbx, roi_lty:roi_rby].copy()
+            stitchResult[oy:oy + tile.shape[0], ox:ox + tile.shape[1]] = tile
+            roiImageRegionB = stitchResult[roi_ltx:roi_rbx, roi_lty:roi_rby].copy()
+            stitchResult[roi_ltx:roi_rbx, roi_lty:roi_rby] = self.fuseImage([roiImageRegionA, roiImageRegionB],
+                                                                            originOffsetList[i][0], originOffsetList[i][1])
+        stitchResult[stitchResult == -1] = 0
+        return stitchResult.astype(np.uint8)
+
+    def fuseImage(self, images, dx, dy):
+        """Stitcher.py:488-525: dispatch on fuseMethod (int64 regions with -1 = empty)."""
+        self.imageFusion.isColorMode = self.isColorMode
+        self.imageFusion._engine = self._engine
+        (imageA, imageB) = images
+        if self.fuseMethod != "fadeInAndFadeOut" and self.fuseMethod != "trigonometric":
+            imageA[imageA == -1] = 0
+            imageB[imageB == -1] = 0
+            imageA[imageA == 0] = imageB[imageA == 0]
+            imageB[imageB == 0] = imageA[imageB == 0]
+        if self.fuseMethod == "notFuse":
+            return imageB
+        if self.fuseMethod == "average":
+            return self.imageFusion.fuseByAverage([imageA, imageB])
+        if self.fuseMethod == "maximum":
+            return self.imageFusion.fuseByMaximum([imageA, imageB])
+        if self.fuseMethod == "minimum":
+            return self.imageFusion.fuseByMinimum([imageA, imageB])
+        if self.fuseMethod == "fadeInAndFadeOut":
+            return self.imageFusion.fuseByFadeInAndFadeOut(images, dx, dy)
+        if self.fuseMethod == "trigonometric":
+            return self.imageFusion.fuseByTrigonometric(images, dx, dy)
+        if self.fuseMethod in ("multiBandBlending", "optimalSeamLine"):
+            raise NotImplementedError("fuseMethod %r is outside the VFSMS hot path (gray-only / interactive in the reference, ImageFusion.py:296-492)" % self.fuseMethod)
+        return np.zeros(imageA.shape, np.uint8)

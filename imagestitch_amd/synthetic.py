@@ -1,0 +1,113 @@
+"""Synthetic micrograph grids with exact integer ground-truth offsets (SURVEY section 8d "Synthetic inputs").
+
+The texture is a pure function of GLOBAL canvas coordinates (hashed-lattice value noise over several
+octaves), so any tile of any grid size can be produced on its own -- per rank, on the fly, without ever
+materialising the canvas (a 32x32 grid of 4096^2 tiles would be 16 GB).  Tiles follow the column-major
+serpentine shooting path of the reference's dendriticCrystal demo set (down, step right, up, ...), with a
+nominal 10 % overlap, integer jitter U{-8..8} on both axes, per-tile gain U(0.97, 1.03) and additive
+Gaussian noise sigma = 2, so overlapping pixels are similar but never identical.
+"""
+import numpy as np
+
+DEFAULT_SEED = 20190158
+
+
+def _hash_u32(ix, iy, salt):
+    """Vectorised 2-D integer hash -> uint32 (splitmix-style avalanche)."""
+    x = (ix.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ (iy.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F)) ^ np.uint64(salt)
+    x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+    x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+    x ^= x >> np.uint64(31)
+    return (x & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+
+
+def _octave(gy0, gx0, h, w, cell, salt):
+    """Smooth-interpolated lattice noise in [0, 1) over the window [gy0, gy0+h) x [gx0, gx0+w)."""
+    gy = np.arange(gy0, gy0 + h, dtype=np.int64)
+    gx = np.arange(gx0, gx0 + w, dtype=np.int64)
+    cy0, cx0 = gy[0] // cell, gx[0] // cell
+    ny, nx = int(gy[-1] // cell - cy0 + 2), int(gx[-1] // cell - cx0 + 2)
+    ly, lx = np.meshgrid(np.arange(cy0, cy0 + ny), np.arange(cx0, cx0 + nx), indexing="ij")
+    with np.errstate(over="ignore"):
+        L = _hash_u32(lx + (1 << 20), ly + (1 << 20), salt).astype(np.float32) * np.float32(1.0 / 4294967296.0)
+    iy = (gy // cell - cy0).astype(np.intp); ix = (gx // cell - cx0).astype(np.intp)
+    fy = ((gy % cell).astype(np.float32) / np.float32(cell)); fx = ((gx % cell).astype(np.float32) / np.float32(cell))
+    fy = fy * fy * (3 - 2 * fy); fx = fx * fx * (3 - 2 * fx)
+    top = L[iy][:, ix] * (1 - fx)[None, :] + L[iy][:, ix + 1] * fx[None, :]
+    bot = L[iy + 1][:, ix] * (1 - fx)[None, :] + L[iy + 1][:, ix + 1] * fx[None, :]
+    return top * (1 - fy)[:, None] + bot * fy[:, None]
+
+
+_OCTAVES = ((192, 0.9), (48, 0.8), (14, 1.0), (7, 1.1), (4, 0.9))
+
+
+def texture_window(gy0, gx0, h, w, seed=DEFAULT_SEED):
+    """float32 texture (roughly mean 0, unit variance) over a window of the infinite canvas."""
+    acc = np.zeros((h, w), np.float32)
+    tot = 0.0
+    for k, (cell, amp) in enumerate(_OCTAVES):
+        acc += np.float32(amp) * (_octave(gy0, gx0, h, w, cell, seed * 131 + k) - np.float32(0.5))
+        tot += amp * amp / 12.0
+    return acc / np.float32(np.sqrt(tot))
+
+
+class SyntheticGrid:
+    """rows x cols tiles of tile_h x tile_w on a column-major serpentine path."""
+
+    def __init__(self, rows, cols, tile_h, tile_w=None, overlap=0.10, jitter=8, seed=DEFAULT_SEED):
+        self.rows, self.cols = int(rows), int(cols)
+        self.th, self.tw = int(tile_h), int(tile_w or tile_h)
+        self.seed = int(seed)
+        rng = np.random.default_rng(self.seed)
+        step_y = self.th - int(round(overlap * self.th))
+        step_x = self.tw - int(round(overlap * self.tw))
+        jy = rng.integers(-jitter, jitter + 1, (self.rows, self.cols))
+        jx = rng.integers(-jitter, jitter + 1, (self.rows, self.cols))
+        self.path = []
+        for c in range(self.cols):
+            rr = range(self.rows) if c % 2 == 0 else range(self.rows - 1, -1, -1)
+            for r in rr:
+                self.path.append((r, c))
+        origins = np.zeros((self.rows, self.cols, 2), np.int64)
+        for r in range(self.rows):
+            for c in range(self.cols):
+                origins[r, c] = (r * step_y + jy[r, c] + 64, c * step_x + jx[r, c] + 64)
+        self.origins = origins
+        self.n_tiles = len(self.path)
+        self.n_pairs = self.n_tiles - 1
+
+    def origin(self, k):
+        r, c = self.path[k]
+        return int(self.origins[r, c, 0]), int(self.origins[r, c, 1])
+
+    def true_offsets(self):
+        """[[dx, dy]] for consecutive path tiles: row / column shift of tile k+1's origin in tile k's frame
+        (the reference's offset convention, Stitcher.py:26-27)."""
+        out = []
+        for k in range(self.n_pairs):
+            (y0, x0), (y1, x1) = self.origin(k), self.origin(k + 1)
+            out.append([y1 - y0, x1 - x0])
+        return out
+
+    def true_directions(self):
+        out = []
+        for dx, dy in self.true_offsets():
+            out.append(1 if dx > self.th // 2 else 3 if dx < -self.th // 2 else 2 if dy > 0 else 4)
+        return out
+
+    def tile(self, k):
+        """uint8 tile k of the path (mean 128, sigma ~45, per-tile gain and noise)."""
+        y0, x0 = self.origin(k)
+        t = texture_window(y0, x0, self.th, self.tw, self.seed)
+        rng = np.random.default_rng(1000 + k + self.seed % 1000)
+        gain = rng.uniform(0.97, 1.03)
+        img = 128.0 + 45.0 * gain * t + rng.normal(0.0, 2.0, t.shape).astype(np.float32)
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+    def tiles(self, ks=None, threads=8):
+        ks = list(range(self.n_tiles)) if ks is None else list(ks)
+        if threads <= 1 or len(ks) < 2:
+            return [self.tile(k) for k in ks]
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(threads) as ex:
+            return list(ex.map(self.tile, ks))

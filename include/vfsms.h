@@ -1,0 +1,163 @@
+/*
+ * vfsms.h -- C ABI of libvfsms.so, the MI355X (gfx950) engine for the VFSMS pairwise-alignment hot path.
+ *
+ * Plain C: opaque context pointer, plain pointers and sizes, int status codes.  No torch / numpy / C++
+ * types cross this boundary.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference repository Keep-Passion/ImageStitch).
+ *
+ * The reference's own FFI for this path is the Boost.Python module `myGpuFeatures`
+ * (appendix/myGpuFeatures.cpp:203-209: detectAndDescribeBySurf, detectAndDescribeByOrb, matchDescriptors),
+ * selected by Method.isGPUAvailable (ImageUtility.py:254,265,285,304); the remaining arithmetic of the path
+ * is reached through cv2 (SURF_create/detectAndCompute ImageUtility.py:258,262; DescriptorMatcher
+ * ImageUtility.py:288-299; cv2.phaseCorrelate Stitcher.py:230) and numpy (ImageFusion.py:43-244).
+ *
+ * Conventions
+ *   - return value: 0 = VFSMS_OK, negative = error (vfsms_last_error gives the message, thread-local).
+ *   - the caller owns every host buffer and pre-allocates outputs with a capacity; the library never
+ *     returns memory it owns and never frees caller memory.
+ *   - all entry points are synchronous at return (host outputs are valid) unless stated otherwise;
+ *     work is issued on the context's own HIP stream.
+ *   - one context per thread/GPU; contexts share no mutable state.
+ *   - "zero keypoints / zero matches" is NOT an error (n_out = 0).
+ */
+#ifndef VFSMS_H
+#define VFSMS_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VFSMS_OK 0
+#define VFSMS_ERR_BAD_ARG (-1)
+#define VFSMS_ERR_CAPACITY (-2)   /* an output or internal capacity was exceeded            */
+#define VFSMS_ERR_HIP (-3)        /* a HIP runtime call failed (message has hipGetErrorString) */
+#define VFSMS_ERR_FFT (-4)        /* hipFFT plan/exec failure                                  */
+#define VFSMS_ERR_NO_DEVICE (-5)
+#define VFSMS_ERR_UNSUPPORTED (-6)
+
+typedef struct vfsms_ctx vfsms_ctx;
+
+/* cv::KeyPoint fields SURF/ORB fill (the reference keeps only pt: ImageUtility.py:264) */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} vfsms_keypoint;
+
+/* SURF parameters: cv2.xfeatures2d.SURF_create() defaults at ImageUtility.py:258 are
+ * {100, 4, 3, extended 0, upright 0}; the DLL path passes Method.surf* (ImageUtility.py:23-28,272). */
+typedef struct {
+    float hessian_threshold;
+    int32_t n_octaves;
+    int32_t n_octave_layers;
+    int32_t extended;     /* 0 -> 64-d, 1 -> 128-d */
+    int32_t upright;
+} vfsms_surf_params;
+
+/* One ROI attempt of the incremental search (Stitcher.py:319-351): ROI rectangles inside two
+ * device-resident tiles, as Method.getROIRegionForIncreMethod (ImageUtility.py:66-101) slices them. */
+typedef struct {
+    int64_t tile_a, tile_b;          /* handles from vfsms_tile_upload / vfsms_tile_wrap */
+    int32_t ay0, ax0, by0, bx0;      /* top-left corner of each ROI inside its tile      */
+    int32_t h, w;                    /* common ROI size                                   */
+} vfsms_roi_pair;
+
+/* result of one feature attempt: out[8] = {status, dx, dy, votes, nA, nB, nMatches, reserved}
+ * (status, [dx,dy]) is exactly Method.getOffsetByMode's return (ImageUtility.py:139-178)
+ * BEFORE the stitch-axis correction of Stitcher.py:352-360 (that stays on the host).          */
+#define VFSMS_ATTEMPT_INTS 8
+
+/* ---- library / context -------------------------------------------------------------------------- */
+int vfsms_version(void);
+int vfsms_device_count(void);
+int vfsms_last_error(char *buf, int buflen);           /* copies the calling thread's last message */
+int vfsms_ctx_create(int device, vfsms_ctx **out);
+int vfsms_ctx_destroy(vfsms_ctx *ctx);
+int vfsms_ctx_sync(vfsms_ctx *ctx);
+/* The context's hipStream_t (as void*), so a host framework can record HIP events on it.          */
+void *vfsms_ctx_stream(vfsms_ctx *ctx);
+/* Max SURF candidates per ROI (default: h*w/24 + 4096).  0 restores the default.                  */
+int vfsms_ctx_set_keypoint_capacity(vfsms_ctx *ctx, int cap);
+
+/* ---- device-resident tiles (grayscale u8, row stride in bytes) ----------------------------------- */
+int vfsms_tile_upload(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int64_t *handle);
+/* adopt memory already on this device (e.g. a framework tensor); not freed by vfsms_tile_free     */
+int vfsms_tile_wrap(vfsms_ctx *ctx, const void *device_ptr, int h, int w, int stride, int64_t *handle);
+int vfsms_tile_free(vfsms_ctx *ctx, int64_t handle);
+
+/* ---- per-operator entry points, host buffers in / out -------------------------------------------- */
+/* cv::integral(CV_8U -> CV_32S) as SURF uses it; sum_out is (h+1) x (w+1) int32                   */
+int vfsms_integral_u8_i32(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int32_t *sum_out);
+
+/* replaces myGpuFeatures.detectAndDescribeBySurf (appendix/myGpuFeatures.cpp:67-104) and
+ * cv2 SURF detectAndCompute (ImageUtility.py:258,262).  kps_xy: float32[cap][2] = (x, y);
+ * desc: float32[cap][64|128]; kps_full optional (may be NULL).                                    */
+int vfsms_surf_detect_describe(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride,
+                               const vfsms_surf_params *params,
+                               float *kps_xy, float *desc, vfsms_keypoint *kps_full,
+                               int cap, int *n_out);
+/* detector only (sorted keypoints before orientation/deletion); for staged parity checks          */
+int vfsms_surf_detect(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride,
+                      const vfsms_surf_params *params, vfsms_keypoint *kps_full, int cap, int *n_out);
+
+/* replaces myGpuFeatures.matchDescriptors(featureType 1|2, param=ratio) (appendix/myGpuFeatures.cpp:160-173)
+ * and BFMatcher("BruteForce").knnMatch(k=2) + ratio filter (ImageUtility.py:288-296).
+ * pairs: int32[cap][2] = (trainIdx, queryIdx) in query order.                                     */
+int vfsms_bf_l2_knn2_ratio(vfsms_ctx *ctx, const float *q, int nq, const float *t, int nt, int dim,
+                           double ratio, int32_t *pairs, int cap, int *m_out);
+/* raw 2-NN (for parity checks): idx1/d1 best, d2 second-best distance (+inf if nt < 2)            */
+int vfsms_bf_l2_knn2(vfsms_ctx *ctx, const float *q, int nq, const float *t, int nt, int dim,
+                     int32_t *idx1, float *d1, float *d2);
+/* replaces matchDescriptors(featureType 3, param=orbMaxDistance) (appendix/myGpuFeatures.cpp:175-187)
+ * and BFMatcher("BruteForce-Hamming").match (ImageUtility.py:297-302).  max_dist < 0: no threshold. */
+int vfsms_bf_hamming_nn(vfsms_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int nbytes,
+                        int max_dist, int32_t *pairs, int cap, int *m_out);
+
+/* Method.getOffsetByMode (ImageUtility.py:139-178).  kps: float32[n][2]=(x,y); out4={status,dx,dy,votes} */
+int vfsms_mode_offset(vfsms_ctx *ctx, const float *kpsA, int nA, const float *kpsB, int nB,
+                      const int32_t *pairs, int m, int offset_evaluate, int32_t *out4);
+
+/* cv2.phaseCorrelate(np.float64(a), np.float64(b)) (Stitcher.py:230): out3 = {x, y, response}     */
+int vfsms_phase_correlate_u8(vfsms_ctx *ctx, const uint8_t *a, const uint8_t *b, int h, int w,
+                             int stride_a, int stride_b, double *out3);
+
+/* ImageFusion.fuseByFadeInAndFadeOut([A,B],dx,dy) (ImageFusion.py:192-244) on the reference's own
+ * representation: int64 [r][c][ch] with -1 = empty (Stitcher.py:434-436).  out: uint8 [r][c][ch].
+ * info (optional, 4 ints) = {mode 0 strip / 1 corner, corner index, rowIndex, colIndex}.           */
+int vfsms_fuse_fade_i64(vfsms_ctx *ctx, const int64_t *A, const int64_t *B, int r, int c, int ch,
+                        int dx, int dy, uint8_t *out, int32_t *info);
+
+/* The separable float32 ramps behind that blend, without blending: ramps = [wA_r(r) | wB_r(r) | wA_c(c) | wB_c(c)].
+ * force_corner != 0 -> ImageFusion.getWeightsMatrix (ImageFusion.py:43-190): weightMatB = wB_r x wB_c,
+ * weightMatA = 1 - weightMatB.  Otherwise the mode fuseByFadeInAndFadeOut itself would pick (info[0]).   */
+int vfsms_fuse_ramps_i64(vfsms_ctx *ctx, const int64_t *A, int r, int c, int ch, int dx, int dy,
+                         int force_corner, float *ramps, int32_t *info);
+
+/* ---- fused, device-resident fast path ------------------------------------------------------------- */
+/* n independent SURF + BF-L2 + ratio + mode-vote attempts in one batch (one launch sequence for all):
+ * the body of the while-loop at Stitcher.py:322-343 for n (pair, direction, i) candidates.
+ * out: int32[n][VFSMS_ATTEMPT_INTS].                                                               */
+int vfsms_attempt_surf_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n,
+                             const vfsms_surf_params *params, double ratio, int offset_evaluate,
+                             int32_t *out);
+/* same for phase correlation (Stitcher.py:224-235): out: double[n][3] = {x, y, response}           */
+int vfsms_attempt_phase_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, double *out);
+
+/* ---- device-resident mosaic canvas (Stitcher.getStitchByOffset, Stitcher.py:369-486) -------------- */
+/* u8 canvas + validity plane instead of the reference's int64 / -1 sentinel                         */
+int vfsms_canvas_create(vfsms_ctx *ctx, int rows, int cols, int ch, int64_t *handle);
+int vfsms_canvas_free(vfsms_ctx *ctx, int64_t handle);
+/* plain paste of a host tile (u8 [h][w][ch]) at (y0, x0): Stitcher.py:444-451 ("notFuse" / tile 0)  */
+int vfsms_canvas_paste(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w, int y0, int x0);
+/* paste + fade-fuse of the ROI [ry0,ry1) x [rx0,rx1) (canvas coords) exactly as Stitcher.py:457-483 +
+ * ImageFusion.py:192-244 do: A = canvas before paste, B = canvas after paste.  info as above.        */
+int vfsms_canvas_fuse_tile(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w,
+                           int y0, int x0, int ry0, int rx0, int ry1, int rx1,
+                           int dx, int dy, int32_t *info);
+/* final image: empty -> 0 (Stitcher.py:485-486).  out: u8 [rows][cols][ch]                           */
+int vfsms_canvas_download(vfsms_ctx *ctx, int64_t canvas, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFSMS_H */

@@ -52,8 +52,21 @@ def lib():
         L.orc_mode_offset.argtypes = [vp, vp, vp, i32, i32, vp]; L.orc_mode_offset.restype = None
         L.orc_phase_correlate_u8.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]; L.orc_phase_correlate_u8.restype = None
         L.orc_fuse_fade.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]; L.orc_fuse_fade.restype = None
+        L.orc_corner_ramps.argtypes = [vp, i32, i32, i32, vp, vp, vp]; L.orc_corner_ramps.restype = i32
         _lib = L
     return _lib
+
+
+def corner_ramps(A):
+    """ImageFusion.getWeightsMatrix -> (wB_r float32[r], wB_c float32[c], info)."""
+    A = np.ascontiguousarray(A, np.int64)
+    r, c = A.shape[:2]
+    ch = 1 if A.ndim == 2 else A.shape[2]
+    wr = np.ones(r, np.float32); wc = np.ones(c, np.float32)
+    info = np.zeros(4, np.int32)
+    if lib().orc_corner_ramps(_p(A), r, c, ch, _p(wr), _p(wc), _p(info)) != 0:
+        raise IndexError("reference getWeightsMatrix would raise on this input")
+    return wr, wc, info
 
 
 def _p(a):

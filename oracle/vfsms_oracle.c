@@ -975,6 +975,12 @@ static int corner_weights(const int64_t *A, int row, int col, int ch, float *wB1
     return 0;
 }
 
+/* ImageFusion.getWeightsMatrix alone: separable factors of weightMatB.  Returns 0, -1 where the reference raises. */
+int orc_corner_ramps(const int64_t *A, int r, int c, int ch, float *wB_r, float *wB_c, int32_t *info)
+{
+    return corner_weights(A, r, c, ch, wB_r, wB_c, info);
+}
+
 void orc_fuse_fade(int64_t *A, const int64_t *B, int r, int c, int ch, int dx, int dy,
                    uint8_t *out, int32_t *info)
 {

@@ -89,6 +89,9 @@ void orc_phase_correlate_u8(const uint8_t *a, const uint8_t *b, int h, int w,
 void orc_fuse_fade(int64_t *A, const int64_t *B, int r, int c, int ch, int dx, int dy,
                    uint8_t *out, int32_t *info);
 
+/* ImageFusion.getWeightsMatrix (ImageFusion.py:43-190): weightMatB = wB_r (x) wB_c, weightMatA = 1 - weightMatB. */
+int orc_corner_ramps(const int64_t *A, int r, int c, int ch, float *wB_r, float *wB_c, int32_t *info);
+
 #ifdef __cplusplus
 }
 #endif

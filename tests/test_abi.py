@@ -1,0 +1,63 @@
+"""CPU tests of the C-ABI boundary: the shared library loads without a GPU and exports exactly what
+include/vfsms.h declares; the Python binding covers every declared entry point; no compute is called."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+import imagestitch_amd as isa
+from imagestitch_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "vfsms.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vfsms_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(isa.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    lib = ctypes.CDLL(isa.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 28
+    for n in names:
+        assert hasattr(lib, n), "libvfsms.so lacks %s declared in include/vfsms.h" % n
+    out = subprocess.check_output(["nm", "-D", "--defined-only", isa.LIB_PATH]).decode()
+    exported = sorted(set(re.findall(r" T (vfsms_[a-z0-9_]+)", out)))
+    assert exported == names, "exported symbols and header declarations differ"
+
+
+def test_python_binding_covers_the_header():
+    assert sorted(_lib.exported_names()) == _declared()
+    lib = isa.load_library()
+    assert lib.vfsms_version() >= 100
+    buf = ctypes.create_string_buffer(64)
+    assert lib.vfsms_last_error(buf, 64) == 0
+
+
+def test_no_cpu_fallback_without_a_device():
+    """Without a visible GPU the product refuses to run: there is no silent CPU path."""
+    lib = isa.load_library()
+    if lib.vfsms_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(isa.VfsmsError):
+        isa.Engine(0)
+    m = isa.Method()
+    import numpy as np
+    with pytest.raises(isa.VfsmsError):
+        m.detectAndDescribe(np.zeros((64, 64), np.uint8), "surf")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "imagestitch_amd")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in src and "from oracle" not in src and "vfsms_oracle" not in src, f

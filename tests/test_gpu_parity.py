@@ -1,0 +1,178 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (imagestitch_amd._lib.Engine ->
+libvfsms.so), against the CPU oracle on the same seeded inputs and against the committed golden fixtures.
+
+Bars: bit-exact for integer / index work (integral, keypoint set, match lists, votes, fuse bytes, offsets of
+phase correlation); float32 descriptors within 2e-5 absolute (unit-norm vectors; the only non-replicated
+operation is sin/cos of the orientation); SURF offsets within +-1 px of Stitcher.py:87."""
+import os
+
+import numpy as np
+import pytest
+
+import imagestitch_amd as isa
+from imagestitch_amd.synthetic import SyntheticGrid
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_img(seed, shape):
+    return np.random.default_rng(seed).integers(0, 256, shape, dtype=np.uint8)
+
+
+def _kp_fields(k):
+    return np.stack([k["x"], k["y"], k["size"], k["response"], k["octave"].astype(np.float32), k["class_id"].astype(np.float32)], 1)
+
+
+@pytest.fixture(scope="module")
+def strips():
+    g = SyntheticGrid(2, 2, 640)
+    t = g.tiles(threads=1)
+    return g, t
+
+
+def test_integral_bit_exact(engine, oracle):
+    for seed, shape in enumerate([(1, 1), (3, 5), (17, 300), (409, 2048), (300, 4200)]):
+        img = _rand_img(seed, shape)
+        assert np.array_equal(engine.integral(img), oracle.integral(img)), shape
+    tile = _rand_img(9, (200, 333))
+    view = tile[:, 333 - 66:]                                  # direction-2 ROI: non-contiguous view
+    assert np.array_equal(engine.integral(view), oracle.integral(view))
+
+
+def test_surf_keypoints_bit_exact(engine, oracle, strips):
+    g, tiles = strips
+    for img in (tiles[0][-128:, :], tiles[1][:, :128], _rand_img(4, (90, 150))):
+        a = engine.surf_detect(img)
+        b = oracle.surf_detect(np.ascontiguousarray(img))
+        assert len(a) == len(b) and len(a) > 50
+        assert np.array_equal(_kp_fields(a), _kp_fields(b))
+
+
+def test_surf_describe_matches_oracle(engine, oracle, strips):
+    g, tiles = strips
+    for extended in (False, True):
+        img = np.ascontiguousarray(tiles[0][-128:, :])
+        p = engine.surf_params(extended=extended)
+        kxy, desc, kfull = engine.surf_detect_describe(img, p, full=True)
+        ko, do = oracle.surf_detect_describe(img, extended=extended)
+        assert len(kfull) == len(ko) and desc.shape == do.shape
+        assert np.array_equal(_kp_fields(kfull), _kp_fields(ko))
+        assert np.array_equal(kfull["angle"], ko["angle"])             # orientation is fully replicated arithmetic
+        assert np.array_equal(kxy, np.stack([ko["x"], ko["y"]], 1))
+        err = np.abs(desc - do).max(1)
+        assert err.max() < 2e-5, err.max()
+        assert (err == 0).mean() > 0.95                                # overwhelmingly bit-identical
+
+
+def test_surf_edge_cases(engine, oracle):
+    flat = np.full((64, 200), 90, np.uint8)
+    kxy, desc = engine.surf_detect_describe(flat)
+    assert len(kxy) == 0 and desc.shape == (0, 64)
+    tiny = _rand_img(2, (8, 8))                                        # smaller than the first Haar wavelet
+    assert len(engine.surf_detect_describe(tiny)[0]) == 0
+    thin = _rand_img(3, (40, 700))                                     # only octave 0 fits
+    a = engine.surf_detect_describe(thin, full=True)[2]; b = oracle.surf_detect_describe(thin)[0]
+    assert np.array_equal(_kp_fields(a), _kp_fields(b))
+    engine.set_keypoint_capacity(16)
+    with pytest.raises(isa.VfsmsError):
+        engine.surf_detect_describe(_rand_img(5, (128, 128)))
+    engine.set_keypoint_capacity(0)
+
+
+def test_bf_l2_bit_exact(engine, oracle):
+    rng = np.random.default_rng(11)
+    for nq, nt, dim in [(1, 1, 64), (5, 2, 64), (300, 700, 64), (1500, 1300, 64), (200, 333, 128)]:
+        q = rng.normal(size=(nq, dim)).astype(np.float32); t = rng.normal(size=(nt, dim)).astype(np.float32)
+        q /= np.linalg.norm(q, axis=1, keepdims=True); t /= np.linalg.norm(t, axis=1, keepdims=True)
+        if nt > 20:
+            t[17] = t[4]; q[0] = t[4]                                  # duplicates: ties -> lower train index
+        i1, d1, d2 = engine.bf_l2_knn2(q, t)
+        oi1, od1, _oi2, od2 = oracle.bf_l2_knn2(q, t)
+        assert np.array_equal(i1, oi1) and np.array_equal(d1, od1) and np.array_equal(d2, od2), (nq, nt, dim)
+        assert np.array_equal(engine.bf_l2_ratio_matches(q, t, 0.75), oracle.bf_l2_ratio_matches(q, t, 0.75))
+    assert engine.bf_l2_ratio_matches(np.zeros((0, 64), np.float32), np.zeros((4, 64), np.float32)).shape == (0, 2)
+
+
+def test_mode_vote_golden(engine, golden_dir):
+    g = np.load(os.path.join(golden_dir, "mode_cases.npz"))
+    for i, (ev, st, dx, dy) in enumerate(g["expected"]):
+        s, off, _v = engine.mode_offset(g["c%d_kpsA" % i], g["c%d_kpsB" % i], g["c%d_pairs" % i], ev)
+        assert (int(s), off[0], off[1]) == (st, dx, dy), i
+
+
+def test_phase_correlation_offsets_bit_exact(engine, oracle, strips):
+    g, tiles = strips
+    cases = [(tiles[0][-128:, :], tiles[1][:128, :]), (tiles[0][:, -128:], tiles[2][:, :128]),
+             (_rand_img(1, (97, 131)), _rand_img(2, (97, 131))), (_rand_img(3, (625, 64)), _rand_img(4, (625, 64)))]
+    a = _rand_img(7, (80, 96)); cases.append((a, np.roll(np.roll(a, 7, 0), -5, 1)))
+    for a, b in cases:
+        (x, y), r = engine.phase_correlate(a, b)
+        (ox, oy), orr = oracle.phase_correlate(np.ascontiguousarray(a), np.ascontiguousarray(b))
+        assert [int(y), int(x)] == [int(oy), int(ox)], (a.shape, (x, y), (ox, oy))      # what Stitcher.py:231-232 keeps
+        assert abs(x - ox) < 1e-6 and abs(y - oy) < 1e-6 and abs(r - orr) < 1e-9
+
+
+def test_fuse_fade_golden_bit_exact(engine, golden_dir):
+    g = np.load(os.path.join(golden_dir, "fuse_cases.npz"))
+    for i, (dx, dy, _c) in enumerate(g["meta"]):
+        out = engine.fuse_fade_i64(g["f%d_A" % i], g["f%d_B" % i], dx, dy)
+        assert np.array_equal(out, g["f%d_out" % i]), i
+
+
+def test_get_stitch_by_offset_golden_bit_exact(engine, golden_dir, tmp_path):
+    """device canvas (u8 + validity) vs the reference's int64/-1 canvas walk, all fuse modes, gray + colour"""
+    from test_host_logic import FUSE_NAMES, _write_tiles
+    g = np.load(os.path.join(golden_dir, "stitch_cases.npz"))
+    for n, (color, fm, _) in enumerate(g["meta"]):
+        files = _write_tiles(tmp_path, list(g["s%d_tiles" % n]), "g%d" % n)
+        s = isa.Stitcher(); s._engine = engine; s.isPrintLog = False
+        s.isColorMode = bool(color); isa.Stitcher.isColorMode = bool(color)
+        s.fuseMethod = FUSE_NAMES[fm]
+        res = s.getStitchByOffset(files, [list(map(int, o)) for o in g["s%d_offsets" % n]])
+        assert np.array_equal(res, g["s%d_out" % n]), (n, FUSE_NAMES[fm], color)
+    isa.Stitcher.isColorMode = True
+
+
+def test_fused_attempt_equals_operator_chain_and_oracle(engine, oracle, strips):
+    g, tiles = strips
+    offs, dirs = g.true_offsets(), g.true_directions()
+    for k in range(g.n_pairs):
+        A, B, d = tiles[k], tiles[k + 1], dirs[k]
+        ra = isa.roi_rect(A.shape, d, "first", 0.2); rb = isa.roi_rect(B.shape, d, "second", 0.2)
+        ha, hb = engine.tile_upload(A), engine.tile_upload(B)
+        row = engine.attempt_surf_batch([(ha, hb, ra[0], ra[1], rb[0], rb[1], ra[2], ra[3])])[0]
+        engine.tile_free(ha); engine.tile_free(hb)
+        roiA = np.ascontiguousarray(A[ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]])
+        roiB = np.ascontiguousarray(B[rb[0]:rb[0] + rb[2], rb[1]:rb[1] + rb[3]])
+        ka, da = oracle.surf_detect_describe(roiA); kb, db = oracle.surf_detect_describe(roiB)
+        pairs = oracle.bf_l2_ratio_matches(da, db, 0.75)
+        st, off, votes = oracle.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, 3)
+        assert list(row[:7]) == [int(st), off[0], off[1], votes, len(ka), len(kb), len(pairs)], (k, row)
+
+
+def test_stitcher_on_real_strips_within_one_pixel(engine, golden_dir):
+    """Stitcher.py:87 is the reference's own ground truth; ROI strips of the real dendriticCrystal tiles."""
+    g = np.load(os.path.join(golden_dir, "real_strips.npz"))
+    for n, (a, b, direction, H, W, gdx, gdy) in enumerate(g["meta"]):
+        ra, rb = g["r%d_roiA" % n], g["r%d_roiB" % n]
+        ha, hb = engine.tile_upload(ra), engine.tile_upload(rb)
+        row = engine.attempt_surf_batch([(ha, hb, 0, 0, 0, 0, ra.shape[0], ra.shape[1])])[0]
+        engine.tile_free(ha); engine.tile_free(hb)
+        off = [int(row[1]), int(row[2])]
+        if direction == 1: off[0] += H - int(0.2 * H)
+        if direction == 3: off[0] -= H - int(0.2 * H)
+        if direction == 2: off[1] += W - int(0.2 * W)
+        assert row[0] == 1 and abs(off[0] - gdx) <= 1 and abs(off[1] - gdy) <= 1, (a, b, off)
+
+
+def test_incremental_search_end_to_end_on_synthetic_grid(engine):
+    """calculateOffsetForFeatureSearchIncre with the direction rotation across a serpentine turn: offsets
+    within +-1 px of the exact ground truth, and the phase path bit-exact vs truth on its own quirk-free case."""
+    g = SyntheticGrid(2, 2, 640)
+    tiles = g.tiles(threads=1)
+    s = isa.Stitcher(); s._engine = engine; s.isPrintLog = False
+    s.roiRatio = 0.2; s.direction = 1; s.directIncre = 1; s.featureMethod = "surf"
+    for k, truth in enumerate(g.true_offsets()):
+        status, off = s.calculateOffsetForFeatureSearchIncre([tiles[k], tiles[k + 1]])
+        assert status and abs(off[0] - truth[0]) <= 1 and abs(off[1] - truth[1]) <= 1, (k, off, truth)
+    assert s.direction == g.true_directions()[-1]

@@ -1,0 +1,197 @@
+"""CPU tests of the host-side mirror (imagestitch_amd.{utility,stitcher,fusion}) against golden vectors
+captured from the reference's own Python (tools/capture_golden.py).  Operators are scripted fakes or the
+oracle-backed engine of tests/fakes.py: this file checks control flow, ROI / layout arithmetic, dispatch and
+return conventions, not kernels."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import imagestitch_amd as isa
+from imagestitch_amd import stitcher as st_mod
+from fakes import OracleEngine
+
+
+def test_roi_rect_matches_reference(golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "roi_cases.json")))
+    m = isa.Method()
+    for c in cases:
+        y0, x0, h, w = isa.roi_rect(c["shape"], c["direction"], c["order"], c["ratio"])
+        assert [h, w] == c["out_shape"] and (y0, x0) == (c["row0"], c["col0"]), c
+    img = np.arange(97 * 131, dtype=np.uint32).astype(np.uint8).reshape(97, 131)
+    v = m.getROIRegionForIncreMethod(img, direction=2, order="first", searchRatio=0.2)
+    assert np.shares_memory(v, img) and v.shape == (97, 26) and v[0, 0] == img[0, 131 - 26]
+
+
+class Scripted(isa.Stitcher):
+    """operators replaced by scripted fakes, exactly like the capture harness did to the reference"""
+
+    def __init__(self, success_at, raw):
+        self.trace, self.pending = [], []
+        self.success_at, self.raw = success_at, raw
+
+    def detectAndDescribe(self, image, featureMethod):
+        self.pending.append(list(image.shape))
+        return (np.zeros((1, 2), np.float32), np.zeros((1, 64), np.float32))
+
+    def matchDescriptors(self, fa, fb):
+        return [(0, 0)]
+
+    def getOffsetByMode(self, kpsA, kpsB, matches, offsetEvaluate=10):
+        self.trace.append(self.pending[-2:])
+        return (len(self.trace) == self.success_at, list(self.raw))
+
+
+class ScriptedPhase(isa.Stitcher):
+    def __init__(self, success_at, value):
+        self.calls, self.success_at, self.value = [], success_at, value
+
+    def _phaseCorrelate(self, a, b):
+        self.calls.append([list(a.shape), list(b.shape)])
+        return self.value, (0.5 if len(self.calls) == self.success_at else 0.1)
+
+
+def test_incremental_state_machines_match_reference(golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "state_machine.json")))
+    assert len(cases) > 1000
+    imgs = {}
+    for c in cases:
+        shape = tuple(c["shape"])
+        if shape not in imgs:
+            imgs[shape] = (np.zeros(shape, np.uint8), np.zeros(shape, np.uint8))
+        A, B = imgs[shape]
+        if c["kind"] == "feature":
+            s = Scripted(c["success_at"], c["raw"])
+        else:
+            s = ScriptedPhase(c["success_at"], tuple(c["raw"]))
+        s.isPrintLog = False
+        s.roiRatio, s.direction, s.directIncre = c["roiRatio"], c["ini"], c["incre"]
+        if c["kind"] == "feature":
+            status, off = s.calculateOffsetForFeatureSearchIncre([A, B])
+            trace = s.trace
+        else:
+            status, off = s.calculateOffsetForPhaseCorrleateIncre([A, B])
+            trace = s.calls
+        assert status == c["status"], c
+        assert (list(off) if status else off) == c["offset"], c
+        assert trace == c["trace"], c
+        assert s.direction == c["final_direction"], c
+
+
+def test_feature_search_cache_matches_reference(golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "feature_search_cache.json")))
+
+    class S(isa.Stitcher):
+        def __init__(self, script):
+            self.script, self.described, self.k = list(script), [], 0
+
+        def detectAndDescribe(self, image, featureMethod):
+            self.described.append(int(image[0, 0]))
+            return (np.full((1, 2), image[0, 0], np.float32), np.full((1, 64), image[0, 0], np.float32))
+
+        def matchDescriptors(self, fa, fb):
+            self.matched = (int(fa[0, 0]), int(fb[0, 0]))
+            return [(0, 0)]
+
+        def getOffsetByMode(self, kpsA, kpsB, matches, offsetEvaluate=10):
+            ok = self.script[self.k]; self.k += 1
+            return (ok, [5, -6])
+    for case in cases:
+        isa.Stitcher.tempImageFeature.isBreak = True
+        s = S(case["script"]); s.isPrintLog = False
+        for k, step in enumerate(case["steps"]):
+            A = np.full((8, 8), 10 + k, np.uint8); B = np.full((8, 8), 11 + k, np.uint8)
+            n0 = len(s.described)
+            status, off = s.calculateOffsetForFeatureSearch([A, B])
+            assert s.described[n0:] == step["described"] and list(s.matched) == step["matched"]
+            assert status == step["status"] and (list(off) if status else off) == step["offset"]
+            assert bool(s.tempImageFeature.isBreak) == step["isBreak"]
+    isa.Stitcher.tempImageFeature.isBreak = True
+
+
+FUSE_NAMES = ["notFuse", "average", "maximum", "minimum", "fadeInAndFadeOut", "trigonometric"]
+
+
+def _write_tiles(tmp_path, tiles, tag):
+    from PIL import Image
+    files = []
+    for k, t in enumerate(tiles):
+        p = os.path.join(str(tmp_path), "%s_%d.png" % (tag, k))
+        Image.fromarray(t[:, :, ::-1] if t.ndim == 3 else t).save(p)
+        files.append(p)
+    return files
+
+
+def test_get_stitch_by_offset_matches_reference(golden_dir, oracle, tmp_path):
+    g = np.load(os.path.join(golden_dir, "stitch_cases.npz"))
+    eng = OracleEngine(oracle)
+    for n, (color, fm, _) in enumerate(g["meta"]):
+        tiles = list(g["s%d_tiles" % n])
+        files = _write_tiles(tmp_path, tiles, "s%d" % n)
+        s = isa.Stitcher()
+        s._engine = eng
+        msgs = []
+        s.printAndWrite = lambda c, msgs=msgs: msgs.append(c)
+        s.isColorMode = bool(color)
+        isa.Stitcher.isColorMode = bool(color)
+        s.fuseMethod = FUSE_NAMES[fm]
+        offs = [list(map(int, o)) for o in g["s%d_offsets" % n]]
+        res = s.getStitchByOffset(files, offs)
+        assert offs[0] == [0, 0] and len(offs) == len(tiles)         # the caller's list is mutated, as in the reference
+        rect = [m for m in msgs if "rectified" in m][0]
+        assert rect == "  The rectified offsetList is " + str([list(map(int, r)) for r in g["s%d_rect" % n]])
+        assert res.shape == g["s%d_out" % n].shape, (n, FUSE_NAMES[fm])
+        assert np.array_equal(res, g["s%d_out" % n]), (n, FUSE_NAMES[fm], color)
+    isa.Stitcher.isColorMode = True
+
+
+def test_flow_stitch_with_multiple_matches_reference(golden_dir, oracle, tmp_path):
+    meta = json.load(open(os.path.join(golden_dir, "flow_cases.json")))
+    g = np.load(os.path.join(golden_dir, "flow_cases.npz"))
+    eng = OracleEngine(oracle)
+    for n, case in enumerate(meta):
+        script = case["script"]
+        tiles = [np.full((20, 24), 10 * (k + 1), np.uint8) for k in range(len(script) + 1)]
+        files = _write_tiles(tmp_path, tiles, "w%d" % n)
+        s = isa.Stitcher(); s._engine = eng
+        msgs = []
+        s.printAndWrite = lambda c, msgs=msgs: msgs.append(c)
+        s.isColorMode = False; isa.Stitcher.isColorMode = False
+        s.fuseMethod = "notFuse"
+
+        def method(images, script=script):
+            a = int(images[0][0, 0]) // 10 - 1
+            return (True, [15, 3]) if script[a] else (False, st_mod.CANNOT_MATCH)
+        res = s.flowStitchWithMutiple(files, method)
+        assert len(res) == case["nres"]
+        for k, r in enumerate(res):
+            assert np.array_equal(r, g["w%d_res%d" % (n, k)]), (n, k)
+        assert len([m for m in msgs if "stitching Break" in m or "can not be stitched" in m]) == case["breaks"]
+    isa.Stitcher.isColorMode = True
+
+
+def test_fusion_dispatch_and_inplace_fill(golden_dir, oracle):
+    """ImageFusion.fuseByFadeInAndFadeOut fills A's holes from B in place (ImageFusion.py:240) and fuseImage
+    pre-processes the non-fade modes (Stitcher.py:498-504)."""
+    f = isa.ImageFusion(); f._engine = OracleEngine(oracle)
+    A = np.array([[-1, 10, 20, 30]] * 6, np.int64); B = np.full((6, 4), 200, np.int64)
+    out = f.fuseByFadeInAndFadeOut([A, B], 1, 1)
+    assert A[0, 0] == 200 and out.dtype == np.uint8 and out.shape == (6, 4)
+    s = isa.Stitcher(); s._engine = f._engine; s.isColorMode = False
+    s.fuseMethod = "maximum"
+    A = np.array([[-1, 0, 7]], np.int64); B = np.array([[5, 6, 0]], np.int64)
+    assert s.fuseImage([A, B], 0, 0).tolist() == [[5, 6, 7]]
+    s.fuseMethod = "optimalSeamLine"
+    with pytest.raises(NotImplementedError):
+        s.fuseImage([A, B], 0, 0)
+
+
+def test_dead_reference_paths_behave_like_the_reference():
+    s = isa.Stitcher()
+    with pytest.raises(AttributeError):
+        s.calculateOffsetForPhaseCorrleate(["a", "b"])     # Stitcher.py:195 dereferences the undefined self.phase
+    assert s.directionIncrease(4) == 1
+    s.directIncre = -1
+    assert s.directionIncrease(1) == 4
+    assert s.getOffsetByMode([], [], []) == (False, [0, 0])
