@@ -43,6 +43,8 @@ _SIGNATURES = {
     "vfsms_ctx_sync": (C.c_int, [C.c_void_p]),
     "vfsms_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "vfsms_ctx_set_keypoint_capacity": (C.c_int, [C.c_void_p, C.c_int]),
+    "vfsms_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "vfsms_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "vfsms_tile_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "vfsms_tile_wrap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "vfsms_tile_free": (C.c_int, [C.c_void_p, C.c_int64]),
@@ -152,6 +154,18 @@ class Engine:
 
     def set_keypoint_capacity(self, cap):
         self._check(self.lib.vfsms_ctx_set_keypoint_capacity(self.ctx, int(cap)))
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.vfsms_profile_enable(self.ctx, int(bool(on))))
+
+    def profile_read(self, reset=True):
+        """-> {stage: (total_ms, launch_groups)} measured with HIP events on the engine's stream."""
+        names = C.create_string_buffer(4096)
+        ms = np.zeros(64, np.float64); calls = np.zeros(64, np.int64)
+        n = C.c_int()
+        self._check(self.lib.vfsms_profile_read(self.ctx, names, 4096, _ptr(ms), _ptr(calls), 64, C.byref(n), int(bool(reset))))
+        keys = names.value.decode().split(",") if n.value else []
+        return {k: (float(ms[i]), int(calls[i])) for i, k in enumerate(keys)}
 
     # -- tiles ---------------------------------------------------------------------------------------------
     def tile_upload(self, img):

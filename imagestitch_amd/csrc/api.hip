@@ -56,6 +56,64 @@ void *ctx_arena_alloc(vfsms_ctx *ctx, size_t bytes, size_t align)
     return ctx->arena + off;
 }
 
+// ---- per-stage profiling with HIP events on the context stream --------------------------------------------
+int prof_begin(vfsms_ctx *ctx, const char *name)
+{
+    if (!ctx->prof_on) return -1;
+    int id = -1;
+    for (size_t k = 0; k < ctx->prof_names.size(); k++) if (ctx->prof_names[k] == name) { id = (int)k; break; }
+    if (id < 0) { id = (int)ctx->prof_names.size(); ctx->prof_names.push_back(name); ctx->prof_ms.push_back(0.0); ctx->prof_calls.push_back(0); }
+    ProfRec r; r.id = id;
+    for (hipEvent_t *e : {&r.a, &r.b}) {
+        if (!ctx->prof_pool.empty()) { *e = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); }
+        else if (hipEventCreate(e) != hipSuccess) return -1;
+    }
+    if (hipEventRecord(r.a, ctx->stream) != hipSuccess) return -1;
+    ctx->prof_recs.push_back(r);
+    return (int)ctx->prof_recs.size() - 1;
+}
+void prof_end(vfsms_ctx *ctx, int rec)
+{
+    if (rec < 0 || rec >= (int)ctx->prof_recs.size()) return;
+    (void)hipEventRecord(ctx->prof_recs[rec].b, ctx->stream);
+}
+static int prof_collect(vfsms_ctx *ctx)
+{
+    if (ctx->prof_recs.empty()) return VFSMS_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (auto &r : ctx->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { ctx->prof_ms[r.id] += ms; ctx->prof_calls[r.id] += 1; }
+        ctx->prof_pool.push_back(r.a); ctx->prof_pool.push_back(r.b);
+    }
+    ctx->prof_recs.clear();
+    return VFSMS_OK;
+}
+extern "C" int vfsms_profile_enable(vfsms_ctx *ctx, int on)
+{
+    if (!ctx) return VFSMS_ERR_BAD_ARG;
+    TRY(prof_collect(ctx));
+    ctx->prof_on = on != 0;
+    return VFSMS_OK;
+}
+extern "C" int vfsms_profile_read(vfsms_ctx *ctx, char *names, int names_len, double *ms, int64_t *calls, int cap, int *n_out, int reset)
+{
+    if (!ctx || !n_out) return VFSMS_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    TRY(prof_collect(ctx));
+    const int n = (int)ctx->prof_names.size();
+    *n_out = n;
+    std::string joined;
+    for (int k = 0; k < n; k++) {
+        if (k) joined += ",";
+        joined += ctx->prof_names[k];
+        if (k < cap) { if (ms) ms[k] = ctx->prof_ms[k]; if (calls) calls[k] = ctx->prof_calls[k]; }
+    }
+    if (names && names_len > 0) snprintf(names, (size_t)names_len, "%s", joined.c_str());
+    if (reset) for (int k = 0; k < n; k++) { ctx->prof_ms[k] = 0; ctx->prof_calls[k] = 0; }
+    return VFSMS_OK;
+}
+
 // ---- SURF tables (resizeHaarPattern for every layer; SURFInvoker constructor tables) -------------------
 static void gaussian_kernel_f32(int n, double sigma, float *cf)   // cv::getGaussianKernel(n, sigma, CV_32F)
 {
@@ -146,6 +204,7 @@ extern "C" int vfsms_ctx_create(int device, vfsms_ctx **out)
     c->device = device; c->arena = nullptr; c->arena_size = 0; c->arena_off = 0;
     c->pinned = nullptr; c->pinned_size = 0; c->kp_cap_override = 0;
     c->tables_valid = false; c->d_layers = nullptr; c->d_tables = nullptr; c->n_layers = 0; c->next_handle = 1;
+    c->prof_on = false;
     memset(&c->cur_params, 0, sizeof(c->cur_params));
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { vfsms_set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete c; return VFSMS_ERR_HIP; }
@@ -161,6 +220,8 @@ extern "C" int vfsms_ctx_destroy(vfsms_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     phase_destroy_plans(ctx);
+    prof_collect(ctx);
+    for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
     for (auto &kv : ctx->tiles) if (kv.second.owned) hipFree(kv.second.ptr);
     for (auto &kv : ctx->canvases) { hipFree(kv.second.pix); hipFree(kv.second.mask); }
     if (ctx->arena) hipFree(ctx->arena);

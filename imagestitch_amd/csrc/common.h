@@ -87,6 +87,7 @@ struct MatchDev {
 struct TileRec { uint8_t *ptr; int h, w, stride; bool owned; };
 struct CanvasRec { uint8_t *pix; uint8_t *mask; int rows, cols, ch; };
 struct FftPlan { int M, N; void *fwd; void *inv; };   // hipfftHandle stored as void* (int in practice)
+struct ProfRec { int id; hipEvent_t a, b; };
 
 struct vfsms_ctx {
     int device;
@@ -104,6 +105,21 @@ struct vfsms_ctx {
     std::unordered_map<int64_t, CanvasRec> canvases;
     int64_t next_handle;
     std::vector<FftPlan> plans;
+    // optional per-stage timing with HIP events on this context's stream (vfsms_profile_*)
+    bool prof_on;
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    std::vector<std::string> prof_names;
+    std::vector<double> prof_ms;
+    std::vector<long long> prof_calls;
+};
+
+int prof_begin(vfsms_ctx *ctx, const char *name);      // returns a record index or -1 when profiling is off
+void prof_end(vfsms_ctx *ctx, int rec);
+struct ProfScope {
+    vfsms_ctx *c; int r;
+    ProfScope(vfsms_ctx *ctx, const char *name) : c(ctx), r(prof_begin(ctx, name)) {}
+    ~ProfScope() { prof_end(c, r); }
 };
 
 int ctx_arena_reserve(vfsms_ctx *ctx, size_t bytes);             // ensure capacity (may sync + realloc), reset offset

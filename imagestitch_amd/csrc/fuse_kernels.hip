@@ -339,6 +339,7 @@ int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int
 {
     const int r = ry1 - ry0, c = rx1 - rx0;
     if (r <= 0 || c <= 0) return canvas_paste_device(ctx, cv, d_tile, h, w, y0, x0);
+    ProfScope ps(ctx, "fuse");
     FuseScratch S;
     TRY(fuse_scratch(ctx, r, c, &S));
     HIP_TRY(hipMemsetAsync(S.st, 0, sizeof(FuseStats), ctx->stream));

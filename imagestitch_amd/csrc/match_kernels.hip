@@ -315,6 +315,7 @@ int match_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int dim, int nsplit)
 int launch_bf_l2(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int nsplit, int dim)
 {
     if (njobs <= 0 || capq <= 0) return VFSMS_OK;
+    ProfScope ps(ctx, "bf_l2");
     if (dim == 64) {
         hipLaunchKernelGGL(k_bf_l2_d64, dim3((capq + 511) / 512, nsplit, njobs), dim3(256), 0, ctx->stream, d_jobs);
     } else if (dim == 128) {
@@ -332,6 +333,7 @@ int launch_bf_l2(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, in
 int launch_ratio_mode(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, double ratio, int offset_evaluate)
 {
     if (njobs <= 0) return VFSMS_OK;
+    ProfScope ps(ctx, "vote");
     hipLaunchKernelGGL(k_merge_ratio, dim3((capq + 255) / 256, njobs), dim3(256), 0, ctx->stream, d_jobs, ratio, 1);
     hipLaunchKernelGGL(k_match_scan, dim3(njobs), dim3(1024), 0, ctx->stream, d_jobs);
     hipLaunchKernelGGL(k_mode_count, dim3((capq + 255) / 256, njobs), dim3(256), 0, ctx->stream, d_jobs);

@@ -183,6 +183,7 @@ int phase_correlate_device(vfsms_ctx *ctx, const uint8_t *a, int stride_a, const
     const int nblk = 1024;
     ArgMax *partial = (ArgMax *)ctx_arena_alloc(ctx, sizeof(ArgMax) * nblk);
     if (!partial) { vfsms_set_error("arena exhausted in phase correlation"); return VFSMS_ERR_CAPACITY; }
+    ProfScope ps(ctx, "phase");
     hipLaunchKernelGGL(k_pad_u8_f64, dim3((N + 255) / 256, M), dim3(256), 0, ctx->stream, a, stride_a, b, stride_b, h, w, M, N, A, B);
     if (hipfftExecD2Z(fwd, A, F1) != HIPFFT_SUCCESS || hipfftExecD2Z(fwd, B, F2) != HIPFFT_SUCCESS) {
         vfsms_set_error("hipfftExecD2Z failed"); return VFSMS_ERR_FFT;

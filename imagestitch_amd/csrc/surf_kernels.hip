@@ -107,6 +107,7 @@ __global__ __launch_bounds__(1024) void k_integral_cols(const RoiDev *rois)
 int launch_integral(vfsms_ctx *ctx, const RoiDev *d_rois, int nrois, int maxh, int maxw)
 {
     if (nrois <= 0) return VFSMS_OK;
+    ProfScope ps(ctx, "integral");
     hipLaunchKernelGGL(k_integral_rows, dim3(maxh + 1, nrois), dim3(256), 0, ctx->stream, d_rois);
     hipLaunchKernelGGL(k_integral_cols, dim3((maxw + 1 + 63) / 64, nrois), dim3(64, 16), 0, ctx->stream, d_rois);
     HIP_TRY(hipGetLastError());
@@ -683,37 +684,49 @@ int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_roi
     if (nrois <= 0) return VFSMS_OK;
     const int lpo = p->n_octave_layers + 2;
     int maxh = 0, maxw = 0, maxcap = 0;
-    for (int r = 0; r < nrois; r++) {
-        maxh = h_rois[r].h > maxh ? h_rois[r].h : maxh;
-        maxw = h_rois[r].w > maxw ? h_rois[r].w : maxw;
-        maxcap = h_rois[r].cap > maxcap ? h_rois[r].cap : maxcap;
-        HIP_TRY(hipMemsetAsync(h_rois[r].counters, 0, 16 * sizeof(int), ctx->stream));
-        // layer arrays are contiguous in the arena: det[0] .. end of trace[last]
-        char *lo = (char *)h_rois[r].det[0];
-        char *hi = (char *)h_rois[r].counters;
-        HIP_TRY(hipMemsetAsync(lo, 0, (size_t)(hi - lo), ctx->stream));
+    {
+        ProfScope ps(ctx, "memset");
+        for (int r = 0; r < nrois; r++) {
+            maxh = h_rois[r].h > maxh ? h_rois[r].h : maxh;
+            maxw = h_rois[r].w > maxw ? h_rois[r].w : maxw;
+            maxcap = h_rois[r].cap > maxcap ? h_rois[r].cap : maxcap;
+            HIP_TRY(hipMemsetAsync(h_rois[r].counters, 0, 16 * sizeof(int), ctx->stream));
+            // layer arrays are contiguous in the arena: det[0] .. end of trace[last]
+            char *lo = (char *)h_rois[r].det[0];
+            char *hi = (char *)h_rois[r].counters;
+            HIP_TRY(hipMemsetAsync(lo, 0, (size_t)(hi - lo), ctx->stream));
+        }
     }
     TRY(launch_integral(ctx, d_rois, nrois, maxh, maxw));
-    int step = 1;
-    for (int o = 0; o < p->n_octaves; o++) {
-        int lrows = maxh / step, lcols = maxw / step;
-        if (lrows > 0 && lcols > 0) {
-            dim3 grid((lcols + 63) / 64, (lrows + 3) / 4, nrois * lpo);
-            hipLaunchKernelGGL(k_hessian, grid, dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo, o);
+    {
+        ProfScope ps(ctx, "hessian");
+        int step = 1;
+        for (int o = 0; o < p->n_octaves; o++) {
+            int lrows = maxh / step, lcols = maxw / step;
+            if (lrows > 0 && lcols > 0) {
+                dim3 grid((lcols + 63) / 64, (lrows + 3) / 4, nrois * lpo);
+                hipLaunchKernelGGL(k_hessian, grid, dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo, o);
+            }
+            step *= 2;
         }
-        step *= 2;
     }
-    step = 1;
-    for (int o = 0; o < p->n_octaves; o++) {
-        int lrows = maxh / step, lcols = maxw / step;
-        if (lrows > 0 && lcols > 0) {
-            dim3 grid((lcols + 63) / 64, (lrows + 3) / 4, nrois * p->n_octave_layers);
-            hipLaunchKernelGGL(k_nms, grid, dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo,
-                               p->n_octave_layers, o, p->hessian_threshold);
+    {
+        ProfScope ps(ctx, "nms");
+        int step = 1;
+        for (int o = 0; o < p->n_octaves; o++) {
+            int lrows = maxh / step, lcols = maxw / step;
+            if (lrows > 0 && lcols > 0) {
+                dim3 grid((lcols + 63) / 64, (lrows + 3) / 4, nrois * p->n_octave_layers);
+                hipLaunchKernelGGL(k_nms, grid, dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo,
+                                   p->n_octave_layers, o, p->hessian_threshold);
+            }
+            step *= 2;
         }
-        step *= 2;
     }
-    hipLaunchKernelGGL(k_rank_sort, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
+    {
+        ProfScope ps(ctx, "sort");
+        hipLaunchKernelGGL(k_rank_sort, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
+    }
     HIP_TRY(hipGetLastError());
     return VFSMS_OK;
 }
@@ -725,10 +738,19 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
     int maxcap = 0;
     for (int r = 0; r < nrois; r++) maxcap = h_rois[r].cap > maxcap ? h_rois[r].cap : maxcap;
     const int dim = p->extended ? 128 : 64;
-    hipLaunchKernelGGL(k_orientation, dim3(maxcap, nrois), dim3(128), 0, ctx->stream, d_rois, ctx->d_tables, p->upright);
-    hipLaunchKernelGGL(k_describe, dim3(maxcap, nrois), dim3(256), 0, ctx->stream, d_rois, ctx->d_tables, p->extended, p->upright);
-    hipLaunchKernelGGL(k_keep_scan, dim3(nrois), dim3(1024), 0, ctx->stream, d_rois);
-    hipLaunchKernelGGL(k_compact, dim3((maxcap + 3) / 4, nrois), dim3(256), 0, ctx->stream, d_rois, dim);
+    {
+        ProfScope ps(ctx, "orientation");
+        hipLaunchKernelGGL(k_orientation, dim3(maxcap, nrois), dim3(128), 0, ctx->stream, d_rois, ctx->d_tables, p->upright);
+    }
+    {
+        ProfScope ps(ctx, "describe");
+        hipLaunchKernelGGL(k_describe, dim3(maxcap, nrois), dim3(256), 0, ctx->stream, d_rois, ctx->d_tables, p->extended, p->upright);
+    }
+    {
+        ProfScope ps(ctx, "compact");
+        hipLaunchKernelGGL(k_keep_scan, dim3(nrois), dim3(1024), 0, ctx->stream, d_rois);
+        hipLaunchKernelGGL(k_compact, dim3((maxcap + 3) / 4, nrois), dim3(256), 0, ctx->stream, d_rois, dim);
+    }
     HIP_TRY(hipGetLastError());
     return VFSMS_OK;
 }

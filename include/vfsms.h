@@ -79,6 +79,13 @@ void *vfsms_ctx_stream(vfsms_ctx *ctx);
 /* Max SURF candidates per ROI (default: h*w/24 + 4096).  0 restores the default.                  */
 int vfsms_ctx_set_keypoint_capacity(vfsms_ctx *ctx, int cap);
 
+/* Per-stage timing with HIP events recorded on the context's own stream around each kernel group
+ * ("integral", "hessian", "nms", "sort", "orientation", "describe", "bf_l2", "vote", "phase", "fuse", ...).
+ * read: comma-separated stage names, accumulated milliseconds and launch-group counts; reset != 0 clears. */
+int vfsms_profile_enable(vfsms_ctx *ctx, int on);
+int vfsms_profile_read(vfsms_ctx *ctx, char *names, int names_len, double *ms, int64_t *calls, int cap,
+                       int *n_out, int reset);
+
 /* ---- device-resident tiles (grayscale u8, row stride in bytes) ----------------------------------- */
 int vfsms_tile_upload(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int64_t *handle);
 /* adopt memory already on this device (e.g. a framework tensor); not freed by vfsms_tile_free     */
