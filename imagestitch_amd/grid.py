@@ -1,0 +1,223 @@
+"""Batched, device-resident registration of a whole shooting path, and its pair-sharded multi-GPU form.
+
+The reference registers pairs one at a time (Stitcher.flowStitch, Stitcher.py:64-79) and threads one piece of
+state from pair to pair: `self.direction` (Stitcher.py:252,361), which decides the ORDER in which the
+(direction, ROI growth i) candidates of the next pair are tried -- and with offsetEvaluate = 3 the first
+accepted candidate wins, so the order is observable.  GridRegistrar produces exactly the sequential result
+while keeping the GPU full:
+
+  * speculation: a window of consecutive pairs is evaluated in ONE fused batch (SURF + BF-L2 + ratio + mode,
+    or phase correlation) under the assumption that the direction does not change; the first pair whose
+    (direction, i = 1) attempt fails is then resolved candidate ring by candidate ring, and speculative results
+    behind it are kept only if the direction it ends in is the one they assumed;
+  * sharding (one process per GPU): ranks take contiguous chunks of the path.  A rank other than 0 does not
+    know the direction its first pair inherits, so it follows the chain for every possible incoming direction
+    (chains merge as soon as they agree, normally after one pair) and ONE all-gather of int32 offset tables
+    (RCCL over xGMI when the process group is "nccl") lets every rank select the consistent chain.
+"""
+import numpy as np
+
+from .utility import roi_rect
+
+RESULT_INTS = 6   # status, dx, dy, direction, i, votes
+
+
+def _rotate(direction, incre):
+    direction += incre
+    if direction == 5:
+        direction = 1
+    if direction == 0:
+        direction = 4
+    return direction
+
+
+class GridRegistrar:
+    def __init__(self, engine, method="surf", roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3, directIncre=1,
+                 surfParams=None, phaseResponseThreshold=0.15, window=16):
+        self.eng = engine
+        self.method = method
+        self.roiRatio = roiRatio
+        self.searchRatio = searchRatio
+        self.offsetEvaluate = offsetEvaluate
+        self.directIncre = directIncre
+        self.params = surfParams
+        self.phaseThr = phaseResponseThreshold
+        self.window = max(1, int(window))
+        self.stats = dict(attempts=0, batches=0, sum_nq_nt=0, sum_nq_plus_nt=0, sum_nq=0, roi_px=0)
+
+    # -- candidate order of Stitcher.py:319-351 --------------------------------------------------------------
+    def maxI(self):
+        return int(np.floor(0.5 / self.roiRatio) + 1) + 1
+
+    def rings(self, d0):
+        """[[(direction, i), ...] per i]: each i restarts at d0 and rotates until it is back at d0."""
+        out = []
+        for i in range(1, self.maxI()):
+            ring, d = [], d0
+            while True:
+                ring.append((d, i))
+                d = _rotate(d, self.directIncre)
+                if d == d0:
+                    break
+            out.append(ring)
+        return out
+
+    # -- one batch of attempts -----------------------------------------------------------------------------------
+    def _attempts(self, handles, shapes, items):
+        """items: [(pair index k, direction, i)] -> [(status, raw_dx, raw_dy, votes)]"""
+        jobs = []
+        for (k, d, i) in items:
+            ra = roi_rect(shapes[k], d, "first", i * self.roiRatio)
+            rb = roi_rect(shapes[k + 1], d, "second", i * self.roiRatio)
+            if ra[2:] != rb[2:]:
+                raise ValueError("tiles of different size in one pair are not supported by the batched path")
+            jobs.append((handles[k], handles[k + 1], ra[0], ra[1], rb[0], rb[1], ra[2], ra[3]))
+            self.stats["roi_px"] += 2 * ra[2] * ra[3]
+        self.stats["attempts"] += len(jobs)
+        self.stats["batches"] += 1
+        if self.method == "surf":
+            rows = self.eng.attempt_surf_batch(jobs, self.params, self.searchRatio, self.offsetEvaluate)
+            nq = rows[:, 4].astype(np.int64); nt = rows[:, 5].astype(np.int64)
+            self.stats["sum_nq_nt"] += int((nq * nt).sum())
+            self.stats["sum_nq_plus_nt"] += int((nq + nt).sum())
+            self.stats["sum_nq"] += int(nq.sum())
+            return [(bool(r[0]) and r[4] > 0 and r[5] > 0, int(r[1]), int(r[2]), int(r[3])) for r in rows]
+        if self.method == "phase":
+            rows = self.eng.attempt_phase_batch(jobs)
+            # offset = [int(y), int(x)] (truncation); accepted when response > threshold (Stitcher.py:231-236)
+            return [(bool(r[2] > self.phaseThr), int(r[1]), int(r[0]), 0) for r in rows]
+        raise ValueError("method %r" % (self.method,))
+
+    def _correct(self, raw, d, i, shapeA, shapeB):
+        """Stitcher.py:352-360: ROI-relative vote -> full-tile offset."""
+        dx, dy = raw
+        if d == 1:
+            dx = dx + shapeA[0] - int(i * self.roiRatio * shapeA[0])
+        elif d == 2:
+            dy = dy + shapeA[1] - int(i * self.roiRatio * shapeA[1])
+        elif d == 3:
+            dx = dx - (shapeB[0] - int(i * self.roiRatio * shapeB[0]))
+        elif d == 4:
+            dy = dy - (shapeB[1] - int(i * self.roiRatio * shapeB[1]))
+        return dx, dy
+
+    # -- sequentially-equivalent chain over pairs [first, last) ------------------------------------------------------
+    def chain(self, handles, shapes, first, last, d_in, memo=None):
+        """-> (int32[last-first, 6], d_out).  memo: {(k, d): (row, d_next)} shared between chains."""
+        memo = {} if memo is None else memo
+        out = np.zeros((last - first, RESULT_INTS), np.int32)
+        spec = {}
+        d = d_in
+        k = first
+        while k < last:
+            if (k, d) in memo:
+                row, d_next = memo[(k, d)]
+                out[k - first] = row
+                d = d_next
+                k += 1
+                continue
+            if (k, d) not in spec:
+                spec.clear()
+                ks = [kk for kk in range(k, min(k + self.window, last)) if (kk, d) not in memo]
+                res = self._attempts(handles, shapes, [(kk, d, 1) for kk in ks])
+                for kk, r in zip(ks, res):
+                    spec[(kk, d)] = r
+            st, rdx, rdy, votes = spec.pop((k, d))
+            found = (d, 1, rdx, rdy, votes) if st else None
+            if found is None:
+                rings = self.rings(d)
+                rings[0] = rings[0][1:]
+                for ring in rings:
+                    if not ring:
+                        continue
+                    res = self._attempts(handles, shapes, [(k, dd, ii) for (dd, ii) in ring])
+                    for (dd, ii), (st2, a, b, v) in zip(ring, res):
+                        if st2:
+                            found = (dd, ii, a, b, v)
+                            break
+                    if found:
+                        break
+            if found:
+                dd, ii, a, b, v = found
+                dx, dy = self._correct((a, b), dd, ii, shapes[k], shapes[k + 1])
+                row = np.array([1, dx, dy, dd, ii, v], np.int32)
+                d_next = dd                       # self.direction = localDirection
+            else:
+                row = np.array([0, 0, 0, d, 0, 0], np.int32)
+                d_next = d                        # a failed pair leaves self.direction untouched
+            memo[(k, d)] = (row, d_next)
+            out[k - first] = row
+            d = d_next
+            k += 1
+        return out, d
+
+    def register(self, handles, shapes, direction=1):
+        """All P = len(handles)-1 consecutive pairs on this GPU.  -> (int32[P, 6], final direction)."""
+        return self.chain(handles, shapes, 0, len(handles) - 1, direction)
+
+    # -- pair-sharded ---------------------------------------------------------------------------------------------------
+    @staticmethod
+    def chunk_bounds(n_pairs, world):
+        per = (n_pairs + world - 1) // world
+        return [(min(r * per, n_pairs), min((r + 1) * per, n_pairs)) for r in range(world)]
+
+    def shard_payload(self, handles, shapes, direction, rank, world):
+        """This rank's offset table: int32[4 * per * 6 + 4] = results for each possible incoming direction
+        (only the true one on rank 0 / when directIncre == 0) followed by the direction each chain ends in."""
+        P = len(shapes) - 1
+        bounds = self.chunk_bounds(P, world)
+        lo, hi = bounds[rank]
+        per = max(b - a for a, b in bounds)
+        dirs = [direction] if (self.directIncre == 0 or rank == 0) else [1, 2, 3, 4]
+        table = np.zeros((4, per, RESULT_INTS), np.int32)
+        d_out = np.zeros(4, np.int32)
+        memo = {}
+        for d_in in dirs:
+            if hi > lo:
+                res, dn = self.chain(handles, shapes, lo, hi, d_in, memo)
+                table[d_in - 1, :hi - lo] = res
+            else:
+                dn = d_in
+            d_out[d_in - 1] = dn
+        return np.concatenate([table.reshape(-1), d_out])
+
+    def assemble(self, gathered, n_pairs, world, direction):
+        """Walk the gathered tables rank by rank, selecting the chain consistent with the true incoming direction."""
+        P = n_pairs
+        bounds = self.chunk_bounds(P, world)
+        per = max(b - a for a, b in bounds)
+        full = np.zeros((P, RESULT_INTS), np.int32)
+        d = direction
+        for r in range(world):
+            a, b = bounds[r]
+            t = np.asarray(gathered[r][:-4]).reshape(4, per, RESULT_INTS)
+            dn = gathered[r][-4:]
+            full[a:b] = t[d - 1, :b - a]
+            d = int(dn[d - 1]) if b > a else d
+        return full, d
+
+    def register_sharded(self, handles, shapes, direction, rank, world, all_gather):
+        """handles/shapes are indexed by GLOBAL tile index (only this rank's chunk + halo need be valid).
+        all_gather(int32 ndarray [C]) -> int32 ndarray [world, C]   (the single collective of the path).
+        Returns the same (int32[P, 6], final direction) on every rank."""
+        P = len(shapes) - 1
+        payload = self.shard_payload(handles, shapes, direction, rank, world)
+        gathered = all_gather(payload)
+        return self.assemble(gathered, P, world, direction)
+
+
+def split_segments(results):
+    """flowStitchWithMutiple's segmentation (Stitcher.py:96-127) from a per-pair result table:
+    -> [(first tile, last tile inclusive, [[dx, dy], ...])]."""
+    segs = []
+    start = 0
+    offs = []
+    P = len(results)
+    for k in range(P):
+        if results[k][0]:
+            offs.append([int(results[k][1]), int(results[k][2])])
+        else:
+            segs.append((start, k, offs))
+            start, offs = k + 1, []
+    segs.append((start, P, offs))
+    return segs

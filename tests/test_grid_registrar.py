@@ -1,0 +1,96 @@
+"""CPU tests: the speculative batched registrar and its pair-sharded form give EXACTLY the sequential result of
+Stitcher.calculateOffsetForFeatureSearchIncre applied pair after pair (direction state threaded through),
+for random truth tables with failures, late successes (i > 1) and false-positive directions."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import imagestitch_amd as isa
+from imagestitch_amd.grid import GridRegistrar, split_segments
+from scripted import ScriptedAttemptEngine, random_truth
+
+SHAPE = (1000, 1400)
+
+
+class SeqStitcher(isa.Stitcher):
+    def __init__(self, eng):
+        self.eng2 = eng
+
+    def _featureAttempt(self, imageA, imageB, direction, searchRatio):
+        ra = isa.roi_rect(SHAPE, direction, "first", searchRatio); rb = isa.roi_rect(SHAPE, direction, "second", searchRatio)
+        row = self.eng2.attempt_surf_batch([(self.k, self.k + 1, ra[0], ra[1], rb[0], rb[1], ra[2], ra[3])])[0]
+        return (bool(row[0]), [int(row[1]), int(row[2])])
+
+
+def sequential(accept, roiRatio, incre, d0):
+    eng = ScriptedAttemptEngine(SHAPE, roiRatio, accept)
+    s = SeqStitcher(eng); s.isPrintLog = False
+    s.roiRatio, s.directIncre, s.direction = roiRatio, incre, d0
+    A = np.zeros(SHAPE, np.uint8)
+    rows = []
+    for k in range(len(accept)):
+        s.k = k
+        st, off = s.calculateOffsetForFeatureSearchIncre([A, A])
+        rows.append([1, off[0], off[1], s.direction] if st else [0, 0, 0, s.direction])
+    return rows, s.direction, len(eng.log)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_chain_and_shards_equal_sequential(seed):
+    rng = np.random.default_rng(seed)
+    roiRatio = float(rng.choice([0.1, 0.2]))
+    incre = int(rng.choice([-1, 0, 1]))
+    d0 = int(rng.integers(1, 5))
+    P = int(rng.integers(1, 40))
+    accept = random_truth(rng, P, roiRatio)
+    seq, d_end, n_seq = sequential(accept, roiRatio, incre, d0)
+    handles = list(range(P + 1)); shapes = [SHAPE] * (P + 1)
+    for window in (1, 4, 16):
+        eng = ScriptedAttemptEngine(SHAPE, roiRatio, accept)
+        reg = GridRegistrar(eng, roiRatio=roiRatio, directIncre=incre, window=window)
+        res, d = reg.register(handles, shapes, d0)
+        assert d == d_end
+        assert [list(r[:4]) for r in res.tolist()] == seq, (seed, window)
+        for world in (1, 2, 3, 5):
+            payloads = []
+            for rank in range(world):
+                e2 = ScriptedAttemptEngine(SHAPE, roiRatio, accept)
+                r2 = GridRegistrar(e2, roiRatio=roiRatio, directIncre=incre, window=window)
+                payloads.append(r2.shard_payload(handles, shapes, d0, rank, world))
+            full, d2 = reg.assemble(np.stack(payloads), P, world, d0)
+            assert d2 == d_end and np.array_equal(full, res), (seed, window, world)
+
+
+def test_speculation_never_reorders_candidates():
+    # pair 1 truly lies in direction 2 but ALSO passes in direction 1 at i=2: the sequential search (ini 1, incre 1)
+    # tries (1,1) (2,1) ... and must accept (2,1) first; a registrar that batched by ring would still agree
+    accept = [{(1, 1): (3, 3)}, {(2, 1): (4, 4), (1, 2): (9, 9)}, {(2, 1): (5, 5)}]
+    seq, d_end, _ = sequential(accept, 0.2, 1, 1)
+    eng = ScriptedAttemptEngine(SHAPE, 0.2, accept)
+    res, d = GridRegistrar(eng, roiRatio=0.2, directIncre=1, window=8).register(list(range(4)), [SHAPE] * 4, 1)
+    assert [list(r[:4]) for r in res.tolist()] == seq and d == d_end == 2
+    assert res[1][4] == 1 and res[1][3] == 2
+
+
+def test_split_segments_matches_flow_restart_arithmetic():
+    rows = [[1, 5, 0], [0, 0, 0], [1, 6, 0], [1, 7, 0], [0, 0, 0]]
+    assert split_segments(rows) == [(0, 1, [[5, 0]]), (2, 4, [[6, 0], [7, 0]]), (5, 5, [])]
+
+
+def test_two_process_gloo_all_gather(tmp_path):
+    """world_size 2 over torch.distributed / gloo on CPU: the N > 1 code path of bench.py's collective."""
+    out = os.path.join(str(tmp_path), "res.json")
+    worker = os.path.join(os.path.dirname(__file__), "dist_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", worker, out]
+    subprocess.check_call(cmd, env=env, timeout=600)
+    got = json.load(open(out))
+    rng = np.random.default_rng(77)
+    accept = random_truth(rng, 23, 0.2)
+    seq, d_end, _ = sequential(accept, 0.2, 1, 1)
+    assert got["direction"] == d_end and [r[:4] for r in got["rows"]] == seq
