@@ -384,7 +384,8 @@ static int pick_nsplit(int nq, int nt, int njobs, int dim)
 {
     const int qpw = dim == 64 ? 128 : 64;                 // queries per wave
     const long long waves = (long long)((nq + qpw - 1) / qpw) * njobs;
-    int ns = (int)((2048 + waves - 1) / (waves > 0 ? waves : 1));
+    // aim at >= 16 waves per SIMD (1024 SIMDs) so the last, partially filled round of workgroups is a small tail
+    int ns = (int)((16384 + waves - 1) / (waves > 0 ? waves : 1));
     ns = std::max(1, std::min(ns, 64));
     ns = std::min(ns, std::max(1, nt / 64));
     return ns;

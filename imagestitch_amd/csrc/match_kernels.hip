@@ -17,6 +17,23 @@
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef const float __attribute__((address_space(4))) cfloat;   // AMDGPU constant address space
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// hand-placed scalar loads (hipcc adds no waits for asm, cdna_hip_programming.md section 5.7): the wait takes the
+// destination tuple as an in/out operand so every use of the data is ordered behind it.
+#define SLOAD16(dst, ptr) asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(dst) : "s"(ptr))
+// prefetch into dst while `live` (the tuple about to be consumed) is threaded through, which pins the issue point
+// of the load in front of the VALU work on `live`
+#define SLOAD16_BEFORE(dst, ptr, live) asm volatile("s_load_dwordx16 %0, %2, 0x0" : "=s"(dst), "+s"(live) : "s"(ptr))
+#define SWAIT(dst) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dst))
+#define BF_CHUNK(buf, base)                                                                    \
+    _Pragma("unroll") for (int d = 0; d < 16; d += 4) {                                        \
+        float2v e0 = qv[base + d + 0] - buf[d + 0];                                            \
+        float2v e1 = qv[base + d + 1] - buf[d + 1];                                            \
+        float2v e2 = qv[base + d + 2] - buf[d + 2];                                            \
+        float2v e3 = qv[base + d + 3] - buf[d + 3];                                            \
+        acc += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;                                          \
+    }
 
 __device__ __forceinline__ void knn_update(float dsq, int j, float &b1, float &b2, int &i1, float &b1sq, float &b2sq)
 {
@@ -52,22 +69,31 @@ __global__ __launch_bounds__(256) void k_bf_l2_d64(const MatchDev *jobs)
     }
     float b1a = INFINITY, b2a = INFINITY, b1sa = INFINITY, b2sa = INFINITY; int i1a = -1;
     float b1b = INFINITY, b2b = INFINITY, b1sb = INFINITY, b2sb = INFINITY; int i1b = -1;
-    // Train descriptors were written by an earlier kernel and are read-only here: address them through the
-    // constant address space so the wave-uniform loads are issued on the scalar unit (s_load_dwordx16).
-    const cfloat *T = (const cfloat *)(uintptr_t)J.t;
-    for (int j = t0; j < t1; j++) {
-        const cfloat *tr = T + (size_t)j * 64;
-        float2v acc = (float2v){0.f, 0.f};
-#pragma unroll
-        for (int d = 0; d < 64; d += 4) {
-            float2v e0 = qv[d + 0] - tr[d + 0];
-            float2v e1 = qv[d + 1] - tr[d + 1];
-            float2v e2 = qv[d + 2] - tr[d + 2];
-            float2v e3 = qv[d + 3] - tr[d + 3];
-            acc += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+    // Train descriptors were written by an earlier kernel and are read-only here and wave-uniform: they are
+    // streamed through the scalar data path, 16 floats (one s_load_dwordx16) at a time, double-buffered by hand:
+    // the load of chunk c+1 is issued before the 48 packed VALU ops on chunk c, so its latency is covered.
+    // (hipcc places s_waitcnt lgkmcnt(0) right behind every scalar load it schedules itself; SMEM returns out
+    // of order, so the only safe wait is 0 and it must sit BEFORE the next prefetch is issued.)
+    const float *T = J.t;
+    if (t0 < t1) {
+        f16v bufA, bufB;
+        const float *nxt = T + (size_t)t0 * 64;
+        SLOAD16(bufA, nxt);
+        for (int j = t0; j < t1; j++) {
+            const float *tn = T + (size_t)min(j + 1, t1 - 1) * 64;      // next train (clamped: harmless re-read)
+            float2v acc = (float2v){0.f, 0.f};
+            SWAIT(bufA); SLOAD16_BEFORE(bufB, T + (size_t)j * 64 + 16, bufA);
+            BF_CHUNK(bufA, 0);
+            SWAIT(bufB); SLOAD16_BEFORE(bufA, T + (size_t)j * 64 + 32, bufB);
+            BF_CHUNK(bufB, 16);
+            SWAIT(bufA); SLOAD16_BEFORE(bufB, T + (size_t)j * 64 + 48, bufA);
+            BF_CHUNK(bufA, 32);
+            SWAIT(bufB); SLOAD16_BEFORE(bufA, tn, bufB);
+            BF_CHUNK(bufB, 48);
+            knn_update(acc.x, j, b1a, b2a, i1a, b1sa, b2sa);
+            knn_update(acc.y, j, b1b, b2b, i1b, b1sb, b2sb);
         }
-        knn_update(acc.x, j, b1a, b2a, i1a, b1sa, b2sa);
-        knn_update(acc.y, j, b1b, b2b, i1b, b1sb, b2sb);
+        SWAIT(bufA);                                                     // drain the last prefetch
     }
     const size_t o = (size_t)sp * J.capq;
     if (qa < nq) { J.p_d1[o + qa] = b1a; J.p_d2[o + qa] = b2a; J.p_i1[o + qa] = i1a; }

@@ -245,29 +245,22 @@ __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat 
 // keypoint ordering: std::sort(KeypointGreater) == rank by counting (N^2 compares through LDS tiles).
 //   order: response desc, size desc, octave desc, y asc, x asc, then (layer, i, j) asc to make it total.
 // ---------------------------------------------------------------------------------------------------
-struct SortKey { uint32_t resp; int32_t size_oct; uint32_t y, x; uint32_t lij_hi, lij_lo; };
+struct SortKey { unsigned long long k1, k2, k3; };
+// k1 (descending): response bits (positive floats order like their bit patterns) then integer size then octave;
+// k2 (ascending): order-preserving images of y then x; k3 (ascending): (layer, i, j), unique per candidate.
 
+__device__ __forceinline__ uint32_t ord_f32(float f)
+{
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
 __device__ __forceinline__ SortKey make_key(const Cand &c)
 {
     SortKey k;
-    k.resp = __float_as_uint(c.response);                 // response > threshold >= 0: bit order == value order
-    k.size_oct = ((int)c.size << 4) | c.octave;           // size is an integer-valued float (may be negative)
-    // y, x: map float to order-preserving uint
-    uint32_t yb = __float_as_uint(c.y), xb = __float_as_uint(c.x);
-    k.y = (yb & 0x80000000u) ? ~yb : (yb | 0x80000000u);
-    k.x = (xb & 0x80000000u) ? ~xb : (xb | 0x80000000u);
-    k.lij_hi = (uint32_t)c.layer;
-    k.lij_lo = ((uint32_t)c.i << 16) | (uint32_t)c.j;
+    k.k1 = ((unsigned long long)__float_as_uint(c.response) << 32) | (uint32_t)((((int)c.size) << 4) | c.octave);
+    k.k2 = ((unsigned long long)ord_f32(c.y) << 32) | ord_f32(c.x);
+    k.k3 = ((unsigned long long)(uint32_t)c.layer << 32) | (((uint32_t)c.i << 16) | (uint32_t)c.j);
     return k;
-}
-__device__ __forceinline__ bool key_before(const SortKey &a, const SortKey &b)   // a sorts strictly before b
-{
-    if (a.resp != b.resp) return a.resp > b.resp;
-    if (a.size_oct != b.size_oct) return a.size_oct > b.size_oct;
-    if (a.y != b.y) return a.y < b.y;
-    if (a.x != b.x) return a.x < b.x;
-    if (a.lij_hi != b.lij_hi) return a.lij_hi < b.lij_hi;
-    return a.lij_lo < b.lij_lo;
 }
 
 __global__ __launch_bounds__(256) void k_rank_sort(const RoiDev *rois)
@@ -276,18 +269,26 @@ __global__ __launch_bounds__(256) void k_rank_sort(const RoiDev *rois)
     const int n = min(R.counters[0], R.cap);
     if ((int)(blockIdx.x * 256) >= n) return;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    __shared__ SortKey tile[256];
+    __shared__ unsigned long long t1[256], t2[256], t3[256];
     Cand me;
-    SortKey mk;
+    SortKey mk; mk.k1 = mk.k2 = mk.k3 = 0;
     if (idx < n) { me = R.cand[idx]; mk = make_key(me); }
     int rank = 0;
     for (int base = 0; base < n; base += 256) {
         int t = base + threadIdx.x;
-        if (t < n) tile[threadIdx.x] = make_key(R.cand[t]);
+        if (t < n) { SortKey k = make_key(R.cand[t]); t1[threadIdx.x] = k.k1; t2[threadIdx.x] = k.k2; t3[threadIdx.x] = k.k3; }
         __syncthreads();
-        int lim = min(256, n - base);
-        if (idx < n)
-            for (int k = 0; k < lim; k++) rank += key_before(tile[k], mk) ? 1 : 0;
+        const int lim = min(256, n - base);
+        if (idx < n) {
+            for (int k = 0; k < lim; k++) {
+                const unsigned long long a = t1[k];          // LDS broadcast read
+                rank += (a > mk.k1) ? 1 : 0;
+                if (a == mk.k1) {                              // rare: self, or equal response/size/octave
+                    const unsigned long long b2 = t2[k];
+                    rank += (b2 < mk.k2 || (b2 == mk.k2 && t3[k] < mk.k3)) ? 1 : 0;
+                }
+            }
+        }
         __syncthreads();
     }
     if (idx < n) {
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(128) void k_orientation(const RoiDev *rois, const S
 //   cv::resize's three area paths.  Row origins (start_x/start_y) are running float sums in the
 //   reference, so lane 0 produces them sequentially into LDS first.
 // ---------------------------------------------------------------------------------------------------
+#define DESC_WBUF 28672           // LDS bytes for the staged descriptor window / band (37 rows x 739 px worst case)
 struct WinGeom {
     int win; float sin_dir, cos_dir;
     int h, w, stride; const uint8_t *img;
@@ -492,11 +494,16 @@ __global__ __launch_bounds__(256) void k_describe(const RoiDev *rois, const Surf
         // correctly rounded sinf/cosf except in double-rounding corner cases)
         G.sin_dir = -(float)sin((double)dir);
         G.cos_dir = (float)cos((double)dir);
+        // row origins are running float sums in the reference (start_x += sin_dir per row): inherently sequential,
+        // so one lane of wave 0 walks x while one lane of wave 1 walks y
         if (threadIdx.x == 0) {
             float win_offset = -(float)(win - 1) / 2;
             float start_x = kp.x + win_offset * G.cos_dir + win_offset * G.sin_dir;
+            for (int i = 0; i < win; i++, start_x += G.sin_dir) sx_row[i] = start_x;
+        } else if (threadIdx.x == 64) {
+            float win_offset = -(float)(win - 1) / 2;
             float start_y = kp.y - win_offset * G.sin_dir + win_offset * G.cos_dir;
-            for (int i = 0; i < win; i++, start_x += G.sin_dir, start_y += G.cos_dir) { sx_row[i] = start_x; sy_row[i] = start_y; }
+            for (int i = 0; i < win; i++, start_y += G.cos_dir) sy_row[i] = start_y;
         }
     } else {
         G.sin_dir = 0.f; G.cos_dir = 0.f;
@@ -512,37 +519,106 @@ __global__ __launch_bounds__(256) void k_describe(const RoiDev *rois, const Surf
     const double scale = 1. / inv_scale;
     const int iscale = cv_round_d(scale);
     const bool is_area_fast = fabs(scale - iscale) < DBL_EPSILON;
-    for (int o = threadIdx.x; o < dsz * dsz; o += 256) {
-        const int dy = o / dsz, dx = o % dsz;
-        uint8_t outv;
-        if (is_area_fast && iscale == 2) {
-            int s00 = win_sample(G, sx_row, sy_row, dy * 2, dx * 2), s01 = win_sample(G, sx_row, sy_row, dy * 2, dx * 2 + 1);
-            int s10 = win_sample(G, sx_row, sy_row, dy * 2 + 1, dx * 2), s11 = win_sample(G, sx_row, sy_row, dy * 2 + 1, dx * 2 + 1);
-            outv = (uint8_t)((s00 + s01 + s10 + s11 + 2) >> 2);
-        } else if (is_area_fast) {
-            int sum = 0;
-            for (int sy = 0; sy < iscale; sy++)
-                for (int sx = 0; sx < iscale; sx++) sum += win_sample(G, sx_row, sy_row, dy * iscale + sy, dx * iscale + sx);
-            outv = sat_u8(sum * (1.f / (iscale * iscale)));
-        } else {
-            AreaSpan Sy = area_span(dy, win, scale), Sx = area_span(dx, win, scale);
-            float sum = 0; bool first = true;
-            for (int pass = 0; pass < 3; pass++) {
-                int r0 = pass == 0 ? Sy.s_left : pass == 1 ? Sy.sx1 : Sy.s_right;
-                int r1 = pass == 1 ? Sy.sx2 : r0 + 1;
-                float beta = pass == 0 ? Sy.a_left : pass == 1 ? Sy.a_full : Sy.a_right;
-                if (pass != 1 && r0 < 0) continue;
-                for (int sy = r0; sy < r1; sy++) {
+    // The rotated window is staged through LDS so that every bilinear sample is produced exactly once by
+    // one of the 256 lanes (even load, no recomputation at cell borders): the whole window when it fits
+    // (win <= 169), otherwise one band of source rows per row of output cells.  The INTER_AREA reduction then
+    // reads bytes from LDS in exactly the accumulation order of cv::resize's three area paths.
+    __shared__ uint8_t WINBUF[DESC_WBUF];
+    __shared__ float rowbuf[21][40];
+    const float inv_win = 1.0f / (float)win;
+    if (win * win <= DESC_WBUF) {
+        for (int sidx = threadIdx.x; sidx < win * win; sidx += 256) {
+            int i = (int)((float)sidx * inv_win);
+            if (i * win > sidx) i--; else if ((i + 1) * win <= sidx) i++;
+            WINBUF[sidx] = (uint8_t)win_sample(G, sx_row, sy_row, i, sidx - i * win);
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < dsz * dsz; o += 256) {
+            const int dy = o / dsz, dx = o % dsz;
+            uint8_t outv;
+            if (is_area_fast && iscale == 2) {
+                const uint8_t *S = WINBUF + (dy * 2) * win + dx * 2;
+                outv = (uint8_t)((S[0] + S[1] + S[win] + S[win + 1] + 2) >> 2);
+            } else if (is_area_fast) {
+                int sum = 0;
+                for (int sy = 0; sy < iscale; sy++)
+                    for (int sx = 0; sx < iscale; sx++) sum += WINBUF[(dy * iscale + sy) * win + dx * iscale + sx];
+                outv = sat_u8(sum * (1.f / (iscale * iscale)));
+            } else {
+                AreaSpan Sy = area_span(dy, win, scale), Sx = area_span(dx, win, scale);
+                float sum = 0; bool first = true;
+                for (int pass = 0; pass < 3; pass++) {
+                    int r0 = pass == 0 ? Sy.s_left : pass == 1 ? Sy.sx1 : Sy.s_right;
+                    int r1 = pass == 1 ? Sy.sx2 : r0 + 1;
+                    float beta = pass == 0 ? Sy.a_left : pass == 1 ? Sy.a_full : Sy.a_right;
+                    if (pass != 1 && r0 < 0) continue;
+                    for (int sy = r0; sy < r1; sy++) {
+                        const uint8_t *S = WINBUF + sy * win;
+                        float buf = 0;
+                        if (Sx.s_left >= 0) buf += (float)S[Sx.s_left] * Sx.a_left;
+                        for (int sxx = Sx.sx1; sxx < Sx.sx2; sxx++) buf += (float)S[sxx] * Sx.a_full;
+                        if (Sx.s_right >= 0) buf += (float)S[Sx.s_right] * Sx.a_right;
+                        if (first) { sum = beta * buf; first = false; } else sum += beta * buf;
+                    }
+                }
+                outv = sat_u8(sum);
+            }
+            PATCH[dy][dx] = outv;
+        }
+    } else {
+        int *irow = reinterpret_cast<int *>(&rowbuf[0][0]);
+        for (int dy = 0; dy < dsz; dy++) {
+            AreaSpan Sy;
+            int rlo, rhi;
+            if (is_area_fast) { rlo = dy * iscale; rhi = rlo + iscale - 1; }
+            else {
+                Sy = area_span(dy, win, scale);
+                rlo = Sy.s_left >= 0 ? Sy.s_left : Sy.sx1;
+                rhi = Sy.s_right >= 0 ? Sy.s_right : Sy.sx2 - 1;
+            }
+            const int nrows = rhi - rlo + 1;                       // <= scale + 2 <= 38
+            for (int sidx = threadIdx.x; sidx < nrows * win; sidx += 256) {
+                int r = (int)((float)sidx * inv_win);
+                if (r * win > sidx) r--; else if ((r + 1) * win <= sidx) r++;
+                WINBUF[sidx] = (uint8_t)win_sample(G, sx_row, sy_row, rlo + r, sidx - r * win);
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < dsz * nrows; t += 256) {  // horizontal sums, one (cell column, source row) per lane
+                const int dx = t / nrows, r = t - dx * nrows;
+                const uint8_t *S = WINBUF + r * win;
+                if (is_area_fast) {
+                    int sum = 0;
+                    for (int sx = 0; sx < iscale; sx++) sum += S[dx * iscale + sx];
+                    irow[dx * 40 + r] = sum;
+                } else {
+                    AreaSpan Sx = area_span(dx, win, scale);
                     float buf = 0;
-                    if (Sx.s_left >= 0) buf += (float)win_sample(G, sx_row, sy_row, sy, Sx.s_left) * Sx.a_left;
-                    for (int sxx = Sx.sx1; sxx < Sx.sx2; sxx++) buf += (float)win_sample(G, sx_row, sy_row, sy, sxx) * Sx.a_full;
-                    if (Sx.s_right >= 0) buf += (float)win_sample(G, sx_row, sy_row, sy, Sx.s_right) * Sx.a_right;
-                    if (first) { sum = beta * buf; first = false; } else sum += beta * buf;
+                    if (Sx.s_left >= 0) buf += (float)S[Sx.s_left] * Sx.a_left;
+                    for (int sxx = Sx.sx1; sxx < Sx.sx2; sxx++) buf += (float)S[sxx] * Sx.a_full;
+                    if (Sx.s_right >= 0) buf += (float)S[Sx.s_right] * Sx.a_right;
+                    rowbuf[dx][r] = buf;
                 }
             }
-            outv = sat_u8(sum);
+            __syncthreads();
+            if (threadIdx.x < dsz) {                                // vertical combine in source-row order
+                const int dx = threadIdx.x;
+                if (is_area_fast) {
+                    int sum = 0;
+                    for (int r = 0; r < nrows; r++) sum += irow[dx * 40 + r];
+                    PATCH[dy][dx] = sat_u8(sum * (1.f / (iscale * iscale)));
+                } else {
+                    float sum = 0; bool first = true;
+                    for (int r = 0; r < nrows; r++) {
+                        const int sy = rlo + r;
+                        const float beta = (sy == Sy.s_left) ? Sy.a_left : (sy == Sy.s_right && sy >= Sy.sx2) ? Sy.a_right : Sy.a_full;
+                        const float buf = rowbuf[dx][r];
+                        if (first) { sum = beta * buf; first = false; } else sum += beta * buf;
+                    }
+                    PATCH[dy][dx] = sat_u8(sum);
+                }
+            }
+            __syncthreads();
         }
-        PATCH[dy][dx] = outv;
     }
     __syncthreads();
     for (int o = threadIdx.x; o < 400; o += 256) {

@@ -76,7 +76,7 @@ class GridRegistrar:
         self.stats["attempts"] += len(jobs)
         self.stats["batches"] += 1
         if self.method == "surf":
-            rows = self.eng.attempt_surf_batch(jobs, self.params, self.searchRatio, self.offsetEvaluate)
+            rows = self._surf_batch(jobs)
             nq = rows[:, 4].astype(np.int64); nt = rows[:, 5].astype(np.int64)
             self.stats["sum_nq_nt"] += int((nq * nt).sum())
             self.stats["sum_nq_plus_nt"] += int((nq + nt).sum())
@@ -87,6 +87,29 @@ class GridRegistrar:
             # offset = [int(y), int(x)] (truncation); accepted when response > threshold (Stitcher.py:231-236)
             return [(bool(r[2] > self.phaseThr), int(r[1]), int(r[0]), 0) for r in rows]
         raise ValueError("method %r" % (self.method,))
+
+    def _surf_batch(self, jobs):
+        """Fused batch with an adaptive keypoint capacity: kernels are launched over capacity-sized grids (no host
+        sync inside a batch), so the capacity follows the largest ROI seen so far (x1.5 + 1024); an overflow falls
+        back to the library default (h*w/24 + 4096) and repeats the batch."""
+        cap = getattr(self, "_kp_cap", 0)
+        try:
+            rows = self.eng.attempt_surf_batch(jobs, self.params, self.searchRatio, self.offsetEvaluate)
+        except Exception:
+            if not cap:
+                raise
+            self._kp_cap = 0
+            self._kp_seen = 0
+            self.eng.set_keypoint_capacity(0)
+            rows = self.eng.attempt_surf_batch(jobs, self.params, self.searchRatio, self.offsetEvaluate)
+        if hasattr(self.eng, "set_keypoint_capacity") and len(rows):
+            seen = max(int(rows[:, 4:6].max()), getattr(self, "_kp_seen", 0))
+            self._kp_seen = seen
+            want = int(seen * 1.5) + 1024
+            if seen > 0 and want != cap and (cap == 0 or want > cap or want < cap * 0.6):
+                self._kp_cap = want
+                self.eng.set_keypoint_capacity(want)
+        return rows
 
     def _correct(self, raw, d, i, shapeA, shapeB):
         """Stitcher.py:352-360: ROI-relative vote -> full-tile offset."""
@@ -102,50 +125,79 @@ class GridRegistrar:
         return dx, dy
 
     # -- sequentially-equivalent chain over pairs [first, last) ------------------------------------------------------
-    def chain(self, handles, shapes, first, last, d_in, memo=None):
-        """-> (int32[last-first, 6], d_out).  memo: {(k, d): (row, d_next)} shared between chains."""
+    def chain(self, handles, shapes, first, last, d_in, memo=None, cache=None):
+        """-> (int32[last-first, 6], d_out).
+
+        An attempt is a pure function of (pair, direction, i), so WHICH attempts are evaluated together is free;
+        the result is always selected in the reference's candidate order.  What is batched is chosen by a small
+        predictor fed with the history of this chain: the length of the run of pairs that kept the direction
+        (shooting paths are serpentines: long run, turn, long run, ...) bounds the speculation window, a predicted
+        turn gets its whole first candidate ring in one batch, and the ring position that resolved the last turn
+        from the same incoming direction bounds the first resolve batch.
+        memo: {(k, d): (row, d_next)} and cache: {(k, d, i): attempt} may be shared between chains."""
         memo = {} if memo is None else memo
+        cache = {} if cache is None else cache
         out = np.zeros((last - first, RESULT_INTS), np.int32)
-        spec = {}
+
+        def evaluate(items):
+            todo = [it for it in dict.fromkeys(items) if it not in cache and it[0] < last]
+            if todo:
+                for it, r in zip(todo, self._attempts(handles, shapes, todo)):
+                    cache[it] = r
+
+        runs, run_len, slow, ring_hint = [], 0, 1, {}
         d = d_in
         k = first
         while k < last:
             if (k, d) in memo:
                 row, d_next = memo[(k, d)]
-                out[k - first] = row
-                d = d_next
-                k += 1
-                continue
-            if (k, d) not in spec:
-                spec.clear()
-                ks = [kk for kk in range(k, min(k + self.window, last)) if (kk, d) not in memo]
-                res = self._attempts(handles, shapes, [(kk, d, 1) for kk in ks])
-                for kk, r in zip(ks, res):
-                    spec[(kk, d)] = r
-            st, rdx, rdy, votes = spec.pop((k, d))
-            found = (d, 1, rdx, rdy, votes) if st else None
-            if found is None:
-                rings = self.rings(d)
-                rings[0] = rings[0][1:]
-                for ring in rings:
-                    if not ring:
-                        continue
-                    res = self._attempts(handles, shapes, [(k, dd, ii) for (dd, ii) in ring])
-                    for (dd, ii), (st2, a, b, v) in zip(ring, res):
-                        if st2:
-                            found = (dd, ii, a, b, v)
-                            break
-                    if found:
-                        break
-            if found:
-                dd, ii, a, b, v = found
-                dx, dy = self._correct((a, b), dd, ii, shapes[k], shapes[k + 1])
-                row = np.array([1, dx, dy, dd, ii, v], np.int32)
-                d_next = dd                       # self.direction = localDirection
             else:
-                row = np.array([0, 0, 0, d, 0, 0], np.int32)
-                d_next = d                        # a failed pair leaves self.direction untouched
-            memo[(k, d)] = (row, d_next)
+                rings = self.rings(d)
+                if (k, d, 1) not in cache:
+                    pred = runs[-2] if len(runs) >= 2 else None
+                    if pred is None:
+                        n = slow
+                    else:
+                        n = min(self.window, pred - run_len)
+                    if n >= 1:
+                        evaluate([(kk, d, 1) for kk in range(k, min(k + n, last)) if (kk, d) not in memo])
+                    else:                                     # a turn is predicted at pair k: its first ring at once
+                        h = ring_hint.get(d, len(rings[0]) - 1)
+                        evaluate([(k, dd, ii) for (dd, ii) in rings[0][:h + 1]])
+                    if (k, d, 1) not in cache:
+                        evaluate([(k, d, 1)])
+                found = None
+                for ri, ring in enumerate(rings):
+                    pos = 0
+                    while pos < len(ring) and found is None:
+                        if (k,) + ring[pos] not in cache:
+                            h = ring_hint.get(d, len(ring) - 1) if ri == 0 else len(ring) - 1
+                            stop = max(pos, min(h, len(ring) - 1))
+                            evaluate([(k,) + c for c in ring[pos:stop + 1]])
+                        st, a, b, v = cache[(k,) + ring[pos]]
+                        if st:
+                            found = ring[pos] + (a, b, v)
+                            if ri == 0:
+                                ring_hint[d] = pos
+                        pos += 1
+                    if found is not None:
+                        break
+                if found is not None:
+                    dd, ii, a, b, v = found
+                    dx, dy = self._correct((a, b), dd, ii, shapes[k], shapes[k + 1])
+                    row = np.array([1, dx, dy, dd, ii, v], np.int32)
+                    d_next = dd                       # self.direction = localDirection
+                else:
+                    row = np.array([0, 0, 0, d, 0, 0], np.int32)
+                    d_next = d                        # a failed pair leaves self.direction untouched
+                memo[(k, d)] = (row, d_next)
+            # predictor bookkeeping
+            if row[0] and d_next == d:
+                run_len += 1
+                slow = min(2 * slow, self.window)
+            elif row[0]:
+                runs.append(run_len)
+                run_len, slow = 1, 1
             out[k - first] = row
             d = d_next
             k += 1
@@ -171,10 +223,10 @@ class GridRegistrar:
         dirs = [direction] if (self.directIncre == 0 or rank == 0) else [1, 2, 3, 4]
         table = np.zeros((4, per, RESULT_INTS), np.int32)
         d_out = np.zeros(4, np.int32)
-        memo = {}
+        memo, cache = {}, {}
         for d_in in dirs:
             if hi > lo:
-                res, dn = self.chain(handles, shapes, lo, hi, d_in, memo)
+                res, dn = self.chain(handles, shapes, lo, hi, d_in, memo, cache)
                 table[d_in - 1, :hi - lo] = res
             else:
                 dn = d_in
