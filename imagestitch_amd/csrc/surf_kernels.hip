@@ -16,6 +16,15 @@
 // ---------------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------------
+// Pointers that travel through the RoiDev records in memory are generic ("flat") to the compiler: it would emit
+// flat_load/flat_store, which tick BOTH vmcnt and lgkmcnt (so they serialise against LDS traffic) and take the
+// aperture-check path.  Everything in a RoiDev is device global memory, so say so.
+#define GAS __attribute__((address_space(1)))
+typedef GAS const uint8_t *g_cu8;
+typedef GAS const int32_t *g_ci32;
+typedef GAS float *g_f32;
+typedef GAS const float *g_cf32;
+typedef GAS int32_t *g_i32;
 __device__ __forceinline__ int cv_round_f(float v) { return (int)rintf(v); }      // round-half-even
 __device__ __forceinline__ int cv_round_d(double v) { return (int)rint(v); }
 __device__ __forceinline__ int cv_floor_d(double v) { return (int)floor(v); }
@@ -43,12 +52,12 @@ __global__ __launch_bounds__(256) void k_integral_rows(const RoiDev *rois)
     const int y = blockIdx.x;
     if (y > R.h) return;
     const int sw = R.w + 1;
-    int32_t *out = R.sum + (size_t)y * sw;
+    g_i32 out = (g_i32)R.sum + (size_t)y * sw;
     if (y == 0) {                                   // row 0 of the integral is zero
         for (int x = threadIdx.x; x < sw; x += 256) out[x] = 0;
         return;
     }
-    const uint8_t *src = R.img + (size_t)(y - 1) * R.stride;
+    g_cu8 src = (g_cu8)R.img + (size_t)(y - 1) * R.stride;
     __shared__ int wsum[4];
     __shared__ int carry_s;
     if (threadIdx.x == 0) { carry_s = 0; out[0] = 0; }
@@ -91,17 +100,18 @@ __global__ __launch_bounds__(1024) void k_integral_cols(const RoiDev *rois)
     const int L = (R.h + 15) / 16;
     const int ya = 1 + seg * L;
     const int yb = min(ya + L, R.h + 1);
+    g_i32 S = (g_i32)R.sum;
     int s = 0;
     if (x < sw)
-        for (int y = ya; y < yb; y++) s += R.sum[(size_t)y * sw + x];
+        for (int y = ya; y < yb; y++) s += S[(size_t)y * sw + x];
     segsum[seg][threadIdx.x] = s;
     __syncthreads();
     if (x >= sw) return;
     int acc = 0;
     for (int k = 0; k < seg; k++) acc += segsum[k][threadIdx.x];
     for (int y = ya; y < yb; y++) {
-        acc += R.sum[(size_t)y * sw + x];
-        R.sum[(size_t)y * sw + x] = acc;
+        acc += S[(size_t)y * sw + x];
+        S[(size_t)y * sw + x] = acc;
     }
 }
 
@@ -120,7 +130,7 @@ int launch_integral(vfsms_ctx *ctx, const RoiDev *d_rois, int nrois, int maxh, i
 //   calcLayerDetAndTrace: box sums are int, each multiplied by its float weight as float, accumulated
 //   in double, cast to float; det = dx*dy - 0.81f*dxy*dxy.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float haar_box(const int32_t *__restrict__ sp, int sw, const LayerPat &P, int k0, int n)
+__device__ __forceinline__ float haar_box(g_ci32 sp, int sw, const LayerPat &P, int k0, int n)
 {
     double d = 0;
     for (int k = k0; k < k0 + n; k++) {
@@ -147,13 +157,13 @@ __global__ __launch_bounds__(256) void k_hessian(const RoiDev *rois, const Layer
     if (i >= samples_i || j >= samples_j) return;
     const int sw = R.w + 1;
     const int lcols = R.w / step;
-    const int32_t *sp = R.sum + (size_t)(i * step) * sw + j * step;
+    g_ci32 sp = (g_ci32)R.sum + (size_t)(i * step) * sw + j * step;
     float dx = haar_box(sp, sw, P, 0, 3);
     float dy = haar_box(sp, sw, P, 3, 3);
     float dxy = haar_box(sp, sw, P, 6, 4);
     size_t o = (size_t)(i + P.margin) * lcols + (j + P.margin);
-    R.det[li][o] = dx * dy - 0.81f * dxy * dxy;
-    R.trace[li][o] = dx + dy;
+    ((g_f32)R.det[li])[o] = dx * dy - 0.81f * dxy * dxy;
+    ((g_f32)R.trace[li])[o] = dx + dy;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -207,11 +217,11 @@ __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat 
     const int i = margin + blockIdx.y * 4 + threadIdx.y;
     if (i >= lrows - margin || j >= lcols - margin) return;
     if (pats[li + 1].size > R.h || pats[li + 1].size > R.w) return;   // upper layer not computed: nothing readable
-    const float *d2 = R.det[li] + (size_t)i * lcols + j;
+    g_cf32 d2 = (g_cf32)R.det[li] + (size_t)i * lcols + j;
     float val0 = d2[0];
     if (!(val0 > hessianThreshold)) return;
-    const float *d1 = R.det[li - 1] + (size_t)i * lcols + j;
-    const float *d3 = R.det[li + 1] + (size_t)i * lcols + j;
+    g_cf32 d1 = (g_cf32)R.det[li - 1] + (size_t)i * lcols + j;
+    g_cf32 d3 = (g_cf32)R.det[li + 1] + (size_t)i * lcols + j;
     const int st = lcols;
     float N9[3][9] = {
         { d1[-st - 1], d1[-st], d1[-st + 1], d1[-1], d1[0], d1[1], d1[st - 1], d1[st], d1[st + 1] },
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat 
     c.size = (float)size;
     c.response = val0;
     c.octave = octave;
-    float tr = R.trace[li][(size_t)i * lcols + j];
+    float tr = ((g_cf32)R.trace[li])[(size_t)i * lcols + j];
     c.class_id = (tr > 0) - (tr < 0);
     c.layer = li; c.i = i; c.j = j;
     const int ds = size - pats[li - 1].size;
@@ -333,7 +343,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)   // core atan
 }
 
 // resizeHaarPattern for the 4-unit gradient wavelets + calcHaarPattern (2 boxes)
-__device__ __forceinline__ float grad_haar(const int32_t *__restrict__ ptr, int sw, int gws, bool is_dx)
+__device__ __forceinline__ float grad_haar(g_ci32 ptr, int sw, int gws, bool is_dx)
 {
     // dx_s = {{0,0,2,4,-1},{2,0,4,4,1}}, dy_s = {{0,0,4,2,1},{0,2,4,4,-1}}
     const float ratio = (float)gws / 4;
@@ -375,7 +385,7 @@ __device__ void orientation_one(const RoiDev &R, const SurfTables *T, const int 
         int x = cv_round_f(kp.x + T->aptx[t] * s - (float)(gws - 1) / 2);
         int y = cv_round_f(kp.y + T->apty[t] * s - (float)(gws - 1) / 2);
         if (!(y < 0 || y >= srows - gws || x < 0 || x >= scols - gws)) {
-            const int32_t *ptr = R.sum + (size_t)y * sw + x;
+            g_ci32 ptr = (g_ci32)R.sum + (size_t)y * sw + x;
             float vx = grad_haar(ptr, sw, gws, true);
             float vy = grad_haar(ptr, sw, gws, false);
             float xx = vx * T->aptw[t], yy = vy * T->aptw[t];
@@ -418,10 +428,19 @@ __device__ void orientation_one(const RoiDev &R, const SurfTables *T, const int 
 //   cv::resize's three area paths.  Row origins (start_x/start_y) are running float sums in the
 //   reference, so lane 0 produces them sequentially into LDS first.
 // ---------------------------------------------------------------------------------------------------
-#define DESC_WBUF 28672           // LDS bytes for the staged descriptor window / band (37 rows x 739 px worst case)
+#ifdef VFSMS_DESC_TIMING
+__device__ unsigned long long g_desc_cycles[8];
+#define DT_MARK(ph) do { if (threadIdx.x == 0) { unsigned long long _n = clock64(); atomicAdd(&g_desc_cycles[ph], _n - _t0); _t0 = _n; } } while (0)
+#define DT_START unsigned long long _t0 = clock64()
+extern "C" int vfsms_debug_desc_cycles(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_desc_cycles), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -3; }
+#else
+#define DT_MARK(ph) do {} while (0)
+#define DT_START do {} while (0)
+#endif
+#define DESC_WBUF 16384           // LDS bytes for the staged descriptor window (win <= 128) / band chunk
 struct WinGeom {
     int win; float sin_dir, cos_dir;
-    int h, w, stride; const uint8_t *img;
+    int h, w, stride; g_cu8 img;
     int upright, usx, usy;            // upright: integer lattice origin (start_x, start_y)
 };
 
@@ -434,7 +453,7 @@ __device__ __forceinline__ int win_sample_xy(const WinGeom &G, double px, double
     const int ix = (int)px, iy = (int)py;                        // trunc; == floor when px, py >= 0
     if (px >= 0.0 && py >= 0.0 && ix < ncols1 && iy < nrows1) {
         const float a = (float)__builtin_amdgcn_fract(px), b = (float)__builtin_amdgcn_fract(py);
-        const uint8_t *p = G.img + (size_t)iy * G.stride + ix;
+        g_cu8 p = G.img + (size_t)iy * G.stride + ix;
         const float v = p[0] * (1.f - a) * (1.f - b) + p[1] * a * (1.f - b) + p[G.stride] * (1.f - a) * b + p[G.stride + 1] * a * b;
         return (int)(uint8_t)cv_round_f(v);
     }
@@ -485,21 +504,27 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
                 act[u] = rok && j < win;
                 px[u] = sxi + (double)j * c;
                 py[u] = syi - (double)j * sn;
-                inb[u] = px[u] >= 0.0 && py[u] >= 0.0 && (int)px[u] < ncols1 && (int)py[u] < nrows1;
+                // interior with 2 px of slack on the right: the fast path reads 4 bytes at (ix, iy) and (ix, iy+1)
+                inb[u] = px[u] >= 0.0 && py[u] >= 0.0 && (int)px[u] < ncols1 - 2 && (int)py[u] < nrows1;
                 all_in = all_in && (inb[u] || !act[u]);
             }
             if (__all(all_in)) {                                   // interior (the common case): branch-free gathers
-                uint8_t t00[STAGE_ILP], t01[STAGE_ILP], t10[STAGE_ILP], t11[STAGE_ILP];
+                // the gather path (one address per lane through the texture-address unit) is what bounds this kernel:
+                // the two horizontally adjacent taps of a row come from ONE unaligned dword load (2 loads / sample, not 4)
+                uint32_t top[STAGE_ILP], bot[STAGE_ILP];
 #pragma unroll
                 for (int u = 0; u < STAGE_ILP; u++) {
                     const int ix = act[u] ? (int)px[u] : 0, iy = act[u] ? (int)py[u] : 0;
-                    const uint8_t *p = G.img + (size_t)iy * G.stride + ix;
-                    t00[u] = p[0]; t01[u] = p[1]; t10[u] = p[G.stride]; t11[u] = p[G.stride + 1];
+                    g_cu8 p = G.img + (size_t)iy * G.stride + ix;
+                    top[u] = *(GAS const uint32_t *)p;          // unaligned dword gather (gfx950 global memory allows it)
+                    bot[u] = *(GAS const uint32_t *)(p + G.stride);
                 }
 #pragma unroll
                 for (int u = 0; u < STAGE_ILP; u++) {
                     const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
-                    const float v = t00[u] * (1.f - a) * (1.f - b) + t01[u] * a * (1.f - b) + t10[u] * (1.f - a) * b + t11[u] * a * b;
+                    const uint8_t t00 = (uint8_t)(top[u] & 0xff), t01 = (uint8_t)((top[u] >> 8) & 0xff);
+                    const uint8_t t10 = (uint8_t)(bot[u] & 0xff), t11 = (uint8_t)((bot[u] >> 8) & 0xff);
+                    const float v = t00 * (1.f - a) * (1.f - b) + t01 * a * (1.f - b) + t10 * (1.f - a) * b + t11 * a * b;
                     if (act[u]) drow[jb + u * 8 + lj] = (uint8_t)cv_round_f(v);
                 }
             } else {                                               // window crosses the image border: per-sample path
@@ -547,6 +572,7 @@ __device__ __forceinline__ float area_row(const uint8_t *S, const AreaSpan &Sx) 
 
 __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, int extended, int upright, int ablate)
 {
+    DT_START;
     vfsms_keypoint kp = R.kps[k];
     if (!(kp.size > 0)) return;                            // deleted by the orientation stage
     if (ablate == 1) return;
@@ -563,7 +589,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
     const float s = kp.size * 1.2f / 9.0f;
     WinGeom G;
     G.win = min((int)((20 + 1) * s), VFSMS_MAX_WIN);
-    G.h = R.h; G.w = R.w; G.stride = R.stride; G.img = R.img;
+    G.h = R.h; G.w = R.w; G.stride = R.stride; G.img = (g_cu8)R.img;
     G.upright = upright; G.usx = 0; G.usy = 0; G.sin_dir = 0.f; G.cos_dir = 0.f;
     const int win = G.win;
     const int dsz = 21;
@@ -598,6 +624,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
     if (!is_area_fast && threadIdx.x >= 128 && threadIdx.x < 128 + dsz) span_s[threadIdx.x - 128] = area_span(threadIdx.x - 128, win, scale);
     __syncthreads();
     if (!upright) { G.sin_dir = trig_s[0]; G.cos_dir = trig_s[1]; }
+    DT_MARK(0);
 
     // The rotated window is staged through LDS so that every bilinear sample is produced exactly once: the whole
     // window when it fits (win <= 169), otherwise one band of source rows per row of output cells.  The INTER_AREA
@@ -605,6 +632,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
     if (win * win <= DESC_WBUF) {
         stage_rows(G, sx_row, sy_row, 0, win, WINBUF);
         __syncthreads();
+        DT_MARK(1);
         for (int o = threadIdx.x; o < dsz * dsz; o += 256) {
             const int dy = o / dsz, dx = o % dsz;
             uint8_t outv;
@@ -633,6 +661,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
             }
             PATCH[dy][dx] = outv;
         }
+        DT_MARK(2);
     } else {
         int *irow = reinterpret_cast<int *>(&rowbuf[0][0]);
         for (int dy = 0; dy < dsz; dy++) {
@@ -644,20 +673,25 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
                 rhi = Sy.s_right >= 0 ? Sy.s_right : Sy.sx2 - 1;
             }
             const int nrows = rhi - rlo + 1;                       // <= scale + 2 <= 38
-            stage_rows(G, sx_row, sy_row, rlo, nrows, WINBUF);
-            __syncthreads();
-            for (int t = threadIdx.x; t < dsz * nrows; t += 256) {  // horizontal sums, one (cell column, source row) per lane
-                const int dx = t / nrows, r = t - dx * nrows;
-                const uint8_t *S = WINBUF + r * win;
-                if (is_area_fast) {
-                    int sum = 0;
-                    for (int sx = 0; sx < iscale; sx++) sum += S[dx * iscale + sx];
-                    irow[dx * 40 + r] = sum;
-                } else {
-                    rowbuf[dx][r] = area_row(S, span_s[dx]);
+            const int crows = max(DESC_WBUF / win, 1);             // band rows staged per chunk (>= 22 for win <= 739)
+            for (int c0 = 0; c0 < nrows; c0 += crows) {
+                const int cn = min(crows, nrows - c0);
+                stage_rows(G, sx_row, sy_row, rlo + c0, cn, WINBUF);
+                __syncthreads();
+                DT_MARK(3);
+                for (int t = threadIdx.x; t < dsz * cn; t += 256) { // horizontal sums, one (cell column, source row) per lane
+                    const int dx = t / cn, r = t - dx * cn;
+                    const uint8_t *S = WINBUF + r * win;
+                    if (is_area_fast) {
+                        int sum = 0;
+                        for (int sx = 0; sx < iscale; sx++) sum += S[dx * iscale + sx];
+                        irow[dx * 40 + c0 + r] = sum;
+                    } else {
+                        rowbuf[dx][c0 + r] = area_row(S, span_s[dx]);
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
             if (threadIdx.x < dsz) {                                // vertical combine in source-row order
                 const int dx = threadIdx.x;
                 if (is_area_fast) {
@@ -676,6 +710,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
                 }
             }
             __syncthreads();
+            DT_MARK(4);
         }
     }
     __syncthreads();
@@ -717,12 +752,13 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
     }
     __syncthreads();
     if (threadIdx.x < dsize) R.desc_raw[(size_t)k * dsize + threadIdx.x] = vec_s[threadIdx.x] * scale_s;
+    DT_MARK(5);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Persistent scheduling for the descriptor kernel.  The number of keypoints of each ROI only exists on the device
 // (no host sync inside a batch), so instead of launching a capacity-sized grid -- mostly workgroups that find
-// nothing to do, each still paying a 42 KB LDS allocation -- 3 resident workgroups per CU draw (ROI, keypoint)
+// nothing to do, each still paying a 30 KB LDS allocation -- 4 resident workgroups per CU draw (ROI, keypoint)
 // tickets from one atomic counter over the concatenation of all ROIs' keypoint lists (prefix sums of the
 // device-side counts, rebuilt per workgroup in LDS).  Window cost varies 100x between keypoints, so dynamic
 // tickets matter: static striding measured 45 % slower, 4-ticket chunks 20 % slower.
@@ -934,7 +970,7 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
         ProfScope ps(ctx, "describe");
         // ticket counter: counters[9] of ROI 0 (zeroed with the other counters by launch_surf_detect)
         static int ablate = getenv("VFSMS_DESC_ABLATE") ? atoi(getenv("VFSMS_DESC_ABLATE")) : 0;
-        hipLaunchKernelGGL(k_describe, dim3(256 * 3), dim3(256), 0, ctx->stream, d_rois, nrois, h_rois[0].counters + 9,
+        hipLaunchKernelGGL(k_describe, dim3(256 * 4), dim3(256), 0, ctx->stream, d_rois, nrois, h_rois[0].counters + 9,
                            ctx->d_tables, p->extended, p->upright, ablate);
     }
     {

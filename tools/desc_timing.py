@@ -1,0 +1,24 @@
+"""Debug: phase cycle counters of describe_one (library built with -DVFSMS_DESC_TIMING)."""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from imagestitch_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvfsms_timing.so")
+import imagestitch_amd as isa
+from imagestitch_amd.synthetic import SyntheticGrid
+eng = isa.Engine(0)
+g = SyntheticGrid(10, 9, 2048)
+N = 8
+tiles = g.tiles(range(N + 1)); hs = [eng.tile_upload(t) for t in tiles]
+ra = isa.roi_rect(tiles[0].shape, 1, "first", 0.2); rb = isa.roi_rect(tiles[0].shape, 1, "second", 0.2)
+jobs = [(hs[k], hs[k + 1], ra[0], ra[1], rb[0], rb[1], ra[2], ra[3]) for k in range(N)]
+rows = eng.attempt_surf_batch(jobs); eng.set_keypoint_capacity(int(rows[:, 4:6].max() * 1.5) + 1024)
+out0 = np.zeros(8, np.uint64); eng.lib.vfsms_debug_desc_cycles(out0.ctypes.data_as(ctypes.c_void_p))
+rows = eng.attempt_surf_batch(jobs)
+out = np.zeros(8, np.uint64); eng.lib.vfsms_debug_desc_cycles(out.ctypes.data_as(ctypes.c_void_p))
+d = (out - out0).astype(np.float64)
+nk = rows[:, 4:6].sum()
+names = ["prologue", "stageA", "outputsA", "stageB", "outputsB", "descriptor"]
+print("keypoints", nk, "total block-cycles %.3g (clock64 ticks)" % d.sum())
+for n, v in zip(names, d[:6]):
+    print("  %-10s %6.1f %%   %.0f ticks/keypoint" % (n, 100 * v / d.sum(), v / nk))
