@@ -16,8 +16,8 @@ _SO = os.path.join(_HERE, "_build", "libvfsms_oracle.so")
 
 def build(force=False):
     """Compile the oracle with gcc (recipe: oracle/Makefile)."""
-    src = os.path.join(_HERE, "vfsms_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("vfsms_oracle.c", "vfsms_oracle_orb.c", "vfsms_oracle.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
 
@@ -52,6 +52,9 @@ def lib():
         L.orc_mode_offset.argtypes = [vp, vp, vp, i32, i32, vp]; L.orc_mode_offset.restype = None
         L.orc_phase_correlate_u8.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]; L.orc_phase_correlate_u8.restype = None
         L.orc_fuse_fade.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]; L.orc_fuse_fade.restype = None
+        L.orc_orb_detect_describe.argtypes = [vp, i32, i32, i32, i32, C.c_float, i32, i32, i32, i32, i32, vp, vp, i32]
+        L.orc_orb_detect_describe.restype = i32
+        L.orc_orb_pattern.argtypes = [i32, i32, vp]; L.orc_orb_pattern.restype = None
         L.orc_corner_ramps.argtypes = [vp, i32, i32, i32, vp, vp, vp]; L.orc_corner_ramps.restype = i32
         _lib = L
     return _lib
@@ -193,3 +196,24 @@ def fuse_fade(A, B, dx, dy, return_info=False):
     if info[0] < 0:
         raise IndexError("reference getWeightsMatrix would raise on this input")
     return (out, info) if return_info else out
+
+
+def orb_pattern(patch_size=31, npoints=512):
+    xy = np.zeros((npoints, 2), np.int32)
+    lib().orc_orb_pattern(int(patch_size), int(npoints), _p(xy))
+    return xy
+
+
+def orb_detect_describe(img, nfeatures=5000, scale_factor=1.2, nlevels=8, edge_threshold=31, first_level=0,
+                        patch_size=31, fast_threshold=20, cap=None):
+    """cv2.ORB_create(...).detectAndCompute(img, None) -> (keypoint records, uint8[N,32])  (ImageUtility.py:260,262)."""
+    img = _u8_2d(img)
+    h, w = img.shape
+    cap = cap or (2 * nfeatures + 4096)
+    kps = np.zeros(cap, KP_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    n = lib().orc_orb_detect_describe(_p(img), h, w, img.strides[0], nfeatures, float(scale_factor), nlevels, edge_threshold,
+                                      first_level, patch_size, fast_threshold, _p(kps), _p(desc), cap)
+    if n < 0:
+        raise RuntimeError("oracle orb: capacity exceeded")
+    return kps[:n].copy(), desc[:n].copy()

@@ -92,6 +92,15 @@ void orc_fuse_fade(int64_t *A, const int64_t *B, int r, int c, int ch, int dx, i
 /* ImageFusion.getWeightsMatrix (ImageFusion.py:43-190): weightMatB = wB_r (x) wB_c, weightMatA = 1 - weightMatB. */
 int orc_corner_ramps(const int64_t *A, int r, int c, int ch, float *wB_r, float *wB_c, int32_t *info);
 
+/* cv2.ORB_create(nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, 2, HARRIS_SCORE, patchSize, fastThreshold)
+ * .detectAndCompute(image, None)  (ImageUtility.py:260,262; vfsms_oracle_orb.c states two deviations from upstream).
+ * kps: x, y (level-0 coordinates), size = patchSize*scale, angle, response (Harris), octave; desc: uint8 [cap][32]. */
+int orc_orb_detect_describe(const uint8_t *image, int h, int w, int stride,
+                            int nfeatures, float scaleFactor, int nlevels, int edgeThreshold, int firstLevel,
+                            int patchSize, int fastThreshold, orc_keypoint *kps, uint8_t *desc, int cap);
+/* orb.cpp makeRandomPattern(patchSize, pattern, npoints): xy = int32[npoints][2] */
+void orc_orb_pattern(int patchSize, int npoints, int32_t *xy);
+
 #ifdef __cplusplus
 }
 #endif
