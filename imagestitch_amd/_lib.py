@@ -24,6 +24,12 @@ class SurfParams(C.Structure):
                 ("extended", C.c_int32), ("upright", C.c_int32)]
 
 
+class OrbParams(C.Structure):
+    _fields_ = [("n_features", C.c_int32), ("scale_factor", C.c_float), ("n_levels", C.c_int32), ("edge_threshold", C.c_int32),
+                ("first_level", C.c_int32), ("wta_k", C.c_int32), ("score_type", C.c_int32), ("patch_size", C.c_int32),
+                ("fast_threshold", C.c_int32)]
+
+
 class RoiPair(C.Structure):
     _fields_ = [("tile_a", C.c_int64), ("tile_b", C.c_int64),
                 ("ay0", C.c_int32), ("ax0", C.c_int32), ("by0", C.c_int32), ("bx0", C.c_int32),
@@ -53,6 +59,9 @@ _SIGNATURES = {
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "vfsms_surf_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(SurfParams),
                                     C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "vfsms_orb_detect_describe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(OrbParams),
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "vfsms_attempt_orb_batch": (C.c_int, [C.c_void_p, C.POINTER(RoiPair), C.c_int, C.POINTER(OrbParams), C.c_int, C.c_int, C.c_void_p]),
     "vfsms_bf_l2_knn2_ratio": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double,
                                          C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "vfsms_bf_l2_knn2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
@@ -221,6 +230,38 @@ class Engine:
         self._check(self.lib.vfsms_surf_detect(self.ctx, _ptr(img), h, w, img.strides[0], C.byref(params),
                                                _ptr(kfull), cap, C.byref(n)))
         return kfull[:n.value].copy()
+
+    @staticmethod
+    def orb_params(nfeatures=5000, scale_factor=1.2, nlevels=8, edge_threshold=31, first_level=0, wta_k=2, score_type=0,
+                   patch_size=31, fast_threshold=20):
+        return OrbParams(int(nfeatures), float(scale_factor), int(nlevels), int(edge_threshold), int(first_level), int(wta_k),
+                         int(score_type), int(patch_size), int(fast_threshold))
+
+    def orb_detect_describe(self, img, params=None, cap=None, full=False):
+        img = _u8_2d(img)
+        h, w = img.shape
+        params = params or self.orb_params()
+        cap = cap or (2 * params.n_features + 2048)
+        kxy = np.empty((cap, 2), np.float32)
+        desc = np.empty((cap, 32), np.uint8)
+        kfull = np.empty(cap, KP_DTYPE) if full else None
+        n = C.c_int()
+        self._check(self.lib.vfsms_orb_detect_describe(self.ctx, _ptr(img), h, w, img.strides[0], C.byref(params),
+                                                       _ptr(kxy), _ptr(desc), _ptr(kfull), cap, C.byref(n)))
+        n = n.value
+        if full:
+            return kxy[:n].copy(), desc[:n].copy(), kfull[:n].copy()
+        return kxy[:n].copy(), desc[:n].copy()
+
+    def attempt_orb_batch(self, jobs, params=None, max_dist=-1, offset_evaluate=3):
+        n = len(jobs)
+        out = np.zeros((n, ATTEMPT_INTS), np.int32)
+        if n == 0:
+            return out
+        arr = jobs if isinstance(jobs, C.Array) else self.make_jobs(jobs)
+        params = params or self.orb_params()
+        self._check(self.lib.vfsms_attempt_orb_batch(self.ctx, arr, n, C.byref(params), int(max_dist), int(offset_evaluate), _ptr(out)))
+        return out
 
     def bf_l2_ratio_matches(self, q, t, ratio=0.75):
         q = np.ascontiguousarray(q, np.float32); t = np.ascontiguousarray(t, np.float32)

@@ -204,7 +204,7 @@ extern "C" int vfsms_ctx_create(int device, vfsms_ctx **out)
     c->device = device; c->arena = nullptr; c->arena_size = 0; c->arena_off = 0;
     c->pinned = nullptr; c->pinned_size = 0; c->kp_cap_override = 0;
     c->tables_valid = false; c->d_layers = nullptr; c->d_tables = nullptr; c->n_layers = 0; c->next_handle = 1;
-    c->prof_on = false;
+    c->prof_on = false; c->orb_valid = false; c->d_orb_tables = nullptr;
     memset(&c->cur_params, 0, sizeof(c->cur_params));
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { vfsms_set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete c; return VFSMS_ERR_HIP; }
@@ -227,6 +227,7 @@ extern "C" int vfsms_ctx_destroy(vfsms_ctx *ctx)
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->d_layers) hipFree(ctx->d_layers);
     if (ctx->d_tables) hipFree(ctx->d_tables);
+    if (ctx->d_orb_tables) hipFree(ctx->d_orb_tables);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return VFSMS_OK;
@@ -726,5 +727,89 @@ extern "C" int vfsms_canvas_download(vfsms_ctx *ctx, int64_t canvas, uint8_t *ou
     // never-written pixels are still 0 (the canvas is zero-initialised), exactly Stitcher.py:485
     HIP_TRY(hipMemcpyAsync(out, cv.pix, (size_t)cv.rows * cv.cols * cv.ch, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VFSMS_OK;
+}
+
+// ---- ORB -------------------------------------------------------------------------------------------------------------------------
+static void orb_caps(const vfsms_orb_params *p, int *cap1, int *cap2, int *cap)
+{
+    // level-0 quota bounds every level; FAST scores are integers, so ties can exceed 2 x quota -- leave generous room
+    const float factor = 1.f / p->scale_factor;
+    const int q0 = (int)lrintf(p->n_features * (1 - factor) / (1 - powf(factor, (float)p->n_levels)));
+    *cap1 = 4 * q0 + 2048; *cap2 = 2 * q0 + 1024; *cap = 2 * p->n_features + 2048;
+}
+
+extern "C" int vfsms_orb_detect_describe(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride,
+                                         const vfsms_orb_params *params, float *kps_xy, uint8_t *desc,
+                                         vfsms_keypoint *kps_full, int cap, int *n_out)
+{
+    CTX_ENTER(ctx);
+    if (!img || !params || !n_out || h <= 0 || w <= 0 || stride < w || cap < 0) { vfsms_set_error("orb: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    TRY(ctx_prepare_orb(ctx, params));
+    int c1, c2, c;
+    orb_caps(params, &c1, &c2, &c);
+    TRY(ctx_arena_reserve(ctx, (size_t)h * w + orb_roi_bytes(params, h, w, c1, c2, c) + 65536));
+    uint8_t *d_img;
+    TRY(upload_image(ctx, img, h, w, stride, &d_img));
+    OrbDev R;
+    TRY(orb_roi_carve(ctx, &R, d_img, w, h, w, params, c1, c2, c));
+    OrbDev *dR;
+    TRY(upload_array(ctx, &R, 1, &dR));
+    TRY(launch_orb(ctx, dR, &R, 1, params));
+    int counters[16];
+    HIP_TRY(hipMemcpyAsync(counters, R.counters, sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (counters[2]) { vfsms_set_error("orb: internal keypoint capacity exceeded"); return VFSMS_ERR_CAPACITY; }
+    const int n = counters[1];
+    *n_out = n;
+    if (n > cap) { vfsms_set_error("orb: %d keypoints exceed the caller's capacity %d", n, cap); return VFSMS_ERR_CAPACITY; }
+    if (n > 0) {
+        if (kps_xy) HIP_TRY(hipMemcpyAsync(kps_xy, R.kps_xy, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+        if (desc) HIP_TRY(hipMemcpyAsync(desc, R.desc, (size_t)32 * n, hipMemcpyDeviceToHost, ctx->stream));
+        if (kps_full) HIP_TRY(hipMemcpyAsync(kps_full, R.kps_out, sizeof(vfsms_keypoint) * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return VFSMS_OK;
+}
+
+extern "C" int vfsms_attempt_orb_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n,
+                                       const vfsms_orb_params *params, int max_dist, int offset_evaluate, int32_t *out)
+{
+    CTX_ENTER(ctx);
+    if (n < 0 || (n && (!jobs || !out)) || !params) { vfsms_set_error("attempt_orb: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    if (n == 0) return VFSMS_OK;
+    TRY(ctx_prepare_orb(ctx, params));
+    int c1, c2, c;
+    orb_caps(params, &c1, &c2, &c);
+    size_t need = 0;
+    for (int k = 0; k < n; k++) need += 2 * orb_roi_bytes(params, jobs[k].h, jobs[k].w, c1, c2, c) + match_bytes(c, 1);
+    need += (sizeof(OrbDev) * 2 + sizeof(MatchDev)) * n + 65536;
+    TRY(ctx_arena_reserve(ctx, need));
+    std::vector<OrbDev> R(2 * n);
+    std::vector<MatchDev> M(n);
+    for (int k = 0; k < n; k++) {
+        const uint8_t *pa, *pb; int sa, sb;
+        TRY(resolve_job(ctx, jobs[k], &pa, &sa, &pb, &sb));
+        TRY(orb_roi_carve(ctx, &R[2 * k], pa, sa, jobs[k].h, jobs[k].w, params, c1, c2, c));
+        TRY(orb_roi_carve(ctx, &R[2 * k + 1], pb, sb, jobs[k].h, jobs[k].w, params, c1, c2, c));
+        memset(&M[k], 0, sizeof(MatchDev));
+        TRY(match_carve(ctx, &M[k], c, 32, 1));
+        M[k].q = (const float *)R[2 * k].desc; M[k].t = (const float *)R[2 * k + 1].desc;
+        M[k].nq_ptr = R[2 * k].counters + 1; M[k].nt_ptr = R[2 * k + 1].counters + 1;
+        M[k].kq = R[2 * k].kps_xy; M[k].kt = R[2 * k + 1].kps_xy;
+    }
+    OrbDev *dR; MatchDev *dM;
+    TRY(upload_array(ctx, R.data(), (size_t)2 * n, &dR));
+    TRY(upload_array(ctx, M.data(), (size_t)n, &dM));
+    TRY(launch_orb(ctx, dR, R.data(), 2 * n, params));
+    TRY(launch_hamming_mode(ctx, dM, n, c, max_dist, offset_evaluate));
+    std::vector<int> counters((size_t)16 * 2 * n);
+    for (int k = 0; k < 2 * n; k++)
+        HIP_TRY(hipMemcpyAsync(&counters[(size_t)16 * k], R[k].counters, 16 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    for (int k = 0; k < n; k++)
+        HIP_TRY(hipMemcpyAsync(out + (size_t)VFSMS_ATTEMPT_INTS * k, M[k].result, VFSMS_ATTEMPT_INTS * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 2 * n; k++)
+        if (counters[(size_t)16 * k + 2]) { vfsms_set_error("attempt_orb: internal keypoint capacity exceeded in ROI %d", k); return VFSMS_ERR_CAPACITY; }
     return VFSMS_OK;
 }

@@ -64,6 +64,24 @@ struct RoiDev {
     vfsms_keypoint *kps_out;          // compacted
 };
 
+// ---- ORB working set of one ROI --------------------------------------------------------------------------
+#define VFSMS_ORB_MAX_LEVELS 8
+struct OrbDev {
+    int h, w;
+    uint8_t *lv[VFSMS_ORB_MAX_LEVELS]; int ls[VFSMS_ORB_MAX_LEVELS];      // pyramid level images + row strides (level 0 = the ROI itself)
+    int lw[VFSMS_ORB_MAX_LEVELS], lh[VFSMS_ORB_MAX_LEVELS]; float lscale[VFSMS_ORB_MAX_LEVELS];
+    uint8_t *bl[VFSMS_ORB_MAX_LEVELS];                                    // blurred levels (descriptor sampling)
+    uint8_t *score[VFSMS_ORB_MAX_LEVELS]; uint8_t *nms[VFSMS_ORB_MAX_LEVELS];
+    int *hist;                        // [levels][256] FAST score histogram of NMS survivors
+    int *counters;                    // [1] keypoints, [2] overflow; thr1 / n1 / n2 live in the same block
+    int *thr1; int *n1; int *n2;
+    int cap1, cap2, cap;
+    int *k1_xy; float *k1_resp;       // per level: survivors of the FAST-score cut (+ Harris response)
+    int *k2_xy; float *k2_resp; float *k2_angle;   // per level: final keypoints
+    float *kps_xy; uint8_t *desc; vfsms_keypoint *kps_out;                // level-major final arrays
+};
+struct OrbTables { int nfeat[VFSMS_ORB_MAX_LEVELS]; int umax[34]; int half_patch; int patch_size; int kf[7]; int pattern[1024]; };
+
 // ---- one (query ROI, train ROI) matching job --------------------------------------------------------
 struct MatchDev {
     const float *q; const float *t;   // descriptors
@@ -101,6 +119,7 @@ struct vfsms_ctx {
     vfsms_surf_params cur_params; bool tables_valid;
     LayerPat *d_layers; int n_layers;
     SurfTables *d_tables;
+    vfsms_orb_params cur_orb; bool orb_valid; OrbTables *d_orb_tables;
     std::unordered_map<int64_t, TileRec> tiles;
     std::unordered_map<int64_t, CanvasRec> canvases;
     int64_t next_handle;
@@ -146,6 +165,14 @@ int launch_ratio_mode(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int cap
 int launch_mode_only(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capm, int offset_evaluate);
 int launch_bf_hamming(vfsms_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int nbytes,
                       int *best_idx, int *best_dist);
+int launch_scan_mode(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int offset_evaluate);
+// orb_kernels.hip
+int ctx_prepare_orb(vfsms_ctx *ctx, const vfsms_orb_params *p);
+size_t orb_roi_bytes(const vfsms_orb_params *p, int h, int w, int cap1, int cap2, int cap);
+int orb_roi_carve(vfsms_ctx *ctx, OrbDev *r, const uint8_t *img, int stride, int h, int w, const vfsms_orb_params *p,
+                  int cap1, int cap2, int cap);
+int launch_orb(vfsms_ctx *ctx, const OrbDev *d_rois, const OrbDev *h_rois, int nrois, const vfsms_orb_params *p);
+int launch_hamming_mode(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int max_dist, int offset_evaluate);
 // phase_kernels.hip
 int phase_correlate_device(vfsms_ctx *ctx, const uint8_t *a, int stride_a, const uint8_t *b, int stride_b,
                            int h, int w, double *d_out3);

@@ -383,6 +383,18 @@ int launch_merge_only(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int cap
     return VFSMS_OK;
 }
 
+// flags / votes already written per query (Hamming matcher): compaction + mode vote
+int launch_scan_mode(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int offset_evaluate)
+{
+    if (njobs <= 0) return VFSMS_OK;
+    ProfScope ps(ctx, "vote");
+    hipLaunchKernelGGL(k_match_scan, dim3(njobs), dim3(1024), 0, ctx->stream, d_jobs);
+    hipLaunchKernelGGL(k_mode_count, dim3((capq + 255) / 256, njobs), dim3(256), 0, ctx->stream, d_jobs);
+    hipLaunchKernelGGL(k_mode_final, dim3((njobs + 63) / 64), dim3(64), 0, ctx->stream, d_jobs, njobs, offset_evaluate);
+    HIP_TRY(hipGetLastError());
+    return VFSMS_OK;
+}
+
 int launch_mode_only(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capm, int offset_evaluate)
 {
     if (njobs <= 0) return VFSMS_OK;

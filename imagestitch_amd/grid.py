@@ -82,6 +82,9 @@ class GridRegistrar:
             self.stats["sum_nq_plus_nt"] += int((nq + nt).sum())
             self.stats["sum_nq"] += int(nq.sum())
             return [(bool(r[0]) and r[4] > 0 and r[5] > 0, int(r[1]), int(r[2]), int(r[3])) for r in rows]
+        if self.method == "orb":
+            rows = self.eng.attempt_orb_batch(jobs, self.params, getattr(self, "orbMaxDistance", -1), self.offsetEvaluate)
+            return [(bool(r[0]) and r[4] > 0 and r[5] > 0, int(r[1]), int(r[2]), int(r[3])) for r in rows]
         if self.method == "phase":
             rows = self.eng.attempt_phase_batch(jobs)
             # offset = [int(y), int(x)] (truncation); accepted when response > threshold (Stitcher.py:231-236)

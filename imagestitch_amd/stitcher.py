@@ -192,7 +192,7 @@ class Stitcher(Utility.Method):
         c = type(self)
         return (c.detectAndDescribe is Utility.Method.detectAndDescribe and c.matchDescriptors is Utility.Method.matchDescriptors
                 and c.getOffsetByMode is Utility.Method.getOffsetByMode and not self.isEnhance
-                and self.featureMethod == "surf" and self.offsetCaculate == "mode")
+                and self.featureMethod in ("surf", "orb") and self.offsetCaculate == "mode")
 
     def _featureAttempt(self, imageA, imageB, direction, searchRatio):
         """One pass of the loop body at Stitcher.py:322-345 -> (status, [dx, dy]) or None when an image has no features."""
@@ -201,7 +201,11 @@ class Stitcher(Utility.Method):
             rb = roi_rect(imageB.shape, direction, "second", searchRatio)
             if ra[2:] == rb[2:] and ra[2] > 0 and ra[3] > 0:
                 job = (self._tileHandle(imageA), self._tileHandle(imageB), ra[0], ra[1], rb[0], rb[1], ra[2], ra[3])
-                row = self.engine.attempt_surf_batch([job], self._surfParams(), self.searchRatio, self.offsetEvaluate)[0]
+                if self.featureMethod == "orb":
+                    max_dist = self.orbMaxDistance if self.isGPUAvailable else -1
+                    row = self.engine.attempt_orb_batch([job], self._orbParams(), max_dist, self.offsetEvaluate)[0]
+                else:
+                    row = self.engine.attempt_surf_batch([job], self._surfParams(), self.searchRatio, self.offsetEvaluate)[0]
                 if row[4] == 0 or row[5] == 0:
                     return None                      # featuresA is None or featuresB is None: status untouched
                 return (bool(row[0]), [int(row[1]), int(row[2])])

@@ -142,6 +142,12 @@ class Method():
                                            self.surfIsExtended, self.surfIsUpright)
         return self.engine.surf_params()      # cv2.xfeatures2d.SURF_create() defaults (ImageUtility.py:258)
 
+    def _orbParams(self):
+        """cv2.ORB_create(orbNfeatures, orbScaleFactor, orbNlevels, orbEdgeThreshold, orbFirstLevel, orbWTA_K, 0, orbPatchSize,
+        orbFastThreshold) -- ImageUtility.py:260 (both backends of the reference pass the same Method.orb* attributes)."""
+        return self.engine.orb_params(self.orbNfeatures, self.orbScaleFactor, self.orbNlevels, self.orbEdgeThreshold,
+                                      self.orbFirstLevel, self.orbWTA_K, 0, self.orbPatchSize, self.orbFastThreshold)
+
     def detectAndDescribe(self, image, featureMethod):
         """ImageUtility.py:248-276 -> (kps float32[N,2] of (x, y), features float32[N,D] or None)."""
         if featureMethod == "surf":
@@ -150,7 +156,10 @@ class Method():
                 return (np.float32([]), None)      # cv2 returns ([], None) for an image without keypoints
             return (kps, feats)
         if featureMethod == "orb":
-            raise NotImplementedError("ORB detect+describe is not built yet in libvfsms (SURVEY section 7.1 step 9)")
+            kps, feats = self.engine.orb_detect_describe(np.asarray(image), self._orbParams())
+            if len(kps) == 0:
+                return (np.float32([]), None)
+            return (kps, feats)
         raise NotImplementedError("featureMethod %r is outside the VFSMS hot path (sift is CPU-only in the reference too)" % (featureMethod,))
 
     def matchDescriptors(self, featuresA, featuresB):

@@ -54,6 +54,15 @@ typedef struct {
     int32_t upright;
 } vfsms_surf_params;
 
+/* ORB parameters: cv2.ORB_create(nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, WTA_K, scoreType, patchSize,
+ * fastThreshold) as built at ImageUtility.py:260 from Method.orb* (ImageUtility.py:30-39): {5000, 1.2, 8, 31, 0, 2, 0, 31, 20}.
+ * Supported: first_level 0, wta_k 2, score_type 0 (HARRIS), n_levels <= 8, patch_size <= 31.                                */
+typedef struct {
+    int32_t n_features;
+    float scale_factor;
+    int32_t n_levels, edge_threshold, first_level, wta_k, score_type, patch_size, fast_threshold;
+} vfsms_orb_params;
+
 /* One ROI attempt of the incremental search (Stitcher.py:319-351): ROI rectangles inside two
  * device-resident tiles, as Method.getROIRegionForIncreMethod (ImageUtility.py:66-101) slices them. */
 typedef struct {
@@ -107,6 +116,12 @@ int vfsms_surf_detect_describe(vfsms_ctx *ctx, const uint8_t *img, int h, int w,
 int vfsms_surf_detect(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride,
                       const vfsms_surf_params *params, vfsms_keypoint *kps_full, int cap, int *n_out);
 
+/* replaces myGpuFeatures.detectAndDescribeByOrb (appendix/myGpuFeatures.cpp:106-146) and cv2 ORB detectAndCompute
+ * (ImageUtility.py:260,262).  kps_xy: float32[cap][2]; desc: uint8[cap][32]; kps_full optional.                   */
+int vfsms_orb_detect_describe(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride,
+                              const vfsms_orb_params *params,
+                              float *kps_xy, uint8_t *desc, vfsms_keypoint *kps_full, int cap, int *n_out);
+
 /* replaces myGpuFeatures.matchDescriptors(featureType 1|2, param=ratio) (appendix/myGpuFeatures.cpp:160-173)
  * and BFMatcher("BruteForce").knnMatch(k=2) + ratio filter (ImageUtility.py:288-296).
  * pairs: int32[cap][2] = (trainIdx, queryIdx) in query order.                                     */
@@ -147,6 +162,9 @@ int vfsms_fuse_ramps_i64(vfsms_ctx *ctx, const int64_t *A, int r, int c, int ch,
 int vfsms_attempt_surf_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n,
                              const vfsms_surf_params *params, double ratio, int offset_evaluate,
                              int32_t *out);
+/* same with ORB + BF-Hamming 1-NN (max_dist < 0: no distance threshold, the cv2 path; else distance < max_dist, the DLL path) */
+int vfsms_attempt_orb_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n,
+                            const vfsms_orb_params *params, int max_dist, int offset_evaluate, int32_t *out);
 /* same for phase correlation (Stitcher.py:224-235): out: double[n][3] = {x, y, response}           */
 int vfsms_attempt_phase_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, double *out);
 

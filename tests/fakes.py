@@ -26,6 +26,17 @@ class OracleEngine:
                                            bool(p.extended), bool(p.upright))
         return np.stack([k["x"], k["y"]], 1).astype(np.float32).reshape(-1, 2), d
 
+    @staticmethod
+    def orb_params(*a, **k):
+        return None
+
+    def orb_detect_describe(self, img, params=None, cap=None, full=False):
+        k, d = self.O.orb_detect_describe(np.ascontiguousarray(img))
+        return np.stack([k["x"], k["y"]], 1).astype(np.float32).reshape(-1, 2), d
+
+    def bf_hamming_matches(self, q, t, max_dist=-1):
+        return self.O.bf_hamming_matches(q, t, max_dist)[0]
+
     def bf_l2_ratio_matches(self, q, t, ratio=0.75):
         return self.O.bf_l2_ratio_matches(q, t, ratio)
 

@@ -179,3 +179,46 @@ def test_incremental_search_end_to_end_on_synthetic_grid(engine):
         status, off = s.calculateOffsetForFeatureSearchIncre([tiles[k], tiles[k + 1]])
         assert status and abs(off[0] - truth[0]) <= 1 and abs(off[1] - truth[1]) <= 1, (k, off, truth)
     assert s.direction == g.true_directions()[-1]
+
+
+def test_orb_bit_exact_vs_oracle(engine, oracle, strips):
+    g, tiles = strips
+    for img in (np.ascontiguousarray(tiles[0][-128:, :]), tiles[1][:, :128], _rand_img(8, (150, 200)), np.full((100, 100), 7, np.uint8)):
+        kxy, desc, kfull = engine.orb_detect_describe(img, full=True)
+        ko, do = oracle.orb_detect_describe(np.ascontiguousarray(img))
+        assert len(kfull) == len(ko), (img.shape, len(kfull), len(ko))
+        if len(ko) == 0:
+            continue
+        for f in ("x", "y", "size", "angle", "response", "octave"):
+            assert np.array_equal(kfull[f], ko[f]), f
+        assert np.array_equal(kxy, np.stack([ko["x"], ko["y"]], 1))
+        same = (desc == do).all(1)
+        print("orb descriptor rows bit-identical: %.4f" % same.mean())
+        assert same.mean() > 0.999                                       # cos/sin of the angle: OCML vs glibc double, rounded to float
+    p = engine.orb_params(nfeatures=300, nlevels=4)
+    kxy, desc, kfull = engine.orb_detect_describe(np.ascontiguousarray(tiles[0][-128:, :]), p, full=True)
+    ko, do = oracle.orb_detect_describe(np.ascontiguousarray(tiles[0][-128:, :]), nfeatures=300, nlevels=4)
+    assert np.array_equal(kfull["x"], ko["x"]) and np.array_equal(desc, do)
+
+
+def test_orb_fused_attempt_and_exact_truth(engine, oracle, strips):
+    g, tiles = strips
+    for k, (truth, d) in enumerate(zip(g.true_offsets(), g.true_directions())):
+        A, B = tiles[k], tiles[k + 1]
+        ra = isa.roi_rect(A.shape, d, "first", 0.2); rb = isa.roi_rect(B.shape, d, "second", 0.2)
+        ha, hb = engine.tile_upload(A), engine.tile_upload(B)
+        row = engine.attempt_orb_batch([(ha, hb, ra[0], ra[1], rb[0], rb[1], ra[2], ra[3])])[0]
+        engine.tile_free(ha); engine.tile_free(hb)
+        roiA = np.ascontiguousarray(A[ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]])
+        roiB = np.ascontiguousarray(B[rb[0]:rb[0] + rb[2], rb[1]:rb[1] + rb[3]])
+        ka, da = oracle.orb_detect_describe(roiA); kb, db = oracle.orb_detect_describe(roiB)
+        pairs, _ = oracle.bf_hamming_matches(da, db)
+        st, off, votes = oracle.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, 3)
+        assert list(row[:7]) == [int(st), off[0], off[1], votes, len(ka), len(kb), len(pairs)], (k, row)
+    s = isa.Stitcher(); s._engine = engine; s.isPrintLog = False
+    s.roiRatio = 0.2; s.direction = 1; s.directIncre = 1; s.featureMethod = "orb"
+    for k, truth in enumerate(g.true_offsets()):
+        status, off = s.calculateOffsetForFeatureSearchIncre([tiles[k], tiles[k + 1]])
+        assert status and off == truth, (k, off, truth)                  # bit-exact for ORB (north_star)
+    a, b = engine.orb_detect_describe(tiles[0])[1], engine.orb_detect_describe(tiles[1])[1]
+    assert np.array_equal(engine.bf_hamming_matches(a, b), oracle.bf_hamming_matches(a, b)[0])

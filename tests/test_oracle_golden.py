@@ -121,3 +121,34 @@ def test_dendritic_offsets_fixture(golden_dir):
     assert len(off) == 89 and off[3] == [1775, 2] and off[15] == [-1734, -1]
     turns = [k for k, (dx, dy) in enumerate(off) if abs(dy) > 1000]
     assert turns == [14, 29, 44, 59, 74]     # 6 columns x 15 tiles, serpentine
+
+
+def test_orb_oracle_exact_truth_and_structure(oracle):
+    """ORB + Hamming 1-NN + mode vote on a synthetic grid must equal the integer ground truth exactly (north_star);
+    structural checks on the restated pipeline (level quotas, border, pattern generator)."""
+    from imagestitch_amd.synthetic import SyntheticGrid
+    from imagestitch_amd.utility import roi_rect
+    pat = oracle.orb_pattern()
+    assert pat.shape == (512, 2) and pat.min() >= -15 and pat.max() <= 15 and pat[:2].tolist() == [[13, -15], [3, 4]]
+    g = SyntheticGrid(2, 2, 640)
+    tiles = g.tiles(threads=1)
+    for k, (truth, d) in enumerate(zip(g.true_offsets(), g.true_directions())):
+        A, B = tiles[k], tiles[k + 1]
+        ra = roi_rect(A.shape, d, "first", 0.2); rb = roi_rect(B.shape, d, "second", 0.2)
+        ka, da = oracle.orb_detect_describe(np.ascontiguousarray(A[ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]]))
+        kb, db = oracle.orb_detect_describe(np.ascontiguousarray(B[rb[0]:rb[0] + rb[2], rb[1]:rb[1] + rb[3]]))
+        assert len(ka) > 500 and da.shape == (len(ka), 32)
+        assert np.all(np.diff(ka["octave"]) >= 0)                       # level-major order
+        q = np.bincount(ka["octave"], minlength=8)
+        assert q[0] <= 1085 + 50 and q[0] >= 900                        # level-0 quota of ORB(5000, 1.2, 8)
+        lx = ka["x"] / (1.2 ** ka["octave"]); ly = ka["y"] / (1.2 ** ka["octave"])
+        assert lx.min() >= 30.9 and ly.min() >= 30.9                    # runByImageBorder(31) in level coordinates
+        pairs, dist = oracle.bf_hamming_matches(da, db)
+        assert len(pairs) == len(ka)                                    # one match per query, no threshold (ImageUtility.py:297-302)
+        st, off, votes = oracle.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, 3)
+        L = int(0.2 * 640)
+        if d == 1: off[0] += 640 - L
+        if d == 3: off[0] -= 640 - L
+        if d == 2: off[1] += 640 - L
+        if d == 4: off[1] -= 640 - L
+        assert st and off == truth, (k, off, truth, votes)
