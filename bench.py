@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--cols", type=int, default=9)
     ap.add_argument("--tile", type=int, default=2048)
     ap.add_argument("--window", type=int, default=16)
+    ap.add_argument("--method", default="surf", choices=["surf", "orb", "phase"],
+                    help="surf = the BASELINE metric; orb / phase time the other registration paths on the same grid")
     ap.add_argument("--cpu-sample", type=int, default=6, help="pairs timed on the host cores for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -58,7 +60,7 @@ def main():
     from imagestitch_amd.synthetic import SyntheticGrid
 
     eng = isa.Engine(local_rank)
-    grid = SyntheticGrid(args.rows, args.cols, args.tile)
+    grid = SyntheticGrid(args.rows, args.cols, args.tile, overlap=0.10 if args.method == "surf" else 0.15)
     P = grid.n_pairs
     truth = np.array(grid.true_offsets(), np.int64)
     bounds = GridRegistrar.chunk_bounds(P, world)
@@ -69,8 +71,9 @@ def main():
     handles = [None] * grid.n_tiles
     for k in need:
         handles[k] = eng.tile_upload(tiles[k])               # tiles resident in HBM before the timed region
-    reg = GridRegistrar(eng, method="surf", roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3, directIncre=1,
-                        surfParams=eng.surf_params(), window=args.window)
+    reg = GridRegistrar(eng, method=args.method, roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3 if args.method == "surf" else 10, directIncre=1,
+                        surfParams=eng.surf_params() if args.method == "surf" else eng.orb_params() if args.method == "orb" else None,
+                        window=args.window)
     gather = make_all_gather(torch.device("cuda", local_rank)) if world > 1 else single_process_all_gather
 
     def step():
@@ -137,7 +140,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a port, cv2 is not installable) on a bounded sample, rank 0 at N = 1 only ------
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and args.method == "surf":
         from oracle import oracle as O
         O.build()
         cores = os.cpu_count() or 1
@@ -158,7 +161,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "image-pairs/sec (2048x2048 grayscale, SURF+BF)",
+            "metric": "image-pairs/sec (2048x2048 grayscale, SURF+BF)" if args.method == "surf" else "image-pairs/sec (%s)" % args.method,
             "value": round(P * args.steps / elapsed, 3),
             "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
