@@ -26,6 +26,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 // of the load in front of the VALU work on `live`
 #define SLOAD16_BEFORE(dst, ptr, live) asm volatile("s_load_dwordx16 %0, %2, 0x0" : "=s"(dst), "+s"(live) : "s"(ptr))
 #define SWAIT(dst) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dst))
+#define SWAIT2(d0, d1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d0), "+s"(d1))
 #define BF_CHUNK(buf, base)                                                                    \
     _Pragma("unroll") for (int d = 0; d < 16; d += 4) {                                        \
         float2v e0 = qv[base + d + 0] - buf[d + 0];                                            \
@@ -76,24 +77,25 @@ __global__ __launch_bounds__(256) void k_bf_l2_d64(const MatchDev *jobs)
     // of order, so the only safe wait is 0 and it must sit BEFORE the next prefetch is issued.)
     const float *T = J.t;
     if (t0 < t1) {
-        f16v bufA, bufB;
-        const float *nxt = T + (size_t)t0 * 64;
-        SLOAD16(bufA, nxt);
+        // half-train granularity: 2 x s_load_dwordx16 per wait, 96 packed VALU ops of cover for each prefetch
+        f16v a0, a1, b0, b1;
+        const float *first = T + (size_t)t0 * 64;
+        SLOAD16(a0, first); SLOAD16(a1, first + 16);
         for (int j = t0; j < t1; j++) {
             const float *tn = T + (size_t)min(j + 1, t1 - 1) * 64;      // next train (clamped: harmless re-read)
             float2v acc = (float2v){0.f, 0.f};
-            SWAIT(bufA); SLOAD16_BEFORE(bufB, T + (size_t)j * 64 + 16, bufA);
-            BF_CHUNK(bufA, 0);
-            SWAIT(bufB); SLOAD16_BEFORE(bufA, T + (size_t)j * 64 + 32, bufB);
-            BF_CHUNK(bufB, 16);
-            SWAIT(bufA); SLOAD16_BEFORE(bufB, T + (size_t)j * 64 + 48, bufA);
-            BF_CHUNK(bufA, 32);
-            SWAIT(bufB); SLOAD16_BEFORE(bufA, tn, bufB);
-            BF_CHUNK(bufB, 48);
+            SWAIT2(a0, a1);
+            SLOAD16_BEFORE(b0, T + (size_t)j * 64 + 32, a0); SLOAD16_BEFORE(b1, T + (size_t)j * 64 + 48, a1);
+            BF_CHUNK(a0, 0);
+            BF_CHUNK(a1, 16);
+            SWAIT2(b0, b1);
+            SLOAD16_BEFORE(a0, tn, b0); SLOAD16_BEFORE(a1, tn + 16, b1);
+            BF_CHUNK(b0, 32);
+            BF_CHUNK(b1, 48);
             knn_update(acc.x, j, b1a, b2a, i1a, b1sa, b2sa);
             knn_update(acc.y, j, b1b, b2b, i1b, b1sb, b2sb);
         }
-        SWAIT(bufA);                                                     // drain the last prefetch
+        SWAIT2(a0, a1);                                                  // drain the last prefetch
     }
     const size_t o = (size_t)sp * J.capq;
     if (qa < nq) { J.p_d1[o + qa] = b1a; J.p_d2[o + qa] = b2a; J.p_i1[o + qa] = i1a; }
