@@ -202,7 +202,7 @@ extern "C" int vfsms_ctx_create(int device, vfsms_ctx **out)
     HIP_TRY(hipSetDevice(device));
     vfsms_ctx *c = new vfsms_ctx();
     c->device = device; c->arena = nullptr; c->arena_size = 0; c->arena_off = 0;
-    c->pinned = nullptr; c->pinned_size = 0; c->kp_cap_override = 0;
+    c->pinned = nullptr; c->pinned_size = 0; c->pinned_off = 0; c->kp_cap_override = 0;
     c->tables_valid = false; c->d_layers = nullptr; c->d_tables = nullptr; c->n_layers = 0; c->next_handle = 1;
     c->prof_on = false; c->orb_valid = false; c->d_orb_tables = nullptr;
     memset(&c->cur_params, 0, sizeof(c->cur_params));
@@ -225,6 +225,7 @@ extern "C" int vfsms_ctx_destroy(vfsms_ctx *ctx)
     for (auto &kv : ctx->tiles) if (kv.second.owned) hipFree(kv.second.ptr);
     for (auto &kv : ctx->canvases) { hipFree(kv.second.pix); hipFree(kv.second.mask); }
     if (ctx->arena) hipFree(ctx->arena);
+    if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->d_layers) hipFree(ctx->d_layers);
     if (ctx->d_tables) hipFree(ctx->d_tables);
     if (ctx->d_orb_tables) hipFree(ctx->d_orb_tables);
@@ -306,6 +307,28 @@ static int upload_array(vfsms_ctx *ctx, const T *src, size_t n, T **d)
     return VFSMS_OK;
 }
 
+// small host->device uploads of launch records through one pinned staging buffer (a pageable hipMemcpyAsync is staged by
+// the runtime and costs a synchronisation each); safe to reuse because every entry point is synchronous at return
+static int upload_pinned(vfsms_ctx *ctx, const void *src, size_t bytes, void **d)
+{
+    *d = ctx_arena_alloc(ctx, bytes ? bytes : 1);
+    if (!*d) { vfsms_set_error("arena exhausted (record upload)"); return VFSMS_ERR_CAPACITY; }
+    if (ctx->pinned_off + bytes > ctx->pinned_size) {
+        if (bytes > ctx->pinned_size || true) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (ctx->pinned) HIP_TRY(hipHostFree(ctx->pinned));
+            ctx->pinned = nullptr;
+            ctx->pinned_size = std::max<size_t>(2 * bytes, (size_t)1 << 20);
+            HIP_TRY(hipHostMalloc((void **)&ctx->pinned, ctx->pinned_size, hipHostMallocDefault));
+            ctx->pinned_off = 0;
+        }
+    }
+    memcpy(ctx->pinned + ctx->pinned_off, src, bytes);
+    HIP_TRY(hipMemcpyAsync(*d, ctx->pinned + ctx->pinned_off, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->pinned_off += (bytes + 255) & ~(size_t)255;
+    return VFSMS_OK;
+}
+
 // ---- integral ----------------------------------------------------------------------------------------------------
 extern "C" int vfsms_integral_u8_i32(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int32_t *sum_out)
 {
@@ -342,6 +365,7 @@ static int surf_host(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int strid
     TRY(surf_roi_carve(ctx, &R, d_img, w, h, w, dcap, params));
     RoiDev *d_R;
     TRY(upload_array(ctx, &R, 1, &d_R));
+    HIP_TRY(hipMemsetAsync(R.counters, 0, 16 * sizeof(int), ctx->stream));
     TRY(launch_surf_detect(ctx, d_R, &R, 1, params));
     int counters[16];
     if (describe) {
@@ -588,29 +612,34 @@ extern "C" int vfsms_attempt_surf_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jo
     TRY(ctx_arena_reserve(ctx, need));
     std::vector<RoiDev> R(2 * n);
     std::vector<MatchDev> M(n);
+    // counters of all ROIs and results of all jobs live in two contiguous blocks: one memset, two D2H copies per batch
+    int *cblock = (int *)ctx_arena_alloc(ctx, sizeof(int) * 16 * 2 * n);
+    int32_t *rblock = (int32_t *)ctx_arena_alloc(ctx, sizeof(int32_t) * VFSMS_ATTEMPT_INTS * n);
     for (int k = 0; k < n; k++) {
         const uint8_t *pa, *pb; int sa, sb;
         TRY(resolve_job(ctx, jobs[k], &pa, &sa, &pb, &sb));
         TRY(surf_roi_carve(ctx, &R[2 * k], pa, sa, jobs[k].h, jobs[k].w, caps[k], params));
         TRY(surf_roi_carve(ctx, &R[2 * k + 1], pb, sb, jobs[k].h, jobs[k].w, caps[k], params));
+        R[2 * k].counters = cblock + 16 * (2 * k); R[2 * k + 1].counters = cblock + 16 * (2 * k + 1);
         memset(&M[k], 0, sizeof(MatchDev));
         TRY(match_carve(ctx, &M[k], caps[k], dim, ns));
+        M[k].result = rblock + VFSMS_ATTEMPT_INTS * k;
         M[k].q = R[2 * k].desc; M[k].t = R[2 * k + 1].desc;
         M[k].nq_ptr = R[2 * k].counters + 1; M[k].nt_ptr = R[2 * k + 1].counters + 1;
         M[k].kq = R[2 * k].kps_xy; M[k].kt = R[2 * k + 1].kps_xy;
     }
+    ctx->pinned_off = 0;
     RoiDev *dR; MatchDev *dM;
-    TRY(upload_array(ctx, R.data(), (size_t)2 * n, &dR));
-    TRY(upload_array(ctx, M.data(), (size_t)n, &dM));
+    TRY(upload_pinned(ctx, R.data(), sizeof(RoiDev) * 2 * n, (void **)&dR));
+    TRY(upload_pinned(ctx, M.data(), sizeof(MatchDev) * n, (void **)&dM));
+    HIP_TRY(hipMemsetAsync(cblock, 0, sizeof(int) * 16 * 2 * n, ctx->stream));
     TRY(launch_surf_detect(ctx, dR, R.data(), 2 * n, params));
     TRY(launch_surf_describe(ctx, dR, R.data(), 2 * n, params));
     TRY(launch_bf_l2(ctx, dM, n, maxcap, ns, dim));
     TRY(launch_ratio_mode(ctx, dM, n, maxcap, ratio, offset_evaluate));
     std::vector<int> counters((size_t)16 * 2 * n);
-    for (int k = 0; k < 2 * n; k++)
-        HIP_TRY(hipMemcpyAsync(&counters[(size_t)16 * k], R[k].counters, 16 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    for (int k = 0; k < n; k++)
-        HIP_TRY(hipMemcpyAsync(out + (size_t)VFSMS_ATTEMPT_INTS * k, M[k].result, VFSMS_ATTEMPT_INTS * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(counters.data(), cblock, sizeof(int) * 16 * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, rblock, sizeof(int32_t) * VFSMS_ATTEMPT_INTS * n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 2 * n; k++)
         if (counters[(size_t)16 * k + 2] || counters[(size_t)16 * k] > R[k].cap) {

@@ -113,7 +113,7 @@ struct vfsms_ctx {
     // bump arena for per-call scratch
     char *arena; size_t arena_size; size_t arena_off;
     // pinned staging for small results
-    char *pinned; size_t pinned_size;
+    char *pinned; size_t pinned_size; size_t pinned_off;
     int kp_cap_override;
     // SURF tables
     vfsms_surf_params cur_params; bool tables_valid;

@@ -907,18 +907,12 @@ int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_roi
     if (nrois <= 0) return VFSMS_OK;
     const int lpo = p->n_octave_layers + 2;
     int maxh = 0, maxw = 0, maxcap = 0;
-    {
-        ProfScope ps(ctx, "memset");
-        for (int r = 0; r < nrois; r++) {
-            maxh = h_rois[r].h > maxh ? h_rois[r].h : maxh;
-            maxw = h_rois[r].w > maxw ? h_rois[r].w : maxw;
-            maxcap = h_rois[r].cap > maxcap ? h_rois[r].cap : maxcap;
-            HIP_TRY(hipMemsetAsync(h_rois[r].counters, 0, 16 * sizeof(int), ctx->stream));
-            // layer arrays are contiguous in the arena: det[0] .. end of trace[last]
-            char *lo = (char *)h_rois[r].det[0];
-            char *hi = (char *)h_rois[r].counters;
-            HIP_TRY(hipMemsetAsync(lo, 0, (size_t)(hi - lo), ctx->stream));
-        }
+    // (the caller zeroes the ROI counters; det/trace layers need no clearing: the non-maximum search only ever reads cells
+    //  that k_hessian wrote -- its margins are those of the layer above -- so the 53 B/px layer memset is gone)
+    for (int r = 0; r < nrois; r++) {
+        maxh = h_rois[r].h > maxh ? h_rois[r].h : maxh;
+        maxw = h_rois[r].w > maxw ? h_rois[r].w : maxw;
+        maxcap = h_rois[r].cap > maxcap ? h_rois[r].cap : maxcap;
     }
     TRY(launch_integral(ctx, d_rois, nrois, maxh, maxw));
     {
