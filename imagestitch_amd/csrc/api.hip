@@ -314,14 +314,12 @@ static int upload_pinned(vfsms_ctx *ctx, const void *src, size_t bytes, void **d
     *d = ctx_arena_alloc(ctx, bytes ? bytes : 1);
     if (!*d) { vfsms_set_error("arena exhausted (record upload)"); return VFSMS_ERR_CAPACITY; }
     if (ctx->pinned_off + bytes > ctx->pinned_size) {
-        if (bytes > ctx->pinned_size || true) {
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            if (ctx->pinned) HIP_TRY(hipHostFree(ctx->pinned));
-            ctx->pinned = nullptr;
-            ctx->pinned_size = std::max<size_t>(2 * bytes, (size_t)1 << 20);
-            HIP_TRY(hipHostMalloc((void **)&ctx->pinned, ctx->pinned_size, hipHostMallocDefault));
-            ctx->pinned_off = 0;
-        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));                 // earlier copies out of the old buffer have landed
+        if (ctx->pinned) HIP_TRY(hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_size = std::max<size_t>(4 * (ctx->pinned_off + bytes), (size_t)1 << 20);
+        HIP_TRY(hipHostMalloc((void **)&ctx->pinned, ctx->pinned_size, hipHostMallocDefault));
+        ctx->pinned_off = 0;
     }
     memcpy(ctx->pinned + ctx->pinned_off, src, bytes);
     HIP_TRY(hipMemcpyAsync(*d, ctx->pinned + ctx->pinned_off, bytes, hipMemcpyHostToDevice, ctx->stream));
