@@ -149,24 +149,49 @@ class GridRegistrar:
                     cache[it] = r
 
         runs, run_len, slow, ring_hint = [], 0, 1, {}
+        trans2 = {}                                   # (direction before, direction) -> direction the next turn led to
+        prev_d = 0
         d = d_in
         k = first
+
+        def plan(k0, d0, p0):
+            """Predicted continuation of the path as one batch (up to `window` attempts): the rest of the current run, the
+            candidate ring of the predicted turn up to the direction it led to last time, the following run(s), ..."""
+            items, R, rl, cd, cp, kk = [], list(runs), run_len, d0, p0, k0
+            while kk < last and len(items) < self.window:
+                pred = R[-2] if len(R) >= 2 else None
+                if pred is None:
+                    break
+                remaining = pred - rl
+                if remaining >= 1:
+                    n = min(remaining, self.window - len(items), last - kk)
+                    items += [(kk + t, cd, 1) for t in range(n)]
+                    kk += n; rl += n
+                    if n < remaining:
+                        break
+                    continue
+                ring = self.rings(cd)[0]
+                nd = trans2.get((cp, cd))
+                if nd is None or all(c[0] != nd for c in ring):
+                    items += [(kk,) + c for c in ring[:ring_hint.get(cd, len(ring) - 1) + 1]]
+                    break
+                upto = [c[0] for c in ring].index(nd)
+                items += [(kk,) + c for c in ring[:upto + 1]]
+                R.append(rl); rl = 1
+                cp, cd = cd, nd
+                kk += 1
+            return items
+
         while k < last:
             if (k, d) in memo:
                 row, d_next = memo[(k, d)]
             else:
                 rings = self.rings(d)
                 if (k, d, 1) not in cache:
-                    pred = runs[-2] if len(runs) >= 2 else None
-                    if pred is None:
-                        n = slow
-                    else:
-                        n = min(self.window, pred - run_len)
-                    if n >= 1:
-                        evaluate([(kk, d, 1) for kk in range(k, min(k + n, last)) if (kk, d) not in memo])
-                    else:                                     # a turn is predicted at pair k: its first ring at once
-                        h = ring_hint.get(d, len(rings[0]) - 1)
-                        evaluate([(k, dd, ii) for (dd, ii) in rings[0][:h + 1]])
+                    items = plan(k, d, prev_d)
+                    if not items:                              # no history yet: slow start
+                        items = [(kk, d, 1) for kk in range(k, min(k + slow, last)) if (kk, d) not in memo]
+                    evaluate(items)
                     if (k, d, 1) not in cache:
                         evaluate([(k, d, 1)])
                 found = None
@@ -201,6 +226,8 @@ class GridRegistrar:
             elif row[0]:
                 runs.append(run_len)
                 run_len, slow = 1, 1
+                trans2[(prev_d, d)] = d_next
+                prev_d = d
             out[k - first] = row
             d = d_next
             k += 1
