@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--rows", type=int, default=10)
     ap.add_argument("--cols", type=int, default=9)
     ap.add_argument("--tile", type=int, default=2048)
-    ap.add_argument("--window", type=int, default=16)
+    ap.add_argument("--window", type=int, default=24)
     ap.add_argument("--method", default="surf", choices=["surf", "orb", "phase"],
                     help="surf = the BASELINE metric; orb / phase time the other registration paths on the same grid")
     ap.add_argument("--cpu-sample", type=int, default=6, help="pairs timed on the host cores for cpu_baseline (0 = skip)")
