@@ -47,6 +47,7 @@ struct Cand {                         // NMS survivor before sorting
 };
 
 // ---- one ROI's device working set; arrays of these drive every batched kernel ---------------------
+#define VFSMS_PATCH_ROW 448
 struct RoiDev {
     const uint8_t *img;
     int stride, h, w;
@@ -57,7 +58,7 @@ struct RoiDev {
     int *counters;                    // [0] n candidates, [1] n kept after deletion, [2] overflow flag
     Cand *cand;
     vfsms_keypoint *kps;              // sorted (KeypointGreater), angle filled by orientation; size=-1 -> deleted
-    float *desc_raw;                  // cap x D, rows aligned with kps
+    uint8_t *patch;                   // cap x VFSMS_PATCH_ROW: 21 x 21 resized descriptor windows, rows aligned with kps
     int *keep_pos;                    // exclusive scan of keep flags
     float *kps_xy;                    // compacted [n][2]
     float *desc;                      // compacted [n][D]

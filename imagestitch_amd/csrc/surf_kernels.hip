@@ -631,12 +631,8 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
     vfsms_keypoint kp = R.kps[k];
     if (!(kp.size > 0)) return;                            // deleted by the orientation stage
     if (ablate == 1) return;
-    const int dsize = extended ? 128 : 64;
     __shared__ float sx_row[VFSMS_MAX_WIN], sy_row[VFSMS_MAX_WIN];
     __shared__ uint8_t PATCH[21][21 + 3];
-    __shared__ float DX[20][20], DY[20][20];
-    __shared__ float vec_s[128];
-    __shared__ float scale_s;
     __shared__ float trig_s[2];
     __shared__ AreaSpan span_s[21];                        // computeResizeAreaTab entries: same table for x and y
     __shared__ uint8_t WINBUF[DESC_WBUF];
@@ -654,13 +650,12 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
     const bool is_area_fast = fabs(scale - iscale) < DBL_EPSILON;
     if (!upright) {
         // Row origins are running float sums in the reference (start_x += sin_dir per row): inherently sequential,
-        // so one lane of wave 0 walks x while one lane of wave 1 walks y; they also own the sin/cos evaluation
-        // (std::sin/std::cos on float in the reference; evaluated in double and rounded here, which agrees with a
-        // correctly rounded sinf/cosf except in double-rounding corner cases).
+        // so one lane of wave 0 walks x while one lane of wave 1 walks y.
+        // sin/cos of the orientation were evaluated one thread per keypoint by k_desc_trig and parked in the keypoint's
+        // patch row (overwritten by the patch itself at the end of this function).
         if (threadIdx.x == 0 || threadIdx.x == 64) {
-            const float dir = kp.angle * (float)(3.1415926535897932384626433832795 / 180);
-            const float sin_dir = -(float)sin((double)dir);
-            const float cos_dir = (float)cos((double)dir);
+            const float sin_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW))[0];
+            const float cos_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW))[1];
             const float win_offset = -(float)(win - 1) / 2;
             if (threadIdx.x == 0) {
                 trig_s[0] = sin_dir; trig_s[1] = cos_dir;
@@ -769,44 +764,8 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
         }
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < 400; o += 256) {
-        const int i = o / 20, j = o % 20;
-        float dw = T->DW[o];
-        float vx = (float)(PATCH[i][j + 1] - PATCH[i][j] + PATCH[i + 1][j + 1] - PATCH[i + 1][j]) * dw;
-        float vy = (float)(PATCH[i + 1][j] - PATCH[i][j] + PATCH[i + 1][j + 1] - PATCH[i][j + 1]) * dw;
-        DX[i][j] = vx; DY[i][j] = vy;
-    }
-    __syncthreads();
-    if (threadIdx.x < 16) {
-        const int ci = threadIdx.x / 4, cj = threadIdx.x % 4;
-        if (extended) {
-            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int y = ci * 5; y < ci * 5 + 5; y++)
-                for (int x = cj * 5; x < cj * 5 + 5; x++) {
-                    float tx = DX[y][x], ty = DY[y][x];
-                    if (ty >= 0) { v[0] += tx; v[1] += fabsf(tx); } else { v[2] += tx; v[3] += fabsf(tx); }
-                    if (tx >= 0) { v[4] += ty; v[5] += fabsf(ty); } else { v[6] += ty; v[7] += fabsf(ty); }
-                }
-            for (int q = 0; q < 8; q++) vec_s[threadIdx.x * 8 + q] = v[q];
-        } else {
-            float v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-            for (int y = ci * 5; y < ci * 5 + 5; y++)
-                for (int x = cj * 5; x < cj * 5 + 5; x++) {
-                    float tx = DX[y][x], ty = DY[y][x];
-                    v0 += tx; v1 += ty; v2 += fabsf(tx); v3 += fabsf(ty);
-                }
-            vec_s[threadIdx.x * 4 + 0] = v0; vec_s[threadIdx.x * 4 + 1] = v1;
-            vec_s[threadIdx.x * 4 + 2] = v2; vec_s[threadIdx.x * 4 + 3] = v3;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double square_mag = 0;
-        for (int q = 0; q < dsize; q++) square_mag += (double)(vec_s[q] * vec_s[q]);
-        scale_s = (float)(1. / (sqrt(square_mag) + DBL_EPSILON));
-    }
-    __syncthreads();
-    if (threadIdx.x < dsize) R.desc_raw[(size_t)k * dsize + threadIdx.x] = vec_s[threadIdx.x] * scale_s;
+    // hand the 21 x 21 patch to k_desc_tail (gradients, cell sums, normalisation run there, 16 keypoints per workgroup)
+    for (int o = threadIdx.x; o < 441; o += 256) R.patch[(size_t)k * VFSMS_PATCH_ROW + o] = PATCH[o / 21][o % 21];
     DT_MARK(5);
 }
 
@@ -892,20 +851,77 @@ __global__ __launch_bounds__(1024) void k_keep_scan(const RoiDev *rois)
     if (threadIdx.x == 0) R.counters[1] = carry;
 }
 
-__global__ __launch_bounds__(256) void k_compact(const RoiDev *rois, int dsize)
+// One thread per keypoint: sin/cos of the descriptor window's rotation (std::sin / std::cos on float in the reference;
+// evaluated in double and rounded here, which agrees with a correctly rounded sinf/cosf except in double-rounding
+// corner cases).  ~400 dependent f64 instructions, so it is kept out of the 256-thread descriptor workgroups.
+__global__ __launch_bounds__(256) void k_desc_trig(const RoiDev *rois)
+{
+    const RoiDev &R = rois[blockIdx.y];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= min(R.counters[0], R.cap)) return;
+    const vfsms_keypoint kp = R.kps[k];
+    if (!(kp.size > 0)) return;
+    const float dir = kp.angle * (float)(3.1415926535897932384626433832795 / 180);
+    float *row = (float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW);
+    row[0] = -(float)sin((double)dir);
+    row[1] = (float)cos((double)dir);
+}
+
+// Descriptor tail, 16 keypoints per workgroup, 16 threads (one per 5 x 5 cell) per keypoint: Gaussian-weighted
+// gradients of the 21 x 21 patch, per-cell sums in raster order, L2 normalisation with the double accumulator of
+// the reference, and the store straight into the COMPACTED descriptor / keypoint arrays (keep_pos from k_keep_scan).
+__global__ __launch_bounds__(256) void k_desc_tail(const RoiDev *rois, const SurfTables *T, int extended)
 {
     const RoiDev &R = rois[blockIdx.y];
     const int n = min(R.counters[0], R.cap);
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);     // one wave per keypoint
-    if (k >= n) return;
-    const int pos = R.keep_pos[k];
-    if (pos < 0) return;
-    const int lane = threadIdx.x & 63;
-    for (int q = lane; q < dsize; q += 64) R.desc[(size_t)pos * dsize + q] = R.desc_raw[(size_t)k * dsize + q];
-    if (lane == 0) {
-        vfsms_keypoint kp = R.kps[k];
+    const int k0 = blockIdx.x * 16;
+    if (k0 >= n) return;
+    const int dsize = extended ? 128 : 64;
+    __shared__ uint32_t P32[16][VFSMS_PATCH_ROW / 4];
+    __shared__ float vec[16][128];
+    __shared__ float scl[16];
+    {
+        const uint32_t __attribute__((address_space(1))) *src =
+            (const uint32_t __attribute__((address_space(1))) *)(R.patch + (size_t)k0 * VFSMS_PATCH_ROW);
+        const int rows = min(16, n - k0);
+        for (int i = threadIdx.x; i < rows * (VFSMS_PATCH_ROW / 4); i += 256) (&P32[0][0])[i] = src[i];
+    }
+    __syncthreads();
+    const int kk = threadIdx.x >> 4, c = threadIdx.x & 15, k = k0 + kk;
+    const int pos = k < n ? R.keep_pos[k] : -1;
+    if (pos >= 0) {
+        const uint8_t *P = (const uint8_t *)&P32[kk][0];
+        const int ci = c >> 2, cj = c & 3;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int y = ci * 5; y < ci * 5 + 5; y++)
+            for (int x = cj * 5; x < cj * 5 + 5; x++) {
+                const float dw = T->DW[y * 20 + x];
+                const int p00 = P[y * 21 + x], p01 = P[y * 21 + x + 1], p10 = P[(y + 1) * 21 + x], p11 = P[(y + 1) * 21 + x + 1];
+                const float tx = (float)(p01 - p00 + p11 - p10) * dw;
+                const float ty = (float)(p10 - p00 + p11 - p01) * dw;
+                if (extended) {
+                    if (ty >= 0) { v[0] += tx; v[1] += fabsf(tx); } else { v[2] += tx; v[3] += fabsf(tx); }
+                    if (tx >= 0) { v[4] += ty; v[5] += fabsf(ty); } else { v[6] += ty; v[7] += fabsf(ty); }
+                } else {
+                    v[0] += tx; v[1] += ty; v[2] += fabsf(tx); v[3] += fabsf(ty);
+                }
+            }
+        const int per = extended ? 8 : 4;
+        for (int q = 0; q < per; q++) vec[kk][c * per + q] = v[q];
+    }
+    __syncthreads();
+    if (pos >= 0 && c == 0) {
+        double square_mag = 0;
+        for (int q = 0; q < dsize; q++) square_mag += (double)(vec[kk][q] * vec[kk][q]);
+        scl[kk] = (float)(1. / (sqrt(square_mag) + DBL_EPSILON));
+        const vfsms_keypoint kp = R.kps[k];
         R.kps_out[pos] = kp;
         R.kps_xy[2 * pos] = kp.x; R.kps_xy[2 * pos + 1] = kp.y;
+    }
+    __syncthreads();
+    if (pos >= 0) {
+        const float sc = scl[kk];
+        for (int q = c; q < dsize; q += 16) R.desc[(size_t)pos * dsize + q] = vec[kk][q] * sc;
     }
 }
 
@@ -922,7 +938,7 @@ size_t surf_roi_bytes(int h, int w, int cap, int nlayers_total, int noctaves, in
         size_t n = (size_t)(h >> o) * (w >> o);
         b += 2 * lpo * al(sizeof(float) * (n ? n : 1));
     }
-    b += al(16 * sizeof(int)) + al(sizeof(Cand) * cap) + al(sizeof(vfsms_keypoint) * cap) + al(sizeof(float) * (size_t)cap * dim);
+    b += al(16 * sizeof(int)) + al(sizeof(Cand) * cap) + al(sizeof(vfsms_keypoint) * cap) + al((size_t)cap * VFSMS_PATCH_ROW);
     b += al(sizeof(int) * cap) + al(sizeof(float) * 2 * cap) + al(sizeof(float) * (size_t)cap * dim) + al(sizeof(vfsms_keypoint) * cap);
     return b + 4096;
 }
@@ -931,7 +947,6 @@ int surf_roi_carve(vfsms_ctx *ctx, RoiDev *r, const uint8_t *img, int stride, in
                    const vfsms_surf_params *p)
 {
     const int lpo = p->n_octave_layers + 2;
-    const int dim = p->extended ? 128 : 64;
     memset(r, 0, sizeof(*r));
     r->img = img; r->stride = stride; r->h = h; r->w = w; r->cap = cap;
     r->sum = (int32_t *)ctx_arena_alloc(ctx, sizeof(int32_t) * (size_t)(h + 1) * (w + 1));
@@ -947,10 +962,10 @@ int surf_roi_carve(vfsms_ctx *ctx, RoiDev *r, const uint8_t *img, int stride, in
     r->counters = (int *)ctx_arena_alloc(ctx, 16 * sizeof(int));
     r->cand = (Cand *)ctx_arena_alloc(ctx, sizeof(Cand) * cap);
     r->kps = (vfsms_keypoint *)ctx_arena_alloc(ctx, sizeof(vfsms_keypoint) * cap);
-    r->desc_raw = (float *)ctx_arena_alloc(ctx, sizeof(float) * (size_t)cap * dim);
+    r->patch = (uint8_t *)ctx_arena_alloc(ctx, (size_t)cap * VFSMS_PATCH_ROW);
     r->keep_pos = (int *)ctx_arena_alloc(ctx, sizeof(int) * cap);
     r->kps_xy = (float *)ctx_arena_alloc(ctx, sizeof(float) * 2 * cap);
-    r->desc = (float *)ctx_arena_alloc(ctx, sizeof(float) * (size_t)cap * dim);
+    r->desc = (float *)ctx_arena_alloc(ctx, sizeof(float) * (size_t)cap * (p->extended ? 128 : 64));
     r->kps_out = (vfsms_keypoint *)ctx_arena_alloc(ctx, sizeof(vfsms_keypoint) * cap);
     if (!r->kps_out) { vfsms_set_error("arena exhausted while carving a SURF ROI"); return VFSMS_ERR_CAPACITY; }
     return VFSMS_OK;
@@ -1016,22 +1031,22 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
     if (nrois > VFSMS_MAX_ROIS) { vfsms_set_error("more than %d ROIs in one batch", VFSMS_MAX_ROIS); return VFSMS_ERR_CAPACITY; }
     int maxcap = 0;
     for (int r = 0; r < nrois; r++) maxcap = h_rois[r].cap > maxcap ? h_rois[r].cap : maxcap;
-    const int dim = p->extended ? 128 : 64;
     {
         ProfScope ps(ctx, "orientation");
         hipLaunchKernelGGL(k_orientation, dim3(maxcap, nrois), dim3(128), 0, ctx->stream, d_rois, ctx->d_tables, p->upright);
     }
     {
+        ProfScope ps(ctx, "compact");
+        hipLaunchKernelGGL(k_keep_scan, dim3(nrois), dim3(1024), 0, ctx->stream, d_rois);
+    }
+    {
         ProfScope ps(ctx, "describe");
         // ticket counter: counters[9] of ROI 0 (zeroed with the other counters by launch_surf_detect)
         static int ablate = getenv("VFSMS_DESC_ABLATE") ? atoi(getenv("VFSMS_DESC_ABLATE")) : 0;
+        if (!p->upright) hipLaunchKernelGGL(k_desc_trig, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
         hipLaunchKernelGGL(k_describe, dim3(256 * 4), dim3(256), 0, ctx->stream, d_rois, nrois, h_rois[0].counters + 9,
                            ctx->d_tables, p->extended, p->upright, ablate);
-    }
-    {
-        ProfScope ps(ctx, "compact");
-        hipLaunchKernelGGL(k_keep_scan, dim3(nrois), dim3(1024), 0, ctx->stream, d_rois);
-        hipLaunchKernelGGL(k_compact, dim3((maxcap + 3) / 4, nrois), dim3(256), 0, ctx->stream, d_rois, dim);
+        hipLaunchKernelGGL(k_desc_tail, dim3((maxcap + 15) / 16, nrois), dim3(256), 0, ctx->stream, d_rois, ctx->d_tables, p->extended);
     }
     HIP_TRY(hipGetLastError());
     return VFSMS_OK;
