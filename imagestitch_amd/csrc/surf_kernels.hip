@@ -257,6 +257,7 @@ __device__ __forceinline__ bool interpolate_keypoint(const float N9[3][9], int d
     return ok;
 }
 
+#define NMS_ROWS 4
 __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat *pats, int layers_per_octave,
                                              int n_middle, int octave, float hessianThreshold)
 {
@@ -268,43 +269,55 @@ __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat 
     const int ss = P.step, size = P.size;
     const int lrows = R.h / ss, lcols = R.w / ss;
     const int margin = (pats[li + 1].size / 2) / ss + 1;
-    const int j = margin + blockIdx.x * 64 + threadIdx.x;
-    const int i = margin + blockIdx.y * 4 + threadIdx.y;
-    if (i >= lrows - margin || j >= lcols - margin) return;
     if (pats[li + 1].size > R.h || pats[li + 1].size > R.w) return;   // upper layer not computed: nothing readable
-    g_cf32 d2 = (g_cf32)R.det[li] + (size_t)i * lcols + j;
-    float val0 = d2[0];
-    if (!(val0 > hessianThreshold)) return;
-    g_cf32 d1 = (g_cf32)R.det[li - 1] + (size_t)i * lcols + j;
-    g_cf32 d3 = (g_cf32)R.det[li + 1] + (size_t)i * lcols + j;
+    // a workgroup owns 64 columns x (4 * NMS_ROWS) rows: the NMS_ROWS centre values of a lane are loaded back to back,
+    // and the 26 neighbours are only touched by cells that pass the threshold -- first the 8 of the own layer (most
+    // cells stop there), then the 18 of the layers below and above.  The conjunction is order-independent.
+    const int j = margin + blockIdx.x * 64 + threadIdx.x;
+    const int i0 = margin + blockIdx.y * (4 * NMS_ROWS) + threadIdx.y;
+    if (j >= lcols - margin) return;
     const int st = lcols;
-    float N9[3][9] = {
-        { d1[-st - 1], d1[-st], d1[-st + 1], d1[-1], d1[0], d1[1], d1[st - 1], d1[st], d1[st + 1] },
-        { d2[-st - 1], d2[-st], d2[-st + 1], d2[-1], d2[0], d2[1], d2[st - 1], d2[st], d2[st + 1] },
-        { d3[-st - 1], d3[-st], d3[-st + 1], d3[-1], d3[0], d3[1], d3[st - 1], d3[st], d3[st + 1] } };
-    bool is_max = true;
+    float v0[NMS_ROWS];
 #pragma unroll
-    for (int a = 0; a < 3; a++)
+    for (int it = 0; it < NMS_ROWS; it++) {
+        const int i = i0 + 4 * it;
+        v0[it] = i < lrows - margin ? ((g_cf32)R.det[li])[(size_t)i * lcols + j] : 0.f;
+    }
 #pragma unroll
-        for (int b = 0; b < 9; b++)
-            if (!(a == 1 && b == 4)) is_max = is_max && (val0 > N9[a][b]);
-    if (!is_max) return;
-    const int sum_i = ss * (i - (size / 2) / ss);
-    const int sum_j = ss * (j - (size / 2) / ss);
-    Cand c;
-    c.y = sum_i + (size - 1) * 0.5f;
-    c.x = sum_j + (size - 1) * 0.5f;
-    c.size = (float)size;
-    c.response = val0;
-    c.octave = octave;
-    float tr = ((g_cf32)R.trace[li])[(size_t)i * lcols + j];
-    c.class_id = (tr > 0) - (tr < 0);
-    c.layer = li; c.i = i; c.j = j;
-    const int ds = size - pats[li - 1].size;
-    if (!interpolate_keypoint(N9, ss, ss, ds, c)) return;
-    int pos = atomicAdd(&R.counters[0], 1);
-    if (pos < R.cap) R.cand[pos] = c;
-    else R.counters[2] = 1;                            // overflow: reported as VFSMS_ERR_CAPACITY by the host
+    for (int it = 0; it < NMS_ROWS; it++) {
+        const int i = i0 + 4 * it;
+        const float val0 = v0[it];
+        if (i >= lrows - margin || !(val0 > hessianThreshold)) continue;
+        g_cf32 d2 = (g_cf32)R.det[li] + (size_t)i * lcols + j;
+        const float m0 = d2[-st - 1], m1 = d2[-st], m2 = d2[-st + 1], m3 = d2[-1], m5 = d2[1], m6 = d2[st - 1], m7 = d2[st], m8 = d2[st + 1];
+        if (!(val0 > m0 && val0 > m1 && val0 > m2 && val0 > m3 && val0 > m5 && val0 > m6 && val0 > m7 && val0 > m8)) continue;
+        g_cf32 d1 = (g_cf32)R.det[li - 1] + (size_t)i * lcols + j;
+        g_cf32 d3 = (g_cf32)R.det[li + 1] + (size_t)i * lcols + j;
+        float N9[3][9] = {
+            { d1[-st - 1], d1[-st], d1[-st + 1], d1[-1], d1[0], d1[1], d1[st - 1], d1[st], d1[st + 1] },
+            { m0, m1, m2, m3, val0, m5, m6, m7, m8 },
+            { d3[-st - 1], d3[-st], d3[-st + 1], d3[-1], d3[0], d3[1], d3[st - 1], d3[st], d3[st + 1] } };
+        bool is_max = true;
+#pragma unroll
+        for (int b = 0; b < 9; b++) is_max = is_max && (val0 > N9[0][b]) && (val0 > N9[2][b]);
+        if (!is_max) continue;
+        const int sum_i = ss * (i - (size / 2) / ss);
+        const int sum_j = ss * (j - (size / 2) / ss);
+        Cand c;
+        c.y = sum_i + (size - 1) * 0.5f;
+        c.x = sum_j + (size - 1) * 0.5f;
+        c.size = (float)size;
+        c.response = val0;
+        c.octave = octave;
+        float tr = ((g_cf32)R.trace[li])[(size_t)i * lcols + j];
+        c.class_id = (tr > 0) - (tr < 0);
+        c.layer = li; c.i = i; c.j = j;
+        const int ds = size - pats[li - 1].size;
+        if (!interpolate_keypoint(N9, ss, ss, ds, c)) continue;
+        int pos = atomicAdd(&R.counters[0], 1);
+        if (pos < R.cap) R.cand[pos] = c;
+        else R.counters[2] = 1;                        // overflow: reported as VFSMS_ERR_CAPACITY by the host
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1009,7 +1022,7 @@ int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_roi
         for (int o = 0; o < p->n_octaves; o++) {
             int lrows = maxh / step, lcols = maxw / step;
             if (lrows > 0 && lcols > 0) {
-                dim3 grid((lcols + 63) / 64, (lrows + 3) / 4, nrois * p->n_octave_layers);
+                dim3 grid((lcols + 63) / 64, (lrows + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), nrois * p->n_octave_layers);
                 hipLaunchKernelGGL(k_nms, grid, dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo,
                                    p->n_octave_layers, o, p->hessian_threshold);
             }
