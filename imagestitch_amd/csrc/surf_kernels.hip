@@ -258,8 +258,9 @@ __device__ __forceinline__ bool interpolate_keypoint(const float N9[3][9], int d
 }
 
 #define NMS_ROWS 4
+#define NMS_LOCAL 96
 __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat *pats, int layers_per_octave,
-                                             int n_middle, int octave, float hessianThreshold)
+                                             int n_middle, int octave, float hessianThreshold, int ablate)
 {
     const int roi = blockIdx.z / n_middle;
     const int l = 1 + blockIdx.z % n_middle;
@@ -270,54 +271,90 @@ __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat 
     const int lrows = R.h / ss, lcols = R.w / ss;
     const int margin = (pats[li + 1].size / 2) / ss + 1;
     if (pats[li + 1].size > R.h || pats[li + 1].size > R.w) return;   // upper layer not computed: nothing readable
-    // a workgroup owns 64 columns x (4 * NMS_ROWS) rows: the NMS_ROWS centre values of a lane are loaded back to back,
-    // and the 26 neighbours are only touched by cells that pass the threshold -- first the 8 of the own layer (most
-    // cells stop there), then the 18 of the layers below and above.  The conjunction is order-independent.
-    const int j = margin + blockIdx.x * 64 + threadIdx.x;
-    const int i0 = margin + blockIdx.y * (4 * NMS_ROWS) + threadIdx.y;
-    if (j >= lcols - margin) return;
-    const int st = lcols;
-    float v0[NMS_ROWS];
-#pragma unroll
-    for (int it = 0; it < NMS_ROWS; it++) {
-        const int i = i0 + 4 * it;
-        v0[it] = i < lrows - margin ? ((g_cf32)R.det[li])[(size_t)i * lcols + j] : 0.f;
+    // A workgroup owns 64 columns x 16 rows of one middle layer.  Its (16+2) x (64+2) halo tile of the layer is read
+    // into LDS with every load of a lane in flight at once; the threshold and the 8 own-layer neighbours are tested
+    // from LDS; the few 2-D maxima (a few per cent of the cells) are queued in LDS and then examined one per lane
+    // against the layers below and above, so a wave pays two global round trips in total.
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int j0 = margin + blockIdx.x * 64, i0 = margin + blockIdx.y * (4 * NMS_ROWS);
+    if (j0 >= lcols - margin || i0 >= lrows - margin) return;
+    __shared__ float tile[4 * NMS_ROWS + 2][64 + 2];
+    __shared__ int queue[64 * 4 * NMS_ROWS];
+    __shared__ int qn, cn, cbase;
+    __shared__ Cand local[NMS_LOCAL];
+    if (tid == 0) { qn = 0; cn = 0; }
+    {
+        g_cf32 d2 = (g_cf32)R.det[li];
+        for (int idx = tid; idx < (4 * NMS_ROWS + 2) * 66; idx += 256) {
+            const int r = idx / 66, c = idx - r * 66;
+            const int gi = i0 - 1 + r, gj = j0 - 1 + c;
+            tile[r][c] = (gi < lrows && gj < lcols) ? d2[(size_t)gi * lcols + gj] : 0.f;
+        }
     }
+    __syncthreads();
+    if (ablate == 1) return;
 #pragma unroll
     for (int it = 0; it < NMS_ROWS; it++) {
-        const int i = i0 + 4 * it;
-        const float val0 = v0[it];
-        if (i >= lrows - margin || !(val0 > hessianThreshold)) continue;
-        g_cf32 d2 = (g_cf32)R.det[li] + (size_t)i * lcols + j;
-        const float m0 = d2[-st - 1], m1 = d2[-st], m2 = d2[-st + 1], m3 = d2[-1], m5 = d2[1], m6 = d2[st - 1], m7 = d2[st], m8 = d2[st + 1];
-        if (!(val0 > m0 && val0 > m1 && val0 > m2 && val0 > m3 && val0 > m5 && val0 > m6 && val0 > m7 && val0 > m8)) continue;
+        const int r = threadIdx.y + 4 * it, c = threadIdx.x;
+        const int i = i0 + r, j = j0 + c;
+        const float val0 = tile[r + 1][c + 1];
+        if (i >= lrows - margin || j >= lcols - margin || !(val0 > hessianThreshold)) continue;
+        if (val0 > tile[r][c] && val0 > tile[r][c + 1] && val0 > tile[r][c + 2] && val0 > tile[r + 1][c] && val0 > tile[r + 1][c + 2] &&
+            val0 > tile[r + 2][c] && val0 > tile[r + 2][c + 1] && val0 > tile[r + 2][c + 2])
+            queue[atomicAdd(&qn, 1)] = (r << 8) | c;
+    }
+    __syncthreads();
+    const int nq = qn;
+    if (ablate == 2) return;
+    if (ablate == 4 && tid == 0) { atomicAdd(&R.counters[10], nq); atomicAdd(&R.counters[11], 1); }
+    const int st = lcols;
+    for (int e = tid; e < nq; e += 256) {
+        const int r = queue[e] >> 8, c = queue[e] & 255;
+        const int i = i0 + r, j = j0 + c;
+        const float val0 = tile[r + 1][c + 1];
         g_cf32 d1 = (g_cf32)R.det[li - 1] + (size_t)i * lcols + j;
         g_cf32 d3 = (g_cf32)R.det[li + 1] + (size_t)i * lcols + j;
         float N9[3][9] = {
             { d1[-st - 1], d1[-st], d1[-st + 1], d1[-1], d1[0], d1[1], d1[st - 1], d1[st], d1[st + 1] },
-            { m0, m1, m2, m3, val0, m5, m6, m7, m8 },
+            { tile[r][c], tile[r][c + 1], tile[r][c + 2], tile[r + 1][c], val0, tile[r + 1][c + 2], tile[r + 2][c], tile[r + 2][c + 1], tile[r + 2][c + 2] },
             { d3[-st - 1], d3[-st], d3[-st + 1], d3[-1], d3[0], d3[1], d3[st - 1], d3[st], d3[st + 1] } };
         bool is_max = true;
 #pragma unroll
         for (int b = 0; b < 9; b++) is_max = is_max && (val0 > N9[0][b]) && (val0 > N9[2][b]);
-        if (!is_max) continue;
+        if (!is_max || ablate == 3) continue;
         const int sum_i = ss * (i - (size / 2) / ss);
         const int sum_j = ss * (j - (size / 2) / ss);
-        Cand c;
-        c.y = sum_i + (size - 1) * 0.5f;
-        c.x = sum_j + (size - 1) * 0.5f;
-        c.size = (float)size;
-        c.response = val0;
-        c.octave = octave;
-        float tr = ((g_cf32)R.trace[li])[(size_t)i * lcols + j];
-        c.class_id = (tr > 0) - (tr < 0);
-        c.layer = li; c.i = i; c.j = j;
+        Cand cd;
+        cd.y = sum_i + (size - 1) * 0.5f;
+        cd.x = sum_j + (size - 1) * 0.5f;
+        cd.size = (float)size;
+        cd.response = val0;
+        cd.octave = octave;
+        const float tr = ((g_cf32)R.trace[li])[(size_t)i * lcols + j];
+        cd.class_id = (tr > 0) - (tr < 0);
+        cd.layer = li; cd.i = i; cd.j = j;
         const int ds = size - pats[li - 1].size;
-        if (!interpolate_keypoint(N9, ss, ss, ds, c)) continue;
-        int pos = atomicAdd(&R.counters[0], 1);
-        if (pos < R.cap) R.cand[pos] = c;
-        else R.counters[2] = 1;                        // overflow: reported as VFSMS_ERR_CAPACITY by the host
+        if (!interpolate_keypoint(N9, ss, ss, ds, cd)) continue;
+        const int slot = atomicAdd(&cn, 1);
+        if (slot < NMS_LOCAL) local[slot] = cd;
+        else {                                           // local list full (never seen on real images): direct append
+            const int pos = atomicAdd(&R.counters[0], 1);
+            if (pos < R.cap) R.cand[pos] = cd; else R.counters[2] = 1;
+        }
     }
+    // one global reservation per workgroup instead of one same-address atomic per candidate
+    __syncthreads();
+    const int nloc = min(cn, NMS_LOCAL);
+    if (nloc == 0) return;
+    if (tid == 0) cbase = atomicAdd(&R.counters[0], nloc);
+    __syncthreads();
+    const int base = cbase;
+    if (base + nloc > R.cap) { if (tid == 0) R.counters[2] = 1; }   // overflow: reported as VFSMS_ERR_CAPACITY by the host
+    constexpr int CW = sizeof(Cand) / 4;
+    const int nfit = max(0, min(nloc, R.cap - base));
+    uint32_t *dst = (uint32_t *)(R.cand + base);
+    const uint32_t *srcw = (const uint32_t *)local;
+    for (int w = tid; w < nfit * CW; w += 256) dst[w] = srcw[w];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1018,13 +1055,14 @@ int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_roi
     }
     {
         ProfScope ps(ctx, "nms");
+        static int nms_ablate = getenv("VFSMS_NMS_ABLATE") ? atoi(getenv("VFSMS_NMS_ABLATE")) : 0;
         int step = 1;
         for (int o = 0; o < p->n_octaves; o++) {
             int lrows = maxh / step, lcols = maxw / step;
             if (lrows > 0 && lcols > 0) {
                 dim3 grid((lcols + 63) / 64, (lrows + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), nrois * p->n_octave_layers);
                 hipLaunchKernelGGL(k_nms, grid, dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo,
-                                   p->n_octave_layers, o, p->hessian_threshold);
+                                   p->n_octave_layers, o, p->hessian_threshold, nms_ablate);
             }
             step *= 2;
         }
