@@ -414,6 +414,15 @@ static int pick_nsplit(int nq, int nt, int njobs, int dim)
     return ns;
 }
 
+// train splits of the MFMA filter: a wave holds 64 queries and two waves share a SIMD, so aim at >= 4 rounds of the
+// 2048 wave slots; more splits mean more candidate lists to verify, hence the cap
+static int pick_filter_nsplit(int nq, int njobs)
+{
+    const long long waves = (long long)((nq + 63) / 64) * njobs;
+    int ns = (int)((8192 + waves - 1) / (waves > 0 ? waves : 1));
+    return std::max(1, std::min(ns, 8));
+}
+
 static int bf_l2_host(vfsms_ctx *ctx, const float *q, int nq, const float *t, int nt, int dim, MatchDev *M, bool with_ratio, double ratio)
 {
     const int capq = std::max(nq, 1);
@@ -603,9 +612,15 @@ extern "C" int vfsms_attempt_surf_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jo
         caps[k] = kp_capacity(ctx, jobs[k].h, jobs[k].w);
         maxcap = std::max(maxcap, caps[k]);
     }
-    const int ns = pick_nsplit(maxcap / 3, maxcap / 3, n, dim);   // typical occupancy of the capacity
+    // 64-d descriptors leave the descriptor kernel with norm <= 1: their 2-NN search runs as an MFMA candidate filter plus
+    // exact verification (match_kernels.hip); other widths, or VFSMS_BF_EXACT=1, take the exhaustive VALU kernel.
+    static const bool force_exact = getenv("VFSMS_BF_EXACT") && atoi(getenv("VFSMS_BF_EXACT")) != 0;
+    const bool filtered = dim == 64 && maxcap < 65536 && !force_exact;
+    const int cns = pick_filter_nsplit(maxcap / 3, n);
+    const int ns = filtered ? 1 : pick_nsplit(maxcap / 3, maxcap / 3, n, dim);   // typical occupancy of the capacity
     for (int k = 0; k < n; k++)
-        need += 2 * surf_roi_bytes(jobs[k].h, jobs[k].w, caps[k], ctx->n_layers, params->n_octaves, dim) + match_bytes(caps[k], ns);
+        need += 2 * surf_roi_bytes(jobs[k].h, jobs[k].w, caps[k], ctx->n_layers, params->n_octaves, dim) + match_bytes(caps[k], ns) +
+                (filtered ? match_filter_bytes(caps[k], cns) : 0);
     need += (sizeof(RoiDev) * 2 + sizeof(MatchDev)) * n + 64 * 3 * n + 65536;
     TRY(ctx_arena_reserve(ctx, need));
     std::vector<RoiDev> R(2 * n);
@@ -621,6 +636,7 @@ extern "C" int vfsms_attempt_surf_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jo
         R[2 * k].counters = cblock + 16 * (2 * k); R[2 * k + 1].counters = cblock + 16 * (2 * k + 1);
         memset(&M[k], 0, sizeof(MatchDev));
         TRY(match_carve(ctx, &M[k], caps[k], dim, ns));
+        if (filtered) TRY(match_filter_carve(ctx, &M[k], caps[k], cns));
         M[k].result = rblock + VFSMS_ATTEMPT_INTS * k;
         M[k].q = R[2 * k].desc; M[k].t = R[2 * k + 1].desc;
         M[k].nq_ptr = R[2 * k].counters + 1; M[k].nt_ptr = R[2 * k + 1].counters + 1;
@@ -633,7 +649,8 @@ extern "C" int vfsms_attempt_surf_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jo
     HIP_TRY(hipMemsetAsync(cblock, 0, sizeof(int) * 16 * 2 * n, ctx->stream));
     TRY(launch_surf_detect(ctx, dR, R.data(), 2 * n, params));
     TRY(launch_surf_describe(ctx, dR, R.data(), 2 * n, params));
-    TRY(launch_bf_l2(ctx, dM, n, maxcap, ns, dim));
+    if (filtered) { TRY(launch_bf_l2_filtered(ctx, dM, n, maxcap, cns)); }
+    else { TRY(launch_bf_l2(ctx, dM, n, maxcap, ns, dim)); }
     TRY(launch_ratio_mode(ctx, dM, n, maxcap, ratio, offset_evaluate));
     std::vector<int> counters((size_t)16 * 2 * n);
     HIP_TRY(hipMemcpyAsync(counters.data(), cblock, sizeof(int) * 16 * 2 * n, hipMemcpyDeviceToHost, ctx->stream));

@@ -92,6 +92,8 @@ struct MatchDev {
     int dim;
     // partial 2-NN per (split, query)
     float *p_d1; float *p_d2; int *p_i1; int nsplit;
+    // MFMA candidate filter (fused SURF path): per (query, split, lane half) lists of train indices + their counts
+    uint16_t *c_idx; int *c_cnt;
     // merged
     float *d1; float *d2; int *i1;
     int *match_flag; int *match_pos;
@@ -159,6 +161,9 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
 // match_kernels.hip
 size_t match_bytes(int capq, int nsplit);
 int match_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int dim, int nsplit);
+size_t match_filter_bytes(int capq, int cns);
+int match_filter_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int cns);
+int launch_bf_l2_filtered(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int cns);
 int launch_bf_l2(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int nsplit, int dim);
 int launch_merge_only(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq);
 int launch_ratio_only(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, double ratio);

@@ -135,6 +135,193 @@ __global__ __launch_bounds__(256) void k_bf_l2_gen(const MatchDev *jobs)
     if (qa < nq) { J.p_d1[o + qa] = b1; J.p_d2[o + qa] = b2; J.p_i1[o + qa] = i1; }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// MFMA candidate filter + exact verification (DIM = 64, descriptors of norm <= 1: the fused SURF attempt path).
+//
+// The 2-NN of a query under the reference's float arithmetic are, with a wide safety margin, among the trains whose
+// f32-MFMA score  s(q,t) = |t|^2 - 2 q.t  (= d^2 - |q|^2 up to ~1e-5) lies within BFM_MARGIN of the second best
+// score.  k_bf_mfma_d64 streams 32-train tiles against 64 resident queries per wave on v_mfma_f32_32x32x2_f32
+// (K = 64 + one augmented step that adds |t|^2, so the accumulator IS the score) and appends to a small per-lane list
+// every train whose score is within the margin of the lane's RUNNING second best -- a superset of the final
+// candidates, since a running second best over a prefix of half the trains can only be larger than the final one.
+// k_bf_verify_d64 then evaluates exactly those few trains (~10 per list) with the arithmetic of k_bf_l2_d64 (4-wide
+// float accumulation, sqrt-domain compares, ties keep the lower index) -- the MFMA decides which distances get
+// computed, never what they are.  A list that overflows makes its query fall back to the exhaustive exact scan.
+// ---------------------------------------------------------------------------------------------------
+#define BFM_CAPL 32
+#define BFM_MARGIN 1e-3f        // >= 40x the worst-case |score - (d_ref^2 - |q|^2)| for K = 65, |q|,|t| <= 1
+#define BFM_FAR 1e30f
+
+struct BfmState { float m1, m2, thr; int cnt; };
+
+__device__ __forceinline__ void bfm_warm(const f16v &acc, BfmState &S)
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const float v = acc[i];
+        S.m2 = fminf(S.m2, fmaxf(S.m1, v));
+        S.m1 = fminf(S.m1, v);
+    }
+}
+__device__ __forceinline__ void bfm_scan(const f16v &acc, BfmState &S, int row0, uint16_t *list, bool update)
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const float v = acc[i];
+        if (v <= S.thr && v < 1e29f) {
+            if (S.cnt < BFM_CAPL) list[S.cnt] = (uint16_t)(row0 + (i & 3) + 8 * (i >> 2));
+            S.cnt++;
+            if (update) {
+                S.m2 = fminf(S.m2, fmaxf(S.m1, v));
+                S.m1 = fminf(S.m1, v);
+                S.thr = S.m2 + BFM_MARGIN;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_bf_mfma_d64(const MatchDev *jobs)
+{
+    const MatchDev &J = jobs[blockIdx.z];
+    const int nq = __builtin_amdgcn_readfirstlane(*J.nq_ptr), nt = __builtin_amdgcn_readfirstlane(*J.nt_ptr);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q0 = (blockIdx.x * 4 + wave) * 64;
+    if (q0 >= nq) return;
+    const int nsplit = gridDim.y, sp = blockIdx.y;
+    const int ntiles = (nt + 31) >> 5;
+    const int tchunk = (ntiles + nsplit - 1) / nsplit;
+    const int tile0 = sp * tchunk, tile1 = min(ntiles, tile0 + tchunk);
+    const int col = lane & 31, half = lane >> 5;
+    // B operand: lane (col, half) supplies query q0 + 32*qt + col, dims 32*half + s at k-step s (the k order is a
+    // permutation of the dims, the same one for A and B); scaled by -2 (exact) so the accumulator holds -2 q.t
+    float bq0[32], bq1[32];
+    {
+        const float4 *p0 = reinterpret_cast<const float4 *>(J.q + (size_t)min(q0 + col, nq - 1) * 64 + 32 * half);
+        const float4 *p1 = reinterpret_cast<const float4 *>(J.q + (size_t)min(q0 + 32 + col, nq - 1) * 64 + 32 * half);
+#pragma unroll
+        for (int s4 = 0; s4 < 8; s4++) {
+            const float4 u = p0[s4], v = p1[s4];
+            bq0[4 * s4 + 0] = -2.f * u.x; bq0[4 * s4 + 1] = -2.f * u.y; bq0[4 * s4 + 2] = -2.f * u.z; bq0[4 * s4 + 3] = -2.f * u.w;
+            bq1[4 * s4 + 0] = -2.f * v.x; bq1[4 * s4 + 1] = -2.f * v.y; bq1[4 * s4 + 2] = -2.f * v.z; bq1[4 * s4 + 3] = -2.f * v.w;
+        }
+    }
+    const float baug = half == 0 ? 1.f : 0.f;
+    const bool va = q0 + col < nq, vb = q0 + 32 + col < nq;
+    BfmState Sa = {INFINITY, INFINITY, INFINITY, 0}, Sb = {INFINITY, INFINITY, INFINITY, 0};
+    const size_t la = (((size_t)(q0 + col) * nsplit + sp) * 2 + half), lb = (((size_t)(q0 + 32 + col) * nsplit + sp) * 2 + half);
+    uint16_t *lista = J.c_idx + la * BFM_CAPL, *listb = J.c_idx + lb * BFM_CAPL;
+    const float *T = J.t;
+    for (int pass = 0; pass < 2; pass++) {          // pass 0: first tile only, to seed the running second best
+        const int tend = pass == 0 ? min(tile0 + 1, tile1) : tile1;
+        float4 an[8];
+        if (tile0 < tend) {
+            const float4 *pn = reinterpret_cast<const float4 *>(T + (size_t)min(tile0 * 32 + col, nt - 1) * 64 + 32 * half);
+#pragma unroll
+            for (int s4 = 0; s4 < 8; s4++) an[s4] = pn[s4];
+        }
+        for (int tl = tile0; tl < tend; tl++) {
+            float a[32];
+#pragma unroll
+            for (int s4 = 0; s4 < 8; s4++) { a[4 * s4] = an[s4].x; a[4 * s4 + 1] = an[s4].y; a[4 * s4 + 2] = an[s4].z; a[4 * s4 + 3] = an[s4].w; }
+            if (tl + 1 < tend) {                    // prefetch the next train tile behind this tile's MFMAs
+                const float4 *pn = reinterpret_cast<const float4 *>(T + (size_t)min((tl + 1) * 32 + col, nt - 1) * 64 + 32 * half);
+#pragma unroll
+                for (int s4 = 0; s4 < 8; s4++) an[s4] = pn[s4];
+            }
+            // |t|^2 of this lane's train row: half sums met across the two lane halves (a + b == b + a, so both agree)
+            float part = 0.f;
+#pragma unroll
+            for (int s = 0; s < 32; s++) part += a[s] * a[s];
+            const float tnorm = part + __shfl_xor(part, 32, 64);
+            const float aaug = half == 0 ? (tl * 32 + col < nt ? tnorm : BFM_FAR) : 0.f;
+            f16v acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+#pragma unroll
+            for (int s = 0; s < 32; s++) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq0[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq1[s], acc1, 0, 0, 0);
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aaug, baug, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aaug, baug, acc1, 0, 0, 0);
+            if (pass == 0) {
+                bfm_warm(acc0, Sa); bfm_warm(acc1, Sb);
+            } else {
+                const int row0 = tl * 32 + 4 * half;
+                // the seed tile is already part of the running statistics: list its candidates without counting them twice
+                bfm_scan(acc0, Sa, row0, lista, tl != tile0); bfm_scan(acc1, Sb, row0, listb, tl != tile0);
+            }
+        }
+        if (pass == 0) {
+            Sa.thr = va ? Sa.m2 + BFM_MARGIN : -INFINITY;      // lanes of queries beyond nq never append
+            Sb.thr = vb ? Sb.m2 + BFM_MARGIN : -INFINITY;
+        }
+    }
+    if (va) J.c_cnt[la] = Sa.cnt;
+    if (vb) J.c_cnt[lb] = Sb.cnt;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(v, d, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// one wave per query: exact distances to the candidate trains, reduced with the semantics of knn_update over ascending
+// train indices (best = lowest index among the smallest sqrt-domain distances; second = next smallest value)
+__global__ __launch_bounds__(256) void k_bf_verify_d64(const MatchDev *jobs, int cns)
+{
+    const MatchDev &J = jobs[blockIdx.y];
+    const int nq = __builtin_amdgcn_readfirstlane(*J.nq_ptr), nt = __builtin_amdgcn_readfirstlane(*J.nt_ptr);
+    const int q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (q >= nq) return;
+    const int lane = threadIdx.x & 63;
+    const int nl = 2 * cns;
+    const int *cc = J.c_cnt + (size_t)q * nl;
+    int total = 0; bool overflow = false;
+    for (int L = 0; L < nl; L++) { const int c = cc[L]; overflow = overflow || c > BFM_CAPL; total += min(c, BFM_CAPL); }
+    const int n_items = overflow ? nt : total;
+    const float *Q = J.q + (size_t)q * 64;
+    float B1 = INFINITY, B2 = INFINITY; int I1 = -1;
+    for (int base = 0; base < n_items; base += 64) {
+        const int f = base + lane;
+        int idx = -1;
+        if (f < n_items) {
+            if (overflow) idx = f;
+            else {
+                int pre = 0;
+                for (int L = 0; L < nl; L++) {
+                    const int c = min(cc[L], BFM_CAPL);
+                    if (f >= pre && f < pre + c) idx = J.c_idx[((size_t)q * nl + L) * BFM_CAPL + (f - pre)];
+                    pre += c;
+                }
+            }
+        }
+        unsigned long long key = ~0ull;
+        if (idx >= 0) {
+            const float4 *tr = reinterpret_cast<const float4 *>(J.t + (size_t)idx * 64);
+            float acc = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < 16; d4++) {
+                const float4 tv = tr[d4];
+                const float e0 = Q[4 * d4] - tv.x, e1 = Q[4 * d4 + 1] - tv.y, e2 = Q[4 * d4 + 2] - tv.z, e3 = Q[4 * d4 + 3] - tv.w;
+                acc += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+            }
+            key = ((unsigned long long)__float_as_uint(sqrtf(acc)) << 32) | (unsigned)idx;    // distances are >= 0: bit order == value order
+        }
+        const unsigned long long k1 = wave_min_u64(key);
+        if (k1 == ~0ull) continue;
+        const unsigned long long k2 = wave_min_u64(key == k1 ? ~0ull : key);   // indices are unique, so exactly one lane holds k1
+        const float b1 = __uint_as_float((unsigned)(k1 >> 32)); const int i1 = (int)(k1 & 0xffffffffu);
+        const float b2 = k2 == ~0ull ? INFINITY : __uint_as_float((unsigned)(k2 >> 32));
+        if (b1 < B1 || (b1 == B1 && i1 < I1)) { B2 = fminf(B1, b2); B1 = b1; I1 = i1; }
+        else B2 = fminf(B2, b1);
+    }
+    if (lane == 0) { J.p_d1[q] = B1; J.p_d2[q] = B2; J.p_i1[q] = I1; }
+}
+
 // merge the per-split 2-NN lists, apply the ratio test (Python double arithmetic on float32 distances,
 // ImageUtility.py:294) and compute the vote of ImageUtility.py:153-161 for surviving matches.
 __global__ __launch_bounds__(256) void k_merge_ratio(const MatchDev *jobs, double ratio, int do_ratio)
@@ -337,6 +524,30 @@ int match_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int dim, int nsplit)
     m->mcount = (int *)ctx_arena_alloc(ctx, 64);
     m->result = (int32_t *)ctx_arena_alloc(ctx, 64);
     if (!m->result) { vfsms_set_error("arena exhausted while carving a match job"); return VFSMS_ERR_CAPACITY; }
+    return VFSMS_OK;
+}
+
+size_t match_filter_bytes(int capq, int cns)
+{
+    return al(sizeof(uint16_t) * (size_t)capq * cns * 2 * BFM_CAPL) + al(sizeof(int) * (size_t)capq * cns * 2) + 1024;
+}
+
+int match_filter_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int cns)
+{
+    m->c_idx = (uint16_t *)ctx_arena_alloc(ctx, sizeof(uint16_t) * (size_t)capq * cns * 2 * BFM_CAPL);
+    m->c_cnt = (int *)ctx_arena_alloc(ctx, sizeof(int) * (size_t)capq * cns * 2);
+    if (!m->c_cnt) { vfsms_set_error("arena exhausted while carving a match filter"); return VFSMS_ERR_CAPACITY; }
+    return VFSMS_OK;
+}
+
+// MFMA-filtered exact 2-NN for 64-d descriptors of norm <= 1 (jobs carved with nsplit == 1 plus match_filter_carve)
+int launch_bf_l2_filtered(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int cns)
+{
+    if (njobs <= 0 || capq <= 0) return VFSMS_OK;
+    ProfScope ps(ctx, "bf_l2");
+    hipLaunchKernelGGL(k_bf_mfma_d64, dim3((capq + 255) / 256, cns, njobs), dim3(256), 0, ctx->stream, d_jobs);
+    hipLaunchKernelGGL(k_bf_verify_d64, dim3((capq + 3) / 4, njobs), dim3(256), 0, ctx->stream, d_jobs, cns);
+    HIP_TRY(hipGetLastError());
     return VFSMS_OK;
 }
 
