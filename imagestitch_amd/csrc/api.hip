@@ -423,22 +423,47 @@ static int pick_filter_nsplit(int nq, int njobs)
     return std::max(1, std::min(ns, 8));
 }
 
+static bool bf_force_exact()
+{
+    static const bool v = getenv("VFSMS_BF_EXACT") && atoi(getenv("VFSMS_BF_EXACT")) != 0;
+    return v;
+}
+
 static int bf_l2_host(vfsms_ctx *ctx, const float *q, int nq, const float *t, int nt, int dim, MatchDev *M, bool with_ratio, double ratio)
 {
     const int capq = std::max(nq, 1);
-    const int ns = pick_nsplit(nq, nt, 1, dim);
-    TRY(ctx_arena_reserve(ctx, sizeof(float) * ((size_t)nq + nt) * dim + match_bytes(capq, ns) + 65536));
+    const int ns_exact = pick_nsplit(nq, nt, 1, dim);
+    const int cns = pick_filter_nsplit(nq, 1);
+    const bool try_filter = dim == 64 && nq > 0 && nt > 0 && !bf_force_exact();
+    TRY(ctx_arena_reserve(ctx, sizeof(float) * ((size_t)nq + nt) * dim + match_bytes(capq, ns_exact) +
+                               (try_filter ? match_filter_bytes(capq, cns) : 0) + 65536));
     memset(M, 0, sizeof(*M));
     float *dq, *dt;
     TRY(upload_array(ctx, q, (size_t)nq * dim, &dq));
     TRY(upload_array(ctx, t, (size_t)nt * dim, &dt));
     int cnt[2] = {nq, nt}; int *dcnt;
     TRY(upload_array(ctx, cnt, 2, &dcnt));
+    // descriptors of norm <= 1 (SURF's are L2-normalised) take the MFMA-filtered search; anything else the exhaustive kernel
+    bool filtered = false;
+    if (try_filter) {
+        unsigned *d_max = (unsigned *)ctx_arena_alloc(ctx, sizeof(unsigned));
+        HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(unsigned), ctx->stream));
+        TRY(launch_max_norm2_d64(ctx, dq, nq, d_max));
+        TRY(launch_max_norm2_d64(ctx, dt, nt, d_max));
+        unsigned bits = 0;
+        HIP_TRY(hipMemcpyAsync(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        float m; memcpy(&m, &bits, sizeof(m));
+        filtered = m <= 1.0001f;
+    }
+    const int ns = filtered ? 1 : ns_exact;
     TRY(match_carve(ctx, M, capq, dim, ns));
+    if (filtered) TRY(match_filter_carve(ctx, M, capq, cns));
     M->q = dq; M->t = dt; M->nq_ptr = dcnt; M->nt_ptr = dcnt + 1; M->kq = nullptr; M->kt = nullptr;
     MatchDev *dM;
     TRY(upload_array(ctx, M, 1, &dM));
-    TRY(launch_bf_l2(ctx, dM, 1, capq, ns, dim));
+    if (filtered) { TRY(launch_bf_l2_filtered(ctx, dM, 1, capq, cns)); }
+    else { TRY(launch_bf_l2(ctx, dM, 1, capq, ns, dim)); }
     if (with_ratio) {
         TRY(launch_ratio_only(ctx, dM, 1, capq, ratio));
     } else {
@@ -614,8 +639,7 @@ extern "C" int vfsms_attempt_surf_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jo
     }
     // 64-d descriptors leave the descriptor kernel with norm <= 1: their 2-NN search runs as an MFMA candidate filter plus
     // exact verification (match_kernels.hip); other widths, or VFSMS_BF_EXACT=1, take the exhaustive VALU kernel.
-    static const bool force_exact = getenv("VFSMS_BF_EXACT") && atoi(getenv("VFSMS_BF_EXACT")) != 0;
-    const bool filtered = dim == 64 && maxcap < 65536 && !force_exact;
+    const bool filtered = dim == 64 && !bf_force_exact();
     const int cns = pick_filter_nsplit(maxcap / 3, n);
     const int ns = filtered ? 1 : pick_nsplit(maxcap / 3, maxcap / 3, n, dim);   // typical occupancy of the capacity
     for (int k = 0; k < n; k++)

@@ -92,8 +92,8 @@ struct MatchDev {
     int dim;
     // partial 2-NN per (split, query)
     float *p_d1; float *p_d2; int *p_i1; int nsplit;
-    // MFMA candidate filter (fused SURF path): per (query, split, lane half) lists of train indices + their counts
-    uint16_t *c_idx; int *c_cnt;
+    // MFMA candidate filter (fused SURF path): per (query, split, lane half) lists of (score bits, train index) + their counts
+    uint2 *c_ent; int *c_cnt;
     // merged
     float *d1; float *d2; int *i1;
     int *match_flag; int *match_pos;
@@ -161,6 +161,7 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
 // match_kernels.hip
 size_t match_bytes(int capq, int nsplit);
 int match_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int dim, int nsplit);
+int launch_max_norm2_d64(vfsms_ctx *ctx, const float *a, int n, unsigned *d_out);
 size_t match_filter_bytes(int capq, int cns);
 int match_filter_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int cns);
 int launch_bf_l2_filtered(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int cns);

@@ -163,13 +163,13 @@ __device__ __forceinline__ void bfm_warm(const f16v &acc, BfmState &S)
         S.m1 = fminf(S.m1, v);
     }
 }
-__device__ __forceinline__ void bfm_scan(const f16v &acc, BfmState &S, int row0, uint16_t *list, bool update)
+__device__ __forceinline__ void bfm_scan(const f16v &acc, BfmState &S, int row0, uint2 *list, bool update)
 {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const float v = acc[i];
         if (v <= S.thr && v < 1e29f) {
-            if (S.cnt < BFM_CAPL) list[S.cnt] = (uint16_t)(row0 + (i & 3) + 8 * (i >> 2));
+            if (S.cnt < BFM_CAPL) list[S.cnt] = make_uint2(__float_as_uint(v), (unsigned)(row0 + (i & 3) + 8 * (i >> 2)));
             S.cnt++;
             if (update) {
                 S.m2 = fminf(S.m2, fmaxf(S.m1, v));
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma_d64(const MatchDev *jobs)
     const bool va = q0 + col < nq, vb = q0 + 32 + col < nq;
     BfmState Sa = {INFINITY, INFINITY, INFINITY, 0}, Sb = {INFINITY, INFINITY, INFINITY, 0};
     const size_t la = (((size_t)(q0 + col) * nsplit + sp) * 2 + half), lb = (((size_t)(q0 + 32 + col) * nsplit + sp) * 2 + half);
-    uint16_t *lista = J.c_idx + la * BFM_CAPL, *listb = J.c_idx + lb * BFM_CAPL;
+    uint2 *lista = J.c_ent + la * BFM_CAPL, *listb = J.c_ent + lb * BFM_CAPL;
     const float *T = J.t;
     for (int pass = 0; pass < 2; pass++) {          // pass 0: first tile only, to seed the running second best
         const int tend = pass == 0 ? min(tile0 + 1, tile1) : tile1;
@@ -269,8 +269,18 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return v;
 }
 
-// one wave per query: exact distances to the candidate trains, reduced with the semantics of knn_update over ascending
-// train indices (best = lowest index among the smallest sqrt-domain distances; second = next smallest value)
+__device__ __forceinline__ float wave_min_f32(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+// One wave per query.  Phase A reads the (score, train) entries of the query's lists and takes the second smallest
+// score S2 over all of them (the lists hold the true 2-NN, so S2 bounds their scores up to the MFMA rounding); phase B
+// evaluates the exact distance only for entries within BFM_MARGIN of S2 -- typically two or three -- and reduces them
+// with the semantics of knn_update over ascending train indices (best = lowest index among the smallest sqrt-domain
+// distances; second = next smallest value).
 __global__ __launch_bounds__(256) void k_bf_verify_d64(const MatchDev *jobs, int cns)
 {
     const MatchDev &J = jobs[blockIdx.y];
@@ -280,9 +290,31 @@ __global__ __launch_bounds__(256) void k_bf_verify_d64(const MatchDev *jobs, int
     const int lane = threadIdx.x & 63;
     const int nl = 2 * cns;
     const int *cc = J.c_cnt + (size_t)q * nl;
+    const uint2 *ent = J.c_ent + (size_t)q * nl * BFM_CAPL;
     int total = 0; bool overflow = false;
     for (int L = 0; L < nl; L++) { const int c = cc[L]; overflow = overflow || c > BFM_CAPL; total += min(c, BFM_CAPL); }
     const int n_items = overflow ? nt : total;
+    float cut = INFINITY;
+    if (!overflow) {                                   // phase A: second smallest score over the lists
+        float s1 = INFINITY, s2 = INFINITY;
+        for (int base = 0; base < n_items; base += 64) {
+            const int f = base + lane;
+            float v = INFINITY;
+            int pre = 0;
+            for (int L = 0; L < nl; L++) {
+                const int c = min(cc[L], BFM_CAPL);
+                if (f >= pre && f < pre + c) v = __uint_as_float(ent[L * BFM_CAPL + (f - pre)].x);
+                pre += c;
+            }
+            const float a1 = wave_min_f32(v);
+            // second smallest of this pass: drop ONE instance of the minimum (lowest lane holding it)
+            const unsigned long long holders = __ballot(v == a1);
+            const int first = holders ? __ffsll((long long)holders) - 1 : -1;
+            const float a2 = wave_min_f32(lane == first ? INFINITY : v);
+            if (a1 < s1) { s2 = fminf(s1, a2); s1 = a1; } else s2 = fminf(s2, a1);
+        }
+        cut = s2 + BFM_MARGIN;
+    }
     const float *Q = J.q + (size_t)q * 64;
     float B1 = INFINITY, B2 = INFINITY; int I1 = -1;
     for (int base = 0; base < n_items; base += 64) {
@@ -294,11 +326,15 @@ __global__ __launch_bounds__(256) void k_bf_verify_d64(const MatchDev *jobs, int
                 int pre = 0;
                 for (int L = 0; L < nl; L++) {
                     const int c = min(cc[L], BFM_CAPL);
-                    if (f >= pre && f < pre + c) idx = J.c_idx[((size_t)q * nl + L) * BFM_CAPL + (f - pre)];
+                    if (f >= pre && f < pre + c) {
+                        const uint2 e = ent[L * BFM_CAPL + (f - pre)];
+                        if (__uint_as_float(e.x) <= cut) idx = (int)e.y;
+                    }
                     pre += c;
                 }
             }
         }
+        if (__ballot(idx >= 0) == 0) continue;
         unsigned long long key = ~0ull;
         if (idx >= 0) {
             const float4 *tr = reinterpret_cast<const float4 *>(J.t + (size_t)idx * 64);
@@ -312,7 +348,6 @@ __global__ __launch_bounds__(256) void k_bf_verify_d64(const MatchDev *jobs, int
             key = ((unsigned long long)__float_as_uint(sqrtf(acc)) << 32) | (unsigned)idx;    // distances are >= 0: bit order == value order
         }
         const unsigned long long k1 = wave_min_u64(key);
-        if (k1 == ~0ull) continue;
         const unsigned long long k2 = wave_min_u64(key == k1 ? ~0ull : key);   // indices are unique, so exactly one lane holds k1
         const float b1 = __uint_as_float((unsigned)(k1 >> 32)); const int i1 = (int)(k1 & 0xffffffffu);
         const float b2 = k2 == ~0ull ? INFINITY : __uint_as_float((unsigned)(k2 >> 32));
@@ -527,14 +562,34 @@ int match_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int dim, int nsplit)
     return VFSMS_OK;
 }
 
+// largest squared row norm of an n x 64 array (one wave per row): decides whether host-supplied descriptors qualify
+// for the MFMA-filtered search, whose margin is absolute and assumes norms <= 1
+__global__ __launch_bounds__(256) void k_max_norm2_d64(const float *a, int n, unsigned *out)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const float v = a[(size_t)row * 64 + lane];
+    float s = v * v;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) atomicMax(out, __float_as_uint(s == s ? s : INFINITY));   // non-negative floats order like their bits; NaN -> inf
+}
+
+int launch_max_norm2_d64(vfsms_ctx *ctx, const float *a, int n, unsigned *d_out)
+{
+    if (n > 0) hipLaunchKernelGGL(k_max_norm2_d64, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, a, n, d_out);
+    HIP_TRY(hipGetLastError());
+    return VFSMS_OK;
+}
+
 size_t match_filter_bytes(int capq, int cns)
 {
-    return al(sizeof(uint16_t) * (size_t)capq * cns * 2 * BFM_CAPL) + al(sizeof(int) * (size_t)capq * cns * 2) + 1024;
+    return al(sizeof(uint2) * (size_t)capq * cns * 2 * BFM_CAPL) + al(sizeof(int) * (size_t)capq * cns * 2) + 1024;
 }
 
 int match_filter_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int cns)
 {
-    m->c_idx = (uint16_t *)ctx_arena_alloc(ctx, sizeof(uint16_t) * (size_t)capq * cns * 2 * BFM_CAPL);
+    m->c_ent = (uint2 *)ctx_arena_alloc(ctx, sizeof(uint2) * (size_t)capq * cns * 2 * BFM_CAPL);
     m->c_cnt = (int *)ctx_arena_alloc(ctx, sizeof(int) * (size_t)capq * cns * 2);
     if (!m->c_cnt) { vfsms_set_error("arena exhausted while carving a match filter"); return VFSMS_ERR_CAPACITY; }
     return VFSMS_OK;

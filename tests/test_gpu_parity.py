@@ -96,6 +96,41 @@ def test_bf_l2_bit_exact(engine, oracle):
     assert engine.bf_l2_ratio_matches(np.zeros((0, 64), np.float32), np.zeros((4, 64), np.float32)).shape == (0, 2)
 
 
+def test_bf_l2_mfma_filter_hard_cases(engine, oracle):
+    """Descriptors of norm <= 1 go through the MFMA candidate filter + exact verification; the result must stay bit-identical
+    to the exhaustive reference arithmetic on inputs built to stress the filter: tight clusters (many near-ties inside the
+    filter margin), exact duplicates, zero rows, more trains than one split, and sizes of the 2048-px workload."""
+    rng = np.random.default_rng(23)
+
+    def unit(a):
+        n = np.linalg.norm(a, axis=1, keepdims=True); n[n == 0] = 1
+        return (a / n).astype(np.float32)
+
+    cases = []
+    centres = unit(rng.normal(size=(40, 64)))
+    t = unit(centres[rng.integers(0, 40, 3000)] + 1e-3 * rng.normal(size=(3000, 64)))       # clusters of radius ~1e-3
+    q = unit(centres[rng.integers(0, 40, 2500)] + 1e-3 * rng.normal(size=(2500, 64)))
+    cases.append((q, t))
+    t2 = unit(rng.normal(size=(5000, 64))); q2 = unit(rng.normal(size=(700, 64)))
+    t2[100] = 0; t2[4000] = 0; q2[5] = 0                                                    # zero descriptors (flat patches)
+    t2[77] = t2[4100]; t2[78] = t2[4100]; q2[6] = t2[4100]                                  # triple tie at distance 0
+    q2[7] = np.float32(0.5) * q2[8]                                                         # norm < 1
+    cases.append((q2, t2))
+    cases.append((unit(rng.normal(size=(9000, 64))), unit(rng.normal(size=(8300, 64)))))    # ~ the keypoint counts of a 409 x 2048 ROI
+    cases.append((unit(rng.normal(size=(130, 64))), unit(rng.normal(size=(33, 64)))))       # one partial second tile
+    cases.append((unit(rng.normal(size=(3, 64))), unit(rng.normal(size=(2, 64)))))
+    for q, t in cases:
+        i1, d1, d2 = engine.bf_l2_knn2(q, t)
+        oi1, od1, _oi2, od2 = oracle.bf_l2_knn2(q, t)
+        assert np.array_equal(i1, oi1) and np.array_equal(d1, od1) and np.array_equal(d2, od2), (q.shape, t.shape)
+        assert np.array_equal(engine.bf_l2_ratio_matches(q, t, 0.75), oracle.bf_l2_ratio_matches(q, t, 0.75))
+    # norms > 1 must take the exhaustive kernel and still agree
+    q = (3 * rng.normal(size=(400, 64))).astype(np.float32); t = (3 * rng.normal(size=(900, 64))).astype(np.float32)
+    i1, d1, d2 = engine.bf_l2_knn2(q, t)
+    oi1, od1, _oi2, od2 = oracle.bf_l2_knn2(q, t)
+    assert np.array_equal(i1, oi1) and np.array_equal(d1, od1) and np.array_equal(d2, od2)
+
+
 def test_mode_vote_golden(engine, golden_dir):
     g = np.load(os.path.join(golden_dir, "mode_cases.npz"))
     for i, (ev, st, dx, dy) in enumerate(g["expected"]):
