@@ -163,13 +163,13 @@ __device__ __forceinline__ void bfm_warm(const f16v &acc, BfmState &S)
         S.m1 = fminf(S.m1, v);
     }
 }
-__device__ __forceinline__ void bfm_scan(const f16v &acc, BfmState &S, int row0, uint2 *list, bool update)
+__device__ __forceinline__ void bfm_scan(const f16v &acc, BfmState &S, int row0, uint2 *list, size_t pitch, bool update)
 {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const float v = acc[i];
         if (v <= S.thr && v < 1e29f) {
-            if (S.cnt < BFM_CAPL) list[S.cnt] = make_uint2(__float_as_uint(v), (unsigned)(row0 + (i & 3) + 8 * (i >> 2)));
+            if (S.cnt < BFM_CAPL) list[S.cnt * pitch] = make_uint2(__float_as_uint(v), (unsigned)(row0 + (i & 3) + 8 * (i >> 2)));
             S.cnt++;
             if (update) {
                 S.m2 = fminf(S.m2, fmaxf(S.m1, v));
@@ -208,8 +208,11 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma_d64(const MatchDev *jobs)
     const float baug = half == 0 ? 1.f : 0.f;
     const bool va = q0 + col < nq, vb = q0 + 32 + col < nq;
     BfmState Sa = {INFINITY, INFINITY, INFINITY, 0}, Sb = {INFINITY, INFINITY, INFINITY, 0};
-    const size_t la = (((size_t)(q0 + col) * nsplit + sp) * 2 + half), lb = (((size_t)(q0 + 32 + col) * nsplit + sp) * 2 + half);
-    uint2 *lista = J.c_ent + la * BFM_CAPL, *listb = J.c_ent + lb * BFM_CAPL;
+    // lists are stored [list][entry][query] (query fastest): the 32 lanes of a half append to neighbouring addresses and
+    // the verifier, one thread per query, reads them coalesced
+    const size_t pitch = (size_t)J.capq;
+    const int lst = sp * 2 + half;
+    uint2 *lista = J.c_ent + (size_t)lst * BFM_CAPL * pitch + (q0 + col), *listb = lista + 32;
     const float *T = J.t;
     for (int pass = 0; pass < 2; pass++) {          // pass 0: first tile only, to seed the running second best
         const int tend = pass == 0 ? min(tile0 + 1, tile1) : tile1;
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma_d64(const MatchDev *jobs)
             } else {
                 const int row0 = tl * 32 + 4 * half;
                 // the seed tile is already part of the running statistics: list its candidates without counting them twice
-                bfm_scan(acc0, Sa, row0, lista, tl != tile0); bfm_scan(acc1, Sb, row0, listb, tl != tile0);
+                bfm_scan(acc0, Sa, row0, lista, pitch, tl != tile0); bfm_scan(acc1, Sb, row0, listb, pitch, tl != tile0);
             }
         }
         if (pass == 0) {
@@ -255,106 +258,79 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma_d64(const MatchDev *jobs)
             Sb.thr = vb ? Sb.m2 + BFM_MARGIN : -INFINITY;
         }
     }
-    if (va) J.c_cnt[la] = Sa.cnt;
-    if (vb) J.c_cnt[lb] = Sb.cnt;
+    if (va) J.c_cnt[(size_t)lst * pitch + q0 + col] = Sa.cnt;
+    if (vb) J.c_cnt[(size_t)lst * pitch + q0 + 32 + col] = Sb.cnt;
 }
 
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+// One THREAD per query (no cross-lane traffic; list reads are coalesced across the queries of a wave).  Sweep 1 takes
+// the second smallest score S2 over the query's lists (the lists hold the true 2-NN, so S2 bounds their scores up to the
+// MFMA rounding); sweep 2 parks the entries within BFM_MARGIN of S2 -- typically two or three -- in a per-thread LDS
+// column; the exact distances are then evaluated hit by hit, all lanes in step, with the arithmetic of k_bf_l2_d64 and
+// the semantics of knn_update over ascending train indices (best = lowest index among the smallest sqrt-domain
+// distances; second = next smallest value), which is order-independent in this form.
+#define BFV_HITS 12
+__device__ __forceinline__ void bfv_exact(const float *__restrict__ Qr, const float *__restrict__ T, int idx, float &B1, float &B2, int &I1)
 {
+    const float4 *tr = reinterpret_cast<const float4 *>(T + (size_t)idx * 64);
+    const float4 *qr = reinterpret_cast<const float4 *>(Qr);
+    float acc = 0.f;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long o = __shfl_xor(v, d, 64);
-        v = o < v ? o : v;
+    for (int d4 = 0; d4 < 16; d4++) {
+        const float4 tv = tr[d4], qv = qr[d4];
+        const float e0 = qv.x - tv.x, e1 = qv.y - tv.y, e2 = qv.z - tv.z, e3 = qv.w - tv.w;
+        acc += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
     }
-    return v;
+    const float d = sqrtf(acc);
+    if (d < B1 || (d == B1 && idx < I1)) { B2 = B1; B1 = d; I1 = idx; }
+    else B2 = fminf(B2, d);
 }
 
-__device__ __forceinline__ float wave_min_f32(float v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
-    return v;
-}
-
-// One wave per query.  Phase A reads the (score, train) entries of the query's lists and takes the second smallest
-// score S2 over all of them (the lists hold the true 2-NN, so S2 bounds their scores up to the MFMA rounding); phase B
-// evaluates the exact distance only for entries within BFM_MARGIN of S2 -- typically two or three -- and reduces them
-// with the semantics of knn_update over ascending train indices (best = lowest index among the smallest sqrt-domain
-// distances; second = next smallest value).
 __global__ __launch_bounds__(256) void k_bf_verify_d64(const MatchDev *jobs, int cns)
 {
     const MatchDev &J = jobs[blockIdx.y];
     const int nq = __builtin_amdgcn_readfirstlane(*J.nq_ptr), nt = __builtin_amdgcn_readfirstlane(*J.nt_ptr);
-    const int q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (q >= nq) return;
-    const int lane = threadIdx.x & 63;
+    if ((int)(blockIdx.x * 256) >= nq) return;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const bool live = q < nq;
     const int nl = 2 * cns;
-    const int *cc = J.c_cnt + (size_t)q * nl;
-    const uint2 *ent = J.c_ent + (size_t)q * nl * BFM_CAPL;
-    int total = 0; bool overflow = false;
-    for (int L = 0; L < nl; L++) { const int c = cc[L]; overflow = overflow || c > BFM_CAPL; total += min(c, BFM_CAPL); }
-    const int n_items = overflow ? nt : total;
-    float cut = INFINITY;
-    if (!overflow) {                                   // phase A: second smallest score over the lists
-        float s1 = INFINITY, s2 = INFINITY;
-        for (int base = 0; base < n_items; base += 64) {
-            const int f = base + lane;
-            float v = INFINITY;
-            int pre = 0;
-            for (int L = 0; L < nl; L++) {
-                const int c = min(cc[L], BFM_CAPL);
-                if (f >= pre && f < pre + c) v = __uint_as_float(ent[L * BFM_CAPL + (f - pre)].x);
-                pre += c;
+    const size_t pitch = (size_t)J.capq;
+    __shared__ int hits[BFV_HITS][256];
+    float s1 = INFINITY, s2 = INFINITY; bool overflow = false;
+    if (live)
+        for (int L = 0; L < nl; L++) {
+            const int c = J.c_cnt[(size_t)L * pitch + q];
+            overflow = overflow || c > BFM_CAPL;
+            const uint2 *e = J.c_ent + (size_t)L * BFM_CAPL * pitch + q;
+            for (int k = 0; k < min(c, BFM_CAPL); k++) {
+                const float v = __uint_as_float(e[k * pitch].x);
+                s2 = fminf(s2, fmaxf(s1, v));
+                s1 = fminf(s1, v);
             }
-            const float a1 = wave_min_f32(v);
-            // second smallest of this pass: drop ONE instance of the minimum (lowest lane holding it)
-            const unsigned long long holders = __ballot(v == a1);
-            const int first = holders ? __ffsll((long long)holders) - 1 : -1;
-            const float a2 = wave_min_f32(lane == first ? INFINITY : v);
-            if (a1 < s1) { s2 = fminf(s1, a2); s1 = a1; } else s2 = fminf(s2, a1);
         }
-        cut = s2 + BFM_MARGIN;
-    }
-    const float *Q = J.q + (size_t)q * 64;
+    const float cut = s2 + BFM_MARGIN;
+    const float *Qr = J.q + (size_t)min(q, nq - 1) * 64;
     float B1 = INFINITY, B2 = INFINITY; int I1 = -1;
-    for (int base = 0; base < n_items; base += 64) {
-        const int f = base + lane;
-        int idx = -1;
-        if (f < n_items) {
-            if (overflow) idx = f;
-            else {
-                int pre = 0;
-                for (int L = 0; L < nl; L++) {
-                    const int c = min(cc[L], BFM_CAPL);
-                    if (f >= pre && f < pre + c) {
-                        const uint2 e = ent[L * BFM_CAPL + (f - pre)];
-                        if (__uint_as_float(e.x) <= cut) idx = (int)e.y;
-                    }
-                    pre += c;
+    int nh = 0;
+    if (live && !overflow)
+        for (int L = 0; L < nl; L++) {
+            const int c = min(J.c_cnt[(size_t)L * pitch + q], BFM_CAPL);
+            const uint2 *e = J.c_ent + (size_t)L * BFM_CAPL * pitch + q;
+            for (int k = 0; k < c; k++) {
+                const uint2 ev = e[k * pitch];
+                if (__uint_as_float(ev.x) <= cut) {
+                    if (nh < BFV_HITS) hits[nh++][threadIdx.x] = (int)ev.y;
+                    else bfv_exact(Qr, J.t, (int)ev.y, B1, B2, I1);      // more near-ties than slots: evaluate in place
                 }
             }
         }
-        if (__ballot(idx >= 0) == 0) continue;
-        unsigned long long key = ~0ull;
-        if (idx >= 0) {
-            const float4 *tr = reinterpret_cast<const float4 *>(J.t + (size_t)idx * 64);
-            float acc = 0.f;
+    int maxh = nh;
 #pragma unroll
-            for (int d4 = 0; d4 < 16; d4++) {
-                const float4 tv = tr[d4];
-                const float e0 = Q[4 * d4] - tv.x, e1 = Q[4 * d4 + 1] - tv.y, e2 = Q[4 * d4 + 2] - tv.z, e3 = Q[4 * d4 + 3] - tv.w;
-                acc += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
-            }
-            key = ((unsigned long long)__float_as_uint(sqrtf(acc)) << 32) | (unsigned)idx;    // distances are >= 0: bit order == value order
-        }
-        const unsigned long long k1 = wave_min_u64(key);
-        const unsigned long long k2 = wave_min_u64(key == k1 ? ~0ull : key);   // indices are unique, so exactly one lane holds k1
-        const float b1 = __uint_as_float((unsigned)(k1 >> 32)); const int i1 = (int)(k1 & 0xffffffffu);
-        const float b2 = k2 == ~0ull ? INFINITY : __uint_as_float((unsigned)(k2 >> 32));
-        if (b1 < B1 || (b1 == B1 && i1 < I1)) { B2 = fminf(B1, b2); B1 = b1; I1 = i1; }
-        else B2 = fminf(B2, b1);
-    }
-    if (lane == 0) { J.p_d1[q] = B1; J.p_d2[q] = B2; J.p_i1[q] = I1; }
+    for (int d = 32; d >= 1; d >>= 1) maxh = max(maxh, __shfl_xor(maxh, d, 64));
+    for (int k = 0; k < maxh; k++)
+        if (k < nh) bfv_exact(Qr, J.t, hits[k][threadIdx.x], B1, B2, I1);
+    if (live && overflow)                                  // a list overflowed: exhaustive exact scan for this query
+        for (int j = 0; j < nt; j++) bfv_exact(Qr, J.t, j, B1, B2, I1);
+    if (live) { J.p_d1[q] = B1; J.p_d2[q] = B2; J.p_i1[q] = I1; }
 }
 
 // merge the per-split 2-NN lists, apply the ratio test (Python double arithmetic on float32 distances,
@@ -601,7 +577,7 @@ int launch_bf_l2_filtered(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int
     if (njobs <= 0 || capq <= 0) return VFSMS_OK;
     ProfScope ps(ctx, "bf_l2");
     hipLaunchKernelGGL(k_bf_mfma_d64, dim3((capq + 255) / 256, cns, njobs), dim3(256), 0, ctx->stream, d_jobs);
-    hipLaunchKernelGGL(k_bf_verify_d64, dim3((capq + 3) / 4, njobs), dim3(256), 0, ctx->stream, d_jobs, cns);
+    hipLaunchKernelGGL(k_bf_verify_d64, dim3((capq + 255) / 256, njobs), dim3(256), 0, ctx->stream, d_jobs, cns);
     HIP_TRY(hipGetLastError());
     return VFSMS_OK;
 }
