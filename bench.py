@@ -111,22 +111,40 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernel (BF-L2) from the live HIP-event timings of this rank ---------------
+    # ---- rooflines from the live HIP-event timings of this rank (library-side events on the kernels' own stream) ----
     stages = {k: dict(ms=round(v[0], 3), launches=v[1], ms_per_launch=round(v[0] / max(v[1], 1), 4)) for k, v in prof.items()}
     st = reg.stats
-    bf_ms, bf_n = prof.get("bf_l2", (0.0, 0))
     roofline = None
     extra = {}
+    de_ms, de_n = prof.get("describe", (0.0, 0))
+    if de_n and args.method == "surf":
+        # dominant kernel: k_describe (descriptor windows).  Algorithmic traffic per keypoint (SURVEY 8d / DESIGN.md 5): the
+        # win x win bilinear samples of the rotated window, 4 source bytes each, plus the 21 x 21 patch written out.
+        # samples/keypoint is measured outside the timed region on the first ROI pair (win = int(21 * size * 1.2 / 9)).
+        ra = isa.roi_rect((grid.th, grid.tw), 1, "first", 0.2)
+        k0 = need[0]
+        _k, _d, kf = eng.surf_detect_describe(np.ascontiguousarray(tiles[k0][ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]]), full=True)
+        win = np.minimum((21 * (kf["size"] * np.float32(1.2) / np.float32(9.0))).astype(np.int64), 739)
+        spk = float((win.astype(np.float64) ** 2).mean()) if len(win) else 0.0
+        kps = st["sum_nq_plus_nt"] / de_n                                   # keypoints described per launch
+        b = kps * (4.0 * spk + 441.0)
+        dur = de_ms / de_n * 1e-3
+        roofline = dict(kernel="k_describe", bound="hbm", achieved=round(b / dur / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(b / dur / 1e9 / HBM_PEAK_GBS, 5), traffic=None, avg_launch_ms=round(dur * 1e3, 4),
+                        bytes_per_launch=b, keypoints_per_launch=kps, samples_per_keypoint=round(spk, 1), launches=de_n,
+                        note="dominant kernel by time; it is VALU-issue bound, not HBM bound: ~45 instructions per bilinear sample "
+                             "(double-precision sample positions as in the reference), PMC in profiles/ shows the SIMDs issuing >90 % "
+                             "of cycles; HBM traffic measured by PMC is a few tens of MB per launch")
+    bf_ms, bf_n = prof.get("bf_mfma", (0.0, 0))
     if bf_n:
         dur = bf_ms / bf_n * 1e-3
-        flops = 3.0 * 64 * st["sum_nq_nt"] / bf_n                         # sub, mul, add per dimension and (query, train)
-        bytes_ = (st["sum_nq_plus_nt"] * 64 * 4 + st["sum_nq"] * 16) / bf_n
-        roofline = dict(kernel="k_bf_l2_d64", bound="mfma", achieved=round(flops / dur / 1e12, 3), peak=FP32_PEAK_TFLOPS,
-                        unit="TFLOP/s", frac=round(flops / dur / 1e12 / FP32_PEAK_TFLOPS, 4), traffic=None,
-                        note="FP32 vector-ALU bound (no MFMA used: not a dense contraction); peak = gfx950 FP32 MFMA == FP32 vector "
-                             "peak, which prices an FMA as 2 flops -- this kernel's sub/mul/add are unfused by specification, "
-                             "so its attainable ceiling is 78.6 TFLOP/s",
-                        avg_launch_ms=round(dur * 1e3, 4), flops_per_launch=flops, launches=bf_n)
+        flops = 2.0 * 64 * st["sum_nq_nt"] / bf_n                         # one 64-d dot product per (query, train)
+        bytes_ = (st["sum_nq_plus_nt"] * 64 * 4) / bf_n
+        extra["bf_l2_mfma"] = dict(kernel="k_bf_mfma_d64", bound="mfma", achieved=round(flops / dur / 1e12, 3), peak=FP32_PEAK_TFLOPS,
+                                   unit="TFLOP/s", frac=round(flops / dur / 1e12 / FP32_PEAK_TFLOPS, 4), traffic=None,
+                                   avg_launch_ms=round(dur * 1e3, 4), flops_per_launch=flops, launches=bf_n,
+                                   note="v_mfma_f32_32x32x2_f32 candidate filter (peak = dense f32 MFMA); the exact distances are "
+                                        "evaluated by k_bf_verify_d64 for the few surviving candidates")
         extra["bf_l2_hbm"] = dict(bound="hbm", achieved=round(bytes_ / dur / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                                   frac=round(bytes_ / dur / 1e9 / HBM_PEAK_GBS, 5), bytes_per_launch=bytes_)
     in_ms, in_n = prof.get("integral", (0.0, 0))
@@ -171,8 +189,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "synthetic %dx%d grid of %dx%d u8 tiles, serpentine path, %d pairs; SURF(100,4,3,64-d)+BF-L2 knn2 "
-                                   "ratio 0.75 + mode vote; roiRatio 0.2, direction 1, directIncre 1" % (args.rows, args.cols, args.tile, args.tile, P),
+            "config": {"workload": "synthetic %dx%d grid of %dx%d u8 tiles, serpentine path, %d pairs; %s; roiRatio 0.2, direction 1, directIncre 1"
+                                   % (args.rows, args.cols, args.tile, args.tile, P,
+                                      {"surf": "SURF(100,4,3,64-d)+BF-L2 knn2 ratio 0.75 + mode vote", "orb": "ORB(5000,1.2,8)+BF-Hamming 1-NN + mode vote",
+                                       "phase": "FFT phase correlation of the ROI strips"}[args.method]),
                        "pairs": P, "parallelism": "pairs%d" % world, "speculation_window": args.window},
             "max_abs_offset_error_px": max_err, "pairs_failed": n_failed,
             "attempts_per_step": st["attempts"] / max(args.steps, 1), "batches_per_step": st["batches"] / max(args.steps, 1),

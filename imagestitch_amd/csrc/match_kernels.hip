@@ -575,9 +575,14 @@ int match_filter_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int cns)
 int launch_bf_l2_filtered(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int cns)
 {
     if (njobs <= 0 || capq <= 0) return VFSMS_OK;
-    ProfScope ps(ctx, "bf_l2");
-    hipLaunchKernelGGL(k_bf_mfma_d64, dim3((capq + 255) / 256, cns, njobs), dim3(256), 0, ctx->stream, d_jobs);
-    hipLaunchKernelGGL(k_bf_verify_d64, dim3((capq + 255) / 256, njobs), dim3(256), 0, ctx->stream, d_jobs, cns);
+    {
+        ProfScope ps(ctx, "bf_mfma");
+        hipLaunchKernelGGL(k_bf_mfma_d64, dim3((capq + 255) / 256, cns, njobs), dim3(256), 0, ctx->stream, d_jobs);
+    }
+    {
+        ProfScope ps(ctx, "bf_verify");
+        hipLaunchKernelGGL(k_bf_verify_d64, dim3((capq + 255) / 256, njobs), dim3(256), 0, ctx->stream, d_jobs, cns);
+    }
     HIP_TRY(hipGetLastError());
     return VFSMS_OK;
 }

@@ -590,7 +590,9 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
     const int ncols1 = G.w - 1, nrows1 = G.h - 1;
     // the image base is the same for the whole workgroup: pinned to SGPRs so gathers use scalar-base + 32-bit-offset addressing
     const uint64_t bp = (uint64_t)G.img;
-    g_cu8 ubase = (g_cu8)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)bp));
+    // (readfirstlane returns int: widen through uint32_t, or a low half with bit 31 set sign-extends into the high half)
+    g_cu8 ubase = (g_cu8)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32)) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)bp));
     for (int ty = wv; ty < strips; ty += 4) {
         const int r = ty * 8 + li;
         const bool rok = r < nrows;
