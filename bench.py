@@ -26,7 +26,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP32_PEAK_TFLOPS = 157.3       # FP32 vector peak == FP32 MFMA peak on gfx950 (counts FMA as 2 flops)
+FP32_PEAK_TFLOPS = 157.3       # dense FP32 MFMA peak of gfx950 (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_summary.txt, written by
+    tools/profile_round.sh from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command; gfx950 x2
+    correction applied to FETCH_SIZE).  PMC counters cannot be collected from inside the timed run, hence the file."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.txt")), reverse=True):
+        for line in open(path):
+            m = re.match(r"^%s\s+launches=\d+ .*total\(x2 rule\)=([0-9.e+]+) B/launch" % re.escape(kernel), line)
+            if m:
+                return float(m.group(1)), os.path.relpath(path, ROOT)
+    return None, None
 
 
 def main():
@@ -129,8 +143,9 @@ def main():
         kps = st["sum_nq_plus_nt"] / de_n                                   # keypoints described per launch
         b = kps * (4.0 * spk + 441.0)
         dur = de_ms / de_n * 1e-3
+        traffic, traffic_src = pmc_traffic("k_describe")
         roofline = dict(kernel="k_describe", bound="hbm", achieved=round(b / dur / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(b / dur / 1e9 / HBM_PEAK_GBS, 5), traffic=None, avg_launch_ms=round(dur * 1e3, 4),
+                        frac=round(b / dur / 1e9 / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src, avg_launch_ms=round(dur * 1e3, 4),
                         bytes_per_launch=b, keypoints_per_launch=kps, samples_per_keypoint=round(spk, 1), launches=de_n,
                         note="dominant kernel by time; it is VALU-issue bound, not HBM bound: ~45 instructions per bilinear sample "
                              "(double-precision sample positions as in the reference), PMC in profiles/ shows the SIMDs issuing >90 % "
@@ -141,7 +156,7 @@ def main():
         flops = 2.0 * 64 * st["sum_nq_nt"] / bf_n                         # one 64-d dot product per (query, train)
         bytes_ = (st["sum_nq_plus_nt"] * 64 * 4) / bf_n
         extra["bf_l2_mfma"] = dict(kernel="k_bf_mfma_d64", bound="mfma", achieved=round(flops / dur / 1e12, 3), peak=FP32_PEAK_TFLOPS,
-                                   unit="TFLOP/s", frac=round(flops / dur / 1e12 / FP32_PEAK_TFLOPS, 4), traffic=None,
+                                   unit="TFLOP/s", frac=round(flops / dur / 1e12 / FP32_PEAK_TFLOPS, 4), traffic=pmc_traffic("k_bf_mfma_d64")[0],
                                    avg_launch_ms=round(dur * 1e3, 4), flops_per_launch=flops, launches=bf_n,
                                    note="v_mfma_f32_32x32x2_f32 candidate filter (peak = dense f32 MFMA); the exact distances are "
                                         "evaluated by k_bf_verify_d64 for the few surviving candidates")
