@@ -263,3 +263,22 @@ def test_orb_fused_attempt_and_exact_truth(engine, oracle):
         assert status and off == truth, (k, off, truth)                  # bit-exact for ORB (north_star)
     a, b = engine.orb_detect_describe(tiles[0])[1], engine.orb_detect_describe(tiles[1])[1]
     assert np.array_equal(engine.bf_hamming_matches(a, b), oracle.bf_hamming_matches(a, b)[0])
+
+
+def test_demo_strips_iron_and_zirconcl(engine, golden_dir):
+    """BASELINE configs[0] / configs[3] on the real micrograph strips: phase-correlation offsets bit-exact against the fixture
+    (integer parts as Stitcher.py:231-232 keeps them, sub-pixel peak within 1e-6), and the fused SURF attempt equal to the
+    oracle's row (status, offset, votes, keypoint and match counts)."""
+    import json
+    meta = json.load(open(os.path.join(golden_dir, "demo_strips.json")))["cases"]
+    g = np.load(os.path.join(golden_dir, "demo_strips.npz"))
+    jobs = []
+    for n, c in enumerate(meta):
+        a, b = g["d%d_roiA" % n], g["d%d_roiB" % n]
+        (x, y), r = engine.phase_correlate(a, b)
+        assert [int(y), int(x)] == c["phase_int"], (n, (x, y), c["phase_xy"])
+        assert abs(x - c["phase_xy"][0]) < 1e-6 and abs(y - c["phase_xy"][1]) < 1e-6 and abs(r - c["phase_response"]) < 1e-9
+        ha, hb = engine.tile_upload(a), engine.tile_upload(b)
+        rows = engine.attempt_surf_batch([(ha, hb, 0, 0, 0, 0, a.shape[0], a.shape[1])])
+        s = c["surf"]
+        assert rows[0].tolist()[:7] == [s["status"], s["offset"][0], s["offset"][1], s["votes"], s["nA"], s["nB"], s["matches"]], (n, rows[0], s)

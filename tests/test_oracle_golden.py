@@ -153,3 +153,23 @@ def test_orb_oracle_exact_truth_and_structure(oracle):
         if d == 2: off[1] += 1024 - L
         if d == 4: off[1] -= 1024 - L
         assert st and off == truth, (k, off, truth, votes)
+
+
+def test_demo_strips_fixture_reproduced_by_oracle(oracle, golden_dir):
+    """BASELINE configs[0] (iron pair) and configs[3] (zirconCL sequence): ROI strips at roiRatio 0.2 with the offsets the oracle
+    produced when the fixture was captured (tools/capture_golden.py demo; oracle-generated because cv2 is not installable).
+    Guards the oracle against regressions; the iron strip is 387 x 2584 -> DFT size 400 x 2592 (SURVEY 8c iv)."""
+    meta = json.load(open(os.path.join(golden_dir, "demo_strips.json")))["cases"]
+    g = np.load(os.path.join(golden_dir, "demo_strips.npz"))
+    assert meta[0]["dataset"] == "iron" and meta[0]["roi"] == [387, 2584]
+    assert oracle.optimal_dft_size(387) == 400 and oracle.optimal_dft_size(2584) == 2592
+    for n, c in enumerate(meta):
+        (x, y), r = oracle.phase_correlate(g["d%d_roiA" % n], g["d%d_roiB" % n])
+        assert [x, y] == c["phase_xy"] and r == c["phase_response"], (n, (x, y), c["phase_xy"])
+    # phase correlation and SURF agree on the iron pair (the reference's sign quirk: phase = -offset; Stitcher.py:231-232)
+    assert meta[0]["phase_int"] == [-149, 0] and meta[0]["surf"]["offset"] == [150, 0]
+    c = meta[1]
+    ka, da = oracle.surf_detect_describe(g["d1_roiA"]); kb, db = oracle.surf_detect_describe(g["d1_roiB"])
+    pairs = oracle.bf_l2_ratio_matches(da, db, 0.75)
+    st, off, votes = oracle.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, 3)
+    assert [int(st), off, int(votes), len(ka), len(kb), len(pairs)] == [c["surf"]["status"], c["surf"]["offset"], c["surf"]["votes"], c["surf"]["nA"], c["surf"]["nB"], c["surf"]["matches"]]

@@ -378,10 +378,48 @@ def cap_real():
     print("real strips", len(meta), os.path.getsize(os.path.join(OUT, "real_strips.npz")) // 1024, "KiB")
 
 
+def cap_demo_strips():
+    """BASELINE configs[0] / configs[3]: ROI strips of the iron pair (direction 1) and of the first zirconCL pairs (direction 4)
+    at roiRatio 0.2.  cv2 is not installable here, so the expected offsets are produced by the oracle (oracle/): these
+    fixtures pin the HIP path to the oracle on real micrographs and guard the oracle against regressions; they are NOT
+    reference-generated values."""
+    from PIL import Image
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import oracle as O
+    O.build()
+
+    def load(path):
+        im = Image.open(path); im.draft("L", im.size)
+        return np.asarray(im.convert("L"))
+    m = RU.Method()
+    store = {}
+    meta = []
+    cases = [("iron", "1.jpg", "2.jpg", 1)]
+    z = sorted(os.listdir(os.path.join(refshim.REF, "demoImages", "zirconCL", "1")))
+    cases += [("zirconCL", z[k], z[k + 1], 4) for k in range(3)]
+    for n, (ds, fa, fb, direction) in enumerate(cases):
+        A = load(os.path.join(refshim.REF, "demoImages", ds, "1", fa)); B = load(os.path.join(refshim.REF, "demoImages", ds, "1", fb))
+        ra = np.ascontiguousarray(m.getROIRegionForIncreMethod(A, direction=direction, order="first", searchRatio=0.2))
+        rb = np.ascontiguousarray(m.getROIRegionForIncreMethod(B, direction=direction, order="second", searchRatio=0.2))
+        (px, py), resp = O.phase_correlate(ra, rb)
+        ka, da = O.surf_detect_describe(ra); kb, db = O.surf_detect_describe(rb)
+        pairs = O.bf_l2_ratio_matches(da, db, 0.75)
+        st, off, votes = O.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, 3)
+        store["d%d_roiA" % n] = ra; store["d%d_roiB" % n] = rb
+        meta.append(dict(dataset=ds, a=fa, b=fb, direction=direction, shape=list(A.shape), roi=list(ra.shape),
+                         phase_xy=[px, py], phase_response=resp, phase_int=[int(py), int(px)],
+                         surf=dict(status=int(st), offset=[int(off[0]), int(off[1])], votes=int(votes), nA=len(ka), nB=len(kb), matches=len(pairs))))
+        print(ds, fa, fb, ra.shape, "phase", (px, py), resp, "surf", st, off, votes, len(ka), len(kb), len(pairs))
+    np.savez_compressed(os.path.join(OUT, "demo_strips.npz"), **store)
+    json.dump(dict(source="oracle-generated (cv2 not installable): regression pin of the oracle + parity target of the HIP path",
+                   cases=meta), open(os.path.join(OUT, "demo_strips.json"), "w"), indent=1)
+    print("demo strips", os.path.getsize(os.path.join(OUT, "demo_strips.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["roi", "mode", "sm", "cache", "fuse", "stitch", "flow", "real"]
+    which = sys.argv[1:] or ["roi", "mode", "sm", "cache", "fuse", "stitch", "flow", "real", "demo"]
     fns = dict(roi=cap_roi, mode=cap_mode, sm=cap_state_machine, cache=cap_feature_search_cache,
-               fuse=cap_fuse, stitch=cap_stitch, flow=cap_flow, real=cap_real)
+               fuse=cap_fuse, stitch=cap_stitch, flow=cap_flow, real=cap_real, demo=cap_demo_strips)
     for w in which:
         fns[w]()
