@@ -93,59 +93,88 @@ __device__ __forceinline__ int corner_score16(const int *d /* 25 differences v -
     return -b0 - 1;
 }
 
-__global__ __launch_bounds__(256) void k_orb_fast_score(const OrbDev *rois, int nlevels, int threshold)
+// ---- fused FAST score + 3x3 NMS + border rule + score histogram: one 64 x 16 pixel tile per workgroup ---------------------------------
+// The tile plus a 4 px halo (1 for the NMS neighbourhood, 3 for the Bresenham ring) is staged in LDS once; scores of the tile and its
+// 1 px halo are computed from LDS and never leave it; only the NMS survivors' byte map goes to HBM.  The histogram of surviving scores
+// is accumulated in LDS and flushed with at most 256 global atomics per workgroup (scores cluster on few values: per-pixel global
+// atomics on the same few addresses were the bulk of this stage).
+#define FT_W 64
+#define FT_H 16
+__global__ __launch_bounds__(256) void k_orb_fast_nms(const OrbDev *rois, int nlevels, int threshold, int edge)
 {
     const OrbDev &R = rois[blockIdx.z / nlevels];
     const int level = blockIdx.z % nlevels;
     const int w = R.lw[level], h = R.lh[level], st = R.ls[level];
-    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
-    if (j >= w || i >= h) return;
-    g_u8 score = (g_u8)R.score[level];
-    int s = 0;
-    if (i >= 3 && i < h - 3 && j >= 3 && j < w - 3) {
-        g_cu8 p = (g_cu8)R.lv[level] + (size_t)i * st + j;
-        const int v = p[0];
-        const int ox[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-        const int oy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-        int d[25];
-        unsigned dark = 0, bright = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int x = p[oy[k] * st + ox[k]];
-            d[k] = v - x;
-            dark |= (unsigned)(x < v - threshold) << k;
-            bright |= (unsigned)(x > v + threshold) << k;
-        }
-#pragma unroll
-        for (int k = 16; k < 25; k++) d[k] = d[k - 16];
-        // a circular run of >= 9: AND of the mask with its 8 rotations
-        unsigned md = dark | (dark << 16), mb = bright | (bright << 16);
-        unsigned rd = md, rb = mb;
-#pragma unroll
-        for (int r = 1; r < 9; r++) { rd &= md >> r; rb &= mb >> r; }
-        if ((rd & 0xffffu) | (rb & 0xffffu)) s = corner_score16(d, threshold) & 0xff;
+    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    if (x0 >= w || y0 >= h) return;
+    __shared__ uint8_t img[FT_H + 8][FT_W + 8];
+    __shared__ uint8_t sc[FT_H + 2][FT_W + 2 + 2];
+    __shared__ int hist[256];
+    const int tid = threadIdx.x;
+    hist[tid] = 0;
+    g_cu8 src = (g_cu8)R.lv[level];
+    for (int idx = tid; idx < (FT_H + 8) * (FT_W + 8); idx += 256) {
+        const int r = idx / (FT_W + 8), c = idx - r * (FT_W + 8);
+        const int gy = y0 - 4 + r, gx = x0 - 4 + c;
+        img[r][c] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? src[(size_t)gy * st + gx] : (uint8_t)0;
     }
-    score[(size_t)i * w + j] = (uint8_t)s;
+    __syncthreads();
+    for (int idx = tid; idx < (FT_H + 2) * (FT_W + 2); idx += 256) {
+        const int r = idx / (FT_W + 2), c = idx - r * (FT_W + 2);
+        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+        int s = 0;
+        if (gy >= 3 && gy < h - 3 && gx >= 3 && gx < w - 3) {
+            const uint8_t *p = &img[r + 3][c + 3];
+            const int v = p[0];
+            const int ox[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+            const int oy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+            int d[25];
+            unsigned dark = 0, bright = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int x = p[oy[k] * (FT_W + 8) + ox[k]];
+                d[k] = v - x;
+                dark |= (unsigned)(x < v - threshold) << k;
+                bright |= (unsigned)(x > v + threshold) << k;
+            }
+#pragma unroll
+            for (int k = 16; k < 25; k++) d[k] = d[k - 16];
+            // a circular run of >= 9: AND of the mask with its 8 rotations
+            unsigned md = dark | (dark << 16), mb = bright | (bright << 16);
+            unsigned rd = md, rb = mb;
+#pragma unroll
+            for (int q = 1; q < 9; q++) { rd &= md >> q; rb &= mb >> q; }
+            if ((rd & 0xffffu) | (rb & 0xffffu)) s = corner_score16(d, threshold) & 0xff;
+        }
+        sc[r][c] = (uint8_t)s;
+    }
+    __syncthreads();
+    g_u8 nm = (g_u8)R.nms[level];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int r = (tid >> 6) + 4 * k, c = tid & 63;
+        const int i = y0 + r, j = x0 + c;
+        if (i >= h || j >= w) continue;
+        const int s = sc[r + 1][c + 1];
+        int keep = 0;
+        if (s && i >= 1 && i < h - 1 && j >= 1 && j < w - 1) {
+            if (s > sc[r + 1][c + 2] && s > sc[r + 1][c] && s > sc[r][c] && s > sc[r][c + 1] && s > sc[r][c + 2] &&
+                s > sc[r + 2][c] && s > sc[r + 2][c + 1] && s > sc[r + 2][c + 2])
+                if (j >= edge && j < w - edge && i >= edge && i < h - edge) keep = s;
+        }
+        nm[(size_t)i * w + j] = (uint8_t)keep;
+        if (keep) atomicAdd(&hist[keep], 1);
+    }
+    __syncthreads();
+    if (hist[tid]) atomicAdd(&R.hist[level * 256 + tid], hist[tid]);
 }
 
-// ---- 3x3 NMS + runByImageBorder + histogram of surviving scores --------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_orb_nms_hist(const OrbDev *rois, int nlevels, int edge)
+// zero the per-ROI histograms and counters of a batch in one launch
+__global__ __launch_bounds__(256) void k_orb_clear(const OrbDev *rois, int nlevels)
 {
-    const OrbDev &R = rois[blockIdx.z / nlevels];
-    const int level = blockIdx.z % nlevels;
-    const int w = R.lw[level], h = R.lh[level];
-    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
-    if (j >= w || i >= h) return;
-    g_cu8 sc = (g_cu8)R.score[level];
-    int keep = 0;
-    const int s = sc[(size_t)i * w + j];
-    if (s && i >= 1 && i < h - 1 && j >= 1 && j < w - 1) {
-        g_cu8 p = sc + (size_t)i * w + j;
-        if (s > p[1] && s > p[-1] && s > p[-w - 1] && s > p[-w] && s > p[-w + 1] && s > p[w - 1] && s > p[w] && s > p[w + 1])
-            if (j >= edge && j < w - edge && i >= edge && i < h - edge) keep = s;
-    }
-    ((g_u8)R.nms[level])[(size_t)i * w + j] = (uint8_t)keep;
-    if (keep) atomicAdd(&R.hist[level * 256 + keep], 1);
+    const OrbDev &R = rois[blockIdx.x];
+    for (int i = threadIdx.x; i < 256 * nlevels; i += 256) R.hist[i] = 0;
+    if (threadIdx.x < 64) R.counters[threadIdx.x] = 0;
 }
 
 // keep every keypoint whose FAST score >= the n-th best (KeyPointsFilter::retainBest, HARRIS_SCORE keeps 2 * quota here)
@@ -196,7 +225,6 @@ __global__ __launch_bounds__(1024) void k_orb_compact1(const OrbDev *rois, int n
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const long long total = (long long)w * h;
     int *out_xy = R.k1_xy + (size_t)level * R.cap1 * 2;
-    float *out_r = R.k1_resp + (size_t)level * R.cap1;
     for (long long base = 0; base < total; base += 4096) {        // 4 consecutive pixels per lane
         const long long p0 = base + (long long)threadIdx.x * 4;
         int f[4], cnt = 0;
@@ -215,7 +243,6 @@ __global__ __launch_bounds__(1024) void k_orb_compact1(const OrbDev *rois, int n
                 const int y = (int)(p / w), x = (int)(p - (long long)y * w);
                 if (off < R.cap1) {
                     out_xy[2 * off] = x; out_xy[2 * off + 1] = y;
-                    out_r[off] = harris_response((g_cu8)R.lv[level], R.ls[level], x, y);
                 } else R.counters[2] = 1;
                 off++;
             }
@@ -225,6 +252,17 @@ __global__ __launch_bounds__(1024) void k_orb_compact1(const OrbDev *rois, int n
         __syncthreads();
     }
     if (threadIdx.x == 0) R.n1[level] = min(carry, R.cap1);
+}
+
+// Harris response of the survivors, one thread each (it used to run inside the single-workgroup compaction loop, one lane at a time)
+__global__ __launch_bounds__(256) void k_orb_harris(const OrbDev *rois, int nlevels)
+{
+    const OrbDev &R = rois[blockIdx.y / nlevels];
+    const int level = blockIdx.y % nlevels;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= R.n1[level]) return;
+    const int *xy = R.k1_xy + (size_t)level * R.cap1 * 2;
+    R.k1_resp[(size_t)level * R.cap1 + idx] = harris_response((g_cu8)R.lv[level], R.ls[level], xy[2 * idx], xy[2 * idx + 1]);
 }
 
 // ---- second retainBest (quota) by Harris response, IC angle, ordered compaction: one workgroup per (roi, level) ----------------------
@@ -486,9 +524,10 @@ int launch_orb(vfsms_ctx *ctx, const OrbDev *d_rois, const OrbDev *h_rois, int n
     for (int r = 0; r < nrois; r++) {
         maxw = h_rois[r].w > maxw ? h_rois[r].w : maxw; maxh = h_rois[r].h > maxh ? h_rois[r].h : maxh;
         maxcap2 = h_rois[r].cap2 > maxcap2 ? h_rois[r].cap2 : maxcap2;
-        HIP_TRY(hipMemsetAsync(h_rois[r].hist, 0, sizeof(int) * 256 * nl, ctx->stream));
-        HIP_TRY(hipMemsetAsync(h_rois[r].counters, 0, 64 * sizeof(int), ctx->stream));
     }
+    int maxcap1 = 0;
+    for (int r = 0; r < nrois; r++) maxcap1 = h_rois[r].cap1 > maxcap1 ? h_rois[r].cap1 : maxcap1;
+    hipLaunchKernelGGL(k_orb_clear, dim3(nrois), dim3(256), 0, ctx->stream, d_rois, nl);
     {
         ProfScope ps(ctx, "orb_pyramid");
         for (int l = 1; l < nl; l++) {
@@ -500,13 +539,14 @@ int launch_orb(vfsms_ctx *ctx, const OrbDev *d_rois, const OrbDev *h_rois, int n
     }
     {
         ProfScope ps(ctx, "orb_fast");
-        hipLaunchKernelGGL(k_orb_fast_score, dim3((maxw + 255) / 256, maxh, nrois * nl), dim3(256), 0, ctx->stream, d_rois, nl, p->fast_threshold < 0 ? 0 : p->fast_threshold > 255 ? 255 : p->fast_threshold);
-        hipLaunchKernelGGL(k_orb_nms_hist, dim3((maxw + 255) / 256, maxh, nrois * nl), dim3(256), 0, ctx->stream, d_rois, nl, p->edge_threshold);
+        hipLaunchKernelGGL(k_orb_fast_nms, dim3((maxw + FT_W - 1) / FT_W, (maxh + FT_H - 1) / FT_H, nrois * nl), dim3(256), 0, ctx->stream, d_rois, nl,
+                           p->fast_threshold < 0 ? 0 : p->fast_threshold > 255 ? 255 : p->fast_threshold, p->edge_threshold);
         hipLaunchKernelGGL(k_orb_threshold, dim3((nrois * nl + 63) / 64), dim3(64), 0, ctx->stream, d_rois, nrois, nl, ctx->d_orb_tables);
     }
     {
         ProfScope ps(ctx, "orb_select");
         hipLaunchKernelGGL(k_orb_compact1, dim3(nrois * nl), dim3(1024), 0, ctx->stream, d_rois, nl);
+        hipLaunchKernelGGL(k_orb_harris, dim3((maxcap1 + 255) / 256, nrois * nl), dim3(256), 0, ctx->stream, d_rois, nl);
         hipLaunchKernelGGL(k_orb_select2, dim3(nrois * nl), dim3(1024), 0, ctx->stream, d_rois, nl, ctx->d_orb_tables);
     }
     {
