@@ -849,35 +849,45 @@ extern "C" int vfsms_attempt_orb_batch(vfsms_ctx *ctx, const vfsms_roi_pair *job
     TRY(ctx_prepare_orb(ctx, params));
     int c1, c2, c;
     orb_caps(params, &c1, &c2, &c);
+    // a wave owns 64 queries and walks its share of the trains: split the trains so that a batch fills the chip a few times over
+    const long long hwaves = (long long)((c + 63) / 64) * n;
+    const int hns = (int)std::max<long long>(1, std::min<long long>(8, (8192 + hwaves - 1) / hwaves));
     size_t need = 0;
-    for (int k = 0; k < n; k++) need += 2 * orb_roi_bytes(params, jobs[k].h, jobs[k].w, c1, c2, c) + match_bytes(c, 1);
-    need += (sizeof(OrbDev) * 2 + sizeof(MatchDev)) * n + 65536;
+    for (int k = 0; k < n; k++) need += 2 * orb_roi_bytes(params, jobs[k].h, jobs[k].w, c1, c2, c) + match_bytes(c, hns);
+    need += (sizeof(OrbDev) * 2 + sizeof(MatchDev)) * n + (64 * 2 + VFSMS_ATTEMPT_INTS) * sizeof(int) * (size_t)n + 65536;
     TRY(ctx_arena_reserve(ctx, need));
     std::vector<OrbDev> R(2 * n);
     std::vector<MatchDev> M(n);
+    // counters of all ROIs and results of all jobs live in two contiguous blocks: two D2H copies per batch
+    int *cblock = (int *)ctx_arena_alloc(ctx, sizeof(int) * 64 * 2 * n);
+    int32_t *rblock = (int32_t *)ctx_arena_alloc(ctx, sizeof(int32_t) * VFSMS_ATTEMPT_INTS * n);
     for (int k = 0; k < n; k++) {
         const uint8_t *pa, *pb; int sa, sb;
         TRY(resolve_job(ctx, jobs[k], &pa, &sa, &pb, &sb));
         TRY(orb_roi_carve(ctx, &R[2 * k], pa, sa, jobs[k].h, jobs[k].w, params, c1, c2, c));
         TRY(orb_roi_carve(ctx, &R[2 * k + 1], pb, sb, jobs[k].h, jobs[k].w, params, c1, c2, c));
+        for (int e = 0; e < 2; e++) {
+            OrbDev &r = R[2 * k + e];
+            r.counters = cblock + 64 * (2 * k + e); r.thr1 = r.counters + 16; r.n1 = r.counters + 32; r.n2 = r.counters + 48;
+        }
         memset(&M[k], 0, sizeof(MatchDev));
-        TRY(match_carve(ctx, &M[k], c, 32, 1));
+        TRY(match_carve(ctx, &M[k], c, 32, hns));
+        M[k].result = rblock + VFSMS_ATTEMPT_INTS * k;
         M[k].q = (const float *)R[2 * k].desc; M[k].t = (const float *)R[2 * k + 1].desc;
         M[k].nq_ptr = R[2 * k].counters + 1; M[k].nt_ptr = R[2 * k + 1].counters + 1;
         M[k].kq = R[2 * k].kps_xy; M[k].kt = R[2 * k + 1].kps_xy;
     }
+    ctx->pinned_off = 0;
     OrbDev *dR; MatchDev *dM;
-    TRY(upload_array(ctx, R.data(), (size_t)2 * n, &dR));
-    TRY(upload_array(ctx, M.data(), (size_t)n, &dM));
+    TRY(upload_pinned(ctx, R.data(), sizeof(OrbDev) * 2 * n, (void **)&dR));
+    TRY(upload_pinned(ctx, M.data(), sizeof(MatchDev) * n, (void **)&dM));
     TRY(launch_orb(ctx, dR, R.data(), 2 * n, params));
-    TRY(launch_hamming_mode(ctx, dM, n, c, max_dist, offset_evaluate));
-    std::vector<int> counters((size_t)16 * 2 * n);
-    for (int k = 0; k < 2 * n; k++)
-        HIP_TRY(hipMemcpyAsync(&counters[(size_t)16 * k], R[k].counters, 16 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    for (int k = 0; k < n; k++)
-        HIP_TRY(hipMemcpyAsync(out + (size_t)VFSMS_ATTEMPT_INTS * k, M[k].result, VFSMS_ATTEMPT_INTS * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    TRY(launch_hamming_mode(ctx, dM, n, c, hns, max_dist, offset_evaluate));
+    std::vector<int> counters((size_t)64 * 2 * n);
+    HIP_TRY(hipMemcpyAsync(counters.data(), cblock, sizeof(int) * 64 * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, rblock, sizeof(int32_t) * VFSMS_ATTEMPT_INTS * n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 2 * n; k++)
-        if (counters[(size_t)16 * k + 2]) { vfsms_set_error("attempt_orb: internal keypoint capacity exceeded in ROI %d", k); return VFSMS_ERR_CAPACITY; }
+        if (counters[(size_t)64 * k + 2]) { vfsms_set_error("attempt_orb: internal keypoint capacity exceeded in ROI %d", k); return VFSMS_ERR_CAPACITY; }
     return VFSMS_OK;
 }

@@ -179,7 +179,7 @@ size_t orb_roi_bytes(const vfsms_orb_params *p, int h, int w, int cap1, int cap2
 int orb_roi_carve(vfsms_ctx *ctx, OrbDev *r, const uint8_t *img, int stride, int h, int w, const vfsms_orb_params *p,
                   int cap1, int cap2, int cap);
 int launch_orb(vfsms_ctx *ctx, const OrbDev *d_rois, const OrbDev *h_rois, int nrois, const vfsms_orb_params *p);
-int launch_hamming_mode(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int max_dist, int offset_evaluate);
+int launch_hamming_mode(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int nsplit, int max_dist, int offset_evaluate);
 // phase_kernels.hip
 int phase_correlate_device(vfsms_ctx *ctx, const uint8_t *a, int stride_a, const uint8_t *b, int stride_b,
                            int h, int w, double *d_out3);

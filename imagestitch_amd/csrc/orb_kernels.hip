@@ -211,25 +211,81 @@ __device__ __forceinline__ float harris_response(g_cu8 img, int st, int x0, int 
     return ((float)a * b - (float)c * c - 0.04f * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
 }
 
-__global__ __launch_bounds__(1024) void k_orb_compact1(const OrbDev *rois, int nlevels)
+// Ordered (row-major) compaction of the survivors in three fully parallel steps.  A level is cut into <= ORB_CHUNKS chunks of whole
+// 4096-pixel blocks; the chunk counts and then the chunk offsets live in the level's score histogram, which k_orb_threshold has
+// finished reading by then (first ORB_CHUNKS bins):   k_orb_count (count per chunk)  ->  k_orb_chunk_scan (exclusive scan, n1)  ->  k_orb_scatter.
+#define ORB_CHUNKS 32
+__device__ __forceinline__ long long orb_chunk_size(long long total)
+{
+    const long long blocks = (total + 4095) / 4096;
+    return ((blocks + ORB_CHUNKS - 1) / ORB_CHUNKS) * 4096;
+}
+
+__global__ __launch_bounds__(1024) void k_orb_count(const OrbDev *rois, int nlevels)
+{
+    const OrbDev &R = rois[blockIdx.y / nlevels];
+    const int level = blockIdx.y % nlevels;
+    const long long total = (long long)R.lw[level] * R.lh[level];
+    const long long cs = orb_chunk_size(total);
+    const long long lo = (long long)blockIdx.x * cs, hi = min(total, lo + cs);
+    const int thr = R.thr1[level];
+    g_cu8 nm = (g_cu8)R.nms[level];
+    int cnt = 0;
+    for (long long p = lo + threadIdx.x; p < hi; p += 1024) { const int v = nm[p]; cnt += (v >= thr && v > 0) ? 1 : 0; }
+    __shared__ int wsum[16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int incl = wave_incl_scan(cnt);
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int k = 0; k < 16; k++) t += wsum[k];
+        R.hist[level * 256 + blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_orb_chunk_scan(const OrbDev *rois, int nlevels)
 {
     const OrbDev &R = rois[blockIdx.x / nlevels];
     const int level = blockIdx.x % nlevels;
+    __shared__ int wsum[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = threadIdx.x < ORB_CHUNKS ? R.hist[level * 256 + threadIdx.x] : 0;
+    const int incl = wave_incl_scan(c);
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    int off = incl - c;
+    for (int k = 0; k < wid; k++) off += wsum[k];
+    if (threadIdx.x < ORB_CHUNKS) R.hist[level * 256 + threadIdx.x] = off;
+    if (threadIdx.x == 255) {
+        const int total = off + c;
+        if (total > R.cap1) R.counters[2] = 1;
+        R.n1[level] = min(total, R.cap1);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_orb_scatter(const OrbDev *rois, int nlevels)
+{
+    const OrbDev &R = rois[blockIdx.y / nlevels];
+    const int level = blockIdx.y % nlevels;
     const int w = R.lw[level], h = R.lh[level];
+    const long long total = (long long)w * h;
+    const long long cs = orb_chunk_size(total);
+    const long long lo = (long long)blockIdx.x * cs, hi = min(total, lo + cs);
+    if (lo >= hi) return;
     const int thr = R.thr1[level];
     g_cu8 nm = (g_cu8)R.nms[level];
     __shared__ int wsum[16];
     __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
+    if (threadIdx.x == 0) carry = R.hist[level * 256 + blockIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const long long total = (long long)w * h;
     int *out_xy = R.k1_xy + (size_t)level * R.cap1 * 2;
-    for (long long base = 0; base < total; base += 4096) {        // 4 consecutive pixels per lane
+    for (long long base = lo; base < hi; base += 4096) {        // 4 consecutive pixels per lane
         const long long p0 = base + (long long)threadIdx.x * 4;
         int f[4], cnt = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const long long p = p0 + q; f[q] = (p < total && nm[p] >= thr && nm[p] > 0) ? 1 : 0; cnt += f[q]; }
+        for (int q = 0; q < 4; q++) { const long long p = p0 + q; f[q] = (p < hi && nm[p] >= thr && nm[p] > 0) ? 1 : 0; cnt += f[q]; }
         const int incl = wave_incl_scan(cnt);
         if (lane == 63) wsum[wid] = incl;
         __syncthreads();
@@ -241,9 +297,7 @@ __global__ __launch_bounds__(1024) void k_orb_compact1(const OrbDev *rois, int n
             if (f[q]) {
                 const long long p = p0 + q;
                 const int y = (int)(p / w), x = (int)(p - (long long)y * w);
-                if (off < R.cap1) {
-                    out_xy[2 * off] = x; out_xy[2 * off + 1] = y;
-                } else R.counters[2] = 1;
+                if (off < R.cap1) { out_xy[2 * off] = x; out_xy[2 * off + 1] = y; }
                 off++;
             }
         }
@@ -251,7 +305,6 @@ __global__ __launch_bounds__(1024) void k_orb_compact1(const OrbDev *rois, int n
         if (threadIdx.x == 1023) carry = off0 + cnt;
         __syncthreads();
     }
-    if (threadIdx.x == 0) R.n1[level] = min(carry, R.cap1);
 }
 
 // Harris response of the survivors, one thread each (it used to run inside the single-workgroup compaction loop, one lane at a time)
@@ -428,7 +481,8 @@ __global__ __launch_bounds__(256) void k_orb_describe(const OrbDev *rois, int nl
 // ---- Hamming 1-NN for a batch of jobs + votes (BFMatcher("BruteForce-Hamming").match, ImageUtility.py:297-302) ------------------------
 // lanes own queries (8 dwords in VGPRs), trains stream through the scalar path like the L2 matcher
 typedef const uint32_t __attribute__((address_space(4))) cu32c;
-__global__ __launch_bounds__(256) void k_bf_hamming_jobs(const MatchDev *jobs, int max_dist)
+// trains are split over blockIdx.z (ascending ranges); per-split first minima land in p_d1 / p_i1 and are merged in split order
+__global__ __launch_bounds__(256) void k_bf_hamming_jobs(const MatchDev *jobs)
 {
     const MatchDev &J = jobs[blockIdx.y];
     const int nq = __builtin_amdgcn_readfirstlane(*J.nq_ptr), nt = __builtin_amdgcn_readfirstlane(*J.nt_ptr);
@@ -438,9 +492,12 @@ __global__ __launch_bounds__(256) void k_bf_hamming_jobs(const MatchDev *jobs, i
     uint32_t v[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) v[k] = pq[k];
+    const int nsplit = gridDim.z, sp = blockIdx.z;
+    const int chunk = (nt + nsplit - 1) / nsplit;
+    const int t0 = sp * chunk, t1 = min(nt, t0 + chunk);
     int best = 0x7fffffff, bi = -1;
     cu32c *T = (cu32c *)(uintptr_t)J.t;
-    for (int j = 0; j < nt; j++) {
+    for (int j = t0; j < t1; j++) {
         cu32c *tr = T + (size_t)j * 8;
         int d = 0;
 #pragma unroll
@@ -448,6 +505,21 @@ __global__ __launch_bounds__(256) void k_bf_hamming_jobs(const MatchDev *jobs, i
         if (d < best) { best = d; bi = j; }              // first minimum wins
     }
     if (q >= nq) return;
+    J.p_d1[(size_t)sp * J.capq + q] = (float)best; J.p_i1[(size_t)sp * J.capq + q] = bi;
+}
+
+__global__ __launch_bounds__(256) void k_hamming_merge(const MatchDev *jobs, int nsplit, int max_dist)
+{
+    const MatchDev &J = jobs[blockIdx.y];
+    const int nq = *J.nq_ptr;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    int best = 0x7fffffff, bi = -1;
+    for (int s = 0; s < nsplit; s++) {
+        const int i = J.p_i1[(size_t)s * J.capq + q];
+        const int d = i >= 0 ? (int)J.p_d1[(size_t)s * J.capq + q] : 0x7fffffff;
+        if (d < best) { best = d; bi = i; }              // splits are ascending train ranges: the first minimum still wins
+    }
     J.i1[q] = bi; J.d1[q] = (float)best; J.d2[q] = 0.f;
     int ok = bi >= 0 && (max_dist < 0 || best < max_dist);
     int vote = 0;
@@ -545,7 +617,9 @@ int launch_orb(vfsms_ctx *ctx, const OrbDev *d_rois, const OrbDev *h_rois, int n
     }
     {
         ProfScope ps(ctx, "orb_select");
-        hipLaunchKernelGGL(k_orb_compact1, dim3(nrois * nl), dim3(1024), 0, ctx->stream, d_rois, nl);
+        hipLaunchKernelGGL(k_orb_count, dim3(ORB_CHUNKS, nrois * nl), dim3(1024), 0, ctx->stream, d_rois, nl);
+        hipLaunchKernelGGL(k_orb_chunk_scan, dim3(nrois * nl), dim3(256), 0, ctx->stream, d_rois, nl);
+        hipLaunchKernelGGL(k_orb_scatter, dim3(ORB_CHUNKS, nrois * nl), dim3(1024), 0, ctx->stream, d_rois, nl);
         hipLaunchKernelGGL(k_orb_harris, dim3((maxcap1 + 255) / 256, nrois * nl), dim3(256), 0, ctx->stream, d_rois, nl);
         hipLaunchKernelGGL(k_orb_select2, dim3(nrois * nl), dim3(1024), 0, ctx->stream, d_rois, nl, ctx->d_orb_tables);
     }
@@ -558,12 +632,13 @@ int launch_orb(vfsms_ctx *ctx, const OrbDev *d_rois, const OrbDev *h_rois, int n
     return VFSMS_OK;
 }
 
-int launch_hamming_mode(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int max_dist, int offset_evaluate)
+int launch_hamming_mode(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int nsplit, int max_dist, int offset_evaluate)
 {
     if (njobs <= 0) return VFSMS_OK;
     {
         ProfScope ps(ctx, "bf_hamming");
-        hipLaunchKernelGGL(k_bf_hamming_jobs, dim3((capq + 255) / 256, njobs), dim3(256), 0, ctx->stream, d_jobs, max_dist);
+        hipLaunchKernelGGL(k_bf_hamming_jobs, dim3((capq + 255) / 256, njobs, nsplit), dim3(256), 0, ctx->stream, d_jobs);
+        hipLaunchKernelGGL(k_hamming_merge, dim3((capq + 255) / 256, njobs), dim3(256), 0, ctx->stream, d_jobs, nsplit, max_dist);
     }
     HIP_TRY(hipGetLastError());
     return launch_scan_mode(ctx, d_jobs, njobs, capq, offset_evaluate);
