@@ -43,6 +43,58 @@ def pmc_traffic(kernel):
     return None, None
 
 
+def bench_fuse(args, eng, grid, tiles, torch):
+    """Secondary metric: mosaic assembly of the whole grid from its true offsets -- layout arithmetic of
+    Stitcher.getStitchByOffset, tile 0 pasted, every further tile blended into the device canvas with fadeInAndFadeOut
+    (strip mode in columns, corner mode after each serpentine turn).  Tiles are handed over as host arrays, as the reference's
+    call surface does, so the figure includes one H2D copy per tile; the final canvas download is timed separately."""
+    import imagestitch_amd as isa
+    if args.gpus != 1:
+        raise SystemExit("--method fuse is a single-GPU measurement (the canvas is order-dependent: replicas only)")
+    n = grid.n_tiles
+    offs = [[0, 0]] + [list(map(int, o)) for o in grid.true_offsets()]
+    shapes = [(grid.th, grid.tw)] * n
+    offsetList, rangeX, rangeY, rows, cols = isa.Stitcher._layout(shapes, offs)
+
+    def assemble(download):
+        canvas = eng.canvas_create(rows, cols, 1)
+        try:
+            for i in range(n):
+                oy, ox = offsetList[i]
+                if i == 0:
+                    eng.canvas_paste(canvas, tiles[i], oy, ox)
+                    continue
+                roi = (max(oy, rangeX[i - 1][0]), max(ox, rangeY[i - 1][0]),
+                       min(oy + grid.th, rangeX[i - 1][1]), min(ox + grid.tw, rangeY[i - 1][1]))
+                eng.canvas_fuse_tile(canvas, tiles[i], oy, ox, roi, offs[i][0], offs[i][1])
+            eng.sync()
+            return eng.canvas_download(canvas, rows, cols, 1) if download else None
+        finally:
+            eng.canvas_free(canvas)
+
+    for _ in range(max(args.warmup, 1)):
+        assemble(False)
+    torch.cuda.synchronize(); eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        assemble(False)
+    torch.cuda.synchronize(); eng.sync()
+    dt = (time.perf_counter() - t0) / args.steps
+    t1 = time.perf_counter()
+    out = assemble(True)
+    dl = time.perf_counter() - t1 - dt
+    mpx = rows * cols / 1e6
+    print(json.dumps({
+        "metric": "fuse Mpx/sec (mosaic pixels, fadeInAndFadeOut)", "value": round(mpx / dt, 2), "unit": "Mpx/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "mosaic of the synthetic %dx%d grid of %dx%d u8 tiles from its true offsets: canvas %d x %d"
+                               % (args.rows, args.cols, args.tile, args.tile, rows, cols), "tiles": n, "includes": "one H2D copy per tile",
+                   "canvas_download_ms": round(dl * 1e3, 1)},
+        "tile_Mpx_per_s": round(n * grid.th * grid.tw / 1e6 / dt, 2), "mosaic_nonzero_fraction": round(float((out > 0).mean()), 4)}))
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,8 +104,9 @@ def main():
     ap.add_argument("--cols", type=int, default=9)
     ap.add_argument("--tile", type=int, default=2048)
     ap.add_argument("--window", type=int, default=24)
-    ap.add_argument("--method", default="surf", choices=["surf", "orb", "phase"],
-                    help="surf = the BASELINE metric; orb / phase time the other registration paths on the same grid")
+    ap.add_argument("--method", default="surf", choices=["surf", "orb", "phase", "fuse"],
+                    help="surf = the BASELINE metric; orb / phase time the other registration paths on the same grid; fuse = the"
+                         " secondary metric of SURVEY 8d (mosaic assembly with fadeInAndFadeOut blending, N = 1 only)")
     ap.add_argument("--cpu-sample", type=int, default=6, help="pairs timed on the host cores for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -85,6 +138,8 @@ def main():
     handles = [None] * grid.n_tiles
     for k in need:
         handles[k] = eng.tile_upload(tiles[k])               # tiles resident in HBM before the timed region
+    if args.method == "fuse":
+        return bench_fuse(args, eng, grid, tiles, torch)
     reg = GridRegistrar(eng, method=args.method, roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3 if args.method == "surf" else 10, directIncre=1,
                         surfParams=eng.surf_params() if args.method == "surf" else eng.orb_params() if args.method == "orb" else None,
                         window=args.window)

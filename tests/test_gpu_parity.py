@@ -282,3 +282,29 @@ def test_demo_strips_iron_and_zirconcl(engine, golden_dir):
         rows = engine.attempt_surf_batch([(ha, hb, 0, 0, 0, 0, a.shape[0], a.shape[1])])
         s = c["surf"]
         assert rows[0].tolist()[:7] == [s["status"], s["offset"][0], s["offset"][1], s["votes"], s["nA"], s["nB"], s["matches"]], (n, rows[0], s)
+
+
+def test_config0_iron_pair_end_to_end(engine, golden_dir):
+    """BASELINE configs[0] through the reference's call surface: Stitcher.calculateOffsetForPhaseCorrleateIncre on the iron
+    pair (direction 1, directIncre 0, roiRatio 0.2) returns the reference-as-written offset [1400, 0] that SURVEY 8d derives
+    (phase correlation reports b - a and the reference adds it with the feature path's sign), and the SURF path returns
+    [1699, 0], within 1 px of the true offset [1699, -1].  The 1936 x 2584 frames are rebuilt around the committed strips:
+    both searches succeed at i = 1 and never look outside them."""
+    import json
+    c = json.load(open(os.path.join(golden_dir, "demo_strips.json")))["cases"][0]
+    g = np.load(os.path.join(golden_dir, "demo_strips.npz"))
+    H, W = c["shape"]
+    A = np.zeros((H, W), np.uint8); B = np.zeros((H, W), np.uint8)
+    A[H - g["d0_roiA"].shape[0]:, :] = g["d0_roiA"]; B[:g["d0_roiB"].shape[0], :] = g["d0_roiB"]
+    st = isa.Stitcher()
+    st._engine = engine
+    st.isPrintLog = False
+    old = (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate)
+    try:
+        isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio = 1, 0, 0.2
+        assert st.calculateOffsetForPhaseCorrleateIncre([A, B]) == (True, [1400, 0])
+        isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate = "surf", 3
+        status, off = st.calculateOffsetForFeatureSearchIncre([A, B])
+        assert status and abs(off[0] - 1699) <= 1 and abs(off[1] - (-1)) <= 1, off
+    finally:
+        isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate = old
