@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_fuse_stats_cols(CanvasView V, int r, in
 // the blend: writes the whole tile rectangle (outside the ROI: plain paste) and marks it valid
 __global__ __launch_bounds__(256) void k_fuse_apply(uint8_t *pix, uint8_t *mask, int ccols, int ch,
                                                     const uint8_t *tile, int th, int tw, int y0, int x0,
-                                                    int ry0, int rx0, int r, int c, int corner,
+                                                    int ry0, int rx0, int r, int c, const int *mode,
                                                     const float *wAr, const float *wAc, const float *wBr, const float *wBc)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_fuse_apply(uint8_t *pix, uint8_t *mask,
     const bool in_roi = (i >= 0 && i < r && j >= 0 && j < c);
     if (in_roi) {
         float wA, wB;
-        if (corner) { wB = wBr[i] * wBc[j]; wA = 1 - wB; }
+        if (mode[0]) { wB = wBr[i] * wBc[j]; wA = 1 - wB; }
         else { wA = wAr[i] * wAc[j]; wB = wBr[i] * wBc[j]; }
         const bool av = mask[co] != 0;
         for (int k = 0; k < ch; k++) {
@@ -174,14 +174,14 @@ __global__ __launch_bounds__(256) void k_i64_stats_cols(I64View V, int r, int c,
         if (V.a_valid(i, j)) { if (first < 0) first = i; last = i; }
     colFirst[j] = first; colLast[j] = last;
 }
-__global__ __launch_bounds__(256) void k_i64_apply(I64View V, int r, int c, int corner, const float *wAr, const float *wAc,
+__global__ __launch_bounds__(256) void k_i64_apply(I64View V, int r, int c, const int *mode, const float *wAr, const float *wAc,
                                                    const float *wBr, const float *wBc, uint8_t *out)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int i = blockIdx.y;
     if (j >= c) return;
     float wA, wB;
-    if (corner) { wB = wBr[i] * wBc[j]; wA = 1 - wB; }
+    if (mode[0]) { wB = wBr[i] * wBc[j]; wA = 1 - wB; }
     else { wA = wAr[i] * wAc[j]; wB = wBr[i] * wBc[j]; }
     for (int k = 0; k < V.ch; k++) {
         long long a = V.a_raw(i, j, k), b = V.b_val(i, j, k);
@@ -194,97 +194,112 @@ __global__ __launch_bounds__(256) void k_i64_apply(I64View V, int r, int c, int 
 }
 
 // ---- host: mode decision + separable ramps (ImageFusion.py:204-239 and :43-190) -----------------------
-static inline int pywrap(int i, int n) { return i < 0 ? i + n : i; }
+// ---------------------------------------------------------------------------------------------------
+// Weight ramps on the device (one workgroup).  fuseByFadeInAndFadeOut's strip ramps (ImageFusion.py:213-235) and
+// getWeightsMatrix's corner ramps (ImageFusion.py:43-190) are separable; the Python scans for the first non-empty pixel
+// become a first-match reduction over the per-row / per-column first/last-valid arrays, the ramp loops their closed
+// forms (each index is written by exactly one loop iteration that survives, see the notes at the loops), with the
+// reference's conventions kept: float32 strip arithmetic, double quotient cast to float32 in the corner ramps, index 0
+// patched to 1, Python's negative-index wrap, and the geometries where the reference itself raises reported in out[5].
+//   out: [0] corner mode, [1..4] info (mode, quadrant, rowIndex, colIndex), [5] error
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pywrap(int i, int n) { return i < 0 ? i + n : i; }
 
-// returns 0 ok, -1 where the reference itself would raise (IndexError / ZeroDivisionError)
-static int build_weights(int r, int c, int ch, int dx, int dy, const FuseStats &st,
-                         const std::vector<int> &rowFirst, const std::vector<int> &rowLast,
-                         const std::vector<int> &colFirst, const std::vector<int> &colLast,
-                         std::vector<float> &wAr, std::vector<float> &wAc, std::vector<float> &wBr, std::vector<float> &wBc,
-                         int *corner_out, int32_t *info)
+__global__ __launch_bounds__(256) void k_fuse_weights(int r, int c, int ch, int dx, int dy, int force_corner, const FuseStats *st,
+                                                      const int *rowFirst, const int *rowLast, const int *colFirst, const int *colLast,
+                                                      float *wAr, float *wAc, float *wBr, float *wBc, int *out)
 {
-    wAr.assign(r, 1.f); wBr.assign(r, 1.f); wAc.assign(c, 1.f); wBc.assign(c, 1.f);
+    const int t = threadIdx.x;
+    __shared__ int s_first, s_geom[4];          // first scan position with a non-zero candidate; index,rowIndex,colIndex,err
+    for (int i = t; i < r; i += 256) { wAr[i] = 1.f; wBr[i] = 1.f; }
+    for (int j = t; j < c; j += 256) { wAc[j] = 1.f; wBc[j] = 1.f; }
+    if (t == 0) s_first = 0x7fffffff;
+    __syncthreads();
     const double nel = (double)r * c * ch;
-    int32_t inf[4] = {0, -1, 0, 0};
-    *corner_out = 0;
-    if ((double)st.valid / nel > 0.65) {
+    const bool strip = !force_corner && (double)st->valid / nel > 0.65;
+    if (strip) {
         if (c <= r) {                       // side-by-side strip: ramps along columns (float32 arithmetic)
-            for (int i = 0; i < c; i++) {
+            for (int i = t; i < c; i += 256) {
                 const float f = (dy >= 0) ? (float)i : (float)(c - i);
-                wAc[c - i - 1] = ((wAc[c - i - 1] * f) * 1.0f) / (float)c;
-                wBc[i] = ((wBc[i] * f) * 1.0f) / (float)c;
+                wAc[c - i - 1] = ((1.f * f) * 1.0f) / (float)c;
+                wBc[i] = ((1.f * f) * 1.0f) / (float)c;
             }
         } else {                            // stacked strip: ramps along rows
-            for (int i = 0; i < r; i++) {
+            for (int i = t; i < r; i += 256) {
                 const float f = (dx <= 0) ? (float)i : (float)(r - i);
-                wAr[i] = ((wAr[i] * f) * 1.0f) / (float)r;
-                wBr[r - i - 1] = ((wBr[r - i - 1] * f) * 1.0f) / (float)r;
+                wAr[i] = ((1.f * f) * 1.0f) / (float)r;
+                wBr[r - i - 1] = ((1.f * f) * 1.0f) / (float)r;
             }
         }
-    } else {
-        *corner_out = 1; inf[0] = 1;
-        int index = 0;
-        for (int q = 1; q < 4; q++) if (st.quad[q] < st.quad[index]) index = q;
-        int rowIndex = 0, colIndex = 0;
-        if (index == 2 || index == 3) {
-            for (int j = 1; j < c; j++) {
-                const int cj = c - j;
-                if (index == 2) { if (colLast[cj] >= 0) rowIndex = colLast[cj] + 1; }
-                else            { if (colFirst[cj] >= 0) rowIndex = colFirst[cj] - 1; }
-                if (rowIndex != 0) break;
-            }
-            if (rowIndex >= r) return -1;
-            const int rr = pywrap(rowIndex, r);
-            if (rowLast[rr] >= 0) colIndex = rowLast[rr] + 1;
-        } else {
-            for (int j = 0; j < c; j++) {
-                if (index == 0) { if (colFirst[j] >= 0) rowIndex = colFirst[j] - 1; }
-                else            { if (colLast[j] >= 0) rowIndex = colLast[j] + 1; }
-                if (rowIndex != 0) break;
-            }
-            if (rowIndex >= r) return -1;
-            const int rr = pywrap(rowIndex, r);
-            if (rowFirst[rr] >= 0) colIndex = rowFirst[rr] - 1;
+        if (t == 0) { out[0] = 0; out[1] = 0; out[2] = -1; out[3] = 0; out[4] = 0; out[5] = 0; }
+        return;
+    }
+    int index = 0;
+    for (int q = 1; q < 4; q++) if (st->quad[q] < st->quad[index]) index = q;
+    // the Python loop walks the columns (from the right for index 2/3, from the left otherwise) until rowIndex becomes non-zero
+    const bool from_right = index == 2 || index == 3;
+    const int jlo = from_right ? 1 : 0;
+    int mine = 0x7fffffff;
+    for (int j = jlo + t; j < c; j += 256) {
+        const int col = from_right ? c - j : j;
+        int cand = 0;
+        if (index == 2 || index == 1) { if (colLast[col] >= 0) cand = colLast[col] + 1; }
+        else                          { if (colFirst[col] >= 0) cand = colFirst[col] - 1; }
+        if (cand != 0) { mine = j; break; }
+    }
+    atomicMin(&s_first, mine);
+    __syncthreads();
+    if (t == 0) {
+        int rowIndex = 0, colIndex = 0, err = 0;
+        if (s_first != 0x7fffffff) {
+            const int col = from_right ? c - s_first : s_first;
+            rowIndex = (index == 2 || index == 1) ? colLast[col] + 1 : colFirst[col] - 1;
         }
-        inf[1] = index; inf[2] = rowIndex; inf[3] = colIndex;
+        if (rowIndex >= r) err = 1;
+        else {
+            const int rr = pywrap(rowIndex, r);
+            if (from_right) { if (rowLast[rr] >= 0) colIndex = rowLast[rr] + 1; }
+            else            { if (rowFirst[rr] >= 0) colIndex = rowFirst[rr] - 1; }
+        }
+        s_geom[0] = index; s_geom[1] = rowIndex; s_geom[2] = colIndex; s_geom[3] = err;
+    }
+    __syncthreads();
+    const int rowIndex = s_geom[1], colIndex = s_geom[2];
+    int err = s_geom[3];
+    if (!err) {
+        // rows.  index 2 / 1: for i in range(rowIndex + 1): wB[ri - i] = (ri - i) / ri  (ri = rowIndex, 0 patched to 1): indices ri..ri-rowIndex, all distinct
+        //        index 3 / 0: for i in range(rowIndex, row): wB[i] = (row - i - 1) / (row - ri - 1); a negative start only writes wrapped indices
+        //                     that later iterations overwrite, so the surviving writes are i = max(rowIndex, 0) .. row - 1
         if (index == 2 || index == 1) {
-            const int n = rowIndex + 1; int ri = rowIndex;
-            for (int i = 0; i < n; i++) {
-                if (ri == 0) ri = 1;
+            const int n = rowIndex + 1, ri = rowIndex == 0 ? 1 : rowIndex;
+            for (int i = t; i < n; i += 256) {
                 const int idx = ri - i;
-                if (idx >= r) return -1;
+                if (idx >= r) { err = 1; break; }
                 wBr[pywrap(idx, r)] = (float)((double)(ri - i) * 1 / ri);
             }
         } else {
-            int ri = rowIndex;
-            for (int i = rowIndex; i < r; i++) {
-                if (ri == 0) ri = 1;
-                if (r - ri - 1 == 0) return -1;
-                wBr[pywrap(i, r)] = (float)((double)(r - i - 1) * 1 / (r - ri - 1));
-            }
+            const int ri = rowIndex == 0 ? 1 : rowIndex;
+            if (rowIndex < r && r - ri - 1 == 0) err = 1;
+            else for (int i = max(rowIndex, 0) + t; i < r; i += 256) wBr[i] = (float)((double)(r - i - 1) * 1 / (r - ri - 1));
         }
         if (index == 2 || index == 3) {
-            const int n = colIndex + 1; int ci = colIndex;
-            for (int i = 0; i < n; i++) {
-                if (ci == 0) ci = 1;
+            const int n = colIndex + 1, ci = colIndex == 0 ? 1 : colIndex;
+            for (int i = t; i < n; i += 256) {
                 const int idx = ci - i;
-                if (idx >= c) return -1;
+                if (idx >= c) { err = 1; break; }
                 wBc[pywrap(idx, c)] = (float)((double)(ci - i) * 1 / ci);
             }
         } else {
-            int ci = colIndex;
-            for (int i = colIndex; i < c; i++) {
-                if (ci == 0) ci = 1;
-                if (c - ci - 1 == 0) return -1;
-                wBc[pywrap(i, c)] = (float)((double)(c - i - 1) * 1 / (c - ci - 1));
-            }
+            const int ci = colIndex == 0 ? 1 : colIndex;
+            if (colIndex < c && c - ci - 1 == 0) err = 1;
+            else for (int i = max(colIndex, 0) + t; i < c; i += 256) wBc[i] = (float)((double)(c - i - 1) * 1 / (c - ci - 1));
         }
     }
-    if (info) for (int k = 0; k < 4; k++) info[k] = inf[k];
-    return 0;
+    if (err) atomicOr(&out[5], 1);
+    if (t == 0) { out[0] = 1; out[1] = 1; out[2] = s_geom[0]; out[3] = rowIndex; out[4] = colIndex; }
 }
 
-struct FuseScratch { FuseStats *st; int *rowFirst, *rowLast, *colFirst, *colLast; float *wAr, *wAc, *wBr, *wBc; };
+struct FuseScratch { FuseStats *st; int *rowFirst, *rowLast, *colFirst, *colLast; float *wAr, *wAc, *wBr, *wBc; int *out; };
 
 static int fuse_scratch(vfsms_ctx *ctx, int r, int c, FuseScratch *S)
 {
@@ -293,35 +308,36 @@ static int fuse_scratch(vfsms_ctx *ctx, int r, int c, FuseScratch *S)
     S->colFirst = (int *)ctx_arena_alloc(ctx, sizeof(int) * c); S->colLast = (int *)ctx_arena_alloc(ctx, sizeof(int) * c);
     S->wAr = (float *)ctx_arena_alloc(ctx, sizeof(float) * r); S->wBr = (float *)ctx_arena_alloc(ctx, sizeof(float) * r);
     S->wAc = (float *)ctx_arena_alloc(ctx, sizeof(float) * c); S->wBc = (float *)ctx_arena_alloc(ctx, sizeof(float) * c);
-    if (!S->wBc) { vfsms_set_error("arena exhausted in fuse"); return VFSMS_ERR_CAPACITY; }
+    S->out = (int *)ctx_arena_alloc(ctx, sizeof(int) * 8);
+    if (!S->out) { vfsms_set_error("arena exhausted in fuse"); return VFSMS_ERR_CAPACITY; }
     return VFSMS_OK;
 }
 
-static int fetch_stats_and_weights(vfsms_ctx *ctx, const FuseScratch &S, int r, int c, int ch, int dx, int dy,
-                                   int *corner, int32_t *info, float *h_ramps = nullptr, int force_corner = 0)
+// launch the ramp kernel; `finish_weights` later brings back its 6 status ints (and the ramps when a caller wants them) in one sync
+static int launch_weights(vfsms_ctx *ctx, const FuseScratch &S, int r, int c, int ch, int dx, int dy, int force_corner = 0)
 {
-    FuseStats st;
-    std::vector<int> rf(r), rl(r), cf(c), cl(c);
-    HIP_TRY(hipMemcpyAsync(&st, S.st, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(rf.data(), S.rowFirst, sizeof(int) * r, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(rl.data(), S.rowLast, sizeof(int) * r, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(cf.data(), S.colFirst, sizeof(int) * c, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(cl.data(), S.colLast, sizeof(int) * c, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemsetAsync(S.out, 0, sizeof(int) * 8, ctx->stream));
+    hipLaunchKernelGGL(k_fuse_weights, dim3(1), dim3(256), 0, ctx->stream, r, c, ch, dx, dy, force_corner, S.st, S.rowFirst, S.rowLast,
+                       S.colFirst, S.colLast, S.wAr, S.wAc, S.wBr, S.wBc, S.out);
+    HIP_TRY(hipGetLastError());
+    return VFSMS_OK;
+}
+
+static int finish_weights(vfsms_ctx *ctx, const FuseScratch &S, int r, int c, int32_t *info, float *h_ramps = nullptr)
+{
+    int out[8];
+    HIP_TRY(hipMemcpyAsync(out, S.out, sizeof(out), hipMemcpyDeviceToHost, ctx->stream));
+    if (h_ramps) {                                 // [wA_r | wB_r | wA_c | wB_c]
+        HIP_TRY(hipMemcpyAsync(h_ramps, S.wAr, sizeof(float) * r, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h_ramps + r, S.wBr, sizeof(float) * r, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h_ramps + 2 * r, S.wAc, sizeof(float) * c, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h_ramps + 2 * r + c, S.wBc, sizeof(float) * c, hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    std::vector<float> wAr, wAc, wBr, wBc;
-    if (force_corner) st.valid = 0;                      // getWeightsMatrix called directly: skip the occupancy test
-    if (build_weights(r, c, ch, dx, dy, st, rf, rl, cf, cl, wAr, wAc, wBr, wBc, corner, info) != 0) {
+    if (info) for (int k = 0; k < 4; k++) info[k] = out[1 + k];
+    if (out[5]) {
         vfsms_set_error("fuse: degenerate corner geometry (the reference's getWeightsMatrix raises here)");
         return VFSMS_ERR_BAD_ARG;
-    }
-    HIP_TRY(hipMemcpyAsync(S.wAr, wAr.data(), sizeof(float) * r, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(S.wBr, wBr.data(), sizeof(float) * r, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(S.wAc, wAc.data(), sizeof(float) * c, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(S.wBc, wBc.data(), sizeof(float) * c, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));    // host vectors go out of scope
-    if (h_ramps) {                                 // [wA_r | wB_r | wA_c | wB_c]
-        memcpy(h_ramps, wAr.data(), sizeof(float) * r); memcpy(h_ramps + r, wBr.data(), sizeof(float) * r);
-        memcpy(h_ramps + 2 * r, wAc.data(), sizeof(float) * c); memcpy(h_ramps + 2 * r + c, wBc.data(), sizeof(float) * c);
     }
     return VFSMS_OK;
 }
@@ -348,12 +364,11 @@ int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int
     V.tile = d_tile; V.tw = w; V.ty0 = ry0 - y0; V.tx0 = rx0 - x0;
     hipLaunchKernelGGL(k_fuse_stats_rows, dim3(r), dim3(256), 0, ctx->stream, V, r, c, S.st, S.rowFirst, S.rowLast);
     hipLaunchKernelGGL(k_fuse_stats_cols, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, V, r, c, S.colFirst, S.colLast);
-    int corner = 0;
-    TRY(fetch_stats_and_weights(ctx, S, r, c, cv->ch, dx, dy, &corner, info));
+    TRY(launch_weights(ctx, S, r, c, cv->ch, dx, dy));
     hipLaunchKernelGGL(k_fuse_apply, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, cv->pix, cv->mask, cv->cols, cv->ch,
-                       d_tile, h, w, y0, x0, ry0, rx0, r, c, corner, S.wAr, S.wAc, S.wBr, S.wBc);
+                       d_tile, h, w, y0, x0, ry0, rx0, r, c, S.out, S.wAr, S.wAc, S.wBr, S.wBc);
     HIP_TRY(hipGetLastError());
-    return VFSMS_OK;
+    return finish_weights(ctx, S, r, c, info);
 }
 
 // A, B: device int64 [r][c][ch]; out: device u8
@@ -366,12 +381,11 @@ int fuse_i64_device(vfsms_ctx *ctx, const long long *dA, const long long *dB, in
     I64View V; V.A = dA; V.B = dB; V.c = c; V.ch = ch;
     hipLaunchKernelGGL(k_i64_stats_rows, dim3(r), dim3(256), 0, ctx->stream, V, r, c, S.st, S.rowFirst, S.rowLast);
     hipLaunchKernelGGL(k_i64_stats_cols, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, V, r, c, S.colFirst, S.colLast);
-    int corner = 0;
-    TRY(fetch_stats_and_weights(ctx, S, r, c, ch, dx, dy, &corner, info));
-    hipLaunchKernelGGL(k_i64_apply, dim3((c + 255) / 256, r), dim3(256), 0, ctx->stream, V, r, c, corner,
+    TRY(launch_weights(ctx, S, r, c, ch, dx, dy));
+    hipLaunchKernelGGL(k_i64_apply, dim3((c + 255) / 256, r), dim3(256), 0, ctx->stream, V, r, c, S.out,
                        S.wAr, S.wAc, S.wBr, S.wBc, d_out);
     HIP_TRY(hipGetLastError());
-    return VFSMS_OK;
+    return finish_weights(ctx, S, r, c, info);
 }
 
 // separable ramps only (ImageFusion.getWeightsMatrix when force_corner, else the mode fuseByFadeInAndFadeOut picks)
@@ -384,7 +398,6 @@ int fuse_i64_ramps(vfsms_ctx *ctx, const long long *dA, int r, int c, int ch, in
     I64View V; V.A = dA; V.B = dA; V.c = c; V.ch = ch;
     hipLaunchKernelGGL(k_i64_stats_rows, dim3(r), dim3(256), 0, ctx->stream, V, r, c, S.st, S.rowFirst, S.rowLast);
     hipLaunchKernelGGL(k_i64_stats_cols, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, V, r, c, S.colFirst, S.colLast);
-    int corner = 0;
-    TRY(fetch_stats_and_weights(ctx, S, r, c, ch, dx, dy, &corner, info, h_ramps, force_corner));
-    return VFSMS_OK;
+    TRY(launch_weights(ctx, S, r, c, ch, dx, dy, force_corner));
+    return finish_weights(ctx, S, r, c, info, h_ramps);
 }
