@@ -907,7 +907,7 @@ __global__ __launch_bounds__(128) void k_orientation(const RoiDev *rois, const S
     orientation_one(R, T, k, upright);
 }
 
-__global__ __launch_bounds__(256) void k_describe(const RoiDev *rois, int nrois, int *counter, const SurfTables *T,
+__global__ __launch_bounds__(256, 5) void k_describe(const RoiDev *rois, int nrois, int *counter, const SurfTables *T,
                                                   int extended, int upright, int ablate)
 {
     __shared__ TicketState S;
@@ -1139,7 +1139,7 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
         // ticket counter: counters[9] of ROI 0 (zeroed with the other counters by launch_surf_detect)
         static int ablate = getenv("VFSMS_DESC_ABLATE") ? atoi(getenv("VFSMS_DESC_ABLATE")) : 0;
         if (!p->upright) hipLaunchKernelGGL(k_desc_trig, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
-        hipLaunchKernelGGL(k_describe, dim3(256 * 4), dim3(256), 0, ctx->stream, d_rois, nrois, h_rois[0].counters + 9,
+        hipLaunchKernelGGL(k_describe, dim3(256 * 5), dim3(256), 0, ctx->stream, d_rois, nrois, h_rois[0].counters + 9,
                            ctx->d_tables, p->extended, p->upright, ablate);
         hipLaunchKernelGGL(k_desc_tail, dim3((maxcap + 15) / 16, nrois), dim3(256), 0, ctx->stream, d_rois, ctx->d_tables, p->extended);
     }
