@@ -308,3 +308,27 @@ def test_config0_iron_pair_end_to_end(engine, golden_dir):
         assert status and abs(off[0] - 1699) <= 1 and abs(off[1] - (-1)) <= 1, off
     finally:
         isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate = old
+
+
+def test_config4_tile_size_4096_pair(engine):
+    """BASELINE configs[4] tile geometry (4096 x 4096 tiles -> 819 x 4096 strips, ~4x the keypoints of the 2048 case): one
+    in-column pair and one turn pair through the grid registrar; offsets within 1 px of the synthetic ground truth, and the
+    fused attempt row identical to the per-operator chain (detect+describe -> exhaustive-arithmetic matcher -> mode vote)."""
+    from imagestitch_amd.grid import GridRegistrar
+    g = SyntheticGrid(2, 2, 4096)
+    tiles = g.tiles(threads=4)
+    hs = [engine.tile_upload(t) for t in tiles]
+    reg = GridRegistrar(engine, method="surf", roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3, directIncre=1)
+    table, _d = reg.register(hs, [t.shape for t in tiles], 1)
+    truth = np.array(g.true_offsets())
+    assert np.all(table[:, 0] == 1) and np.abs(table[:, 1:3] - truth).max() <= 1, (table, truth)
+    ra = isa.roi_rect(tiles[0].shape, 1, "first", 0.2); rb = isa.roi_rect(tiles[1].shape, 1, "second", 0.2)
+    assert ra[2:] == (819, 4096)
+    row = engine.attempt_surf_batch([(hs[0], hs[1], ra[0], ra[1], rb[0], rb[1], ra[2], ra[3])])[0]
+    A = np.ascontiguousarray(tiles[0][ra[0]:ra[0] + ra[2]]); B = np.ascontiguousarray(tiles[1][:rb[2]])
+    ka, da = engine.surf_detect_describe(A); kb, db = engine.surf_detect_describe(B)
+    pairs = engine.bf_l2_ratio_matches(da, db, 0.75)
+    st, off, votes = engine.mode_offset(ka, kb, pairs, 3)
+    assert row[:7].tolist() == [int(st), off[0], off[1], votes, len(ka), len(kb), len(pairs)], (row, st, off, votes, len(ka), len(kb), len(pairs))
+    for h in hs:
+        engine.tile_free(h)
