@@ -640,7 +640,7 @@ extern "C" int vfsms_attempt_surf_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jo
     // 64-d descriptors leave the descriptor kernel with norm <= 1: their 2-NN search runs as an MFMA candidate filter plus
     // exact verification (match_kernels.hip); other widths, or VFSMS_BF_EXACT=1, take the exhaustive VALU kernel.
     const bool filtered = dim == 64 && !bf_force_exact();
-    const int cns = pick_filter_nsplit(maxcap / 3, n);
+    const int cns = pick_filter_nsplit(maxcap * 2 / 3, n);   // the registrar sizes the capacity at 1.5x the largest ROI seen
     const int ns = filtered ? 1 : pick_nsplit(maxcap / 3, maxcap / 3, n, dim);   // typical occupancy of the capacity
     for (int k = 0; k < n; k++)
         need += 2 * surf_roi_bytes(jobs[k].h, jobs[k].w, caps[k], ctx->n_layers, params->n_octaves, dim) + match_bytes(caps[k], ns) +

@@ -269,6 +269,13 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma_d64(const MatchDev *jobs)
 // the semantics of knn_update over ascending train indices (best = lowest index among the smallest sqrt-domain
 // distances; second = next smallest value), which is order-independent in this form.
 #define BFV_HITS 12
+#ifdef VFSMS_DESC_TIMING
+__device__ unsigned g_bfv_stats[4];        // debug build: [0] queries, [1] queries with an overflowed list, [2] list entries read, [3] exact evaluations
+extern "C" int vfsms_debug_bfv_stats(unsigned *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bfv_stats), sizeof(unsigned) * 4) == hipSuccess ? 0 : -3; }
+#define BFV_STAT(i, v) atomicAdd(&g_bfv_stats[i], (unsigned)(v))
+#else
+#define BFV_STAT(i, v) do {} while (0)
+#endif
 __device__ __forceinline__ void bfv_exact(const float *__restrict__ Qr, const float *__restrict__ T, int idx, float &B1, float &B2, int &I1)
 {
     const float4 *tr = reinterpret_cast<const float4 *>(T + (size_t)idx * 64);
@@ -308,6 +315,7 @@ __global__ __launch_bounds__(256) void k_bf_verify_d64(const MatchDev *jobs, int
             }
         }
     const float cut = s2 + BFM_MARGIN;
+    if (live) { BFV_STAT(0, 1); BFV_STAT(1, overflow ? 1 : 0); }
     const float *Qr = J.q + (size_t)min(q, nq - 1) * 64;
     float B1 = INFINITY, B2 = INFINITY; int I1 = -1;
     int nh = 0;
@@ -323,13 +331,34 @@ __global__ __launch_bounds__(256) void k_bf_verify_d64(const MatchDev *jobs, int
                 }
             }
         }
+    if (live) BFV_STAT(3, nh);
     int maxh = nh;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) maxh = max(maxh, __shfl_xor(maxh, d, 64));
     for (int k = 0; k < maxh; k++)
         if (k < nh) bfv_exact(Qr, J.t, hits[k][threadIdx.x], B1, B2, I1);
-    if (live && overflow)                                  // a list overflowed: exhaustive exact scan for this query
-        for (int j = 0; j < nt; j++) bfv_exact(Qr, J.t, j, B1, B2, I1);
+    // A list overflowed (a query with dozens of trains inside the margin, e.g. an all-zero descriptor): exhaustive exact scan of
+    // all trains for that query, shared by the 64 lanes of its wave and merged with the same first-index / second-value rule.
+    {
+        const int lane = threadIdx.x & 63;
+        unsigned long long om = __ballot(live && overflow);
+        while (om) {
+            const int src = __ffsll((long long)om) - 1;
+            om &= om - 1;
+            const int qo = __shfl(q, src, 64);
+            const float *Qo = J.q + (size_t)qo * 64;
+            float b1 = INFINITY, b2 = INFINITY; int i1 = -1;
+            for (int j = lane; j < nt; j += 64) bfv_exact(Qo, J.t, j, b1, b2, i1);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const float ob1 = __shfl_xor(b1, d, 64), ob2 = __shfl_xor(b2, d, 64);
+                const int oi1 = __shfl_xor(i1, d, 64);
+                if (ob1 < b1 || (ob1 == b1 && oi1 >= 0 && (i1 < 0 || oi1 < i1))) { b2 = fminf(b1, ob2); b1 = ob1; i1 = oi1; }
+                else b2 = fminf(b2, ob1);
+            }
+            if (lane == src) { B1 = b1; B2 = b2; I1 = i1; }
+        }
+    }
     if (live) { J.p_d1[q] = B1; J.p_d2[q] = B2; J.p_i1[q] = I1; }
 }
 
