@@ -260,7 +260,7 @@ __device__ __forceinline__ bool interpolate_keypoint(const float N9[3][9], int d
 #define NMS_ROWS 4
 #define NMS_LOCAL 96
 __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat *pats, int layers_per_octave,
-                                             int n_middle, int octave, float hessianThreshold, int ablate)
+                                             int n_middle, int octave, float hessianThreshold)
 {
     const int roi = blockIdx.z / n_middle;
     const int l = 1 + blockIdx.z % n_middle;
@@ -292,7 +292,6 @@ __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat 
         }
     }
     __syncthreads();
-    if (ablate == 1) return;
 #pragma unroll
     for (int it = 0; it < NMS_ROWS; it++) {
         const int r = threadIdx.y + 4 * it, c = threadIdx.x;
@@ -305,8 +304,6 @@ __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat 
     }
     __syncthreads();
     const int nq = qn;
-    if (ablate == 2) return;
-    if (ablate == 4 && tid == 0) { atomicAdd(&R.counters[10], nq); atomicAdd(&R.counters[11], 1); }
     const int st = lcols;
     for (int e = tid; e < nq; e += 256) {
         const int r = queue[e] >> 8, c = queue[e] & 255;
@@ -321,7 +318,7 @@ __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat 
         bool is_max = true;
 #pragma unroll
         for (int b = 0; b < 9; b++) is_max = is_max && (val0 > N9[0][b]) && (val0 > N9[2][b]);
-        if (!is_max || ablate == 3) continue;
+        if (!is_max) continue;
         const int sum_i = ss * (i - (size / 2) / ss);
         const int sum_j = ss * (j - (size / 2) / ss);
         Cand cd;
@@ -719,12 +716,11 @@ __device__ __forceinline__ float area_row(const uint8_t *S, const AreaSpan &Sx) 
     return buf;
 }
 
-__device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, int extended, int upright, int ablate)
+__device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, int extended, int upright)
 {
     DT_START;
     vfsms_keypoint kp = R.kps[k];
     if (!(kp.size > 0)) return;                            // deleted by the orientation stage
-    if (ablate == 1) return;
     __shared__ float sx_row[VFSMS_MAX_WIN], sy_row[VFSMS_MAX_WIN];
     __shared__ uint8_t PATCH[21][21 + 3];
     __shared__ float trig_s[2];
@@ -908,12 +904,12 @@ __global__ __launch_bounds__(128) void k_orientation(const RoiDev *rois, const S
 }
 
 __global__ __launch_bounds__(256, 5) void k_describe(const RoiDev *rois, int nrois, int *counter, const SurfTables *T,
-                                                  int extended, int upright, int ablate)
+                                                  int extended, int upright)
 {
     __shared__ TicketState S;
     ticket_init(rois, nrois, S);
     int roi, k;
-    while (ticket_next(counter, nrois, S, roi, k)) describe_one(rois[roi], T, k, extended, upright, ablate);
+    while (ticket_next(counter, nrois, S, roi, k)) describe_one(rois[roi], T, k, extended, upright);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1099,14 +1095,13 @@ int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_roi
     }
     {
         ProfScope ps(ctx, "nms");
-        static int nms_ablate = getenv("VFSMS_NMS_ABLATE") ? atoi(getenv("VFSMS_NMS_ABLATE")) : 0;
         int step = 1;
         for (int o = 0; o < p->n_octaves; o++) {
             int lrows = maxh / step, lcols = maxw / step;
             if (lrows > 0 && lcols > 0) {
                 dim3 grid((lcols + 63) / 64, (lrows + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), nrois * p->n_octave_layers);
                 hipLaunchKernelGGL(k_nms, grid, dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo,
-                                   p->n_octave_layers, o, p->hessian_threshold, nms_ablate);
+                                   p->n_octave_layers, o, p->hessian_threshold);
             }
             step *= 2;
         }
@@ -1137,10 +1132,9 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
     {
         ProfScope ps(ctx, "describe");
         // ticket counter: counters[9] of ROI 0 (zeroed with the other counters by launch_surf_detect)
-        static int ablate = getenv("VFSMS_DESC_ABLATE") ? atoi(getenv("VFSMS_DESC_ABLATE")) : 0;
         if (!p->upright) hipLaunchKernelGGL(k_desc_trig, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
         hipLaunchKernelGGL(k_describe, dim3(256 * 5), dim3(256), 0, ctx->stream, d_rois, nrois, h_rois[0].counters + 9,
-                           ctx->d_tables, p->extended, p->upright, ablate);
+                           ctx->d_tables, p->extended, p->upright);
         hipLaunchKernelGGL(k_desc_tail, dim3((maxcap + 15) / 16, nrois), dim3(256), 0, ctx->stream, d_rois, ctx->d_tables, p->extended);
     }
     HIP_TRY(hipGetLastError());

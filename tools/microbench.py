@@ -1,5 +1,5 @@
 """Stage-level micro benchmark: a fixed batch of N in-column pairs, K repetitions, per-stage HIP-event times.
-(Attempt count does not depend on results, so kernel ablations via VFSMS_DESC_ABLATE are comparable.)"""
+(A fixed batch keeps per-stage timings of kernel variants comparable.)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
