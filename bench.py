@@ -115,10 +115,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    # VFSMS_DIST_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices, the
+    # all-gather and the timing reduction run over gloo on host tensors); the driver's runs use the default, nccl == RCCL
+    backend = os.environ.get("VFSMS_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     assert world == args.gpus, "launch with --nproc-per-node == --gpus"
 
     import imagestitch_amd as isa
@@ -143,7 +152,7 @@ def main():
     reg = GridRegistrar(eng, method=args.method, roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3 if args.method == "surf" else 10, directIncre=1,
                         surfParams=eng.surf_params() if args.method == "surf" else eng.orb_params() if args.method == "orb" else None,
                         window=args.window)
-    gather = make_all_gather(torch.device("cuda", local_rank)) if world > 1 else single_process_all_gather
+    gather = make_all_gather(coll_device) if world > 1 else single_process_all_gather
 
     def step():
         return reg.register_sharded(handles, shapes, 1, rank, world, gather)
@@ -176,7 +185,7 @@ def main():
     prof = eng.profile_read(reset=True)
     eng.profile_enable(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

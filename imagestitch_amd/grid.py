@@ -128,7 +128,7 @@ class GridRegistrar:
         return dx, dy
 
     # -- sequentially-equivalent chain over pairs [first, last) ------------------------------------------------------
-    def chain(self, handles, shapes, first, last, d_in, memo=None, cache=None):
+    def chain(self, handles, shapes, first, last, d_in, memo=None, cache=None, midpath=False):
         """-> (int32[last-first, 6], d_out).
 
         An attempt is a pure function of (pair, direction, i), so WHICH attempts are evaluated together is free;
@@ -163,6 +163,8 @@ class GridRegistrar:
                 if pred is None:
                     break
                 remaining = pred - rl
+                if remaining < 0:
+                    break                                  # this run already outlived the prediction: no basis for a turn, slow start instead
                 if remaining >= 1:
                     n = min(remaining, self.window - len(items), last - kk)
                     items += [(kk + t, cd, 1) for t in range(n)]
@@ -222,7 +224,9 @@ class GridRegistrar:
             # predictor bookkeeping
             if row[0] and d_next == d:
                 run_len += 1
-                slow = min(2 * slow, self.window)
+                # a chain that starts in the middle of a path sees a truncated run and a turn soon after: until it has seen two
+                # runs, an overshoot past that turn is all waste, so it speculates at most 4 pairs ahead
+                slow = min(2 * slow, 4 if (midpath and len(runs) < 2) else self.window)
             elif row[0]:
                 runs.append(run_len)
                 run_len, slow = 1, 1
@@ -240,8 +244,14 @@ class GridRegistrar:
     # -- pair-sharded ---------------------------------------------------------------------------------------------------
     @staticmethod
     def chunk_bounds(n_pairs, world):
-        per = (n_pairs + world - 1) // world
-        return [(min(r * per, n_pairs), min((r + 1) * per, n_pairs)) for r in range(world)]
+        # balanced contiguous chunks; the remainder goes to the lowest ranks (rank 0 is the cheapest: it knows its incoming direction)
+        base, extra = divmod(n_pairs, world)
+        bounds, lo = [], 0
+        for r in range(world):
+            hi = lo + base + (1 if r < extra else 0)
+            bounds.append((lo, hi))
+            lo = hi
+        return bounds
 
     def shard_payload(self, handles, shapes, direction, rank, world):
         """This rank's offset table: int32[4 * per * 6 + 4] = results for each possible incoming direction
@@ -254,9 +264,14 @@ class GridRegistrar:
         table = np.zeros((4, per, RESULT_INTS), np.int32)
         d_out = np.zeros(4, np.int32)
         memo, cache = {}, {}
+        if len(dirs) > 1 and hi > lo:
+            # the incoming direction is unknown here: every chain needs its own first candidate of the first pair, so all four
+            # are evaluated as one batch instead of being discovered one chain after the other
+            for it, r in zip([(lo, d, 1) for d in dirs], self._attempts(handles, shapes, [(lo, d, 1) for d in dirs])):
+                cache[it] = r
         for d_in in dirs:
             if hi > lo:
-                res, dn = self.chain(handles, shapes, lo, hi, d_in, memo, cache)
+                res, dn = self.chain(handles, shapes, lo, hi, d_in, memo, cache, midpath=rank > 0)
                 table[d_in - 1, :hi - lo] = res
             else:
                 dn = d_in
