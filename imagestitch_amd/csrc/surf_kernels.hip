@@ -466,7 +466,7 @@ __device__ __forceinline__ float grad_haar(g_ci32 ptr, int sw, int gws, bool is_
 __device__ void orientation_one(const RoiDev &R, const SurfTables *T, const int k, int upright)
 {
     __shared__ float X[128], Y[128];
-    __shared__ int A[128];
+    __shared__ __attribute__((aligned(16))) int A[128];
     __shared__ float mod_s[72], sx_s[72], sy_s[72];
     vfsms_keypoint kp = R.kps[k];
     const float s = kp.size * 1.2f / 9.0f;
@@ -505,11 +505,16 @@ __device__ void orientation_one(const RoiDev &R, const SurfTables *T, const int 
     if (t < 72) {
         const int i = t * 5;
         float sumx = 0, sumy = 0;
-        for (int j = 0; j < nori; j++) {
-            int a = A[j];
-            if (a == -100000) continue;
-            int d = abs(a - i);
-            if (d < 30 || d > 330) { sumx += X[j]; sumy += Y[j]; }
+        // four rounded angles per LDS read (entries past nOriSamples hold the sentinel); the sums still visit the samples in index order
+        for (int j = 0; j < nori; j += 4) {
+            const int4 a4 = *reinterpret_cast<const int4 *>(&A[j]);
+            const int aa[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (aa[q] == -100000) continue;
+                const int d = abs(aa[q] - i);
+                if (d < 30 || d > 330) { sumx += X[j + q]; sumy += Y[j + q]; }
+            }
         }
         mod_s[t] = sumx * sumx + sumy * sumy;
         sx_s[t] = sumx; sy_s[t] = sumy;
