@@ -465,7 +465,7 @@ __device__ __forceinline__ float grad_haar(g_ci32 ptr, int sw, int gws, bool is_
 
 __device__ void orientation_one(const RoiDev &R, const SurfTables *T, const int k, int upright)
 {
-    __shared__ float X[128], Y[128];
+    __shared__ __attribute__((aligned(16))) float X[128], Y[128];
     __shared__ __attribute__((aligned(16))) int A[128];
     __shared__ float mod_s[72], sx_s[72], sy_s[72];
     vfsms_keypoint kp = R.kps[k];
@@ -508,12 +508,15 @@ __device__ void orientation_one(const RoiDev &R, const SurfTables *T, const int 
         // four rounded angles per LDS read (entries past nOriSamples hold the sentinel); the sums still visit the samples in index order
         for (int j = 0; j < nori; j += 4) {
             const int4 a4 = *reinterpret_cast<const int4 *>(&A[j]);
+            const float4 x4 = *reinterpret_cast<const float4 *>(&X[j]), y4 = *reinterpret_cast<const float4 *>(&Y[j]);
             const int aa[4] = {a4.x, a4.y, a4.z, a4.w};
+            const float xx[4] = {x4.x, x4.y, x4.z, x4.w}, yy[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                if (aa[q] == -100000) continue;
                 const int d = abs(aa[q] - i);
-                if (d < 30 || d > 330) { sumx += X[j + q]; sumy += Y[j + q]; }
+                const bool m = aa[q] != -100000 && (d < 30 || d > 330);
+                sumx = m ? sumx + xx[q] : sumx;
+                sumy = m ? sumy + yy[q] : sumy;
             }
         }
         mod_s[t] = sumx * sumx + sumy * sumy;
