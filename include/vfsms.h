@@ -124,7 +124,11 @@ int vfsms_orb_detect_describe(vfsms_ctx *ctx, const uint8_t *img, int h, int w, 
 
 /* replaces myGpuFeatures.matchDescriptors(featureType 1|2, param=ratio) (appendix/myGpuFeatures.cpp:160-173)
  * and BFMatcher("BruteForce").knnMatch(k=2) + ratio filter (ImageUtility.py:288-296).
- * pairs: int32[cap][2] = (trainIdx, queryIdx) in query order.                                     */
+ * pairs: int32[cap][2] = (trainIdx, queryIdx) in query order.
+ * Results are those of the reference's float arithmetic (4-wide accumulation of (a-b)^2, sqrt-domain compares, ties to the
+ * lower train index) for every input.  64-d inputs whose rows all have norm <= 1 (SURF descriptors are L2-normalised; checked
+ * on the device) are searched with the f32-MFMA candidate filter + exact verification, anything else with the exhaustive
+ * kernel; VFSMS_BF_EXACT=1 in the environment forces the exhaustive kernel.                                                  */
 int vfsms_bf_l2_knn2_ratio(vfsms_ctx *ctx, const float *q, int nq, const float *t, int nt, int dim,
                            double ratio, int32_t *pairs, int cap, int *m_out);
 /* raw 2-NN (for parity checks): idx1/d1 best, d2 second-best distance (+inf if nt < 2)            */
