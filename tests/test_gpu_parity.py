@@ -332,3 +332,26 @@ def test_config4_tile_size_4096_pair(engine):
     assert row[:7].tolist() == [int(st), off[0], off[1], votes, len(ka), len(kb), len(pairs)], (row, st, off, votes, len(ka), len(kb), len(pairs))
     for h in hs:
         engine.tile_free(h)
+
+
+def test_config3_zirconcl_phase_incremental(engine, golden_dir):
+    """BASELINE configs[3]: zirconCL pairs (1024 x 1280, direction 4, directIncre 0, roiRatio 0.2) through
+    Stitcher.calculateOffsetForPhaseCorrleateIncre.  Expected = the fixture's integer phase offsets plus the reference's axis
+    correction for direction 4 (Stitcher.py:244-251: dy -= W - int(i * roiRatio * W)); the response gate is 0.15."""
+    import json
+    cases = json.load(open(os.path.join(golden_dir, "demo_strips.json")))["cases"][1:]
+    g = np.load(os.path.join(golden_dir, "demo_strips.npz"))
+    st = isa.Stitcher(); st._engine = engine; st.isPrintLog = False
+    old = (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio)
+    try:
+        isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio = 4, 0, 0.2
+        for n, c in enumerate(cases, start=1):
+            H, W = c["shape"]
+            ra, rb = g["d%d_roiA" % n], g["d%d_roiB" % n]
+            A = np.zeros((H, W), np.uint8); B = np.zeros((H, W), np.uint8)
+            A[:, :ra.shape[1]] = ra; B[:, W - rb.shape[1]:] = rb            # direction 4: A's left strip against B's right strip
+            assert c["phase_response"] > 0.15
+            exp = [c["phase_int"][0], c["phase_int"][1] - (W - int(0.2 * W))]
+            assert st.calculateOffsetForPhaseCorrleateIncre([A, B]) == (True, exp), (n, exp)
+    finally:
+        isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio = old
