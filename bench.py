@@ -145,8 +145,11 @@ def main():
     tiles = dict(zip(need, grid.tiles(need, threads=min(8, os.cpu_count() or 1))))
     shapes = [(grid.th, grid.tw)] * grid.n_tiles
     handles = [None] * grid.n_tiles
+    t_up = time.perf_counter()
     for k in need:
         handles[k] = eng.tile_upload(tiles[k])               # tiles resident in HBM before the timed region
+    eng.sync()
+    t_up = time.perf_counter() - t_up                        # one H2D copy per tile (pageable host memory), reported as a side note only
     if args.method == "fuse":
         return bench_fuse(args, eng, grid, tiles, torch)
     reg = GridRegistrar(eng, method=args.method, roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3 if args.method == "surf" else 10, directIncre=1,
@@ -274,6 +277,8 @@ def main():
                                        "phase": "FFT phase correlation of the ROI strips"}[args.method]),
                        "pairs": P, "parallelism": "pairs%d" % world, "speculation_window": args.window},
             "max_abs_offset_error_px": max_err, "pairs_failed": n_failed,
+            "h2d_ms_rank0": round(t_up * 1e3, 2),
+            "value_incl_h2d": round(P * args.steps / (elapsed + t_up * args.steps), 3),   # if every step also had to upload its tiles (never `value`)
             "attempts_per_step": st["attempts"] / max(args.steps, 1), "batches_per_step": st["batches"] / max(args.steps, 1),
             "roofline": roofline,
             "cpu_baseline": cpu,
