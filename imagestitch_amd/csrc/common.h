@@ -60,6 +60,7 @@ struct RoiDev {
     vfsms_keypoint *kps;              // sorted (KeypointGreater), angle filled by orientation; size=-1 -> deleted
     uint8_t *patch;                   // cap x VFSMS_PATCH_ROW: 21 x 21 resized descriptor windows, rows aligned with kps
     int *keep_pos;                    // exclusive scan of keep flags
+    int *order;                       // surviving keypoints grouped by descriptor-window class (largest first); counts in counters[12..15]
     float *kps_xy;                    // compacted [n][2]
     float *desc;                      // compacted [n][D]
     vfsms_keypoint *kps_out;          // compacted

@@ -875,31 +875,89 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
 // device-side counts, rebuilt per workgroup in LDS).  Window cost varies 100x between keypoints, so dynamic
 // tickets matter: static striding measured 45 % slower, 4-ticket chunks 20 % slower.
 // ---------------------------------------------------------------------------------------------------
-#define VFSMS_MAX_ROIS 1024
+#define VFSMS_MAX_ROIS 256
+#define DESC_NCLS 4                  // window-size classes, largest first: win > 256, > 128, > 64, rest
 
-struct TicketState { int prefix[VFSMS_MAX_ROIS + 1]; int ticket; };
+// Tickets are drawn class by class, largest descriptor windows first: one window of 700 px costs as much as 300 windows of 40 px,
+// and in response order such a window could be drawn last and leave the whole chip waiting for a single workgroup.  k_desc_order
+// builds, per ROI, the list of surviving keypoints grouped by class (a counting sort by one workgroup); the order inside a class
+// is irrelevant, every keypoint is described independently into its own patch row.
+__device__ __forceinline__ int desc_class(float size)
+{
+    const float s = size * 1.2f / 9.0f;
+    const int win = min((int)((20 + 1) * s), VFSMS_MAX_WIN);
+    return win > 256 ? 0 : win > 128 ? 1 : win > 64 ? 2 : 3;
+}
+
+__global__ __launch_bounds__(1024) void k_desc_order(const RoiDev *rois)
+{
+    const RoiDev &R = rois[blockIdx.x];
+    const int n = min(R.counters[0], R.cap);
+    __shared__ int cnt[DESC_NCLS], base[DESC_NCLS], cur[DESC_NCLS];
+    if (threadIdx.x < DESC_NCLS) { cnt[threadIdx.x] = 0; cur[threadIdx.x] = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int k0 = 0; k0 < n; k0 += 1024) {
+        const int k = k0 + threadIdx.x;
+        const float size = k < n ? R.kps[k].size : -1.f;
+        const int cls = size > 0 ? desc_class(size) : -1;
+#pragma unroll
+        for (int c = 0; c < DESC_NCLS; c++) {
+            const unsigned long long m = __ballot(cls == c);
+            if (m && lane == __ffsll((long long)m) - 1) atomicAdd(&cnt[c], __popcll(m));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int c = 0; c < DESC_NCLS; c++) { base[c] = acc; acc += cnt[c]; R.counters[12 + c] = cnt[c]; }
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += 1024) {
+        const int k = k0 + threadIdx.x;
+        const float size = k < n ? R.kps[k].size : -1.f;
+        const int cls = size > 0 ? desc_class(size) : -1;
+#pragma unroll
+        for (int c = 0; c < DESC_NCLS; c++) {
+            const unsigned long long m = __ballot(cls == c);
+            if (!m) continue;
+            const int leader = __ffsll((long long)m) - 1;
+            int start = 0;
+            if (lane == leader) start = atomicAdd(&cur[c], __popcll(m));
+            start = __shfl(start, leader, 64);
+            if (cls == c) R.order[base[c] + start + __popcll(m & ((1ull << lane) - 1))] = k;
+        }
+    }
+}
+
+struct TicketState { int prefix[DESC_NCLS * VFSMS_MAX_ROIS + 1]; int ticket; };
 
 __device__ __forceinline__ void ticket_init(const RoiDev *rois, int nrois, TicketState &S)
 {
-    for (int r = threadIdx.x; r < nrois; r += blockDim.x) S.prefix[r + 1] = min(rois[r].counters[0], rois[r].cap);
+    for (int e = threadIdx.x; e < DESC_NCLS * nrois; e += blockDim.x) S.prefix[e + 1] = rois[e % nrois].counters[12 + e / nrois];
     __syncthreads();
     if (threadIdx.x == 0) {
         S.prefix[0] = 0;
-        for (int r = 0; r < nrois; r++) S.prefix[r + 1] += S.prefix[r];
+        for (int e = 0; e < DESC_NCLS * nrois; e++) S.prefix[e + 1] += S.prefix[e];
     }
     __syncthreads();
 }
 // returns false when the batch is exhausted; otherwise (roi, k).  Contains workgroup barriers.
-__device__ __forceinline__ bool ticket_next(int *counter, int nrois, TicketState &S, int &roi, int &k)
+__device__ __forceinline__ bool ticket_next(const RoiDev *rois, int *counter, int nrois, TicketState &S, int &roi, int &k)
 {
     __syncthreads();
     if (threadIdx.x == 0) S.ticket = atomicAdd(counter, 1);
     __syncthreads();
     const int t = S.ticket;
-    if (t >= S.prefix[nrois]) return false;
-    int lo = 0, hi = nrois;                                   // prefix[lo] <= t < prefix[hi]
+    const int ne = DESC_NCLS * nrois;
+    if (t >= S.prefix[ne]) return false;
+    int lo = 0, hi = ne;                                      // prefix[lo] <= t < prefix[hi]
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (S.prefix[mid] <= t) lo = mid; else hi = mid; }
-    roi = lo; k = t - S.prefix[lo];
+    const int cls = lo / nrois;
+    roi = lo - cls * nrois;
+    int within = t - S.prefix[lo];                            // position inside (class, roi); the ROI's list is class-major
+    for (int c = 0; c < cls; c++) within += S.prefix[c * nrois + roi + 1] - S.prefix[c * nrois + roi];
+    k = rois[roi].order[within];
     return true;
 }
 
@@ -917,7 +975,7 @@ __global__ __launch_bounds__(256, 5) void k_describe(const RoiDev *rois, int nro
     __shared__ TicketState S;
     ticket_init(rois, nrois, S);
     int roi, k;
-    while (ticket_next(counter, nrois, S, roi, k)) describe_one(rois[roi], T, k, extended, upright);
+    while (ticket_next(rois, counter, nrois, S, roi, k)) describe_one(rois[roi], T, k, extended, upright);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1037,7 +1095,7 @@ size_t surf_roi_bytes(int h, int w, int cap, int nlayers_total, int noctaves, in
         b += 2 * lpo * al(sizeof(float) * (n ? n : 1));
     }
     b += al(16 * sizeof(int)) + al(sizeof(Cand) * cap) + al(sizeof(vfsms_keypoint) * cap) + al((size_t)cap * VFSMS_PATCH_ROW);
-    b += al(sizeof(int) * cap) + al(sizeof(float) * 2 * cap) + al(sizeof(float) * (size_t)cap * dim) + al(sizeof(vfsms_keypoint) * cap);
+    b += 2 * al(sizeof(int) * cap) + al(sizeof(float) * 2 * cap) + al(sizeof(float) * (size_t)cap * dim) + al(sizeof(vfsms_keypoint) * cap);
     return b + 4096;
 }
 
@@ -1062,6 +1120,7 @@ int surf_roi_carve(vfsms_ctx *ctx, RoiDev *r, const uint8_t *img, int stride, in
     r->kps = (vfsms_keypoint *)ctx_arena_alloc(ctx, sizeof(vfsms_keypoint) * cap);
     r->patch = (uint8_t *)ctx_arena_alloc(ctx, (size_t)cap * VFSMS_PATCH_ROW);
     r->keep_pos = (int *)ctx_arena_alloc(ctx, sizeof(int) * cap);
+    r->order = (int *)ctx_arena_alloc(ctx, sizeof(int) * cap);
     r->kps_xy = (float *)ctx_arena_alloc(ctx, sizeof(float) * 2 * cap);
     r->desc = (float *)ctx_arena_alloc(ctx, sizeof(float) * (size_t)cap * (p->extended ? 128 : 64));
     r->kps_out = (vfsms_keypoint *)ctx_arena_alloc(ctx, sizeof(vfsms_keypoint) * cap);
@@ -1140,6 +1199,7 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
     {
         ProfScope ps(ctx, "describe");
         // ticket counter: counters[9] of ROI 0 (zeroed with the other counters by launch_surf_detect)
+        hipLaunchKernelGGL(k_desc_order, dim3(nrois), dim3(1024), 0, ctx->stream, d_rois);
         if (!p->upright) hipLaunchKernelGGL(k_desc_trig, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
         hipLaunchKernelGGL(k_describe, dim3(256 * 5), dim3(256), 0, ctx->stream, d_rois, nrois, h_rois[0].counters + 9,
                            ctx->d_tables, p->extended, p->upright);
