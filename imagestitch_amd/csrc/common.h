@@ -47,7 +47,8 @@ struct Cand {                         // NMS survivor before sorting
 };
 
 // ---- one ROI's device working set; arrays of these drive every batched kernel ---------------------
-#define VFSMS_PATCH_ROW 448
+#define VFSMS_PATCH_ROW 464       // 441 patch bytes, then at VFSMS_PATCH_TRIG the (sin, cos) of the window rotation
+#define VFSMS_PATCH_TRIG 448
 struct RoiDev {
     const uint8_t *img;
     int stride, h, w;

@@ -724,7 +724,8 @@ __device__ __forceinline__ float area_row(const uint8_t *S, const AreaSpan &Sx) 
     return buf;
 }
 
-__device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, int extended, int upright)
+// band >= 0: only row `band` of the 21 x 21 patch (tickets of the largest windows are split by output row, see ticket_next)
+__device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, int extended, int upright, const int band)
 {
     DT_START;
     vfsms_keypoint kp = R.kps[k];
@@ -749,19 +750,21 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
     if (!upright) {
         // Row origins are running float sums in the reference (start_x += sin_dir per row): inherently sequential,
         // so one lane of wave 0 walks x while one lane of wave 1 walks y.
-        // sin/cos of the orientation were evaluated one thread per keypoint by k_desc_trig and parked in the keypoint's
-        // patch row (overwritten by the patch itself at the end of this function).
+        // sin/cos of the orientation were evaluated one thread per keypoint by k_desc_trig and parked behind the keypoint's
+        // patch row (several workgroups may work on one large keypoint, so the patch bytes themselves cannot be borrowed).
         if (threadIdx.x == 0 || threadIdx.x == 64) {
-            const float sin_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW))[0];
-            const float cos_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW))[1];
+            const float sin_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[0];
+            const float cos_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[1];
             const float win_offset = -(float)(win - 1) / 2;
+            // a band ticket only needs the origins up to the last source row of its band (<= floor((band + 1) * scale))
+            const int need = band >= 0 ? min(win, (int)((band + 1) * scale) + 2) : win;
             if (threadIdx.x == 0) {
                 trig_s[0] = sin_dir; trig_s[1] = cos_dir;
                 float start_x = kp.x + win_offset * cos_dir + win_offset * sin_dir;
-                for (int i = 0; i < win; i++, start_x += sin_dir) sx_row[i] = start_x;
+                for (int i = 0; i < need; i++, start_x += sin_dir) sx_row[i] = start_x;
             } else {
                 float start_y = kp.y - win_offset * sin_dir + win_offset * cos_dir;
-                for (int i = 0; i < win; i++, start_y += cos_dir) sy_row[i] = start_y;
+                for (int i = 0; i < need; i++, start_y += cos_dir) sy_row[i] = start_y;
             }
         }
     } else {
@@ -812,7 +815,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
         DT_MARK(2);
     } else {
         int *irow = reinterpret_cast<int *>(&rowbuf[0][0]);
-        for (int dy = 0; dy < dsz; dy++) {
+        for (int dy = band >= 0 ? band : 0; dy < (band >= 0 ? band + 1 : dsz); dy++) {
             AreaSpan Sy = span_s[dy];
             int rlo, rhi;
             if (is_area_fast) { rlo = dy * iscale; rhi = rlo + iscale - 1; }
@@ -863,7 +866,11 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
     }
     __syncthreads();
     // hand the 21 x 21 patch to k_desc_tail (gradients, cell sums, normalisation run there, 16 keypoints per workgroup)
-    for (int o = threadIdx.x; o < 441; o += 256) R.patch[(size_t)k * VFSMS_PATCH_ROW + o] = PATCH[o / 21][o % 21];
+    if (band >= 0) {
+        if (threadIdx.x < 21) R.patch[(size_t)k * VFSMS_PATCH_ROW + band * 21 + threadIdx.x] = PATCH[band][threadIdx.x];
+    } else {
+        for (int o = threadIdx.x; o < 441; o += 256) R.patch[(size_t)k * VFSMS_PATCH_ROW + o] = PATCH[o / 21][o % 21];
+    }
     DT_MARK(5);
 }
 
@@ -934,7 +941,9 @@ struct TicketState { int prefix[DESC_NCLS * VFSMS_MAX_ROIS + 1]; int ticket; };
 
 __device__ __forceinline__ void ticket_init(const RoiDev *rois, int nrois, TicketState &S)
 {
-    for (int e = threadIdx.x; e < DESC_NCLS * nrois; e += blockDim.x) S.prefix[e + 1] = rois[e % nrois].counters[12 + e / nrois];
+    // class 0 (win > 256) keypoints are drawn as 21 tickets each, one per output row of the patch
+    for (int e = threadIdx.x; e < DESC_NCLS * nrois; e += blockDim.x)
+        S.prefix[e + 1] = rois[e % nrois].counters[12 + e / nrois] * (e < nrois ? 21 : 1);
     __syncthreads();
     if (threadIdx.x == 0) {
         S.prefix[0] = 0;
@@ -943,7 +952,7 @@ __device__ __forceinline__ void ticket_init(const RoiDev *rois, int nrois, Ticke
     __syncthreads();
 }
 // returns false when the batch is exhausted; otherwise (roi, k).  Contains workgroup barriers.
-__device__ __forceinline__ bool ticket_next(const RoiDev *rois, int *counter, int nrois, TicketState &S, int &roi, int &k)
+__device__ __forceinline__ bool ticket_next(const RoiDev *rois, int *counter, int nrois, TicketState &S, int &roi, int &k, int &band)
 {
     __syncthreads();
     if (threadIdx.x == 0) S.ticket = atomicAdd(counter, 1);
@@ -956,7 +965,10 @@ __device__ __forceinline__ bool ticket_next(const RoiDev *rois, int *counter, in
     const int cls = lo / nrois;
     roi = lo - cls * nrois;
     int within = t - S.prefix[lo];                            // position inside (class, roi); the ROI's list is class-major
-    for (int c = 0; c < cls; c++) within += S.prefix[c * nrois + roi + 1] - S.prefix[c * nrois + roi];
+    band = -1;
+    if (cls == 0) { band = within % 21; within /= 21; }
+    else within += (S.prefix[roi + 1] - S.prefix[roi]) / 21;
+    for (int c = 1; c < cls; c++) within += S.prefix[c * nrois + roi + 1] - S.prefix[c * nrois + roi];
     k = rois[roi].order[within];
     return true;
 }
@@ -974,8 +986,8 @@ __global__ __launch_bounds__(256, 5) void k_describe(const RoiDev *rois, int nro
 {
     __shared__ TicketState S;
     ticket_init(rois, nrois, S);
-    int roi, k;
-    while (ticket_next(rois, counter, nrois, S, roi, k)) describe_one(rois[roi], T, k, extended, upright);
+    int roi, k, band;
+    while (ticket_next(rois, counter, nrois, S, roi, k, band)) describe_one(rois[roi], T, k, extended, upright, band);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1018,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_desc_trig(const RoiDev *rois)
     const vfsms_keypoint kp = R.kps[k];
     if (!(kp.size > 0)) return;
     const float dir = kp.angle * (float)(3.1415926535897932384626433832795 / 180);
-    float *row = (float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW);
+    float *row = (float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG);
     row[0] = -(float)sin((double)dir);
     row[1] = (float)cos((double)dir);
 }
