@@ -937,17 +937,21 @@ __global__ __launch_bounds__(1024) void k_desc_order(const RoiDev *rois)
     }
 }
 
-struct TicketState { int prefix[DESC_NCLS * VFSMS_MAX_ROIS + 1]; int ticket; };
+struct TicketState { int prefix[DESC_NCLS * VFSMS_MAX_ROIS + 1]; int ticket; int split; };
 
 __device__ __forceinline__ void ticket_init(const RoiDev *rois, int nrois, TicketState &S)
 {
-    // class 0 (win > 256) keypoints are drawn as 21 tickets each, one per output row of the patch
-    for (int e = threadIdx.x; e < DESC_NCLS * nrois; e += blockDim.x)
-        S.prefix[e + 1] = rois[e % nrois].counters[12 + e / nrois] * (e < nrois ? 21 : 1);
+    for (int e = threadIdx.x; e < DESC_NCLS * nrois; e += blockDim.x) S.prefix[e + 1] = rois[e % nrois].counters[12 + e / nrois];
     __syncthreads();
     if (threadIdx.x == 0) {
+        // Small batches (fewer than ~48 keypoints per resident workgroup) are bounded by their few largest windows: those
+        // (class 0, win > 256) are then drawn as 21 tickets each, one per output row of the patch.  Large batches keep one
+        // ticket per keypoint (the split repeats the row-origin prologue 21 times).
+        int total = 0;
+        for (int e = 0; e < DESC_NCLS * nrois; e++) total += S.prefix[e + 1];
+        S.split = total < (int)gridDim.x * 48 ? 21 : 1;
         S.prefix[0] = 0;
-        for (int e = 0; e < DESC_NCLS * nrois; e++) S.prefix[e + 1] += S.prefix[e];
+        for (int e = 0; e < DESC_NCLS * nrois; e++) S.prefix[e + 1] = S.prefix[e] + S.prefix[e + 1] * (e < nrois ? S.split : 1);
     }
     __syncthreads();
 }
@@ -966,8 +970,8 @@ __device__ __forceinline__ bool ticket_next(const RoiDev *rois, int *counter, in
     roi = lo - cls * nrois;
     int within = t - S.prefix[lo];                            // position inside (class, roi); the ROI's list is class-major
     band = -1;
-    if (cls == 0) { band = within % 21; within /= 21; }
-    else within += (S.prefix[roi + 1] - S.prefix[roi]) / 21;
+    if (cls == 0) { if (S.split > 1) { band = within % S.split; within /= S.split; } }
+    else within += (S.prefix[roi + 1] - S.prefix[roi]) / S.split;
     for (int c = 1; c < cls; c++) within += S.prefix[c * nrois + roi + 1] - S.prefix[c * nrois + roi];
     k = rois[roi].order[within];
     return true;
