@@ -92,7 +92,10 @@ class Stitcher(Utility.Method):
         status = True
         endfileIndex = 0
         imageB = None
-        for fileIndex in range(0, fileNum - 1):
+        batched = self._registerBatched(fileList, caculateOffsetMethod)
+        if batched is not None:
+            (status, endfileIndex, offsetList, describtion) = batched
+        for fileIndex in (range(0, fileNum - 1) if batched is None else ()):
             self.printAndWrite("stitching " + str(fileList[fileIndex]) + " and " + str(fileList[fileIndex + 1]))
             imageA = imageB if imageB is not None else _imread(fileList[fileIndex], False)   # decoded once per tile
             imageB = _imread(fileList[fileIndex + 1], False)
@@ -116,6 +119,53 @@ class Stitcher(Utility.Method):
         if status == False:
             self.printAndWrite(describtion)
         return ((status, endfileIndex), stitchImage)
+
+    batchRegistration = True     # let flowStitch register a whole file list in fused device batches when the stock search is used
+
+    def _registerBatched(self, fileList, caculateOffsetMethod):
+        """The pair loop of flowStitch (Stitcher.py:64-79) through grid.GridRegistrar when `caculateOffsetMethod` is this
+        object's own calculateOffsetForFeatureSearchIncre / calculateOffsetForPhaseCorrleateIncre with the stock operators:
+        all tiles go to the GPU once and the pairs are registered in speculative fused batches whose selected results equal
+        the pair-by-pair search (same offsets, same self.direction threading, same log lines).  Returns None when the
+        sequential loop has to run (custom method or operators, tiles of different sizes, switch off)
+        else (status, endfileIndex, offsetList, description of the break)."""
+        fn, owner = getattr(caculateOffsetMethod, "__func__", None), getattr(caculateOffsetMethod, "__self__", None)
+        if not self.batchRegistration or owner is not self or len(fileList) < 2:
+            return None
+        if fn is Stitcher.calculateOffsetForFeatureSearchIncre and self._usesStockOperators():
+            method = self.featureMethod
+        elif fn is Stitcher.calculateOffsetForPhaseCorrleateIncre:
+            method = "phase"
+        else:
+            return None
+        images = [_imread(f, False) for f in fileList]
+        if any(im.shape != images[0].shape for im in images):
+            return None
+        from .grid import GridRegistrar
+        eng = self.engine
+        params = None if method == "phase" else (self._orbParams() if method == "orb" else self._surfParams())
+        reg = GridRegistrar(eng, method=method, roiRatio=self.roiRatio, searchRatio=self.searchRatio, offsetEvaluate=self.offsetEvaluate,
+                            directIncre=self.directIncre, surfParams=params,
+                            phaseResponseThreshold=self.phaseResponseThreshold, window=24)
+        reg.orbMaxDistance = self.orbMaxDistance if self.isGPUAvailable else -1
+        handles = [eng.tile_upload(im) for im in images]
+        try:
+            table, _d = reg.register(handles, [im.shape for im in images], self.direction)
+        finally:
+            for h in handles:
+                eng.tile_free(h)
+        offsetList, endfileIndex, status, describtion = [], 0, True, ""
+        for k, row in enumerate(table):
+            self.printAndWrite("stitching " + str(fileList[k]) + " and " + str(fileList[k + 1]))
+            if not row[0]:
+                status = False
+                describtion = "  " + str(fileList[k]) + " and " + str(fileList[k + 1]) + " can not be stitched"
+                break
+            self.direction = int(row[3])
+            self.printAndWrite("  The offset of stitching: dx is " + str(int(row[1])) + " dy is " + str(int(row[2])))
+            offsetList.append([int(row[1]), int(row[2])])
+            endfileIndex = k + 1
+        return (status, endfileIndex, offsetList, describtion)
 
     def flowStitchWithMutiple(self, fileList, caculateOffsetMethod):
         """Stitcher.py:96-127: restart after every registration break; a trailing lone tile is its own result."""

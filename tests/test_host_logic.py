@@ -195,3 +195,74 @@ def test_dead_reference_paths_behave_like_the_reference():
     s.directIncre = -1
     assert s.directionIncrease(1) == 4
     assert s.getOffsetByMode([], [], []) == (False, [0, 0])
+
+
+def test_flow_stitch_batched_registration_equals_pair_by_pair(oracle, tmp_path):
+    """flowStitch routes the stock incremental searches through grid.GridRegistrar (all tiles on the device, speculative fused
+    batches).  On a 2 x 3 serpentine of synthetic tiles the offsets, the threaded self.direction, the log lines and the mosaic
+    must equal the pair-by-pair loop (batchRegistration = False), for the SURF and the phase-correlation search."""
+    from imagestitch_amd.synthetic import SyntheticGrid
+
+    class FusedOracleEngine(OracleEngine):
+        """OracleEngine plus the fused-attempt entry points, evaluated operator by operator with the oracle."""
+        def __init__(self, o):
+            super().__init__(o); self.tiles = {}; self.batches = 0
+
+        def tile_upload(self, img):
+            self.tiles[len(self.tiles) + 1] = np.ascontiguousarray(img); return len(self.tiles)
+
+        def tile_free(self, h):
+            pass
+
+        def set_keypoint_capacity(self, n):
+            pass
+
+        def _rois(self, job):
+            ta, tb, ay0, ax0, by0, bx0, h, w = [int(v) for v in job]
+            return (np.ascontiguousarray(self.tiles[ta][ay0:ay0 + h, ax0:ax0 + w]), np.ascontiguousarray(self.tiles[tb][by0:by0 + h, bx0:bx0 + w]))
+
+        def attempt_surf_batch(self, jobs, params=None, ratio=0.75, offset_evaluate=3):
+            self.batches += 1
+            out = np.zeros((len(jobs), 8), np.int32)
+            for n, job in enumerate(jobs):
+                a, b = self._rois(job)
+                ka, da = self.surf_detect_describe(a); kb, db = self.surf_detect_describe(b)
+                if len(ka) == 0 or len(kb) == 0:
+                    out[n] = [0, 0, 0, 0, len(ka), len(kb), 0, 0]; continue
+                pairs = self.bf_l2_ratio_matches(da, db, ratio)
+                st, off, votes = self.mode_offset(ka, kb, pairs, offset_evaluate) if len(pairs) else (False, [0, 0], 0)
+                out[n] = [int(st), off[0], off[1], votes, len(ka), len(kb), len(pairs), 0]
+            return out
+
+        def attempt_phase_batch(self, jobs):
+            self.batches += 1
+            rows = []
+            for job in jobs:
+                a, b = self._rois(job)
+                (x, y), r = self.phase_correlate(a, b)
+                rows.append([x, y, r])
+            return np.array(rows, np.float64)
+
+    g = SyntheticGrid(2, 3, 256, overlap=0.2)
+    files = _write_tiles(tmp_path, g.tiles(threads=1), "bf")
+    old = (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod)
+    try:
+        isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod = 1, 0.3, False, "surf"
+        for which in ("calculateOffsetForFeatureSearchIncre", "calculateOffsetForPhaseCorrleateIncre"):
+            runs = []
+            for batched in (False, True):
+                eng = FusedOracleEngine(oracle)
+                s = isa.Stitcher(); s._engine = eng; s.batchRegistration = batched
+                s.direction = 1; s.fuseMethod = "notFuse"
+                msgs = []
+                s.printAndWrite = lambda c, msgs=msgs: msgs.append(c)
+                (status, mosaic) = s.flowStitch(list(files), getattr(s, which))
+                runs.append((status, mosaic, s.direction, [m for m in msgs if "offset of stitching" in m or "stitching " in m], eng.batches))
+            a, b = runs
+            assert a[0] == b[0] and a[2] == b[2] and a[3] == b[3], (which, a[0], b[0], a[3], b[3])
+            assert np.array_equal(a[1], b[1])
+            if which == "calculateOffsetForFeatureSearchIncre":
+                assert a[0][0] is True and a[0][1] == 5          # all five pairs registered, through two turns
+                assert b[4] < a[4]                                # fewer, larger fused batches than pair-by-pair attempts
+    finally:
+        isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod = old
