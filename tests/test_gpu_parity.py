@@ -355,3 +355,42 @@ def test_config3_zirconcl_phase_incremental(engine, golden_dir):
             assert st.calculateOffsetForPhaseCorrleateIncre([A, B]) == (True, exp), (n, exp)
     finally:
         isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio = old
+
+
+def test_main_py_driver_end_to_end(engine, tmp_path):
+    """The entry point Main.py uses: imageSetStitchWithMutiple(project, output, 1, stitcher.calculateOffsetForFeatureSearchIncre)
+    on a folder of tiles (a 3 x 3 serpentine of 768-px synthetic tiles written as PNG).  The batched registration inside
+    flowStitch and the pair-by-pair loop must log the same offsets, each within 1 px of the ground truth, and write the
+    same mosaic file."""
+    from PIL import Image
+    g = SyntheticGrid(3, 3, 768, overlap=0.15)
+    tiles = g.tiles(threads=2)
+    proj = tmp_path / "demo"; (proj / "1").mkdir(parents=True)
+    for k, t in enumerate(tiles):
+        Image.fromarray(t).save(str(proj / "1" / ("1-%03d.png" % (k + 1))))
+    old = (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod,
+           isa.Stitcher.fuseMethod, isa.Stitcher.offsetEvaluate)
+    outs = []
+    try:
+        isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode = 1, 0.2, False
+        isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod, isa.Stitcher.offsetEvaluate = "surf", "fadeInAndFadeOut", 3
+        for batched in (True, False):
+            st = isa.Stitcher(); st._engine = engine; st.batchRegistration = batched
+            isa.Stitcher.direction = 1; st.direction = 1
+            msgs = []
+            st.printAndWrite = lambda c, msgs=msgs: msgs.append(c)
+            out = tmp_path / ("out%d" % batched)
+            st.imageSetStitchWithMutiple(str(proj), str(out) + os.sep, 1, st.calculateOffsetForFeatureSearchIncre,
+                                         startNum=1, fileExtension="png", outputfileExtension="png")
+            offs = [m for m in msgs if "offset of stitching" in m]
+            outs.append((offs, np.asarray(Image.open(str(out / "stitching_result_1.png")))))
+        assert outs[0][0] == outs[1][0] and len(outs[0][0]) == 8
+        assert np.array_equal(outs[0][1], outs[1][1])
+        truth = g.true_offsets()
+        for line, t in zip(outs[0][0], truth):
+            dx, dy = int(line.split("dx is ")[1].split(" ")[0]), int(line.split("dy is ")[1])
+            assert abs(dx - t[0]) <= 1 and abs(dy - t[1]) <= 1, (line, t)
+        assert outs[0][1].shape[0] > 2 * 768 and outs[0][1].shape[1] > 2 * 768
+    finally:
+        (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod,
+         isa.Stitcher.fuseMethod, isa.Stitcher.offsetEvaluate) = old
