@@ -82,6 +82,9 @@ _SIGNATURES = {
     "vfsms_canvas_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "vfsms_canvas_free": (C.c_int, [C.c_void_p, C.c_int64]),
     "vfsms_canvas_paste": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vfsms_canvas_paste_tile": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]),
+    "vfsms_canvas_fuse_tile_resident": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                  C.c_int, C.c_int, C.c_void_p]),
     "vfsms_canvas_fuse_tile": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vfsms_canvas_download": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
@@ -379,6 +382,17 @@ class Engine:
         ry0, rx0, ry1, rx1 = [int(v) for v in roi]
         self._check(self.lib.vfsms_canvas_fuse_tile(self.ctx, C.c_int64(handle), _ptr(tile), tile.shape[0], tile.shape[1],
                                                     int(y0), int(x0), ry0, rx0, ry1, rx1, int(dx), int(dy), _ptr(info)))
+        return info
+
+    def canvas_paste_tile(self, handle, tile_handle, y0, x0):
+        """paste of a single-channel tile that is already resident in HBM (tile_upload handle)."""
+        self._check(self.lib.vfsms_canvas_paste_tile(self.ctx, C.c_int64(handle), C.c_int64(tile_handle), int(y0), int(x0)))
+
+    def canvas_fuse_tile_resident(self, handle, tile_handle, y0, x0, roi, dx, dy):
+        info = np.zeros(4, np.int32)
+        ry0, rx0, ry1, rx1 = [int(v) for v in roi]
+        self._check(self.lib.vfsms_canvas_fuse_tile_resident(self.ctx, C.c_int64(handle), C.c_int64(tile_handle), int(y0), int(x0),
+                                                             ry0, rx0, ry1, rx1, int(dx), int(dy), _ptr(info)))
         return info
 
     def canvas_download(self, handle, rows, cols, ch):

@@ -786,6 +786,45 @@ extern "C" int vfsms_canvas_fuse_tile(vfsms_ctx *ctx, int64_t canvas, const uint
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return VFSMS_OK;
 }
+static int canvas_resident_args(vfsms_ctx *ctx, int64_t canvas, int64_t tile, int y0, int x0, CanvasRec **cv, TileRec **tr)
+{
+    auto it = ctx->canvases.find(canvas);
+    auto jt = ctx->tiles.find(tile);
+    if (it == ctx->canvases.end() || jt == ctx->tiles.end()) { vfsms_set_error("canvas: unknown canvas or tile handle"); return VFSMS_ERR_BAD_ARG; }
+    *cv = &it->second; *tr = &jt->second;
+    if ((*cv)->ch != 1 || (*tr)->stride != (*tr)->w) {
+        vfsms_set_error("canvas: resident tiles must be single-channel and densely packed (stride == w)"); return VFSMS_ERR_BAD_ARG;
+    }
+    if (y0 < 0 || x0 < 0 || y0 + (*tr)->h > (*cv)->rows || x0 + (*tr)->w > (*cv)->cols) {
+        vfsms_set_error("canvas: tile rectangle outside the canvas"); return VFSMS_ERR_BAD_ARG;
+    }
+    return VFSMS_OK;
+}
+extern "C" int vfsms_canvas_paste_tile(vfsms_ctx *ctx, int64_t canvas, int64_t tile, int y0, int x0)
+{
+    CTX_ENTER(ctx);
+    CanvasRec *cv; TileRec *tr;
+    TRY(canvas_resident_args(ctx, canvas, tile, y0, x0, &cv, &tr));
+    TRY(canvas_paste_device(ctx, cv, tr->ptr, tr->h, tr->w, y0, x0));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VFSMS_OK;
+}
+extern "C" int vfsms_canvas_fuse_tile_resident(vfsms_ctx *ctx, int64_t canvas, int64_t tile,
+                                               int y0, int x0, int ry0, int rx0, int ry1, int rx1, int dx, int dy, int32_t *info)
+{
+    CTX_ENTER(ctx);
+    CanvasRec *cv; TileRec *tr;
+    TRY(canvas_resident_args(ctx, canvas, tile, y0, x0, &cv, &tr));
+    const int h = tr->h, w = tr->w;
+    if (ry1 > ry0 && rx1 > rx0 && (ry0 < y0 || rx0 < x0 || ry1 > y0 + h || rx1 > x0 + w)) {
+        vfsms_set_error("canvas_fuse_tile: fuse ROI must lie inside the tile rectangle"); return VFSMS_ERR_BAD_ARG;
+    }
+    const int r = std::max(ry1 - ry0, 0), c = std::max(rx1 - rx0, 0);
+    TRY(ctx_arena_reserve(ctx, sizeof(float) * 8 * ((size_t)r + c) + 65536));
+    TRY(canvas_fuse_device(ctx, cv, tr->ptr, h, w, y0, x0, ry0, rx0, ry1, rx1, dx, dy, info));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VFSMS_OK;
+}
 extern "C" int vfsms_canvas_download(vfsms_ctx *ctx, int64_t canvas, uint8_t *out)
 {
     CTX_ENTER(ctx);

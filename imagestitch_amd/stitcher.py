@@ -149,11 +149,19 @@ class Stitcher(Utility.Method):
                             phaseResponseThreshold=self.phaseResponseThreshold, window=24)
         reg.orbMaxDistance = self.orbMaxDistance if self.isGPUAvailable else -1
         handles = [eng.tile_upload(im) for im in images]
+        keep = (not self.isColorMode) and self.fuseMethod in ("notFuse", "fadeInAndFadeOut") and hasattr(eng, "canvas_fuse_tile_resident")
         try:
             table, _d = reg.register(handles, [im.shape for im in images], self.direction)
+        except BaseException:
+            keep = False
+            raise
         finally:
-            for h in handles:
-                eng.tile_free(h)
+            if keep:
+                # gray mosaics are assembled from these very tiles: getStitchByOffset takes them over (and frees them)
+                self._resident = dict(zip(fileList, zip(handles, [im.shape for im in images])))
+            else:
+                for h in handles:
+                    eng.tile_free(h)
         offsetList, endfileIndex, status, describtion = [], 0, True, ""
         for k, row in enumerate(table):
             self.printAndWrite("stitching " + str(fileList[k]) + " and " + str(fileList[k + 1]))
@@ -429,31 +437,47 @@ class Stitcher(Utility.Method):
         color = self.isColorMode
         originOffsetList.insert(0, [0, 0])
         n = len(originOffsetList)
-        imageList = [_imread(fileList[0], color)]
-        for i in range(1, n):
-            imageList.append(_imread(fileList[i], Stitcher.isColorMode))
-        offsetList, rangeX, rangeY, resultRow, resultCol = self._layout([im.shape for im in imageList], originOffsetList)
-        self.printAndWrite("  The rectified offsetList is " + str(offsetList))
-        if self.fuseMethod not in ("notFuse", "fadeInAndFadeOut"):
-            return self._stitchWithHostFuse(fileList, imageList, originOffsetList, offsetList, rangeX, rangeY, resultRow, resultCol)
         eng = self.engine
-        ch = 3 if color else 1
-        canvas = eng.canvas_create(resultRow, resultCol, ch)
+        # tiles the batched registration left in HBM (gray mosaics only): fused from where they are, no second decode / upload
+        resident = self.__dict__.pop("_resident", None) or {}
+        use_res = (not color) and self.fuseMethod in ("notFuse", "fadeInAndFadeOut") and all(fileList[i] in resident for i in range(n))
         try:
-            for i in range(0, n):
-                self.printAndWrite("  stitching " + str(fileList[i]))
-                tile = imageList[i]
-                oy, ox = offsetList[i][0], offsetList[i][1]
-                if i == 0 or self.fuseMethod == "notFuse":
-                    eng.canvas_paste(canvas, tile, oy, ox)
-                    continue
-                roi_ltx = max(oy, rangeX[i - 1][0]); roi_lty = max(ox, rangeY[i - 1][0])
-                roi_rbx = min(oy + tile.shape[0], rangeX[i - 1][1]); roi_rby = min(ox + tile.shape[1], rangeY[i - 1][1])
-                eng.canvas_fuse_tile(canvas, tile, oy, ox, (roi_ltx, roi_lty, roi_rbx, roi_rby),
-                                     originOffsetList[i][0], originOffsetList[i][1])
-            return eng.canvas_download(canvas, resultRow, resultCol, ch)
+            if use_res:
+                shapes = [resident[fileList[i]][1] for i in range(n)]
+            else:
+                imageList = [_imread(fileList[0], color)]
+                for i in range(1, n):
+                    imageList.append(_imread(fileList[i], Stitcher.isColorMode))
+                shapes = [im.shape for im in imageList]
+            offsetList, rangeX, rangeY, resultRow, resultCol = self._layout(shapes, originOffsetList)
+            self.printAndWrite("  The rectified offsetList is " + str(offsetList))
+            if self.fuseMethod not in ("notFuse", "fadeInAndFadeOut"):
+                return self._stitchWithHostFuse(fileList, imageList, originOffsetList, offsetList, rangeX, rangeY, resultRow, resultCol)
+            ch = 3 if color else 1
+            canvas = eng.canvas_create(resultRow, resultCol, ch)
+            try:
+                for i in range(0, n):
+                    self.printAndWrite("  stitching " + str(fileList[i]))
+                    th, tw = shapes[i][0], shapes[i][1]
+                    oy, ox = offsetList[i][0], offsetList[i][1]
+                    if i == 0 or self.fuseMethod == "notFuse":
+                        if use_res:
+                            eng.canvas_paste_tile(canvas, resident[fileList[i]][0], oy, ox)
+                        else:
+                            eng.canvas_paste(canvas, imageList[i], oy, ox)
+                        continue
+                    roi = (max(oy, rangeX[i - 1][0]), max(ox, rangeY[i - 1][0]),
+                           min(oy + th, rangeX[i - 1][1]), min(ox + tw, rangeY[i - 1][1]))
+                    if use_res:
+                        eng.canvas_fuse_tile_resident(canvas, resident[fileList[i]][0], oy, ox, roi, originOffsetList[i][0], originOffsetList[i][1])
+                    else:
+                        eng.canvas_fuse_tile(canvas, imageList[i], oy, ox, roi, originOffsetList[i][0], originOffsetList[i][1])
+                return eng.canvas_download(canvas, resultRow, resultCol, ch)
+            finally:
+                eng.canvas_free(canvas)
         finally:
-            eng.canvas_free(canvas)
+            for h, _shape in resident.values():
+                eng.tile_free(h)
 
     def _stitchWithHostFuse(self, fileList, imageList, originOffsetList, offsetList, rangeX, rangeY, resultRow, resultCol):
         """average / maximum / minimum / trigonometric: outside the accelerated scope (SURVEY section 2 rows 7-8);

@@ -183,6 +183,12 @@ int vfsms_canvas_paste(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int 
 int vfsms_canvas_fuse_tile(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w,
                            int y0, int x0, int ry0, int rx0, int ry1, int rx1,
                            int dx, int dy, int32_t *info);
+/* the same two operations for a single-channel tile that is already resident in HBM (a handle from vfsms_tile_upload /
+ * vfsms_tile_wrap with stride == w, e.g. the tiles the registration phase uploaded): no host copy, canvas ch must be 1 */
+int vfsms_canvas_paste_tile(vfsms_ctx *ctx, int64_t canvas, int64_t tile, int y0, int x0);
+int vfsms_canvas_fuse_tile_resident(vfsms_ctx *ctx, int64_t canvas, int64_t tile,
+                                    int y0, int x0, int ry0, int rx0, int ry1, int rx1,
+                                    int dx, int dy, int32_t *info);
 /* final image: empty -> 0 (Stitcher.py:485-486).  out: u8 [rows][cols][ch]                           */
 int vfsms_canvas_download(vfsms_ctx *ctx, int64_t canvas, uint8_t *out);
 
