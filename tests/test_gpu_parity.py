@@ -394,3 +394,41 @@ def test_main_py_driver_end_to_end(engine, tmp_path):
     finally:
         (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod,
          isa.Stitcher.fuseMethod, isa.Stitcher.offsetEvaluate) = old
+
+
+def test_dll_mode_parameter_set(engine, oracle, strips):
+    """Method.isGPUAvailable = True selects the reference's DLL parameter set (ImageUtility.py:22-40, 265-274, 304-308): SURF
+    with extended (128-d) descriptors, whose 2-NN search runs on the exhaustive kernel, and ORB matches cut at
+    orbMaxDistance = 30.  Fused attempts must equal the operator chain, and the Hamming cut must equal the oracle's."""
+    g, tiles = strips
+    ra = isa.roi_rect(tiles[0].shape, 1, "first", 0.2); rb = isa.roi_rect(tiles[1].shape, 1, "second", 0.2)
+    A = np.ascontiguousarray(tiles[0][ra[0]:ra[0] + ra[2]]); B = np.ascontiguousarray(tiles[1][:rb[2]])
+    ha, hb = engine.tile_upload(tiles[0]), engine.tile_upload(tiles[1])
+    job = [(ha, hb, ra[0], ra[1], rb[0], rb[1], ra[2], ra[3])]
+    # SURF, extended descriptors
+    p = engine.surf_params(100.0, 4, 3, True, False)
+    row = engine.attempt_surf_batch(job, p, 0.75, 3)[0]
+    ka, da = engine.surf_detect_describe(A, p); kb, db = engine.surf_detect_describe(B, p)
+    assert da.shape[1] == 128
+    pairs = engine.bf_l2_ratio_matches(da, db, 0.75)
+    assert np.array_equal(pairs, oracle.bf_l2_ratio_matches(da, db, 0.75))
+    st, off, votes = engine.mode_offset(ka, kb, pairs, 3)
+    assert row[:7].tolist() == [int(st), off[0], off[1], votes, len(ka), len(kb), len(pairs)], (row, st, off, votes)
+    # ORB with the distance threshold of the DLL path
+    g2 = SyntheticGrid(2, 1, 1024, overlap=0.15)
+    t2 = g2.tiles(threads=1)
+    ra = isa.roi_rect(t2[0].shape, 1, "first", 0.2); rb = isa.roi_rect(t2[1].shape, 1, "second", 0.2)
+    A = np.ascontiguousarray(t2[0][ra[0]:ra[0] + ra[2]]); B = np.ascontiguousarray(t2[1][:rb[2]])
+    ka, da = engine.orb_detect_describe(A); kb, db = engine.orb_detect_describe(B)
+    for md in (30, 64, -1):
+        gp = engine.bf_hamming_matches(da, db, md)
+        op, _od = oracle.bf_hamming_matches(da, db, md)
+        assert np.array_equal(gp, op), md
+    h0, h1 = engine.tile_upload(t2[0]), engine.tile_upload(t2[1])
+    row = engine.attempt_orb_batch([(h0, h1, ra[0], ra[1], rb[0], rb[1], ra[2], ra[3])], engine.orb_params(), 30, 3)[0]
+    pairs = engine.bf_hamming_matches(da, db, 30)
+    st, off, votes = engine.mode_offset(ka, kb, pairs, 3) if len(pairs) else (False, [0, 0], 0)
+    assert row[:7].tolist() == [int(st), off[0], off[1], votes, len(ka), len(kb), len(pairs)], (row, st, off, votes, len(pairs))
+    assert 0 < len(pairs) < len(ka)                     # the threshold really cuts
+    for h in (ha, hb, h0, h1):
+        engine.tile_free(h)
