@@ -432,3 +432,25 @@ def test_dll_mode_parameter_set(engine, oracle, strips):
     assert 0 < len(pairs) < len(ka)                     # the threshold really cuts
     for h in (ha, hb, h0, h1):
         engine.tile_free(h)
+
+
+def test_fused_batch_with_featureless_rois(engine, strips):
+    """A batch is ragged: ROIs without a single keypoint (flat tiles) sit next to ordinary ones.  Their rows must report zero
+    keypoints and no match (Stitcher treats that as "features is None"), and must not disturb their neighbours' rows."""
+    g, tiles = strips
+    flat = np.full_like(tiles[0], 97)
+    ra = isa.roi_rect(tiles[0].shape, 1, "first", 0.2); rb = isa.roi_rect(tiles[1].shape, 1, "second", 0.2)
+    hs = [engine.tile_upload(t) for t in (tiles[0], tiles[1], flat)]
+    geom = (ra[0], ra[1], rb[0], rb[1], ra[2], ra[3])
+    alone = engine.attempt_surf_batch([(hs[0], hs[1]) + geom])[0]
+    rows = engine.attempt_surf_batch([(hs[2], hs[1]) + geom, (hs[0], hs[1]) + geom, (hs[0], hs[2]) + geom, (hs[2], hs[2]) + geom])
+    assert rows[1].tolist() == alone.tolist() and alone[0] == 1
+    assert rows[0][:7].tolist() == [0, 0, 0, 0, 0, int(alone[5]), 0]
+    assert rows[2][:7].tolist() == [0, 0, 0, 0, int(alone[4]), 0, 0]
+    assert rows[3][:7].tolist() == [0, 0, 0, 0, 0, 0, 0]
+    orows = engine.attempt_orb_batch([(hs[2], hs[1]) + geom, (hs[0], hs[2]) + geom, (hs[2], hs[2]) + geom])
+    assert orows[:, 0].tolist() == [0, 0, 0] and orows[0][4] == 0 and orows[1][5] == 0 and orows[2][4] == 0 and orows[2][5] == 0
+    prow = engine.attempt_phase_batch([(hs[2], hs[2]) + geom])      # identical flat strips: zero spectrum, response 0, no offset
+    assert prow.shape == (1, 3) and np.isfinite(prow).all() and prow[0][2] < 0.15
+    for h in hs:
+        engine.tile_free(h)
