@@ -454,3 +454,36 @@ def test_fused_batch_with_featureless_rois(engine, strips):
     assert prow.shape == (1, 3) and np.isfinite(prow).all() and prow[0][2] < 0.15
     for h in hs:
         engine.tile_free(h)
+
+
+def test_full_size_roi_properties(engine):
+    """Size-independent properties at the BASELINE geometry (409 x 2048 strips of 2048 x 2048 tiles, ~8.7 k keypoints): keypoints
+    come out in KeypointGreater order, descriptors have unit norm, 2-NN distances are ordered and consistent with the descriptors,
+    matching a set against itself finds itself at distance 0, and the attempt is symmetric: swapping the tiles with the opposite
+    direction negates the offset (+-1 px, the truncation bias of the vote)."""
+    g = SyntheticGrid(2, 1, 2048)
+    t = g.tiles(threads=2)
+    ra = isa.roi_rect(t[0].shape, 1, "first", 0.2); rb = isa.roi_rect(t[1].shape, 1, "second", 0.2)
+    A = np.ascontiguousarray(t[0][ra[0]:ra[0] + ra[2]]); B = np.ascontiguousarray(t[1][:rb[2]])
+    kxy, da, kf = engine.surf_detect_describe(A, full=True)
+    _kb, db = engine.surf_detect_describe(B)
+    assert len(kf) > 5000
+    r = kf["response"]
+    assert np.all(r[:-1] >= r[1:])                                               # response descending (ties broken further down the key)
+    tie = r[:-1] == r[1:]
+    assert np.all(kf["size"][:-1][tie] >= kf["size"][1:][tie])
+    n = np.linalg.norm(da.astype(np.float64), axis=1)
+    assert np.all((np.abs(n - 1) < 1e-5) | (n == 0))                             # unit norm (or the zero descriptor of a flat patch)
+    i1, d1, d2 = engine.bf_l2_knn2(da, db)
+    assert np.all(d1 <= d2) and np.all(i1 >= 0) and np.all(i1 < len(db))
+    ref = np.sqrt(((da.astype(np.float64) - db[i1].astype(np.float64)) ** 2).sum(1))
+    assert np.abs(ref - d1).max() < 1e-5
+    s1, e1, _e2 = engine.bf_l2_knn2(da[:3000], da[:3000])
+    nz = n[:3000] > 0
+    assert np.all(e1[nz] == 0) and np.all(da[s1[nz]] == da[:3000][nz])          # self match (identical rows may tie on a lower index)
+    ha, hb = engine.tile_upload(t[0]), engine.tile_upload(t[1])
+    fwd = engine.attempt_surf_batch([(ha, hb, ra[0], ra[1], rb[0], rb[1], ra[2], ra[3])])[0]
+    bwd = engine.attempt_surf_batch([(hb, ha, rb[0], rb[1], ra[0], ra[1], ra[2], ra[3])])[0]     # direction 3: B's top against A's bottom
+    assert fwd[0] == 1 and bwd[0] == 1
+    assert abs(fwd[1] + bwd[1]) <= 1 and abs(fwd[2] + bwd[2]) <= 1, (fwd, bwd)
+    engine.tile_free(ha); engine.tile_free(hb)
