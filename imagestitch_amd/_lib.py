@@ -388,11 +388,12 @@ class Engine:
         """paste of a single-channel tile that is already resident in HBM (tile_upload handle)."""
         self._check(self.lib.vfsms_canvas_paste_tile(self.ctx, C.c_int64(handle), C.c_int64(tile_handle), int(y0), int(x0)))
 
-    def canvas_fuse_tile_resident(self, handle, tile_handle, y0, x0, roi, dx, dy):
-        info = np.zeros(4, np.int32)
+    def canvas_fuse_tile_resident(self, handle, tile_handle, y0, x0, roi, dx, dy, want_info=False):
+        """want_info=False: the call only enqueues work; geometry errors surface in canvas_download."""
+        info = np.zeros(4, np.int32) if want_info else None
         ry0, rx0, ry1, rx1 = [int(v) for v in roi]
         self._check(self.lib.vfsms_canvas_fuse_tile_resident(self.ctx, C.c_int64(handle), C.c_int64(tile_handle), int(y0), int(x0),
-                                                             ry0, rx0, ry1, rx1, int(dx), int(dy), _ptr(info)))
+                                                             ry0, rx0, ry1, rx1, int(dx), int(dy), _ptr(info) if want_info else None))
         return info
 
     def canvas_download(self, handle, rows, cols, ch):

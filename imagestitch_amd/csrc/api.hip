@@ -729,6 +729,8 @@ extern "C" int vfsms_canvas_create(vfsms_ctx *ctx, int rows, int cols, int ch, i
     CanvasRec cv; cv.rows = rows; cv.cols = cols; cv.ch = ch;
     HIP_TRY(hipMalloc((void **)&cv.pix, (size_t)rows * cols * ch));
     HIP_TRY(hipMalloc((void **)&cv.mask, (size_t)rows * cols));
+    HIP_TRY(hipMalloc((void **)&cv.d_err, sizeof(int)));
+    HIP_TRY(hipMemsetAsync(cv.d_err, 0, sizeof(int), ctx->stream));
     HIP_TRY(hipMemsetAsync(cv.pix, 0, (size_t)rows * cols * ch, ctx->stream));
     HIP_TRY(hipMemsetAsync(cv.mask, 0, (size_t)rows * cols, ctx->stream));
     *handle = ctx->next_handle++;
@@ -741,7 +743,7 @@ extern "C" int vfsms_canvas_free(vfsms_ctx *ctx, int64_t handle)
     auto it = ctx->canvases.find(handle);
     if (it == ctx->canvases.end()) { vfsms_set_error("canvas_free: unknown handle"); return VFSMS_ERR_BAD_ARG; }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(it->second.pix)); HIP_TRY(hipFree(it->second.mask));
+    HIP_TRY(hipFree(it->second.pix)); HIP_TRY(hipFree(it->second.mask)); HIP_TRY(hipFree(it->second.d_err));
     ctx->canvases.erase(it);
     return VFSMS_OK;
 }
@@ -806,8 +808,7 @@ extern "C" int vfsms_canvas_paste_tile(vfsms_ctx *ctx, int64_t canvas, int64_t t
     CanvasRec *cv; TileRec *tr;
     TRY(canvas_resident_args(ctx, canvas, tile, y0, x0, &cv, &tr));
     TRY(canvas_paste_device(ctx, cv, tr->ptr, tr->h, tr->w, y0, x0));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return VFSMS_OK;
+    return VFSMS_OK;                                       // enqueued only: resident tiles need no host synchronisation
 }
 extern "C" int vfsms_canvas_fuse_tile_resident(vfsms_ctx *ctx, int64_t canvas, int64_t tile,
                                                int y0, int x0, int ry0, int rx0, int ry1, int rx1, int dx, int dy, int32_t *info)
@@ -822,7 +823,7 @@ extern "C" int vfsms_canvas_fuse_tile_resident(vfsms_ctx *ctx, int64_t canvas, i
     const int r = std::max(ry1 - ry0, 0), c = std::max(rx1 - rx0, 0);
     TRY(ctx_arena_reserve(ctx, sizeof(float) * 8 * ((size_t)r + c) + 65536));
     TRY(canvas_fuse_device(ctx, cv, tr->ptr, h, w, y0, x0, ry0, rx0, ry1, rx1, dx, dy, info));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (info) HIP_TRY(hipStreamSynchronize(ctx->stream));   // without a readback the call only enqueues (stream order keeps the canvas consistent)
     return VFSMS_OK;
 }
 extern "C" int vfsms_canvas_download(vfsms_ctx *ctx, int64_t canvas, uint8_t *out)
@@ -832,8 +833,14 @@ extern "C" int vfsms_canvas_download(vfsms_ctx *ctx, int64_t canvas, uint8_t *ou
     if (it == ctx->canvases.end() || !out) { vfsms_set_error("canvas_download: bad arguments"); return VFSMS_ERR_BAD_ARG; }
     const CanvasRec &cv = it->second;
     // never-written pixels are still 0 (the canvas is zero-initialised), exactly Stitcher.py:485
+    int err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, cv.d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(out, cv.pix, (size_t)cv.rows * cv.cols * cv.ch, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (err) {
+        vfsms_set_error("fuse: degenerate corner geometry in one of the fused tiles (the reference's getWeightsMatrix raises there)");
+        return VFSMS_ERR_BAD_ARG;
+    }
     return VFSMS_OK;
 }
 

@@ -108,7 +108,7 @@ struct MatchDev {
 
 // ---- context ------------------------------------------------------------------------------------------
 struct TileRec { uint8_t *ptr; int h, w, stride; bool owned; };
-struct CanvasRec { uint8_t *pix; uint8_t *mask; int rows, cols, ch; };
+struct CanvasRec { uint8_t *pix; uint8_t *mask; int rows, cols, ch; int *d_err; };   // d_err: sticky "degenerate fuse geometry" flag for calls made without an info readback
 struct FftPlan { int M, N; void *fwd; void *inv; };   // hipfftHandle stored as void* (int in practice)
 struct ProfRec { int id; hipEvent_t a, b; };
 

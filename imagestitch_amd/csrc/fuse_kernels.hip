@@ -207,7 +207,7 @@ __device__ __forceinline__ int pywrap(int i, int n) { return i < 0 ? i + n : i; 
 
 __global__ __launch_bounds__(256) void k_fuse_weights(int r, int c, int ch, int dx, int dy, int force_corner, const FuseStats *st,
                                                       const int *rowFirst, const int *rowLast, const int *colFirst, const int *colLast,
-                                                      float *wAr, float *wAc, float *wBr, float *wBc, int *out)
+                                                      float *wAr, float *wAc, float *wBr, float *wBc, int *out, int *sticky_err)
 {
     const int t = threadIdx.x;
     __shared__ int s_first, s_geom[4];          // first scan position with a non-zero candidate; index,rowIndex,colIndex,err
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void k_fuse_weights(int r, int c, int ch, int 
             else for (int i = max(colIndex, 0) + t; i < c; i += 256) wBc[i] = (float)((double)(c - i - 1) * 1 / (c - ci - 1));
         }
     }
-    if (err) atomicOr(&out[5], 1);
+    if (err) { atomicOr(&out[5], 1); if (sticky_err) atomicOr(sticky_err, 1); }
     if (t == 0) { out[0] = 1; out[1] = 1; out[2] = s_geom[0]; out[3] = rowIndex; out[4] = colIndex; }
 }
 
@@ -314,11 +314,11 @@ static int fuse_scratch(vfsms_ctx *ctx, int r, int c, FuseScratch *S)
 }
 
 // launch the ramp kernel; `finish_weights` later brings back its 6 status ints (and the ramps when a caller wants them) in one sync
-static int launch_weights(vfsms_ctx *ctx, const FuseScratch &S, int r, int c, int ch, int dx, int dy, int force_corner = 0)
+static int launch_weights(vfsms_ctx *ctx, const FuseScratch &S, int r, int c, int ch, int dx, int dy, int force_corner = 0, int *sticky_err = nullptr)
 {
     HIP_TRY(hipMemsetAsync(S.out, 0, sizeof(int) * 8, ctx->stream));
     hipLaunchKernelGGL(k_fuse_weights, dim3(1), dim3(256), 0, ctx->stream, r, c, ch, dx, dy, force_corner, S.st, S.rowFirst, S.rowLast,
-                       S.colFirst, S.colLast, S.wAr, S.wAc, S.wBr, S.wBc, S.out);
+                       S.colFirst, S.colLast, S.wAr, S.wAc, S.wBr, S.wBc, S.out, sticky_err);
     HIP_TRY(hipGetLastError());
     return VFSMS_OK;
 }
@@ -364,10 +364,11 @@ int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int
     V.tile = d_tile; V.tw = w; V.ty0 = ry0 - y0; V.tx0 = rx0 - x0;
     hipLaunchKernelGGL(k_fuse_stats_rows, dim3(r), dim3(256), 0, ctx->stream, V, r, c, S.st, S.rowFirst, S.rowLast);
     hipLaunchKernelGGL(k_fuse_stats_cols, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, V, r, c, S.colFirst, S.colLast);
-    TRY(launch_weights(ctx, S, r, c, cv->ch, dx, dy));
+    TRY(launch_weights(ctx, S, r, c, cv->ch, dx, dy, 0, cv->d_err));
     hipLaunchKernelGGL(k_fuse_apply, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, cv->pix, cv->mask, cv->cols, cv->ch,
                        d_tile, h, w, y0, x0, ry0, rx0, r, c, S.out, S.wAr, S.wAc, S.wBr, S.wBc);
     HIP_TRY(hipGetLastError());
+    if (!info) return VFSMS_OK;          // no readback wanted: a degenerate geometry is latched in the canvas and reported by the download
     return finish_weights(ctx, S, r, c, info);
 }
 

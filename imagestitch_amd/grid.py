@@ -96,22 +96,30 @@ class GridRegistrar:
         sync inside a batch), so the capacity follows the largest ROI seen so far (x1.5 + 1024); an overflow falls
         back to the library default (h*w/24 + 4096) and repeats the batch."""
         cap = getattr(self, "_kp_cap", 0)
+        adaptive = hasattr(self.eng, "set_keypoint_capacity")
         try:
-            rows = self.eng.attempt_surf_batch(jobs, self.params, self.searchRatio, self.offsetEvaluate)
-        except Exception:
-            if not cap:
-                raise
-            self._kp_cap = 0
-            self._kp_seen = 0
-            self.eng.set_keypoint_capacity(0)
-            rows = self.eng.attempt_surf_batch(jobs, self.params, self.searchRatio, self.offsetEvaluate)
-        if hasattr(self.eng, "set_keypoint_capacity") and len(rows):
+            # the override is in force only around this registrar's own batches: other users of the engine keep the default
+            if adaptive and cap:
+                self.eng.set_keypoint_capacity(cap)
+            try:
+                rows = self.eng.attempt_surf_batch(jobs, self.params, self.searchRatio, self.offsetEvaluate)
+            except Exception:
+                if not cap:
+                    raise
+                self._kp_cap = 0
+                self._kp_seen = 0
+                self.eng.set_keypoint_capacity(0)
+                rows = self.eng.attempt_surf_batch(jobs, self.params, self.searchRatio, self.offsetEvaluate)
+        finally:
+            if adaptive and cap:
+                self.eng.set_keypoint_capacity(0)
+        if adaptive and len(rows):
             seen = max(int(rows[:, 4:6].max()), getattr(self, "_kp_seen", 0))
             self._kp_seen = seen
             want = int(seen * 1.5) + 1024
+            cap = getattr(self, "_kp_cap", 0)
             if seen > 0 and want != cap and (cap == 0 or want > cap or want < cap * 0.6):
                 self._kp_cap = want
-                self.eng.set_keypoint_capacity(want)
         return rows
 
     def _correct(self, raw, d, i, shapeA, shapeB):

@@ -184,7 +184,9 @@ int vfsms_canvas_fuse_tile(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, 
                            int y0, int x0, int ry0, int rx0, int ry1, int rx1,
                            int dx, int dy, int32_t *info);
 /* the same two operations for a single-channel tile that is already resident in HBM (a handle from vfsms_tile_upload /
- * vfsms_tile_wrap with stride == w, e.g. the tiles the registration phase uploaded): no host copy, canvas ch must be 1 */
+ * vfsms_tile_wrap with stride == w, e.g. the tiles the registration phase uploaded): no host copy, canvas ch must be 1.
+ * With info == NULL the fuse only enqueues work (no host synchronisation per tile); a degenerate corner geometry -- where the
+ * reference's getWeightsMatrix raises -- is then latched in the canvas and reported by vfsms_canvas_download.               */
 int vfsms_canvas_paste_tile(vfsms_ctx *ctx, int64_t canvas, int64_t tile, int y0, int x0);
 int vfsms_canvas_fuse_tile_resident(vfsms_ctx *ctx, int64_t canvas, int64_t tile,
                                     int y0, int x0, int ry0, int rx0, int ry1, int rx1,
