@@ -487,3 +487,27 @@ def test_full_size_roi_properties(engine):
     assert fwd[0] == 1 and bwd[0] == 1
     assert abs(fwd[1] + bwd[1]) <= 1 and abs(fwd[2] + bwd[2]) <= 1, (fwd, bwd)
     engine.tile_free(ha); engine.tile_free(hb)
+
+
+def test_surf_parameter_variants(engine, oracle, strips):
+    """Parameter sets off the default path: upright descriptors (surfIsUpright: no orientation, axis-aligned window, where the
+    only non-replicated operation disappears, so descriptors must be bit-exact), a different threshold, and pyramids with other
+    octave / layer counts (those take the generic Hessian kernel and other NMS margins)."""
+    g, tiles = strips
+    img = np.ascontiguousarray(tiles[2][:200, :])
+    big = np.ascontiguousarray(tiles[1])                                   # 640 x 640: windows of every class, many cross the border
+    for im, kw in ((img, dict(upright=True)), (big, dict(upright=True)), (img, dict(hessian=400.0)), (img, dict(n_octaves=2, n_layers=2)),
+                   (big, dict(n_octaves=3, n_layers=4)), (img, dict(n_octaves=4, n_layers=3, extended=True, upright=True))):
+        p = engine.surf_params(kw.get("hessian", 100.0), kw.get("n_octaves", 4), kw.get("n_layers", 3), kw.get("extended", False), kw.get("upright", False))
+        kxy, desc, kfull = engine.surf_detect_describe(im, p, full=True)
+        ko, do = oracle.surf_detect_describe(im, **kw)
+        assert len(kfull) == len(ko) and len(ko) > 50, (kw, len(kfull), len(ko))
+        assert np.array_equal(_kp_fields(kfull), _kp_fields(ko)), kw
+        assert np.array_equal(kfull["angle"], ko["angle"]), kw
+        if kw.get("upright"):
+            assert np.array_equal(desc, do), kw
+        else:
+            assert np.abs(desc - do).max() < 1e-3, kw
+    # five octaves would need descriptor windows beyond VFSMS_MAX_WIN (768 px): refused loudly, not computed differently
+    with pytest.raises(isa.VfsmsError):
+        engine.surf_detect_describe(img, engine.surf_params(100.0, 5, 3, False, False))
