@@ -582,7 +582,8 @@ __device__ __forceinline__ int win_sample_upright(const WinGeom &G, int i, int j
 // Stage rows [r0, r0 + nrows) x all `win` columns of the window into LDS (row-major, pitch win).  Each wave sweeps
 // 8-row strips left to right in 8x8-lane tiles (a wave's byte gathers touch ~10 cache lines instead of ~45), FOUR
 // tiles per trip: the 16 byte loads of a lane are issued back to back behind ONE wave-uniform interior test, so the
-// L2 latency is paid once per four samples (the kernel is latency-bound at the 3 workgroups/CU its LDS allows).
+// L2 latency is paid once per four samples.  (Measured: the kernel as a whole is bound by instruction issue at 5 workgroups/CU;
+// changes of tile shape, ILP depth or occupancy beyond that left its time unchanged -- DESIGN.md section 9.)
 #define STAGE_ILP 4
 __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row, const float *sy_row,
                                            int r0, int nrows, uint8_t *dst)
@@ -877,7 +878,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
 // ---------------------------------------------------------------------------------------------------
 // Persistent scheduling for the descriptor kernel.  The number of keypoints of each ROI only exists on the device
 // (no host sync inside a batch), so instead of launching a capacity-sized grid -- mostly workgroups that find
-// nothing to do, each still paying a 30 KB LDS allocation -- 4 resident workgroups per CU draw (ROI, keypoint)
+// nothing to do, each still paying a 30 KB LDS allocation -- 5 resident workgroups per CU draw (ROI, keypoint)
 // tickets from one atomic counter over the concatenation of all ROIs' keypoint lists (prefix sums of the
 // device-side counts, rebuilt per workgroup in LDS).  Window cost varies 100x between keypoints, so dynamic
 // tickets matter: static striding measured 45 % slower, 4-ticket chunks 20 % slower.
