@@ -67,6 +67,11 @@ class Stitcher(Utility.Method):
     directIncre = 1             # rotation step of the direction search: 1, 0 or -1
     fuseMethod = "notFuse"
     phaseResponseThreshold = 0.15
+    # cv2.phaseCorrelate(a, b) reports the shift of b's content relative to a's (b - a); the feature path votes a - b, and the
+    # reference adds both with the same sign (Stitcher.py:244-251), so its phase offsets come out mirrored (SURVEY 8a row G:
+    # iron gives [1400, 0] where the true offset is [1699, -1]).  The default reproduces the reference as written; True negates
+    # the raw shift before the axis correction (iron -> [1698, 0]).  The batched registrar follows the reference only.
+    phaseSignFix = False
     tempImageFeature = ImageFeature()
 
     imageFusion = ImageFusion.ImageFusion()
@@ -134,7 +139,7 @@ class Stitcher(Utility.Method):
             return None
         if fn is Stitcher.calculateOffsetForFeatureSearchIncre and self._usesStockOperators():
             method = self.featureMethod
-        elif fn is Stitcher.calculateOffsetForPhaseCorrleateIncre:
+        elif fn is Stitcher.calculateOffsetForPhaseCorrleateIncre and not self.phaseSignFix:
             method = "phase"
         else:
             return None
@@ -315,6 +320,8 @@ class Stitcher(Utility.Method):
                 (offsetTemp, response) = self._phaseCorrelate(roiImageA, roiImageB)
                 offset[0] = int(offsetTemp[1])
                 offset[1] = int(offsetTemp[0])
+                if self.phaseSignFix:                  # opt-in, not the reference's behaviour: see the class attribute
+                    offset[0], offset[1] = -offset[0], -offset[1]
                 if response > self.phaseResponseThreshold:
                     status = True
                 if status == True:

@@ -266,3 +266,24 @@ def test_flow_stitch_batched_registration_equals_pair_by_pair(oracle, tmp_path):
                 assert b[4] < a[4]                                # fewer, larger fused batches than pair-by-pair attempts
     finally:
         isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod = old
+
+
+def test_phase_sign_fix_is_opt_in(oracle, golden_dir):
+    """The reference-as-written phase search mirrors the offset; phaseSignFix = True is an opt-in that is NOT the
+    reference's behaviour.  On the iron pair: default [1400, 0] (what the reference would return), fixed [1698, 0] (the SURF
+    search gives [1699, 0], the true offset is [1699, -1])."""
+    c = json.load(open(os.path.join(golden_dir, "demo_strips.json")))["cases"][0]
+    g = np.load(os.path.join(golden_dir, "demo_strips.npz"))
+    H, W = c["shape"]
+    A = np.zeros((H, W), np.uint8); B = np.zeros((H, W), np.uint8)
+    A[H - g["d0_roiA"].shape[0]:, :] = g["d0_roiA"]; B[:g["d0_roiB"].shape[0], :] = g["d0_roiB"]
+    old = (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio)
+    try:
+        isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio = 1, 0, 0.2
+        s = isa.Stitcher(); s._engine = OracleEngine(oracle); s.isPrintLog = False
+        assert s.phaseSignFix is False
+        assert s.calculateOffsetForPhaseCorrleateIncre([A, B]) == (True, [1400, 0])
+        s.phaseSignFix = True
+        assert s.calculateOffsetForPhaseCorrleateIncre([A, B]) == (True, [1698, 0])
+    finally:
+        isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio = old
