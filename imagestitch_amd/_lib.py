@@ -82,6 +82,8 @@ _SIGNATURES = {
     "vfsms_canvas_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "vfsms_canvas_free": (C.c_int, [C.c_void_p, C.c_int64]),
     "vfsms_canvas_paste": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vfsms_canvas_blend_tile": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int]),
     "vfsms_canvas_paste_tile": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "vfsms_canvas_fuse_tile_resident": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                   C.c_int, C.c_int, C.c_void_p]),
@@ -383,6 +385,13 @@ class Engine:
         self._check(self.lib.vfsms_canvas_fuse_tile(self.ctx, C.c_int64(handle), _ptr(tile), tile.shape[0], tile.shape[1],
                                                     int(y0), int(x0), ry0, rx0, ry1, rx1, int(dx), int(dy), _ptr(info)))
         return info
+
+    def canvas_blend_tile(self, handle, tile, y0, x0, roi, mode):
+        """fuseMethod average / maximum / minimum (mode 0 / 1 / 2) of a host tile into the canvas."""
+        tile = np.ascontiguousarray(tile, np.uint8)
+        ry0, rx0, ry1, rx1 = [int(v) for v in roi]
+        self._check(self.lib.vfsms_canvas_blend_tile(self.ctx, C.c_int64(handle), _ptr(tile), tile.shape[0], tile.shape[1],
+                                                     int(y0), int(x0), ry0, rx0, ry1, rx1, int(mode)))
 
     def canvas_paste_tile(self, handle, tile_handle, y0, x0):
         """paste of a single-channel tile that is already resident in HBM (tile_upload handle)."""

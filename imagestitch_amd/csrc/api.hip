@@ -788,6 +788,24 @@ extern "C" int vfsms_canvas_fuse_tile(vfsms_ctx *ctx, int64_t canvas, const uint
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return VFSMS_OK;
 }
+extern "C" int vfsms_canvas_blend_tile(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w,
+                                       int y0, int x0, int ry0, int rx0, int ry1, int rx1, int mode)
+{
+    CTX_ENTER(ctx);
+    CanvasRec *cv;
+    TRY(canvas_tile_args(ctx, canvas, tile, h, w, y0, x0, &cv));
+    if (mode < 0 || mode > 2) { vfsms_set_error("canvas_blend_tile: mode must be 0 (average), 1 (maximum) or 2 (minimum)"); return VFSMS_ERR_BAD_ARG; }
+    if (ry1 > ry0 && rx1 > rx0 && (ry0 < y0 || rx0 < x0 || ry1 > y0 + h || rx1 > x0 + w)) {
+        vfsms_set_error("canvas_blend_tile: fuse ROI must lie inside the tile rectangle"); return VFSMS_ERR_BAD_ARG;
+    }
+    const size_t nb = (size_t)h * w * cv->ch;
+    TRY(ctx_arena_reserve(ctx, nb + 65536));
+    uint8_t *d_tile;
+    TRY(upload_array(ctx, tile, nb, &d_tile));
+    TRY(canvas_blend_device(ctx, cv, d_tile, h, w, y0, x0, ry0, rx0, ry1, rx1, mode));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VFSMS_OK;
+}
 static int canvas_resident_args(vfsms_ctx *ctx, int64_t canvas, int64_t tile, int y0, int x0, CanvasRec **cv, TileRec **tr)
 {
     auto it = ctx->canvases.find(canvas);

@@ -188,4 +188,6 @@ int phase_correlate_device(vfsms_ctx *ctx, const uint8_t *a, int stride_a, const
 // fuse_kernels.hip
 int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0,
                        int ry0, int rx0, int ry1, int rx1, int dx, int dy, int32_t *info);
+int canvas_blend_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0,
+                        int ry0, int rx0, int ry1, int rx1, int mode);
 int canvas_paste_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0);

@@ -342,6 +342,43 @@ static int finish_weights(vfsms_ctx *ctx, const FuseScratch &S, int r, int c, in
     return VFSMS_OK;
 }
 
+// average / maximum / minimum (ImageFusion.py:12-41) behind fuseImage's pre-processing (Stitcher.py:498-504): empty (-1) and zero
+// elements of A are filled from B, then zero elements of B from the updated A, element by element; outside the ROI the tile is
+// pasted.  mode: 0 average = uint8((A + B) / 2), 1 maximum, 2 minimum.
+__global__ __launch_bounds__(256) void k_fuse_simple(uint8_t *pix, uint8_t *mask, int ccols, int ch, const uint8_t *tile, int h, int w,
+                                                     int y0, int x0, int ry0, int rx0, int r, int c, int mode)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= w || i >= h) return;
+    const int cy = y0 + i, cx = x0 + j;
+    const size_t idx = (size_t)cy * ccols + cx;
+    const bool inroi = cy >= ry0 && cy < ry0 + r && cx >= rx0 && cx < rx0 + c;
+    const int m = mask[idx];
+    for (int k = 0; k < ch; k++) {
+        const int B0 = tile[((size_t)i * w + j) * ch + k];
+        int res = B0;
+        if (inroi) {
+            const int A0 = m ? pix[idx * ch + k] : 0;
+            const int A1 = A0 == 0 ? B0 : A0;
+            const int B1 = B0 == 0 ? A1 : B0;
+            res = mode == 0 ? (A1 + B1) >> 1 : mode == 1 ? max(A1, B1) : min(A1, B1);
+        }
+        pix[idx * ch + k] = (uint8_t)res;
+    }
+    mask[idx] = 1;
+}
+
+int canvas_blend_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0,
+                        int ry0, int rx0, int ry1, int rx1, int mode)
+{
+    const int r = ry1 - ry0 > 0 ? ry1 - ry0 : 0, c = rx1 - rx0 > 0 ? rx1 - rx0 : 0;
+    ProfScope ps(ctx, "fuse");
+    hipLaunchKernelGGL(k_fuse_simple, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, cv->pix, cv->mask, cv->cols, cv->ch,
+                       d_tile, h, w, y0, x0, ry0, rx0, r, c, mode);
+    HIP_TRY(hipGetLastError());
+    return VFSMS_OK;
+}
+
 int canvas_paste_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0)
 {
     hipLaunchKernelGGL(k_paste, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, cv->pix, cv->mask, cv->cols, cv->ch,

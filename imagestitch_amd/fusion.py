@@ -4,7 +4,8 @@ Stitcher.getStitchByOffset hands to fuseImage (Stitcher.py:434-436,475-483).
 
 On the hot path (north_star): fuseByFadeInAndFadeOut + getWeightsMatrix -> HIP (csrc/fuse_kernels.hip).
 fuseByAverage / Maximum / Minimum / Trigonometric are listed OUT OF SCOPE for kernels in SURVEY section 2
-(rows 7-8); they are kept as numpy one-liners so the `fuseMethod` switch keeps working.
+(rows 7-8); as array operators they are kept as numpy one-liners so the `fuseMethod` switch keeps working.  (Inside
+Stitcher.getStitchByOffset the first three run on the device canvas: vfsms_canvas_blend_tile.)
 """
 import math
 

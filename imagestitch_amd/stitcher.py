@@ -458,7 +458,10 @@ class Stitcher(Utility.Method):
                 shapes = [im.shape for im in imageList]
             offsetList, rangeX, rangeY, resultRow, resultCol = self._layout(shapes, originOffsetList)
             self.printAndWrite("  The rectified offsetList is " + str(offsetList))
-            if self.fuseMethod not in ("notFuse", "fadeInAndFadeOut"):
+            simple = {"average": 0, "maximum": 1, "minimum": 2}.get(self.fuseMethod)
+            if simple is not None and not hasattr(eng, "canvas_blend_tile"):
+                simple = None
+            if self.fuseMethod not in ("notFuse", "fadeInAndFadeOut") and simple is None:
                 return self._stitchWithHostFuse(fileList, imageList, originOffsetList, offsetList, rangeX, rangeY, resultRow, resultCol)
             ch = 3 if color else 1
             canvas = eng.canvas_create(resultRow, resultCol, ch)
@@ -475,7 +478,9 @@ class Stitcher(Utility.Method):
                         continue
                     roi = (max(oy, rangeX[i - 1][0]), max(ox, rangeY[i - 1][0]),
                            min(oy + th, rangeX[i - 1][1]), min(ox + tw, rangeY[i - 1][1]))
-                    if use_res:
+                    if simple is not None:
+                        eng.canvas_blend_tile(canvas, imageList[i], oy, ox, roi, simple)
+                    elif use_res:
                         eng.canvas_fuse_tile_resident(canvas, resident[fileList[i]][0], oy, ox, roi, originOffsetList[i][0], originOffsetList[i][1])
                     else:
                         eng.canvas_fuse_tile(canvas, imageList[i], oy, ox, roi, originOffsetList[i][0], originOffsetList[i][1])

@@ -183,6 +183,10 @@ int vfsms_canvas_paste(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int 
 int vfsms_canvas_fuse_tile(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w,
                            int y0, int x0, int ry0, int rx0, int ry1, int rx1,
                            int dx, int dy, int32_t *info);
+/* paste + element-wise blend of the ROI for fuseMethod "average" / "maximum" / "minimum" (mode 0 / 1 / 2): ImageFusion.py:12-41
+ * behind the zero / empty filling of Stitcher.fuseImage (Stitcher.py:498-504).                                              */
+int vfsms_canvas_blend_tile(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w,
+                            int y0, int x0, int ry0, int rx0, int ry1, int rx1, int mode);
 /* the same two operations for a single-channel tile that is already resident in HBM (a handle from vfsms_tile_upload /
  * vfsms_tile_wrap with stride == w, e.g. the tiles the registration phase uploaded): no host copy, canvas ch must be 1.
  * With info == NULL the fuse only enqueues work (no host synchronisation per tile); a degenerate corner geometry -- where the
