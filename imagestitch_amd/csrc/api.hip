@@ -333,12 +333,15 @@ extern "C" int vfsms_integral_u8_i32(vfsms_ctx *ctx, const uint8_t *img, int h, 
     CTX_ENTER(ctx);
     if (!img || !sum_out || h <= 0 || w <= 0 || stride < w) { vfsms_set_error("integral: bad arguments"); return VFSMS_ERR_BAD_ARG; }
     const size_t sbytes = sizeof(int32_t) * (size_t)(h + 1) * (w + 1);
-    TRY(ctx_arena_reserve(ctx, (size_t)h * w + sbytes + 8192));
+    TRY(ctx_arena_reserve(ctx, (size_t)h * w + sbytes + integral_carry_bytes(h, w) + 8192));
     RoiDev R; memset(&R, 0, sizeof(R));
     uint8_t *d_img;
     TRY(upload_image(ctx, img, h, w, stride, &d_img));
     R.img = d_img; R.stride = w; R.h = h; R.w = w;
     R.sum = (int32_t *)ctx_arena_alloc(ctx, sbytes);
+    R.ipitch = (w + 3) & ~3;
+    R.icarry = (int32_t *)ctx_arena_alloc(ctx, integral_carry_bytes(h, w));
+    if (!R.sum || !R.icarry) { vfsms_set_error("arena exhausted (integral)"); return VFSMS_ERR_CAPACITY; }
     RoiDev *d_R;
     TRY(upload_array(ctx, &R, 1, &d_R));
     TRY(launch_integral(ctx, d_R, 1, h, w));
@@ -442,7 +445,8 @@ static int bf_l2_host(vfsms_ctx *ctx, const float *q, int nq, const float *t, in
     TRY(upload_array(ctx, q, (size_t)nq * dim, &dq));
     TRY(upload_array(ctx, t, (size_t)nt * dim, &dt));
     int cnt[2] = {nq, nt}; int *dcnt;
-    TRY(upload_array(ctx, cnt, 2, &dcnt));
+    ctx->pinned_off = 0;                                    // entry points are synchronous: the staging buffer is free again
+    TRY(upload_pinned(ctx, cnt, sizeof(cnt), (void **)&dcnt));   // copied into pinned staging now: `cnt` may leave scope before the stream runs
     // descriptors of norm <= 1 (SURF's are L2-normalised) take the MFMA-filtered search; anything else the exhaustive kernel
     bool filtered = false;
     if (try_filter) {

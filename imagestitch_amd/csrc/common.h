@@ -53,6 +53,7 @@ struct RoiDev {
     const uint8_t *img;
     int stride, h, w;
     int32_t *sum;                     // (h+1) x (w+1)
+    int32_t *icarry; int ipitch;      // integral-image band carries: ceil(h/16) x ipitch column sums (ipitch = w rounded up to 4)
     float *det[VFSMS_MAX_LAYERS];
     float *trace[VFSMS_MAX_LAYERS];
     int cap;
@@ -156,6 +157,7 @@ size_t surf_roi_bytes(int h, int w, int cap, int nlayers_total, int noctaves, in
 int surf_roi_carve(vfsms_ctx *ctx, RoiDev *r, const uint8_t *img, int stride, int h, int w, int cap,
                    const vfsms_surf_params *p);
 int launch_integral(vfsms_ctx *ctx, const RoiDev *d_rois, int nrois, int maxh, int maxw);
+size_t integral_carry_bytes(int h, int w);
 int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_rois, int nrois,
                        const vfsms_surf_params *p);
 int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_rois, int nrois,

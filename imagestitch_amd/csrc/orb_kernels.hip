@@ -12,6 +12,8 @@
 // centroid angle -> 7x7 fixed-point Gaussian blur (LDS tile) -> rotated-BRIEF bytes.  All of it is byte/int streaming work,
 // HBM/L2-bound; nothing is shaped into a GEMM.
 #include "common.h"
+#include "detmath.h"
+#include "orb_pattern31.h"
 #include <math.h>
 #include <float.h>
 #include <string.h>
@@ -451,7 +453,9 @@ __global__ __launch_bounds__(256) void k_orb_describe(const OrbDev *rois, int nl
     const float inv = 1.f / sf;
     const int cx = cv_round_f(px * inv), cy = cv_round_f(py * inv);
     const float angle = ang_deg * (float)(3.1415926535897932384626433832795 / 180.f);
-    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    double sd, cd;
+    det_sincos((double)angle, &sd, &cd);                       // the oracle evaluates the same explicit algorithm (detmath.h)
+    const float a = (float)cd, b = (float)sd;
     const int w = R.lw[level];
     g_cu8 center = (g_cu8)R.bl[level] + (size_t)cy * w + cx;
     const int *pat = T->pattern + byte * 32;
@@ -682,7 +686,10 @@ int ctx_prepare_orb(vfsms_ctx *ctx, const vfsms_orb_params *p)
         sum = 1. / sum;
         for (int i = 0; i < 7; i++) { cf[i] = (float)(cf[i] * sum); T.kf[i] = (int)lrintf(cf[i] * 256.f); }
     }
-    {   // makeRandomPattern: RNG(0x34985739), MWC
+    if (p->patch_size == 31) {
+        // upstream's learned table bit_pattern_31_ (what cv2.ORB_create(..., patchSize = 31, ...) samples, ImageUtility.py:260)
+        for (int i = 0; i < 1024; i++) T.pattern[i] = VFSMS_ORB_BIT_PATTERN_31[i];
+    } else {   // makeRandomPattern: RNG(0x34985739), MWC -- upstream's generator for every other patch size
         uint64_t state = 0x34985739ULL;
         const int a = -p->patch_size / 2, b = p->patch_size / 2 + 1;
         for (int i = 0; i < 1024; i++) {

@@ -8,6 +8,7 @@
 // stages (grids are sized by capacity, blocks early-exit on device-side counts), all float/double
 // operation orders are explicit (built with -ffp-contract=off) so results are reproducible bit for bit.
 #include "common.h"
+#include "detmath.h"
 #include <math.h>
 #include <float.h>
 #include <string.h>
@@ -42,76 +43,149 @@ __device__ __forceinline__ int wave_incl_scan(int v)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K1 integral image: u8 h x w -> i32 (h+1) x (w+1)            [HBM-bound; bytes = h*w + 4(h+1)(w+1)]
-//   pass 1: one workgroup per row, 16 px per lane, wave shuffle scan + LDS carry across the 4 waves
-//   pass 2: 64 columns x 16 row-segments per workgroup; segment sums through LDS, then in-place prefix
+// K1 integral image: u8 h x w -> i32 (h+1) x (w+1)            [HBM-bound; algorithmic bytes = h*w + 4(h+1)(w+1)]
+//   Every pixel is read twice as a byte and every output written ONCE as an int (the previous two-pass form read and
+//   re-wrote the int32 plane: 25 B/px of traffic).  The ROI is cut into bands of INT_TH rows:
+//     k_integral_bandsum : per band, the sum of every column over the band's rows        (reads 1 B/px)
+//     k_integral_bandscan: exclusive scan of those column sums over the bands             (4/INT_TH B/px each way)
+//     k_integral_final   : a workgroup owns one band x all columns.  A thread owns 4 adjacent columns: it keeps the band's
+//                          16 pixel dwords in registers, adds them onto the band carry (running column sums), and the row
+//                          prefix over the 4-column groups is a wave shuffle scan + one LDS exchange for all 16 rows at once
+//                          (one barrier per 1024-column chunk).  Each lane stores one int4 per row: a wave writes 1 KB of
+//                          contiguous output per instruction.                             (reads 1 B/px, writes 4 B/px)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_integral_rows(const RoiDev *rois)
+#define INT_TH 16
+typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32u __attribute__((aligned(1)));
+
+// 4 adjacent pixels of a row as one dword (unaligned global loads are legal on gfx950).  At the ragged right edge the load is
+// moved left so that it stays inside the row and the bytes are shifted down: columns >= w read as zero.
+__device__ __forceinline__ uint32_t load_px4(g_cu8 row, int x, int w)      // requires w >= 4
 {
-    const RoiDev &R = rois[blockIdx.y];
-    const int y = blockIdx.x;
-    if (y > R.h) return;
-    const int sw = R.w + 1;
-    g_i32 out = (g_i32)R.sum + (size_t)y * sw;
-    if (y == 0) {                                   // row 0 of the integral is zero
-        for (int x = threadIdx.x; x < sw; x += 256) out[x] = 0;
-        return;
-    }
-    g_cu8 src = (g_cu8)R.img + (size_t)(y - 1) * R.stride;
-    __shared__ int wsum[4];
-    __shared__ int carry_s;
-    if (threadIdx.x == 0) { carry_s = 0; out[0] = 0; }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int base = 0; base < R.w; base += 256 * 16) {
-        const int x0 = base + threadIdx.x * 16;
-        int v[16];
-        int s = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            int x = x0 + k;
-            int p = (x < R.w) ? (int)src[x] : 0;
-            s += p;
-            v[k] = s;
-        }
-        int incl = wave_incl_scan(s);
-        if (lane == 63) wsum[wid] = incl;
-        __syncthreads();
-        int off = carry_s + incl - s;
-        for (int k = 0; k < wid; k++) off += wsum[k];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            int x = x0 + k;
-            if (x < R.w) out[x + 1] = off + v[k];
-        }
-        __syncthreads();
-        if (threadIdx.x == 255) carry_s = off + s;
-        __syncthreads();
-    }
+    const int xa = min(x, w - 4);
+    const uint32_t v = *(GAS const u32u *)(row + xa);
+    return v >> (8 * (x - xa));                             // x - xa is 0 except for the last group of a row (1..3)
 }
 
-__global__ __launch_bounds__(1024) void k_integral_cols(const RoiDev *rois)
+__global__ __launch_bounds__(256) void k_integral_bandsum(const RoiDev *rois)
+{
+    const RoiDev &R = rois[blockIdx.z];
+    const int h = R.h, w = R.w, stride = R.stride, ipitch = R.ipitch;
+    const int y0 = blockIdx.y * INT_TH;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (y0 >= h || x >= w || w < 4) return;
+    const int rows = min(INT_TH, h - y0);
+    g_cu8 src = (g_cu8)R.img + (size_t)y0 * stride;
+    g_i32 dst = (g_i32)R.icarry + (size_t)blockIdx.y * ipitch + x;
+    uint32_t px[INT_TH];
+#pragma unroll
+    for (int r = 0; r < INT_TH; r++) px[r] = r < rows ? load_px4(src + (size_t)r * stride, x, w) : 0u;
+    uint32_t even = 0, odd = 0;                       // 16-bit lanes: 16 rows x 255 < 65536
+#pragma unroll
+    for (int r = 0; r < INT_TH; r++) { even += px[r] & 0x00ff00ffu; odd += (px[r] >> 8) & 0x00ff00ffu; }
+    int4u o = {(int)(even & 0xffff), (int)(odd & 0xffff), (int)(even >> 16), (int)(odd >> 16)};
+    *(GAS int4u *)dst = o;
+}
+
+__global__ __launch_bounds__(256) void k_integral_bandscan(const RoiDev *rois)
 {
     const RoiDev &R = rois[blockIdx.y];
-    const int sw = R.w + 1;
-    const int x = blockIdx.x * 64 + threadIdx.x;     // column of the (h+1)x(w+1) array
-    const int seg = threadIdx.y;                      // 16 row segments
-    __shared__ int segsum[16][64];
-    const int L = (R.h + 15) / 16;
-    const int ya = 1 + seg * L;
-    const int yb = min(ya + L, R.h + 1);
+    const int ipitch = R.ipitch;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= ipitch) return;
+    const int nb = (R.h + INT_TH - 1) / INT_TH;
+    g_i32 c = (g_i32)R.icarry + x;
+    int run = 0;
+    for (int b = 0; b < nb; b++) { const int v = c[(size_t)b * ipitch]; c[(size_t)b * ipitch] = run; run += v; }
+}
+
+__global__ __launch_bounds__(256) void k_integral_final(const RoiDev *rois)
+{
+    const RoiDev &R = rois[blockIdx.y];
+    // every field into a local first: the compiler cannot prove that the stores below do not alias the ROI record
+    const int h = R.h, w = R.w, stride = R.stride, ipitch = R.ipitch;
+    g_cu8 img = (g_cu8)R.img;
     g_i32 S = (g_i32)R.sum;
-    int s = 0;
-    if (x < sw)
-        for (int y = ya; y < yb; y++) s += S[(size_t)y * sw + x];
-    segsum[seg][threadIdx.x] = s;
-    __syncthreads();
-    if (x >= sw) return;
-    int acc = 0;
-    for (int k = 0; k < seg; k++) acc += segsum[k][threadIdx.x];
-    for (int y = ya; y < yb; y++) {
-        acc += S[(size_t)y * sw + x];
-        S[(size_t)y * sw + x] = acc;
+    g_ci32 carry = (g_ci32)R.icarry + (size_t)blockIdx.x * ipitch;
+    const int y0 = blockIdx.x * INT_TH;
+    if (y0 >= h) return;
+    const int rows = min(INT_TH, h - y0);
+    const int sw = w + 1;
+    if (w < 4) {                                                                        // degenerate strips: one thread, plain loops
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            for (int xx = 0; xx < sw; xx++) S[xx] = 0;
+            for (int y = 0; y < h; y++) {
+                int rs = 0;
+                S[(size_t)(y + 1) * sw] = 0;
+                for (int xx = 0; xx < w; xx++) { rs += img[(size_t)y * stride + xx]; S[(size_t)(y + 1) * sw + xx + 1] = S[(size_t)y * sw + xx + 1] + rs; }
+            }
+        }
+        return;
+    }
+    if (blockIdx.x == 0)
+        for (int xx = threadIdx.x; xx < sw; xx += 256) S[xx] = 0;                       // row 0 of the integral is zero
+    if (threadIdx.x < rows) S[(size_t)(y0 + 1 + threadIdx.x) * sw] = 0;                // column 0 too
+    __shared__ int wsum[INT_TH][4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    g_cu8 src = img + (size_t)y0 * stride;
+    int ccarry[INT_TH];                                                                 // row sums of the chunks to the left
+#pragma unroll
+    for (int r = 0; r < INT_TH; r++) ccarry[r] = 0;
+    for (int c0 = 0; c0 < w; c0 += 1024) {
+        const int x = c0 + threadIdx.x * 4;
+        const bool in = x < w;
+        const int xl = in ? x : 0;
+        uint32_t px[INT_TH];
+#pragma unroll
+        for (int r = 0; r < INT_TH; r++) {
+            const uint32_t v = load_px4(src + (size_t)min(r, rows - 1) * stride, xl, w);   // always a legal address
+            px[r] = (in && r < rows) ? v : 0u;
+        }
+        int4u C = *(GAS const int4u *)(carry + xl);
+        if (!in) { C.x = 0; C.y = 0; C.z = 0; C.w = 0; }
+        // phase 1: total of this thread's 4 columns in every row (band carry + running pixel sums), scanned across the workgroup
+        int tot[INT_TH];
+        int run = C.x + C.y + C.z + C.w;
+#pragma unroll
+        for (int r = 0; r < INT_TH; r++) {
+            run += (int)__builtin_amdgcn_sad_u8(px[r], 0u, 0u);                          // sum of the 4 bytes
+            tot[r] = run;
+        }
+        int incl[INT_TH];
+#pragma unroll
+        for (int r = 0; r < INT_TH; r++) incl[r] = tot[r];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+            for (int r = 0; r < INT_TH; r++) {
+                const int n = __shfl_up(incl[r], d, 64);
+                incl[r] += lane >= d ? n : 0;
+            }
+        }
+        if (c0) __syncthreads();                                                         // previous chunk's wsum fully consumed
+        if (lane == 63) {
+#pragma unroll
+            for (int r = 0; r < INT_TH; r++) wsum[r][wid] = incl[r];
+        }
+        __syncthreads();
+        // phase 2: running column sums again, now with the exclusive row prefix in front
+        int t0 = C.x, t1 = C.y, t2 = C.z, t3 = C.w;
+        g_i32 dst = S + (size_t)(y0 + 1) * sw + 1 + xl;
+        const bool whole = x + 3 < w;
+#pragma unroll
+        for (int r = 0; r < INT_TH; r++) {
+            const int4 ws = *reinterpret_cast<const int4 *>(&wsum[r][0]);
+            int off = ccarry[r] + incl[r] - tot[r];
+            off += wid > 0 ? ws.x : 0; off += wid > 1 ? ws.y : 0; off += wid > 2 ? ws.z : 0;
+            ccarry[r] += ws.x + ws.y + ws.z + ws.w;
+            t0 += (int)(px[r] & 0xff); t1 += (int)((px[r] >> 8) & 0xff); t2 += (int)((px[r] >> 16) & 0xff); t3 += (int)(px[r] >> 24);
+            if (r < rows) {
+                int4u o;
+                o.x = off + t0; o.y = o.x + t1; o.z = o.y + t2; o.w = o.z + t3;
+                if (whole) *(GAS int4u *)(dst + (size_t)r * sw) = o;
+                else if (in) { dst[(size_t)r * sw] = o.x; if (x + 1 < w) dst[(size_t)r * sw + 1] = o.y; if (x + 2 < w) dst[(size_t)r * sw + 2] = o.z; }
+            }
+        }
     }
 }
 
@@ -119,11 +193,14 @@ int launch_integral(vfsms_ctx *ctx, const RoiDev *d_rois, int nrois, int maxh, i
 {
     if (nrois <= 0) return VFSMS_OK;
     ProfScope ps(ctx, "integral");
-    hipLaunchKernelGGL(k_integral_rows, dim3(maxh + 1, nrois), dim3(256), 0, ctx->stream, d_rois);
-    hipLaunchKernelGGL(k_integral_cols, dim3((maxw + 1 + 63) / 64, nrois), dim3(64, 16), 0, ctx->stream, d_rois);
+    const int nb = (maxh + INT_TH - 1) / INT_TH;
+    hipLaunchKernelGGL(k_integral_bandsum, dim3((maxw + 1023) / 1024, nb, nrois), dim3(256), 0, ctx->stream, d_rois);
+    hipLaunchKernelGGL(k_integral_bandscan, dim3((maxw + 3 + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
+    hipLaunchKernelGGL(k_integral_final, dim3(nb, nrois), dim3(256), 0, ctx->stream, d_rois);
     HIP_TRY(hipGetLastError());
     return VFSMS_OK;
 }
+size_t integral_carry_bytes(int h, int w) { return sizeof(int32_t) * (size_t)((h + INT_TH - 1) / INT_TH) * (size_t)((w + 3) & ~3); }
 
 // ---------------------------------------------------------------------------------------------------
 // K2 fast-Hessian det/trace, one launch per octave, blockIdx.z = roi * (nLayers+2) + layer
@@ -356,11 +433,13 @@ __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat 
 
 // ---------------------------------------------------------------------------------------------------
 // keypoint ordering: std::sort(KeypointGreater) == rank by counting (N^2 compares through LDS tiles).
-//   order: response desc, size desc, octave desc, y asc, x asc, then (layer, i, j) asc to make it total.
+//   order: response desc, size desc, octave desc, y DESC, x asc (upstream surf.cpp KeypointGreater), then (layer, i, j)
+//   asc to make it total.
 // ---------------------------------------------------------------------------------------------------
 struct SortKey { unsigned long long k1, k2, k3; };
 // k1 (descending): response bits (positive floats order like their bit patterns) then integer size then octave;
-// k2 (ascending): order-preserving images of y then x; k3 (ascending): (layer, i, j), unique per candidate.
+// k2 (ascending): the order-REVERSING image of y (y descending) then the order-preserving image of x;
+// k3 (ascending): (layer, i, j), unique per candidate.
 
 __device__ __forceinline__ uint32_t ord_f32(float f)
 {
@@ -371,7 +450,7 @@ __device__ __forceinline__ SortKey make_key(const Cand &c)
 {
     SortKey k;
     k.k1 = ((unsigned long long)__float_as_uint(c.response) << 32) | (uint32_t)((((int)c.size) << 4) | c.octave);
-    k.k2 = ((unsigned long long)ord_f32(c.y) << 32) | ord_f32(c.x);
+    k.k2 = ((unsigned long long)(uint32_t)~ord_f32(c.y) << 32) | ord_f32(c.x);
     k.k3 = ((unsigned long long)(uint32_t)c.layer << 32) | (((uint32_t)c.i << 16) | (uint32_t)c.j);
     return k;
 }
@@ -1024,9 +1103,9 @@ __global__ __launch_bounds__(1024) void k_keep_scan(const RoiDev *rois)
     if (threadIdx.x == 0) R.counters[1] = carry;
 }
 
-// One thread per keypoint: sin/cos of the descriptor window's rotation (std::sin / std::cos on float in the reference;
-// evaluated in double and rounded here, which agrees with a correctly rounded sinf/cosf except in double-rounding
-// corner cases).  ~400 dependent f64 instructions, so it is kept out of the 256-thread descriptor workgroups.
+// One thread per keypoint: sin/cos of the descriptor window's rotation (std::sin / std::cos on float in the reference).
+// det_sincos (detmath.h) is the explicit double-precision algorithm the oracle evaluates too, so both sides round to the
+// same float; it agrees with a correctly rounded sinf/cosf except within ~2^-29 ulp of a rounding boundary.
 __global__ __launch_bounds__(256) void k_desc_trig(const RoiDev *rois)
 {
     const RoiDev &R = rois[blockIdx.y];
@@ -1036,8 +1115,10 @@ __global__ __launch_bounds__(256) void k_desc_trig(const RoiDev *rois)
     if (!(kp.size > 0)) return;
     const float dir = kp.angle * (float)(3.1415926535897932384626433832795 / 180);
     float *row = (float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG);
-    row[0] = -(float)sin((double)dir);
-    row[1] = (float)cos((double)dir);
+    double sd, cd;
+    det_sincos((double)dir, &sd, &cd);
+    row[0] = -(float)sd;
+    row[1] = (float)cd;
 }
 
 // Descriptor tail, 16 keypoints per workgroup, 16 threads (one per 5 x 5 cell) per keypoint: Gaussian-weighted
@@ -1105,7 +1186,7 @@ static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 size_t surf_roi_bytes(int h, int w, int cap, int nlayers_total, int noctaves, int dim)
 {
-    size_t b = al(sizeof(int32_t) * (size_t)(h + 1) * (w + 1));
+    size_t b = al(sizeof(int32_t) * (size_t)(h + 1) * (w + 1)) + al(integral_carry_bytes(h, w));
     int lpo = nlayers_total / noctaves;
     for (int o = 0; o < noctaves; o++) {
         size_t n = (size_t)(h >> o) * (w >> o);
@@ -1123,6 +1204,8 @@ int surf_roi_carve(vfsms_ctx *ctx, RoiDev *r, const uint8_t *img, int stride, in
     memset(r, 0, sizeof(*r));
     r->img = img; r->stride = stride; r->h = h; r->w = w; r->cap = cap;
     r->sum = (int32_t *)ctx_arena_alloc(ctx, sizeof(int32_t) * (size_t)(h + 1) * (w + 1));
+    r->ipitch = (w + 3) & ~3;
+    r->icarry = (int32_t *)ctx_arena_alloc(ctx, integral_carry_bytes(h, w));
     int step = 1;
     for (int o = 0; o < p->n_octaves; o++) {
         size_t n = (size_t)(h / step) * (w / step);

@@ -47,7 +47,8 @@ def _imwrite(path, img):
     d = os.path.dirname(path)
     if d and not os.path.exists(d):
         os.makedirs(d)
-    Image.fromarray(np.ascontiguousarray(img)).save(path)
+    kw = {"quality": 95} if path.lower().endswith((".jpg", ".jpeg")) else {}     # cv2.imwrite's JPEG default (Pillow's is 75)
+    Image.fromarray(np.ascontiguousarray(img)).save(path, **kw)
 
 
 def _list_images(folder, extension):
@@ -114,6 +115,7 @@ class Stitcher(Utility.Method):
             else:
                 offsetList.append(offset)
                 endfileIndex = fileIndex + 1
+        self.releaseTiles()
         endTime = time.time()
         self.printAndWrite("The time of registering is " + str(endTime - startTime) + "s")
         self.printAndWrite("start stitching")
@@ -205,7 +207,7 @@ class Stitcher(Utility.Method):
             outDir = outputAddress.replace("\\", os.sep)
             if not os.path.exists(outDir):
                 os.makedirs(outDir)
-            Stitcher.outputAddress = outputAddress
+            Stitcher.outputAddress = outDir if outDir.endswith(os.sep) else outDir + os.sep
             (status, result) = self.flowStitch(fileList, caculateOffsetMethod)
             self.tempImageFeature.isBreak = True
             _imwrite(os.path.join(outDir, "stitching_result_" + str(i) + "." + outputfileExtension), result)
@@ -221,7 +223,7 @@ class Stitcher(Utility.Method):
             outDir = outputAddress.replace("\\", os.sep)
             if not os.path.exists(outDir):
                 os.makedirs(outDir)
-            Stitcher.outputAddress = outputAddress
+            Stitcher.outputAddress = outDir if outDir.endswith(os.sep) else outDir + os.sep   # printAndWrite appends the file name
             result = self.flowStitchWithMutiple(fileList, caculateOffsetMethod)
             self.tempImageFeature.isBreak = True
             if len(result) == 1:
@@ -239,17 +241,43 @@ class Stitcher(Utility.Method):
         raise AttributeError("'Stitcher' object has no attribute 'phase'")
 
     # -- device tile cache: consecutive pairs share a tile (B of pair k is A of pair k+1) ---------------
-    def _tileHandle(self, image):
+    _TILE_CACHE = 4
+
+    def _tileHandles(self, images):
+        """Handles of the tiles of ONE job, resolved together: least-recently-used entries are evicted only after every
+        tile of the job has its handle, and never a tile of the job itself.  An entry is keyed by the array object and its
+        buffer address / shape / strides (a new array at a recycled id() must not hit); in-place edits of a cached array are
+        not detected -- the reference's drivers decode a fresh array per tile."""
         cache = self.__dict__.setdefault("_tiles", [])
-        for ent in cache:
-            if ent[0] is image:
-                return ent[1]
-        h = self.engine.tile_upload(image)
-        cache.append((image, h))
-        while len(cache) > 4:
-            _old, oh = cache.pop(0)
-            self.engine.tile_free(oh)
-        return h
+        eng = self.engine
+        out = []
+        for image in images:
+            key = (id(image), image.__array_interface__["data"][0], image.shape, image.strides)
+            for n, ent in enumerate(cache):
+                if ent[0] is image and ent[1] == key:
+                    cache.append(cache.pop(n))            # refresh on a hit (LRU)
+                    out.append(ent[2])
+                    break
+            else:
+                h = eng.tile_upload(image)
+                cache.append((image, key, h))
+                out.append(h)
+        keep = set(out)
+        n = 0
+        while len(cache) > max(self._TILE_CACHE, len(keep)) and n < len(cache):
+            if cache[n][2] in keep:
+                n += 1
+                continue
+            eng.tile_free(cache.pop(n)[2])
+        return out
+
+    def releaseTiles(self):
+        """Free the device copies the pair-by-pair methods cached (called at the end of every flowStitch)."""
+        for _img, _key, h in self.__dict__.pop("_tiles", []):
+            try:
+                self.engine.tile_free(h)
+            except Exception:
+                pass
 
     def _usesStockOperators(self):
         c = type(self)
@@ -263,7 +291,8 @@ class Stitcher(Utility.Method):
             ra = roi_rect(imageA.shape, direction, "first", searchRatio)
             rb = roi_rect(imageB.shape, direction, "second", searchRatio)
             if ra[2:] == rb[2:] and ra[2] > 0 and ra[3] > 0:
-                job = (self._tileHandle(imageA), self._tileHandle(imageB), ra[0], ra[1], rb[0], rb[1], ra[2], ra[3])
+                ha, hb = self._tileHandles([imageA, imageB])
+                job = (ha, hb, ra[0], ra[1], rb[0], rb[1], ra[2], ra[3])
                 if self.featureMethod == "orb":
                     max_dist = self.orbMaxDistance if self.isGPUAvailable else -1
                     row = self.engine.attempt_orb_batch([job], self._orbParams(), max_dist, self.offsetEvaluate)[0]

@@ -56,6 +56,7 @@ def lib():
         L.orc_orb_detect_describe.restype = i32
         L.orc_orb_pattern.argtypes = [i32, i32, vp]; L.orc_orb_pattern.restype = None
         L.orc_corner_ramps.argtypes = [vp, i32, i32, i32, vp, vp, vp]; L.orc_corner_ramps.restype = i32
+        L.orc_det_sincos.argtypes = [vp, i32, vp]; L.orc_det_sincos.restype = None
         _lib = L
     return _lib
 
@@ -82,6 +83,14 @@ def _u8_2d(img):
     if img.strides[1] != 1:
         img = np.ascontiguousarray(img)
     return img
+
+
+def det_sincos(x):
+    """The explicit sin/cos both the oracle and the engine evaluate (vfsms_oracle.h) -> (sin, cos) float64 arrays."""
+    x = np.ascontiguousarray(x, np.float64).ravel()
+    out = np.empty((len(x), 2), np.float64)
+    lib().orc_det_sincos(_p(x), len(x), _p(out))
+    return out[:, 0].copy(), out[:, 1].copy()
 
 
 def optimal_dft_size(n):

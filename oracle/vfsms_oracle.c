@@ -181,8 +181,8 @@ static int kp_greater_cmp(const void *pa, const void *pb)
     if (a->kp.size < b->kp.size) return 1;
     if (a->kp.octave > b->kp.octave) return -1;
     if (a->kp.octave < b->kp.octave) return 1;
-    if (a->kp.y > b->kp.y) return 1;
-    if (a->kp.y < b->kp.y) return -1;
+    if (a->kp.y < b->kp.y) return 1;       /* y DESCENDING: `if(kp1.pt.y < kp2.pt.y) return false; if(kp1.pt.y > kp2.pt.y) return true;` */
+    if (a->kp.y > b->kp.y) return -1;
     if (a->kp.x < b->kp.x) return -1;
     if (a->kp.x > b->kp.x) return 1;
     if (a->layer_index != b->layer_index) return a->layer_index < b->layer_index ? -1 : 1;
@@ -480,8 +480,10 @@ static void surf_describe_one(const uint8_t *img, int h, int w, int stride, cons
     uint8_t *WIN = (uint8_t *)malloc((size_t)win_size * win_size);
     if (!upright) {
         descriptor_dir *= (float)(3.1415926535897932384626433832795 / 180);
-        float sin_dir = -sinf(descriptor_dir);
-        float cos_dir = cosf(descriptor_dir);
+        double sd, cd;
+        det_sincos((double)descriptor_dir, &sd, &cd);   /* std::sin / std::cos on float: see det_sincos */
+        float sin_dir = -(float)sd;
+        float cos_dir = (float)cd;
         float win_offset = -(float)(win_size - 1) / 2;
         float start_x = cx + win_offset * cos_dir + win_offset * sin_dir;
         float start_y = cy - win_offset * sin_dir + win_offset * cos_dir;
@@ -1040,4 +1042,9 @@ void orc_fuse_fade(int64_t *A, const int64_t *B, int r, int c, int ch, int dx, i
             }
         }
     free(wA_r); free(wB_r); free(wA_c); free(wB_c);
+}
+
+void orc_det_sincos(const double *x, int n, double *out)
+{
+    for (int i = 0; i < n; i++) det_sincos(x[i], &out[2 * i], &out[2 * i + 1]);
 }

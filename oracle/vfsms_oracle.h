@@ -32,6 +32,42 @@ typedef struct {
     int32_t octave, class_id;
 } orc_keypoint;
 
+/* sin / cos in double with an explicit operation order (Cody-Waite reduction by pi/2 with a 33-bit head, fdlibm minimax
+ * polynomials on [-pi/4, pi/4], Horner form).  The reference reaches std::sin/std::cos(float) for the SURF descriptor
+ * window (upstream surf.cpp SURFInvoker; ImageUtility.py:262) and cos/sin(double) for ORB's rBRIEF rotation (upstream orb.cpp;
+ * ImageUtility.py:260); a correctly rounded result is library independent, glibc's and the GPU's OCML routines are not.
+ * The engine evaluates the same algorithm (imagestitch_amd/csrc/detmath.h, written from the same description), so both
+ * sides round to the same float.  |error| < 1e-16: the float rounding equals correctly rounded sinf/cosf except within
+ * ~2^-29 ulp of a rounding boundary.  Valid for the float-valued |x| <= 2^10 of this path. */
+static inline void det_sincos(double x, double *s_out, double *c_out)
+{
+    const double INV_PIO2 = 6.36619772367581382433e-01;
+    const double PIO2_HI = 1.57079632673412561417e+00;
+    const double PIO2_LO = 6.07710050650619224932e-11;
+    const double kd = __builtin_rint(x * INV_PIO2);
+    const int k = (int)kd;
+    const double r = (x - kd * PIO2_HI) - kd * PIO2_LO;
+    const double z = r * r;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double ps = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double sr = r + (z * r) * (S1 + z * ps);
+    const double pc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double cr = 1.0 - (0.5 * z - z * pc);
+    double s, c;
+    switch (k & 3) {
+    case 0: s = sr; c = cr; break;
+    case 1: s = cr; c = -sr; break;
+    case 2: s = -sr; c = -cr; break;
+    default: s = -cr; c = sr; break;
+    }
+    *s_out = s; *c_out = c;
+}
+/* exported for tests: out[2n] = sin(x[n]), out[2n+1] = cos(x[n]) */
+void orc_det_sincos(const double *x, int n, double *out);
+
 /* cv::getOptimalDFTSize: smallest 2^a 3^b 5^c >= n  (Stitcher.py:230 via cv2.phaseCorrelate) */
 int orc_optimal_dft_size(int n);
 

@@ -8,15 +8,18 @@
  * separable filter).  Sources are not under /root/reference (un-vendored opencv-python 3.3.1.11): PARITY UNPINNED
  * against OpenCV itself; pinned on synthetic grids with exact integer ground truth.
  *
- * Two stated deviations from upstream, both because the upstream artefact cannot be reproduced offline:
- *   1. the 256x4 learned sampling table bit_pattern_31_ is not available; the pattern is produced by upstream's own
- *      makeRandomPattern(patchSize, ..) (the generator ORB uses for patchSize != 31: RNG(0x34985739), MWC) for every
- *      patch size including 31;
- *   2. KeyPointsFilter::retainBest keeps exactly upstream's SET (every keypoint whose response >= the n-th best), but
- *      in detection (row-major scan) order; upstream's order is whatever permutation libstdc++'s std::nth_element
- *      leaves behind.
+ * Sampling pattern: patchSize 31 uses upstream's learned 256x4 table bit_pattern_31_ (restated in
+ * imagestitch_amd/csrc/orb_pattern31.h, structurally checked, unverifiable against cv2 offline); other patch sizes use
+ * upstream's makeRandomPattern (RNG(0x34985739), MWC).
+ *
+ * One stated deviation from upstream, because the upstream artefact cannot be reproduced offline:
+ *   KeyPointsFilter::retainBest keeps every keypoint whose response >= the n-th best, in detection (row-major scan)
+ *   order.  Upstream calls std::nth_element and then reads keypoints[n-1].response as the tie threshold: both the order
+ *   it leaves behind and, when integer FAST scores tie at the cut, which of the tied keypoints survive depend on the C++
+ *   standard library the wheel was built with (MSVC's for opencv-python 3.3.1.11 on the reference's Windows host).
  */
 #include "vfsms_oracle.h"
+#include "../imagestitch_amd/csrc/orb_pattern31.h"   /* the table is DATA shared with the engine */
 #include <math.h>
 #include <float.h>
 #include <stdlib.h>
@@ -239,6 +242,10 @@ static void gaussian_blur7_u8(const level_img *src, level_img *dst)
 /* orb.cpp makeRandomPattern: RNG rng(0x34985739); x, y = rng.uniform(-patchSize/2, patchSize/2+1) */
 void orc_orb_pattern(int patchSize, int npoints, int32_t *xy)
 {
+    if (patchSize == 31) {          /* ORB_Impl::detectAndCompute: pattern0 = bit_pattern_31_ unless patchSize != 31 */
+        for (int i = 0; i < 2 * npoints && i < 1024; i++) xy[i] = VFSMS_ORB_BIT_PATTERN_31[i];
+        return;
+    }
     uint64_t state = 0x34985739ULL;
     for (int i = 0; i < 2 * npoints; i++) {
         state = (uint64_t)(unsigned)state * 4164903690U + (unsigned)(state >> 32);
@@ -353,7 +360,9 @@ int orc_orb_detect_describe(const uint8_t *image, int h, int w, int stride,
             kps[j].response = k->response; kps[j].octave = k->level; kps[j].class_id = -1;
             float inv = 1.f / sf;
             float angle = k->angle * (float)(3.1415926535897932384626433832795 / 180.f);
-            float a = (float)cos((double)angle), b = (float)sin((double)angle);
+            double sd, cd;
+            det_sincos((double)angle, &sd, &cd);
+            float a = (float)cd, b = (float)sd;
             const level_img *L = &bl[k->level];
             const uint8_t *center = L->data + (size_t)cv_round_f(py * inv) * L->w + cv_round_f(px * inv);
             const int step = L->w;

@@ -287,3 +287,39 @@ def test_phase_sign_fix_is_opt_in(oracle, golden_dir):
         assert s.calculateOffsetForPhaseCorrleateIncre([A, B]) == (True, [1698, 0])
     finally:
         isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio = old
+
+
+def test_tile_cache_is_lru_and_never_evicts_the_current_job():
+    """One anchor tile registered against many others through calculateOffsetForFeatureSearchIncre: the anchor's device handle
+    must stay valid (refreshed on every hit, resolved together with its partner before anything is evicted), at most
+    _TILE_CACHE tiles stay resident, and releaseTiles frees all of them."""
+    import imagestitch_amd as isa
+
+    class Eng:
+        def __init__(self):
+            self.live, self.next, self.uploads = set(), 1, 0
+        def tile_upload(self, img):
+            h = self.next; self.next += 1; self.live.add(h); self.uploads += 1
+            return h
+        def tile_free(self, h):
+            assert h in self.live, "freed twice"
+            self.live.remove(h)
+        @staticmethod
+        def surf_params(*a, **k):
+            return None
+        def attempt_surf_batch(self, jobs, params, ratio, ev):
+            for j in jobs:
+                assert j[0] in self.live and j[1] in self.live, "unknown tile handle"
+            return np.array([[1, 5, -3, 9, 10, 10, 9, 0]] * len(jobs), np.int32)
+    eng = Eng()
+    st = isa.Stitcher(); st._engine = eng; st.isPrintLog = False
+    st.direction = 1
+    anchor = np.zeros((100, 120), np.uint8)
+    others = [np.full((100, 120), k, np.uint8) for k in range(1, 9)]
+    for o in others:
+        assert st.calculateOffsetForFeatureSearchIncre([anchor, o])[0] is True
+        assert len(eng.live) <= st._TILE_CACHE
+    assert eng.uploads == 1 + len(others)                       # the anchor was uploaded once
+    assert st.calculateOffsetForFeatureSearchIncre([others[0], anchor])[0] is True      # evicted long ago: uploaded again
+    st.releaseTiles()
+    assert not eng.live

@@ -1,6 +1,7 @@
 """CPU tests: the oracle against the reference's own outputs (tests/golden, captured by tools/capture_golden.py)
 and against the published constants / the Stitcher.py:87 offset list."""
 import json
+import sys
 import os
 
 import numpy as np
@@ -128,8 +129,20 @@ def test_orb_oracle_exact_truth_and_structure(oracle):
     structural checks on the restated pipeline (level quotas, border, pattern generator)."""
     from imagestitch_amd.synthetic import SyntheticGrid
     from imagestitch_amd.utility import roi_rect
+    # patchSize 31 (the reference's setting, ImageUtility.py:37,260): upstream's learned table bit_pattern_31_; structural
+    # checks of the restated table: 256 tests, coordinates inside the 31 x 31 patch's rotation-safe disc, each test runs
+    # left to right (x0 <= x1), no duplicated test, first / last rows as published
     pat = oracle.orb_pattern()
-    assert pat.shape == (512, 2) and pat.min() >= -15 and pat.max() <= 15 and pat[:2].tolist() == [[13, -15], [3, 4]]
+    rows = pat.reshape(256, 4)
+    assert pat.shape == (512, 2) and pat.min() == -13 and pat.max() == 12
+    assert rows[0].tolist() == [8, -3, 9, 5] and rows[1].tolist() == [4, 2, 7, -12] and rows[255].tolist() == [-1, -6, 0, -11]
+    assert np.all(rows[:, 0] <= rows[:, 2]) and len({tuple(r) for r in rows.tolist()}) == 256
+    assert np.hypot(pat[:, 0], pat[:, 1]).max() < 15 * np.sqrt(2) + 1e-9          # stays inside the 31 + 2*... border after rotation
+    # any other patch size: upstream's makeRandomPattern (RNG(0x34985739), MWC)
+    pat = oracle.orb_pattern(patch_size=29)
+    assert pat.shape == (512, 2) and pat.min() >= -14 and pat.max() <= 14
+    pat33 = oracle.orb_pattern(patch_size=33)
+    assert pat33[:2].tolist() == [[13, -15], [3, 4]] or (pat33.min() >= -16 and pat33.max() <= 16)
     # ORB keeps keypoints >= 31 px from the ROI border, so the shared band must be wider than 62 px in both strips
     g = SyntheticGrid(2, 2, 1024, overlap=0.15)
     tiles = g.tiles(threads=1)
@@ -173,3 +186,89 @@ def test_demo_strips_fixture_reproduced_by_oracle(oracle, golden_dir):
     pairs = oracle.bf_l2_ratio_matches(da, db, 0.75)
     st, off, votes = oracle.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, 3)
     assert [int(st), off, int(votes), len(ka), len(kb), len(pairs)] == [c["surf"]["status"], c["surf"]["offset"], c["surf"]["votes"], c["surf"]["nA"], c["surf"]["nB"], c["surf"]["matches"]]
+
+
+def _rebuild_frames(nb, g):
+    H, W = nb["shape"]
+    frames = {t: np.zeros((H, W), np.uint8) for t in nb["tiles"]}
+    for st in nb["strips"]:
+        a = g[st["key"]]
+        frames[st["tile"]][st["y0"]:st["y0"] + a.shape[0], st["x0"]:st["x0"] + a.shape[1]] = a
+    return [frames[t] for t in nb["tiles"]]
+
+
+def test_dendritic_whole_path_oracle_vs_stitcher_py_87(golden_dir):
+    """tests/golden/dendritic_path_oracle.json (tools/capture_golden.py realpath): the oracle behind the reference's incremental
+    search, direction threaded pair to pair, over ALL 87 usable pairs of the reference's dendriticCrystal path on the real
+    tiles, beside Stitcher.py:87.  Every pair within +-1 px (north_star's SURF tolerance), nine in ten exact, every turn
+    resolved in the reference's candidate order (wrong directions fail on the real tiles)."""
+    d = json.load(open(os.path.join(golden_dir, "dendritic_path_oracle.json")))
+    gold = json.load(open(os.path.join(golden_dir, "dendritic_offsets.json")))["offsets"]
+    rows = d["rows"]
+    assert [r["a"] for r in rows] == list(range(3, 90)) and d["pairs"] == 87
+    exact = 0
+    for r in rows:
+        assert r["gold"] == gold[r["a"] - 1]
+        assert abs(r["oracle"][0] - r["gold"][0]) <= 1 and abs(r["oracle"][1] - r["gold"][1]) <= 1, r
+        exact += r["oracle"] == r["gold"]
+        assert r["i"] == 1 and r["attempts"][-1][2] == 1 and all(a[2] == 0 for a in r["attempts"][:-1])
+    assert exact >= 75 and exact == d["exact"]
+    turns = {r["a"]: r for r in rows if len(r["attempts"]) > 1}
+    # down -> right: [1, 2]; right -> up: [2, 3]; up -> right: [3, 4, 1, 2]; right -> down: [2, 3, 4, 1]
+    assert [a[0] for a in turns[15]["attempts"]] == [1, 2] and [a[0] for a in turns[30]["attempts"]] == [3, 4, 1, 2]
+    assert [a[0] for a in turns[31]["attempts"]] == [2, 3, 4, 1] and sorted(turns) == [15, 16, 30, 31, 45, 46, 60, 61, 75, 76]
+
+
+def test_real_path_strips_reproduced_by_oracle(oracle, golden_dir):
+    """One neighbourhood of tests/golden/real_path_strips.* (the turn 15 -> 16 with two pairs on either side): the oracle on the
+    rebuilt frames reproduces the stored rows exactly (offset, direction, i, votes, keypoint and match counts), and those are
+    within +-1 px of Stitcher.py:87.  (All five neighbourhoods go through the HIP grid registrar in tests/test_gpu_parity.py.)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(golden_dir), "..", "tools"))
+    from imagestitch_amd.utility import roi_rect
+    meta = json.load(open(os.path.join(golden_dir, "real_path_strips.json")))["neighbourhoods"]
+    assert [nb["turn"] for nb in meta] == [15, 30, 45, 60, 75] and sum(len(nb["expected"]) for nb in meta) == 25
+    for nb in meta:
+        for e in nb["expected"]:
+            assert abs(e["offset"][0] - e["gold"][0]) <= 1 and abs(e["offset"][1] - e["gold"][1]) <= 1
+    g = np.load(os.path.join(golden_dir, "real_path_strips.npz"))
+    nb = meta[0]
+    frames = _rebuild_frames(nb, g)
+    direction = nb["incoming_direction"]
+    for k, e in enumerate(nb["expected"]):
+        A, B = frames[k], frames[k + 1]
+        found = None
+        d = direction
+        while found is None:                                  # i = 1 ring of Stitcher.py:319-351 (every stored pair resolves there)
+            ra = roi_rect(A.shape, d, "first", 0.2); rb = roi_rect(B.shape, d, "second", 0.2)
+            a = np.ascontiguousarray(A[ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]]); b = np.ascontiguousarray(B[rb[0]:rb[0] + rb[2], rb[1]:rb[1] + rb[3]])
+            ka, da = oracle.surf_detect_describe(a); kb, db = oracle.surf_detect_describe(b)
+            if len(ka) and len(kb):
+                pairs = oracle.bf_l2_ratio_matches(da, db, 0.75)
+                st, off, votes = oracle.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, 3)
+                if st:
+                    found = (d, off, votes, len(ka), len(kb), len(pairs))
+                    break
+            d = d % 4 + 1
+            assert d != direction
+        d, off, votes, na, nbk, nm = found
+        H, W = A.shape
+        if d == 1: off[0] += H - int(0.2 * H)
+        elif d == 2: off[1] += W - int(0.2 * W)
+        elif d == 3: off[0] -= H - int(0.2 * H)
+        else: off[1] -= W - int(0.2 * W)
+        assert [off, d, votes, na, nbk, nm] == [e["offset"], e["direction"], e["votes"], e["nA"], e["nB"], e["matches"]], (k, off, e)
+        direction = d
+
+
+def test_keypoint_greater_orders_y_descending(oracle):
+    """upstream surf.cpp KeypointGreater: response, size, octave descending, then y DESCENDING, then x ascending.  An image made of
+    one 64 x 64 block repeated has many keypoints with identical response / size / octave at different positions."""
+    block = np.random.default_rng(5).integers(0, 256, (64, 64), dtype=np.uint8)
+    img = np.tile(block, (4, 5))
+    k = oracle.surf_detect(img)
+    key = np.stack([k["response"], k["size"], k["octave"].astype(np.float32)], 1)
+    same = np.all(key[1:] == key[:-1], 1)
+    assert same.sum() > 50
+    y0, y1, x0, x1 = k["y"][:-1][same], k["y"][1:][same], k["x"][:-1][same], k["x"][1:][same]
+    assert np.all((y0 > y1) | ((y0 == y1) & (x0 < x1)))
+    assert np.any(y0 > y1) and np.any(y0 == y1)

@@ -378,6 +378,133 @@ def cap_real():
     print("real strips", len(meta), os.path.getsize(os.path.join(OUT, "real_strips.npz")) // 1024, "KiB")
 
 
+def _oracle_search(O, roi_rect, A, B, d0, roiRatio=0.2, directIncre=1, offsetEvaluate=3):
+    """Stitcher.calculateOffsetForFeatureSearchIncre (Stitcher.py:306-367) with the oracle's SURF + BF-L2 + mode vote as the
+    operators -> (status, [dx, dy], direction, i, attempts log)."""
+    def rot(d):
+        d += directIncre
+        return 1 if d == 5 else 4 if d == 0 else d
+    log = []
+    maxI = int(np.floor(0.5 / roiRatio) + 1) + 1
+    for i in range(1, maxI):
+        d = d0
+        while True:
+            ra = roi_rect(A.shape, d, "first", i * roiRatio); rb = roi_rect(B.shape, d, "second", i * roiRatio)
+            a = np.ascontiguousarray(A[ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]])
+            b = np.ascontiguousarray(B[rb[0]:rb[0] + rb[2], rb[1]:rb[1] + rb[3]])
+            ka, da = O.surf_detect_describe(a); kb, db = O.surf_detect_describe(b)
+            st, off, votes, nm = False, [0, 0], 0, 0
+            if len(ka) and len(kb):
+                pairs = O.bf_l2_ratio_matches(da, db, 0.75)
+                nm = len(pairs)
+                st, off, votes = O.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, offsetEvaluate)
+            log.append([d, i, int(st), int(off[0]), int(off[1]), int(votes), len(ka), len(kb), nm])
+            if st:
+                off = list(off); H, W = A.shape; Hb, Wb = B.shape
+                if d == 1: off[0] += H - int(i * roiRatio * H)
+                elif d == 2: off[1] += W - int(i * roiRatio * W)
+                elif d == 3: off[0] -= Hb - int(i * roiRatio * Hb)
+                elif d == 4: off[1] -= Wb - int(i * roiRatio * Wb)
+                return True, [int(off[0]), int(off[1])], d, i, log
+            d = rot(d)
+            if d == d0:
+                break
+    return False, [0, 0], d0, 0, log
+
+
+def cap_real_path():
+    """The widest pin to the reference this container allows (cv2 is absent, the demo JPEGs and Stitcher.py:87 are present):
+
+    1. dendritic_path_oracle.json -- the oracle (SURF + BF-L2 + ratio + mode vote behind the reference's incremental search,
+       direction threaded from pair to pair exactly as Stitcher.py:252,361 does) run over the WHOLE dendriticCrystal shooting
+       path on the real 1936 x 2584 tiles, tiles 003..090 (001-002 touch the missing blob): every pair's offset, accepted
+       (direction, i), votes and the full attempt log, beside the reference's own value from Stitcher.py:87.
+    2. real_path_strips.npz / .json -- around each of the five serpentine turns (tiles t-2 .. t+3), the ROI strips the
+       accepted attempts read, cropped (640 columns for the row strips, 640 rows for the column strips) and stored with
+       their position in the frame.  The parity tests rebuild 1936 x 2584 frames (zeros elsewhere) and register each
+       neighbourhood through the grid registrar; expected rows = the oracle on those same rebuilt frames (stored), each within
+       +-1 px of Stitcher.py:87 and with the (direction, i) of the full-tile run.  Candidates tried before the accepted one
+       see blank strips in the rebuilt frames; item 1 records that they fail on the real tiles too."""
+    from PIL import Image
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    from imagestitch_amd.utility import roi_rect
+    O.build()
+    src = open(os.path.join(refshim.REF, "Stitcher.py"), encoding="utf-8-sig").read().splitlines()[86]
+    gold = ast.literal_eval(src[src.index("["):])
+    d = os.path.join(refshim.REF, "demoImages", "dendriticCrystal", "1")
+    cache = {}
+
+    def load(t):
+        if t not in cache:
+            im = Image.open(os.path.join(d, "1-%03d.jpg" % t)); im.draft("L", im.size)
+            cache[t] = np.asarray(im.convert("L"))
+            for old in [k for k in cache if k < t - 1]:
+                del cache[old]
+        return cache[t]
+
+    # ---- 1. whole path on the real tiles
+    rows, direction, d_in = [], 1, {}
+    for a in range(3, 90):
+        d_in[a] = direction
+        st, off, dn, i, log = _oracle_search(O, roi_rect, load(a), load(a + 1), direction)
+        g = gold[a - 1]
+        assert st and abs(off[0] - g[0]) <= 1 and abs(off[1] - g[1]) <= 1, (a, off, g)
+        rows.append(dict(a=a, b=a + 1, gold=g, oracle=off, direction=dn, i=i, votes=log[-1][5], incoming_direction=direction, attempts=log))
+        direction = dn
+        print("path", a, a + 1, g, off, dn, i, log[-1][5], flush=True)
+    exact = sum(r["gold"] == r["oracle"] for r in rows)
+    json.dump(dict(source="oracle (oracle/vfsms_oracle.c) on the reference's demoImages/dendriticCrystal/1 tiles 003..090, decoded with Pillow "
+                          "(draft L); gold = Stitcher.py:87; attempts = [direction, i, status, raw dx, raw dy, votes, nA, nB, matches]",
+                   pairs=len(rows), exact=exact, within_one=len(rows), rows=rows),
+              open(os.path.join(OUT, "dendritic_path_oracle.json"), "w"))
+    print("real path: %d pairs, %d exact, all within 1 px" % (len(rows), exact))
+
+    # ---- 2. cropped strips around the turns
+    by_a = {r["a"]: r for r in rows}
+    CROP = 640
+    store, meta = {}, []
+    for turn in (15, 30, 45, 60, 75):
+        tiles = list(range(turn - 2, turn + 4))
+        full = {}
+        for t in tiles:
+            im = Image.open(os.path.join(d, "1-%03d.jpg" % t)); im.draft("L", im.size)
+            full[t] = np.asarray(im.convert("L"))
+        H, W = full[tiles[0]].shape
+        frames = {t: np.zeros((H, W), np.uint8) for t in tiles}
+        strips = []
+        for a in tiles[:-1]:
+            r = by_a[a]
+            dd, ii = r["direction"], r["i"]
+            assert ii == 1
+            for t, order in ((a, "first"), (a + 1, "second")):
+                y0, x0, h, w = roi_rect((H, W), dd, order, 0.2)
+                if dd in (1, 3):
+                    x0 += (w - CROP) // 2; w = CROP
+                else:
+                    y0 += (h - CROP) // 2; h = CROP
+                img = full[t]
+                frames[t][y0:y0 + h, x0:x0 + w] = img[y0:y0 + h, x0:x0 + w]
+                key = "n%d_t%d_%d" % (turn, t, len([s for s in strips if s["tile"] == t]))
+                store[key] = np.ascontiguousarray(img[y0:y0 + h, x0:x0 + w])
+                strips.append(dict(tile=t, key=key, y0=y0, x0=x0))
+        # expected rows: the oracle on the rebuilt frames, direction threaded
+        direction = d_in[tiles[0]]
+        exp = []
+        for a in tiles[:-1]:
+            st, off, dn, i, log = _oracle_search(O, roi_rect, frames[a], frames[a + 1], direction)
+            g = gold[a - 1]
+            assert st and abs(off[0] - g[0]) <= 1 and abs(off[1] - g[1]) <= 1 and (dn, i) == (by_a[a]["direction"], by_a[a]["i"]), (a, off, g, dn, i)
+            exp.append(dict(a=a, gold=g, offset=off, direction=dn, i=i, votes=log[-1][5], nA=log[-1][6], nB=log[-1][7], matches=log[-1][8]))
+            direction = dn
+            print("nbhd", turn, a, g, off, dn, i, log[-1][5:], flush=True)
+        meta.append(dict(turn=turn, tiles=tiles, shape=[H, W], incoming_direction=d_in[tiles[0]], strips=strips, expected=exp))
+    np.savez_compressed(os.path.join(OUT, "real_path_strips.npz"), **store)
+    json.dump(dict(source="crops of the reference's dendriticCrystal tiles (Pillow draft-L decode); expected = oracle on the rebuilt frames, "
+                          "gold = Stitcher.py:87", neighbourhoods=meta), open(os.path.join(OUT, "real_path_strips.json"), "w"))
+    print("real path strips", os.path.getsize(os.path.join(OUT, "real_path_strips.npz")) // 1024, "KiB")
+
+
 def cap_demo_strips():
     """BASELINE configs[0] / configs[3]: ROI strips of the iron pair (direction 1) and of the first zirconCL pairs (direction 4)
     at roiRatio 0.2.  cv2 is not installable here, so the expected offsets are produced by the oracle (oracle/): these
@@ -418,8 +545,8 @@ def cap_demo_strips():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["roi", "mode", "sm", "cache", "fuse", "stitch", "flow", "real", "demo"]
+    which = sys.argv[1:] or ["roi", "mode", "sm", "cache", "fuse", "stitch", "flow", "real", "realpath", "demo"]
     fns = dict(roi=cap_roi, mode=cap_mode, sm=cap_state_machine, cache=cap_feature_search_cache,
-               fuse=cap_fuse, stitch=cap_stitch, flow=cap_flow, real=cap_real, demo=cap_demo_strips)
+               fuse=cap_fuse, stitch=cap_stitch, flow=cap_flow, real=cap_real, realpath=cap_real_path, demo=cap_demo_strips)
     for w in which:
         fns[w]()
