@@ -96,7 +96,15 @@ __global__ __launch_bounds__(256) void k_integral_bandscan(const RoiDev *rois)
     const int nb = (R.h + INT_TH - 1) / INT_TH;
     g_i32 c = (g_i32)R.icarry + x;
     int run = 0;
-    for (int b = 0; b < nb; b++) { const int v = c[(size_t)b * ipitch]; c[(size_t)b * ipitch] = run; run += v; }
+    // 16 bands per trip: the loads of a trip are all issued before its stores (in-place update: the compiler must otherwise order
+    // every load behind the previous store, one memory round trip per band)
+    for (int b0 = 0; b0 < nb; b0 += 16) {
+        int v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = b0 + k < nb ? c[(size_t)(b0 + k) * ipitch] : 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { if (b0 + k < nb) c[(size_t)(b0 + k) * ipitch] = run; run += v[k]; }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_integral_final(const RoiDev *rois)
@@ -626,6 +634,9 @@ extern "C" int vfsms_debug_desc_cycles(unsigned long long *out) { return hipMemc
 #define DT_MARK(ph) do {} while (0)
 #define DT_START do {} while (0)
 #endif
+#ifndef VFSMS_EXP
+#define VFSMS_EXP 0
+#endif
 #define DESC_WBUF 16384           // LDS bytes for the staged descriptor window (win <= 128) / band chunk
 struct WinGeom {
     int win; float sin_dir, cos_dir;
@@ -664,6 +675,9 @@ __device__ __forceinline__ int win_sample_upright(const WinGeom &G, int i, int j
 // L2 latency is paid once per four samples.  (Measured: the kernel as a whole is bound by instruction issue at 5 workgroups/CU;
 // changes of tile shape, ILP depth or occupancy beyond that left its time unchanged -- DESIGN.md section 9.)
 #define STAGE_ILP 4
+#ifndef BORDER_ILP
+#define BORDER_ILP 1            // strips that cross the image border (rare): short trips keep the register budget of the hot path
+#endif
 __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row, const float *sy_row,
                                            int r0, int nrows, uint8_t *dst)
 {
@@ -728,12 +742,12 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
                 continue;
             }
         }
-        for (int jb = 0; jb < win; jb += 8 * STAGE_ILP) {
-            double px[STAGE_ILP], py[STAGE_ILP];
-            bool act[STAGE_ILP], inb[STAGE_ILP];
+        for (int jb = 0; jb < win; jb += 8 * BORDER_ILP) {
+            double px[BORDER_ILP], py[BORDER_ILP];
+            bool act[BORDER_ILP], inb[BORDER_ILP];
             bool all_in = true;
 #pragma unroll
-            for (int u = 0; u < STAGE_ILP; u++) {
+            for (int u = 0; u < BORDER_ILP; u++) {
                 const int j = jb + u * 8 + lj;
                 act[u] = rok && j < win;
                 px[u] = sxi + (double)j * c;
@@ -745,16 +759,16 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
             if (__all(all_in)) {                                   // interior (the common case): branch-free gathers
                 // the gather path (one address per lane through the texture-address unit) is what bounds this kernel:
                 // the two horizontally adjacent taps of a row come from ONE unaligned dword load (2 loads / sample, not 4)
-                uint32_t top[STAGE_ILP], bot[STAGE_ILP];
+                uint32_t top[BORDER_ILP], bot[BORDER_ILP];
 #pragma unroll
-                for (int u = 0; u < STAGE_ILP; u++) {
+                for (int u = 0; u < BORDER_ILP; u++) {
                     const int ix = act[u] ? (int)px[u] : 0, iy = act[u] ? (int)py[u] : 0;
                     g_cu8 p = G.img + (size_t)iy * G.stride + ix;
                     top[u] = *(GAS const uint32_t *)p;          // unaligned dword gather (gfx950 global memory allows it)
                     bot[u] = *(GAS const uint32_t *)(p + G.stride);
                 }
 #pragma unroll
-                for (int u = 0; u < STAGE_ILP; u++) {
+                for (int u = 0; u < BORDER_ILP; u++) {
                     const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
                     const uint8_t t00 = (uint8_t)(top[u] & 0xff), t01 = (uint8_t)((top[u] >> 8) & 0xff);
                     const uint8_t t10 = (uint8_t)(bot[u] & 0xff), t11 = (uint8_t)((bot[u] >> 8) & 0xff);
@@ -763,7 +777,7 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
                 }
             } else {                                               // window crosses the image border: per-sample path
 #pragma unroll
-                for (int u = 0; u < STAGE_ILP; u++)
+                for (int u = 0; u < BORDER_ILP; u++)
                     if (act[u]) drow[jb + u * 8 + lj] = (uint8_t)win_sample_xy(G, px[u], py[u]);
             }
         }
@@ -896,10 +910,10 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
     } else {
         int *irow = reinterpret_cast<int *>(&rowbuf[0][0]);
         for (int dy = band >= 0 ? band : 0; dy < (band >= 0 ? band + 1 : dsz); dy++) {
-            AreaSpan Sy = span_s[dy];
             int rlo, rhi;
             if (is_area_fast) { rlo = dy * iscale; rhi = rlo + iscale - 1; }
             else {
+                const AreaSpan Sy = span_s[dy];
                 rlo = Sy.s_left >= 0 ? Sy.s_left : Sy.sx1;
                 rhi = Sy.s_right >= 0 ? Sy.s_right : Sy.sx2 - 1;
             }
@@ -925,6 +939,11 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
             }
             if (threadIdx.x < dsz) {                                // vertical combine in source-row order
                 const int dx = threadIdx.x;
+                // the span is read again here (volatile: no value kept live across the staging loop above -- that cost four
+                // VGPR spills per band, ~1.1 GB of scratch traffic per launch at 5 workgroups per CU)
+                const volatile AreaSpan *vs = &span_s[dy];
+                AreaSpan Sy; Sy.s_left = vs->s_left; Sy.a_left = vs->a_left; Sy.sx2 = vs->sx2; Sy.a_full = vs->a_full;
+                Sy.s_right = vs->s_right; Sy.a_right = vs->a_right; Sy.sx1 = vs->sx1;
                 if (is_area_fast) {
                     int sum = 0;
                     for (int r = 0; r < nrows; r++) sum += irow[dx * 40 + r];
@@ -1017,7 +1036,13 @@ __global__ __launch_bounds__(1024) void k_desc_order(const RoiDev *rois)
     }
 }
 
-struct TicketState { int prefix[DESC_NCLS * VFSMS_MAX_ROIS + 1]; int ticket; int split; };
+// The ticket counter is sharded 8 ways (one head per XCD, 256 B apart): a single device-scope word saturates near 90 returning
+// atomics per microsecond, which for the ~280 k keypoints of a 16-pair batch is 3 ms of a 7.7 ms kernel.  Head q serves the
+// tickets t = q, q + 8, q + 16, ... of the one class-major order, so every head carries the same mix of window classes, largest
+// first; a workgroup starts on the head of its XCD (blockIdx % 8) and moves on to the next head when one runs dry.
+#define DESC_HEADS 8
+#define DESC_HEAD_STRIDE 64          // ints between heads
+struct TicketState { int prefix[DESC_NCLS * VFSMS_MAX_ROIS + 1]; int ticket; int split; int head; };
 
 __device__ __forceinline__ void ticket_init(const RoiDev *rois, int nrois, TicketState &S)
 {
@@ -1032,6 +1057,7 @@ __device__ __forceinline__ void ticket_init(const RoiDev *rois, int nrois, Ticke
         S.split = total < (int)gridDim.x * 48 ? 21 : 1;
         S.prefix[0] = 0;
         for (int e = 0; e < DESC_NCLS * nrois; e++) S.prefix[e + 1] = S.prefix[e] + S.prefix[e + 1] * (e < nrois ? S.split : 1);
+        S.head = 0;
     }
     __syncthreads();
 }
@@ -1039,10 +1065,21 @@ __device__ __forceinline__ void ticket_init(const RoiDev *rois, int nrois, Ticke
 __device__ __forceinline__ bool ticket_next(const RoiDev *rois, int *counter, int nrois, TicketState &S, int &roi, int &k, int &band)
 {
     __syncthreads();
-    if (threadIdx.x == 0) S.ticket = atomicAdd(counter, 1);
+    const int ne = DESC_NCLS * nrois;
+    if (threadIdx.x == 0) {
+        const int total = S.prefix[ne];
+        int t = total;
+        while (S.head < DESC_HEADS) {
+            const int q = (blockIdx.x + S.head) & (DESC_HEADS - 1);
+            t = atomicAdd(counter + q * DESC_HEAD_STRIDE, 1) * DESC_HEADS + q;
+            if (t < total) break;
+            S.head++;                                            // this head is exhausted (it stays exhausted): steal from the next
+            t = total;
+        }
+        S.ticket = t;
+    }
     __syncthreads();
     const int t = S.ticket;
-    const int ne = DESC_NCLS * nrois;
     if (t >= S.prefix[ne]) return false;
     int lo = 0, hi = ne;                                      // prefix[lo] <= t < prefix[hi]
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (S.prefix[mid] <= t) lo = mid; else hi = mid; }
@@ -1065,13 +1102,25 @@ __global__ __launch_bounds__(128) void k_orientation(const RoiDev *rois, const S
     orientation_one(R, T, k, upright);
 }
 
-__global__ __launch_bounds__(256, 5) void k_describe(const RoiDev *rois, int nrois, int *counter, const SurfTables *T,
+#ifndef DESC_WGS
+#define DESC_WGS 5
+#endif
+__global__ __launch_bounds__(256, DESC_WGS) void k_describe(const RoiDev *rois, int nrois, int *counter, const SurfTables *T,
                                                   int extended, int upright)
 {
     __shared__ TicketState S;
     ticket_init(rois, nrois, S);
     int roi, k, band;
+#ifdef VFSMS_DESC_TIMING
+    unsigned long long tq = clock64();
+    while (ticket_next(rois, counter, nrois, S, roi, k, band)) {
+        if (threadIdx.x == 0) atomicAdd(&g_desc_cycles[6], clock64() - tq);
+        describe_one(rois[roi], T, k, extended, upright, band);
+        tq = clock64();
+    }
+#else
     while (ticket_next(rois, counter, nrois, S, roi, k, band)) describe_one(rois[roi], T, k, extended, upright, band);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1298,10 +1347,13 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
     }
     {
         ProfScope ps(ctx, "describe");
-        // ticket counter: counters[9] of ROI 0 (zeroed with the other counters by launch_surf_detect)
+        // ticket heads: 8 counters, 256 B apart, out of the call's arena (callers reserve 64 KB of slack)
+        int *tickets = (int *)ctx_arena_alloc(ctx, sizeof(int) * DESC_HEADS * DESC_HEAD_STRIDE);
+        if (!tickets) { vfsms_set_error("arena exhausted (descriptor tickets)"); return VFSMS_ERR_CAPACITY; }
+        HIP_TRY(hipMemsetAsync(tickets, 0, sizeof(int) * DESC_HEADS * DESC_HEAD_STRIDE, ctx->stream));
         hipLaunchKernelGGL(k_desc_order, dim3(nrois), dim3(1024), 0, ctx->stream, d_rois);
         if (!p->upright) hipLaunchKernelGGL(k_desc_trig, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
-        hipLaunchKernelGGL(k_describe, dim3(256 * 5), dim3(256), 0, ctx->stream, d_rois, nrois, h_rois[0].counters + 9,
+        hipLaunchKernelGGL(k_describe, dim3(256 * DESC_WGS), dim3(256), 0, ctx->stream, d_rois, nrois, tickets,
                            ctx->d_tables, p->extended, p->upright);
         hipLaunchKernelGGL(k_desc_tail, dim3((maxcap + 15) / 16, nrois), dim3(256), 0, ctx->stream, d_rois, ctx->d_tables, p->extended);
     }

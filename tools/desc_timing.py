@@ -18,7 +18,7 @@ rows = eng.attempt_surf_batch(jobs)
 out = np.zeros(8, np.uint64); eng.lib.vfsms_debug_desc_cycles(out.ctypes.data_as(ctypes.c_void_p))
 d = (out - out0).astype(np.float64)
 nk = rows[:, 4:6].sum()
-names = ["prologue", "stageA", "outputsA", "stageB", "outputsB", "descriptor"]
+names = ["prologue", "stageA", "outputsA", "stageB", "outputsB", "descriptor", "ticket"]
 print("keypoints", nk, "total block-cycles %.3g (clock64 ticks)" % d.sum())
-for n, v in zip(names, d[:6]):
+for n, v in zip(names, d[:7]):
     print("  %-10s %6.1f %%   %.0f ticks/keypoint" % (n, 100 * v / d.sum(), v / nk))

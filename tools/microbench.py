@@ -3,6 +3,9 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("VFSMS_LIB"):
+    from imagestitch_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ["VFSMS_LIB"])
 import imagestitch_amd as isa
 from imagestitch_amd.synthetic import SyntheticGrid
 
