@@ -8,10 +8,17 @@
 Workload (BASELINE.json metric / SURVEY section 8d): a synthetic 10 x 9 grid of 2048 x 2048 grayscale tiles on a
 column-major serpentine path (89 consecutive pairs, 8 turns), SURF (hessian 100, 4 octaves, 3 layers, 64-d) +
 BF-L2 2-NN + ratio 0.75 + mode vote (>= 3), incremental ROI (roiRatio 0.2) with direction rotation
-(direction 1, directIncre 1) -- exactly Main.py's settings.  One "step" = registering all 89 pairs, tiles
-already resident in HBM.  With N > 1 the pairs are sharded in contiguous chunks, one process per GPU, and ONE
-all-gather (RCCL) of the int32 offset tables closes the step ("strong" scaling: total work is fixed).
-Prints ONE JSON line on rank 0.
+(direction 1, directIncre 1) -- exactly Main.py's settings.  One "step" = registering all 89 pairs.
+
+`value`: tiles already resident in HBM when the timed region starts.  `value_host_resident_tiles`: the same K steps with
+the tiles in (pinned) host memory at the start of every step -- uploaded inside the timed region on the engine's copy
+stream, overlapped with the registration of earlier pairs (SURVEY 8d's reading: "tiles decoded and resident in host memory").
+
+With N > 1 the pairs are sharded in contiguous chunks, one process per GPU, and ONE all-gather (RCCL) of the int32 offset
+tables closes the step ("strong" scaling: total work is fixed).  Prints ONE JSON line on rank 0.
+
+--method orb | phase | fuse time the other paths of the scope table on the same grid (each with its own roofline object);
+the default, surf, is the BASELINE metric.
 """
 import argparse
 import json
@@ -27,20 +34,57 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3       # dense FP32 MFMA peak of gfx950 (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md
+# VALU issue peak in lane-operations: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.  (157.3 TFLOP/s = this x 2 flop per FMA x 2 for packed
+# FP32; SQ_INSTS_VALU == SQ_ACTIVE_INST_VALU quad-cycles in profiles/r02_pmc_describe.txt: one wave64 VALU instruction = 4 cycles.)
+VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+# VALU instructions per bilinear sample of k_describe's staging loop, counted in its gfx950 assembly (interior path: 2 v_fma_f64,
+# 2 v_cvt_i32_f64, 3 address, 2 v_fract_f64, 2 v_cvt_f32_f64, 2 v_sub, 4 v_cvt_f32_ubyte, 4 v_pk_mul (+2 moves), 3 v_add, v_rndne,
+# v_cvt, 2 loop / index) -- the ALGORITHMIC work of one sample as this kernel formulates it
+DESC_VALU_PER_SAMPLE = 32
+MIN_WARM_S = 1.5
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_summary.txt, written by
-    tools/profile_round.sh from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command; gfx950 x2
-    correction applied to FETCH_SIZE).  PMC counters cannot be collected from inside the timed run, hence the file."""
+def pmc_value(kernel, key):
+    """A per-launch PMC figure of `kernel` from the newest committed summary (profiles/*_pmc_summary.txt, written by
+    tools/profile_round.sh from separate rocprofv3 --pmc passes of this same command).  PMC counters cannot be collected
+    from inside the timed run, hence the file."""
     import glob
     import re
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.txt")), reverse=True):
         for line in open(path):
-            m = re.match(r"^%s\s+launches=\d+ .*total\(x2 rule\)=([0-9.e+]+) B/launch" % re.escape(kernel), line)
-            if m:
-                return float(m.group(1)), os.path.relpath(path, ROOT)
+            if line.startswith(kernel + " ") and "launches=" in line:
+                m = re.search(re.escape(key) + r"=([0-9.e+]+)", line)
+                if m:
+                    return float(m.group(1)), os.path.relpath(path, ROOT)
     return None, None
+
+
+def pmc_traffic(kernel):
+    return pmc_value(kernel, "total(x2 rule)")
+
+
+def hbm_roofline(kernel, bytes_per_launch, ms_per_launch, launches, note=None, **extra):
+    dur = ms_per_launch * 1e-3
+    gbs = bytes_per_launch / dur / 1e9 if dur > 0 else 0.0
+    traffic, src = pmc_traffic(kernel.split("+")[0].split(" ")[0])
+    d = dict(kernel=kernel, bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 5),
+             traffic=traffic, traffic_source=src, bytes_per_launch=bytes_per_launch, avg_launch_ms=round(ms_per_launch, 4), launches=launches)
+    if note:
+        d["note"] = note
+    d.update(extra)
+    return d
+
+
+def optimal_dft_size(n):
+    m = max(int(n), 1)
+    while True:
+        k = m
+        for p in (2, 3, 5):
+            while k % p == 0:
+                k //= p
+        if k == 1:
+            return m
+        m += 1
 
 
 def bench_fuse(args, eng, grid, tiles, handles, torch):
@@ -56,6 +100,10 @@ def bench_fuse(args, eng, grid, tiles, handles, torch):
     offs = [[0, 0]] + [list(map(int, o)) for o in grid.true_offsets()]
     shapes = [(grid.th, grid.tw)] * n
     offsetList, rangeX, rangeY, rows, cols = isa.Stitcher._layout(shapes, offs)
+    rois = []
+    for i in range(1, n):
+        oy, ox = offsetList[i]
+        rois.append((max(oy, rangeX[i - 1][0]), max(ox, rangeY[i - 1][0]), min(oy + grid.th, rangeX[i - 1][1]), min(ox + grid.tw, rangeY[i - 1][1])))
 
     def assemble(download, resident=True):
         canvas = eng.canvas_create(rows, cols, 1)
@@ -65,12 +113,10 @@ def bench_fuse(args, eng, grid, tiles, handles, torch):
                 if i == 0:
                     eng.canvas_paste_tile(canvas, handles[i], oy, ox) if resident else eng.canvas_paste(canvas, tiles[i], oy, ox)
                     continue
-                roi = (max(oy, rangeX[i - 1][0]), max(ox, rangeY[i - 1][0]),
-                       min(oy + grid.th, rangeX[i - 1][1]), min(ox + grid.tw, rangeY[i - 1][1]))
                 if resident:
-                    eng.canvas_fuse_tile_resident(canvas, handles[i], oy, ox, roi, offs[i][0], offs[i][1])
+                    eng.canvas_fuse_tile_resident(canvas, handles[i], oy, ox, rois[i - 1], offs[i][0], offs[i][1])
                 else:
-                    eng.canvas_fuse_tile(canvas, tiles[i], oy, ox, roi, offs[i][0], offs[i][1])
+                    eng.canvas_fuse_tile(canvas, tiles[i], oy, ox, rois[i - 1], offs[i][0], offs[i][1])
             eng.sync()
             return eng.canvas_download(canvas, rows, cols, 1) if download else None
         finally:
@@ -78,12 +124,15 @@ def bench_fuse(args, eng, grid, tiles, handles, torch):
 
     for _ in range(max(args.warmup, 1)):
         assemble(False)
+    eng.profile_enable(True); eng.profile_read(reset=True)
     torch.cuda.synchronize(); eng.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         assemble(False)
     torch.cuda.synchronize(); eng.sync()
     dt = (time.perf_counter() - t0) / args.steps
+    prof = eng.profile_read(reset=True)
+    eng.profile_enable(False)
     t1 = time.perf_counter()
     out = assemble(True)
     dl = time.perf_counter() - t1 - dt
@@ -92,15 +141,59 @@ def bench_fuse(args, eng, grid, tiles, handles, torch):
     dt_host = time.perf_counter() - t2 - dl
     assert np.array_equal(out, out_host)
     mpx = rows * cols / 1e6
+    # algorithmic bytes: per fused tile read canvas ROI + read tile ROI + write ROI (3 r c) plus the paste of the
+    # tile's pixels outside the ROI (read + write); the validity plane adds r c / 8 -- not counted
+    fuse_bytes = sum(3 * (r[2] - r[0]) * (r[3] - r[1]) + 2 * (grid.th * grid.tw - (r[2] - r[0]) * (r[3] - r[1])) for r in rois) + 2 * grid.th * grid.tw
+    f_ms, f_n = prof.get("fuse", (0.0, 0))
+    roof = None
+    if f_n:
+        roof = hbm_roofline("k_fuse_apply", fuse_bytes, f_ms / args.steps, args.steps,
+                            note="one 'launch' = the whole mosaic (%d tiles: stats, weights, blend, paste per tile); bytes = 3 r c per fuse ROI + "
+                                 "2 B/px pasted outside it" % n, launch_groups=f_n)
     print(json.dumps({
         "metric": "fuse Mpx/sec (mosaic pixels, fadeInAndFadeOut)", "value": round(mpx / dt, 2), "unit": "Mpx/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "mosaic of the synthetic %dx%d grid of %dx%d u8 tiles from its true offsets: canvas %d x %d"
+        "config": {"workload": "synthetic %dx%d grid of %dx%d u8 tiles assembled from the ground-truth offsets, fadeInAndFadeOut, mosaic %dx%d"
                                % (args.rows, args.cols, args.tile, args.tile, rows, cols), "tiles": n, "tiles_resident_in_hbm": True,
                    "canvas_download_ms": round(dl * 1e3, 1), "ms_per_step_with_host_tiles": round(dt_host * 1e3, 1)},
+        "roofline": roof, "cpu_baseline": None, "stages": {k: dict(ms=round(v[0], 3), launches=v[1]) for k, v in prof.items()},
         "tile_Mpx_per_s": round(n * grid.th * grid.tw / 1e6 / dt, 2), "mosaic_nonzero_fraction": round(float((out > 0).mean()), 4)}))
     eng.close()
+
+
+def cpu_baseline_surf(args, grid, tiles, isa):
+    """The oracle (a port: cv2 is not installable) on a bounded sample of the same grid, built -O3 -march=native ON this box
+    (oracle/Makefile `native`): single-thread row and all-host-threads row.  One ROI attempt per pair at the true
+    direction; reported, never credited."""
+    from oracle import oracle as O
+    O.build()
+    try:
+        O.use_native()
+    except Exception as e:                      # no compiler on the box: the portable build is timed instead
+        print("cpu_baseline: native oracle build unavailable (%s)" % e, file=sys.stderr)
+    cores = os.cpu_count() or 1
+    dirs = grid.true_directions()
+    S = min(args.cpu_sample, grid.n_pairs)
+
+    def run(pairs, nthreads):
+        t1 = time.perf_counter()
+        for k in pairs:
+            A, B = tiles[k], tiles[k + 1]
+            ra = isa.roi_rect(A.shape, dirs[k], "first", 0.2); rb = isa.roi_rect(B.shape, dirs[k], "second", 0.2)
+            ka, da = O.surf_detect_describe(np.ascontiguousarray(A[ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]]), nthreads=nthreads)
+            kb, db = O.surf_detect_describe(np.ascontiguousarray(B[rb[0]:rb[0] + rb[2], rb[1]:rb[1] + rb[3]]), nthreads=nthreads)
+            pr = O.bf_l2_ratio_matches(da, db, 0.75, nthreads=nthreads)
+            O.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pr, 3)
+        return time.perf_counter() - t1
+    dt_all = run(range(S), cores)
+    S1 = max(1, min(S, 2))
+    dt_one = run(range(S1), 1)
+    return dict(value=round(S / dt_all, 4), unit="image-pairs/s", cores=cores, kind="port",
+                sample="first %d pairs of the same grid, one ROI attempt each at the true direction (oracle SURF+BF-L2+mode built -O3 "
+                       "-march=native here, OpenMP over %d threads), %.1f s" % (S, cores, dt_all),
+                single_thread=dict(value=round(S1 / dt_one, 4), cores=1, sample="first %d pair(s), %.1f s" % (S1, dt_one)),
+                build=O.build_kind())
 
 
 def main():
@@ -115,7 +208,10 @@ def main():
     ap.add_argument("--method", default="surf", choices=["surf", "orb", "phase", "fuse"],
                     help="surf = the BASELINE metric; orb / phase time the other registration paths on the same grid; fuse = the"
                          " secondary metric of SURVEY 8d (mosaic assembly with fadeInAndFadeOut blending, N = 1 only)")
-    ap.add_argument("--cpu-sample", type=int, default=6, help="pairs timed on the host cores for cpu_baseline (0 = skip)")
+    ap.add_argument("--overlap", type=float, default=0.10, help="nominal tile overlap of the synthetic grid (SURVEY 8d: 10 %%)")
+    ap.add_argument("--offset-evaluate", type=int, default=3, help="Method.offsetEvaluate (Main.py:12: 3)")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="pairs timed on the host cores for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the host-resident-tiles measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,29 +240,45 @@ def main():
     from imagestitch_amd.synthetic import SyntheticGrid
 
     eng = isa.Engine(local_rank)
-    grid = SyntheticGrid(args.rows, args.cols, args.tile, overlap=0.10 if args.method == "surf" else 0.15)
+    grid = SyntheticGrid(args.rows, args.cols, args.tile, overlap=args.overlap)
     P = grid.n_pairs
     truth = np.array(grid.true_offsets(), np.int64)
     bounds = GridRegistrar.chunk_bounds(P, world)
     lo, hi = bounds[rank]
     need = list(range(lo, hi + 1)) if hi > lo else []
-    tiles = dict(zip(need, grid.tiles(need, threads=min(8, os.cpu_count() or 1))))
+    # tiles live in pinned host memory (what a decoder feeding this engine would write into): uploads from it are asynchronous DMA
+    tiles = {}
+    for k, t in zip(need, grid.tiles(need, threads=min(8, os.cpu_count() or 1))):
+        buf = eng.pinned_empty(t.shape)
+        buf[...] = t
+        tiles[k] = buf
     shapes = [(grid.th, grid.tw)] * grid.n_tiles
     handles = [None] * grid.n_tiles
     t_up = time.perf_counter()
     for k in need:
         handles[k] = eng.tile_upload(tiles[k])               # tiles resident in HBM before the timed region
     eng.sync()
-    t_up = time.perf_counter() - t_up                        # one H2D copy per tile (pageable host memory), reported as a side note only
+    t_up = time.perf_counter() - t_up
     if args.method == "fuse":
         return bench_fuse(args, eng, grid, tiles, handles, torch)
-    reg = GridRegistrar(eng, method=args.method, roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3 if args.method == "surf" else 10, directIncre=1,
+    reg = GridRegistrar(eng, method=args.method, roiRatio=0.2, searchRatio=0.75, offsetEvaluate=args.offset_evaluate, directIncre=1,
                         surfParams=eng.surf_params() if args.method == "surf" else eng.orb_params() if args.method == "orb" else None,
                         window=args.window)
     gather = make_all_gather(coll_device) if world > 1 else single_process_all_gather
 
-    def step():
-        return reg.register_sharded(handles, shapes, 1, rank, world, gather)
+    def step(hs=handles):
+        return reg.register_sharded(hs, shapes, 1, rank, world, gather)
+
+    def step_from_host():
+        """the same step with the tiles in host memory at its start: asynchronous uploads in path order on the copy stream (the
+        first batch waits only for the tiles it names), registration, release of the device copies"""
+        hs = [None] * grid.n_tiles
+        for k in need:
+            hs[k] = eng.tile_upload_async(tiles[k])
+        out = step(hs)
+        for k in need:
+            eng.tile_free(hs[k])
+        return out
 
     def fence():
         if dist is not None:
@@ -174,10 +286,18 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
+    t_w = time.perf_counter()
     for _ in range(args.warmup):
         res, _d = step()
     if args.warmup == 0:
         res, _d = step()
+    # The MI355X needs about a second of sustained load to reach its steady clocks (and the first touches of the arena to
+    # settle): measured here, the step right after a short warmup runs 5-100 % slower than the steady state.  More untimed
+    # steps are run until the warmup has lasted MIN_WARM_S; they are reported, and the K timed steps below are exactly K.
+    warm_extra = 0
+    while time.perf_counter() - t_w < MIN_WARM_S:
+        step()
+        warm_extra += 1
     ok = res[:, 0] == 1
     err = np.abs(res[:, 1:3].astype(np.int64) - truth)
     max_err = int(err[ok].max()) if ok.any() else -1
@@ -195,36 +315,54 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = eng.profile_read(reset=True)
     eng.profile_enable(False)
+    st = dict(reg.stats)
+
+    elapsed_host = None
+    if not args.no_host_leg:
+        res_h, _d = step_from_host()                              # warm the tile pool
+        assert np.array_equal(res_h, res)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_from_host()
+        fence()
+        elapsed_host = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
+        t = torch.tensor([elapsed, elapsed_host or 0.0], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        elapsed_host = float(t[1].item()) if elapsed_host is not None else None
 
     # ---- rooflines from the live HIP-event timings of this rank (library-side events on the kernels' own stream) ----
     stages = {k: dict(ms=round(v[0], 3), launches=v[1], ms_per_launch=round(v[0] / max(v[1], 1), 4)) for k, v in prof.items()}
-    st = reg.stats
     roofline = None
     extra = {}
+    roi_h, roi_w = isa.roi_rect((grid.th, grid.tw), 1, "first", 0.2)[2:]
     de_ms, de_n = prof.get("describe", (0.0, 0))
     if de_n and args.method == "surf":
-        # dominant kernel: k_describe (descriptor windows).  Algorithmic traffic per keypoint (SURVEY 8d / DESIGN.md 5): the
-        # win x win bilinear samples of the rotated window, 4 source bytes each, plus the 21 x 21 patch written out.
-        # samples/keypoint is measured outside the timed region on the first ROI pair (win = int(21 * size * 1.2 / 9)).
-        ra = isa.roi_rect((grid.th, grid.tw), 1, "first", 0.2)
+        # dominant kernel: k_describe (descriptor windows), bound by VALU issue (profiles/r02_pmc_describe.txt: SQ_INSTS_VALU x 4
+        # cycles = 60 % of the SIMD cycles of the launch; HBM traffic is a few per cent of what 8 TB/s would move in that time).
+        # Algorithmic work per launch = bilinear samples (win x win per keypoint, win = int(21 * size * 1.2 / 9)) x the VALU
+        # instructions one sample takes in the kernel's own inner loop; samples/keypoint is measured outside the timed region.
         k0 = need[0]
+        ra = isa.roi_rect((grid.th, grid.tw), 1, "first", 0.2)
         _k, _d, kf = eng.surf_detect_describe(np.ascontiguousarray(tiles[k0][ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]]), full=True)
         win = np.minimum((21 * (kf["size"] * np.float32(1.2) / np.float32(9.0))).astype(np.int64), 739)
         spk = float((win.astype(np.float64) ** 2).mean()) if len(win) else 0.0
         kps = st["sum_nq_plus_nt"] / de_n                                   # keypoints described per launch
-        b = kps * (4.0 * spk + 441.0)
         dur = de_ms / de_n * 1e-3
+        laneops = kps * spk * DESC_VALU_PER_SAMPLE
         traffic, traffic_src = pmc_traffic("k_describe")
-        roofline = dict(kernel="k_describe", bound="hbm", achieved=round(b / dur / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(b / dur / 1e9 / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src, avg_launch_ms=round(dur * 1e3, 4),
-                        bytes_per_launch=b, keypoints_per_launch=kps, samples_per_keypoint=round(spk, 1), launches=de_n,
-                        note="dominant kernel by time; it is VALU-issue bound, not HBM bound: ~45 instructions per bilinear sample "
-                             "(double-precision sample positions as in the reference), PMC in profiles/ shows the SIMDs issuing >90 % "
-                             "of cycles; HBM traffic measured by PMC is a few tens of MB per launch")
+        valu_insts, _src = pmc_value("k_describe", "INSTS_VALU")
+        roofline = dict(kernel="k_describe", bound="valu", achieved=round(laneops / dur / 1e12, 3), peak=round(VALU_PEAK_TLANEOPS, 2),
+                        unit="Tlane-op/s", frac=round(laneops / dur / 1e12 / VALU_PEAK_TLANEOPS, 4), traffic=traffic, traffic_source=traffic_src,
+                        compulsory_bytes_per_launch=round(kps / max(len(kf), 1) * (roi_h * roi_w) + kps * 441.0), avg_launch_ms=round(dur * 1e3, 4),
+                        lane_ops_per_launch=laneops, valu_ops_per_sample=DESC_VALU_PER_SAMPLE, keypoints_per_launch=kps,
+                        samples_per_keypoint=round(spk, 1), launches=de_n,
+                        note="dominant kernel by time (%.0f %% of the GPU time of a step); VALU-issue bound: achieved counts only the inner-loop "
+                             "instructions of the samples; all VALU instructions the kernel issues (PMC SQ_INSTS_VALU, profiles/) occupy "
+                             "~60 %% of the SIMD cycles" % (100.0 * de_ms / max(sum(v[0] for v in prof.values()), 1e-9)),
+                        valu_insts_per_launch_pmc=valu_insts)
     bf_ms, bf_n = prof.get("bf_mfma", (0.0, 0))
     if bf_n:
         dur = bf_ms / bf_n * 1e-3
@@ -240,54 +378,65 @@ def main():
     in_ms, in_n = prof.get("integral", (0.0, 0))
     if in_n:
         # algorithmic bytes of cv::integral per ROI: h*w (u8 in) + 4 (h+1)(w+1) (i32 out) ~ 5 B/px
-        px = st["roi_px"] / in_n
-        b = px * 5.0
-        extra["integral_hbm"] = dict(kernel="k_integral_rows+k_integral_cols", bound="hbm", achieved=round(b / (in_ms / in_n * 1e-3) / 1e9, 2),
-                                     peak=HBM_PEAK_GBS, unit="GB/s", frac=round(b / (in_ms / in_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                                     bytes_per_launch=b, avg_launch_ms=round(in_ms / in_n, 4))
+        extra["integral_hbm"] = hbm_roofline("k_integral_final+k_integral_bandsum+k_integral_bandscan", st["roi_px"] / in_n * 5.0, in_ms / in_n, in_n)
+        tr = [pmc_traffic(k)[0] for k in ("k_integral_final", "k_integral_bandsum", "k_integral_bandscan")]
+        extra["integral_hbm"]["traffic"] = sum(tr) if all(v is not None for v in tr) else None
+    he_ms, he_n = prof.get("hessian", (0.0, 0))
+    if he_n:
+        # reads S once per octave pass 4 (h+1)(w+1) x 4 + writes det + trace 8 x sum_o 5 (h/2^o)(w/2^o) = 69.1 B/px
+        extra["hessian_hbm"] = hbm_roofline("k_hessian_lds<1,64>+k_hessian_lds<2,32>+k_hessian", st["roi_px"] / he_n * 69.1, he_ms / he_n, he_n)
+    if args.method == "phase":
+        ph_ms, ph_n = prof.get("phase", (0.0, 0))
+        if ph_n:
+            M, N = optimal_dft_size(roi_h), optimal_dft_size(roi_w)
+            per_attempt = 2 * roi_h * roi_w + 240 * M * (N // 2 + 1) + 8 * M * N
+            roofline = hbm_roofline("rocFFT r2c/c2r + k_pad_u8_f64 + k_cross_power + k_argmax_*", per_attempt * st["attempts"] / ph_n, ph_ms / ph_n, ph_n,
+                                    note="one 'launch' = one batched phase correlation (pad, 2 forward + 1 inverse FP64 transforms, cross power, "
+                                         "argmax, centroid) over all attempts of a batch; bytes per attempt = 2hw + 240 M (N/2+1) + 8 MN",
+                                    attempts_per_launch=st["attempts"] / ph_n, padded=[M, N])
+    if args.method == "orb":
+        fa_ms, fa_n = prof.get("orb_fast", (0.0, 0))
+        if fa_n:
+            # fused FAST-9/16 + NMS over the 8-level pyramid of every ROI: each level read once (sum of level areas = 3.27 h w at
+            # scale 1.2), 1 B/px; scores never leave LDS
+            roofline = hbm_roofline("k_orb_fast_nms", st["roi_px"] / fa_n * 3.27, fa_ms / fa_n, fa_n,
+                                    note="dominant ORB stage; bytes = pyramid levels read once")
+        py_ms, py_n = prof.get("orb_pyramid", (0.0, 0))
+        if py_n:
+            extra["orb_pyramid_hbm"] = hbm_roofline("k_orb_resize", st["roi_px"] / py_n * (3.27 + 2.27), py_ms / py_n, py_n)
+        bh_ms, bh_n = prof.get("bf_hamming", (0.0, 0))
+        if bh_n:
+            extra["bf_hamming_ms_per_launch"] = round(bh_ms / bh_n, 4)
 
     # ---- CPU baseline: the oracle (a port, cv2 is not installable) on a bounded sample, rank 0 at N = 1 only ------
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0 and args.method == "surf":
-        from oracle import oracle as O
-        O.build()
-        cores = os.cpu_count() or 1
-        dirs = grid.true_directions()
-        S = min(args.cpu_sample, P)
-        t1 = time.perf_counter()
-        for k in range(S):
-            A, B = tiles[k], tiles[k + 1]
-            ra = isa.roi_rect(A.shape, dirs[k], "first", 0.2); rb = isa.roi_rect(B.shape, dirs[k], "second", 0.2)
-            ka, da = O.surf_detect_describe(np.ascontiguousarray(A[ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]]), nthreads=cores)
-            kb, db = O.surf_detect_describe(np.ascontiguousarray(B[rb[0]:rb[0] + rb[2], rb[1]:rb[1] + rb[3]]), nthreads=cores)
-            pairs = O.bf_l2_ratio_matches(da, db, 0.75, nthreads=cores)
-            O.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, 3)
-        dt = time.perf_counter() - t1
-        cpu = dict(value=round(S / dt, 4), unit="image-pairs/s", cores=cores, kind="port",
-                   sample="first %d pairs of the same grid, one ROI attempt each at the true direction (oracle SURF+BF-L2+mode, "
-                          "OpenMP over %d threads), %.1f s" % (S, cores, dt))
+        cpu = cpu_baseline_surf(args, grid, tiles, isa)
 
     if rank == 0:
         out = {
             "metric": "image-pairs/sec (2048x2048 grayscale, SURF+BF)" if args.method == "surf" else "image-pairs/sec (%s)" % args.method,
             "value": round(P * args.steps / elapsed, 3),
             "unit": "image-pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_extra_steps_until_1p5s": warm_extra,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f64" if args.method == "phase" else "u8" if args.method == "orb" else "f32",
             "data": "synthetic",
-            "config": {"workload": "synthetic %dx%d grid of %dx%d u8 tiles, serpentine path, %d pairs; %s; roiRatio 0.2, direction 1, directIncre 1"
-                                   % (args.rows, args.cols, args.tile, args.tile, P,
+            "config": {"workload": "synthetic %dx%d grid of %dx%d u8 tiles (overlap %.0f %%), serpentine path, %d pairs; %s; roiRatio 0.2, offsetEvaluate %d, "
+                                   "direction 1, directIncre 1" % (args.rows, args.cols, args.tile, args.tile, 100 * args.overlap, P,
                                       {"surf": "SURF(100,4,3,64-d)+BF-L2 knn2 ratio 0.75 + mode vote", "orb": "ORB(5000,1.2,8)+BF-Hamming 1-NN + mode vote",
-                                       "phase": "FFT phase correlation of the ROI strips"}[args.method]),
+                                       "phase": "FFT phase correlation of the ROI strips"}[args.method], args.offset_evaluate),
                        "pairs": P, "parallelism": "pairs%d" % world, "speculation_window": args.window},
             "max_abs_offset_error_px": max_err, "pairs_failed": n_failed,
-            "h2d_ms_rank0": round(t_up * 1e3, 2),
-            "value_incl_h2d": round(P * args.steps / (elapsed + t_up * args.steps), 3),   # if every step also had to upload its tiles (never `value`)
+            "value_host_resident_tiles": round(P * args.steps / elapsed_host, 3) if elapsed_host else None,
+            "ms_per_step_host_resident_tiles": round(elapsed_host / args.steps * 1e3, 3) if elapsed_host else None,
+            "h2d_ms_rank0_blocking": round(t_up * 1e3, 2),
             "attempts_per_step": st["attempts"] / max(args.steps, 1), "batches_per_step": st["batches"] / max(args.steps, 1),
+            "keypoints_per_roi": round(st["sum_nq_plus_nt"] / max(2 * st["attempts"], 1), 1) if args.method == "surf" else None,
+            "capacity_retries": getattr(reg, "capacity_retries", 0),
             "roofline": roofline,
             "cpu_baseline": cpu,
             "stages": stages,

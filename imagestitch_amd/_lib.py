@@ -52,6 +52,9 @@ _SIGNATURES = {
     "vfsms_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "vfsms_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "vfsms_tile_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "vfsms_tile_upload_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "vfsms_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "vfsms_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vfsms_tile_wrap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "vfsms_tile_free": (C.c_int, [C.c_void_p, C.c_int64]),
     "vfsms_integral_u8_i32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -151,6 +154,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "ctx", None):
+            for p in self.__dict__.pop("_pinned", []):
+                self.lib.vfsms_host_free(self.ctx, C.c_void_p(p))
             self.lib.vfsms_ctx_destroy(self.ctx)
             self.ctx = None
 
@@ -162,6 +167,7 @@ class Engine:
 
     def sync(self):
         self._check(self.lib.vfsms_ctx_sync(self.ctx))
+        self.__dict__.pop("_inflight", None)
 
     def stream_handle(self):
         return self.lib.vfsms_ctx_stream(self.ctx)
@@ -187,6 +193,24 @@ class Engine:
         h = C.c_int64()
         self._check(self.lib.vfsms_tile_upload(self.ctx, _ptr(img), img.shape[0], img.shape[1], img.strides[0], C.byref(h)))
         return h.value
+
+    def tile_upload_async(self, img):
+        """Upload without waiting: the copy overlaps the compute stream; `img` must stay alive and unchanged until sync() or
+        the first synchronous call that used the tile (arrays from pinned_empty() make the copy a true asynchronous DMA)."""
+        img = _u8_2d(img)
+        h = C.c_int64()
+        self._check(self.lib.vfsms_tile_upload_async(self.ctx, _ptr(img), img.shape[0], img.shape[1], img.strides[0], C.byref(h)))
+        self.__dict__.setdefault("_inflight", []).append(img)
+        return h.value
+
+    def pinned_empty(self, shape, dtype=np.uint8):
+        """numpy array over pinned host memory (vfsms_host_alloc); freed when the engine closes."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._check(self.lib.vfsms_host_alloc(self.ctx, C.c_size_t(max(n, 1)), C.byref(p)))
+        self.__dict__.setdefault("_pinned", []).append(p.value)
+        buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def tile_wrap(self, device_ptr, h, w, stride):
         hd = C.c_int64()

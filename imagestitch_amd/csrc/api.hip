@@ -6,7 +6,6 @@
 #include <string.h>
 #include <algorithm>
 
-size_t phase_bytes(int h, int w);
 int fuse_i64_device(vfsms_ctx *ctx, const long long *dA, const long long *dB, int r, int c, int ch, int dx, int dy,
                     uint8_t *d_out, int32_t *info);
 
@@ -207,6 +206,7 @@ extern "C" int vfsms_ctx_create(int device, vfsms_ctx **out)
     c->prof_on = false; c->orb_valid = false; c->d_orb_tables = nullptr;
     memset(&c->cur_params, 0, sizeof(c->cur_params));
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { vfsms_set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete c; return VFSMS_ERR_HIP; }
     *out = c;
     return VFSMS_OK;
@@ -222,7 +222,11 @@ extern "C" int vfsms_ctx_destroy(vfsms_ctx *ctx)
     phase_destroy_plans(ctx);
     prof_collect(ctx);
     for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
-    for (auto &kv : ctx->tiles) if (kv.second.owned) hipFree(kv.second.ptr);
+    hipStreamSynchronize(ctx->copy_stream);
+    for (auto &kv : ctx->tiles) { if (kv.second.owned) hipFree(kv.second.ptr); if (kv.second.ready) hipEventDestroy(kv.second.ready); }
+    for (auto &pe : ctx->tile_pool) hipFree(pe.second);
+    for (hipEvent_t ev : ctx->event_pool) hipEventDestroy(ev);
+    hipStreamDestroy(ctx->copy_stream);
     for (auto &kv : ctx->canvases) { hipFree(kv.second.pix); hipFree(kv.second.mask); }
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->pinned) hipHostFree(ctx->pinned);
@@ -236,6 +240,7 @@ extern "C" int vfsms_ctx_destroy(vfsms_ctx *ctx)
 extern "C" int vfsms_ctx_sync(vfsms_ctx *ctx)
 {
     if (!ctx) return VFSMS_ERR_BAD_ARG;
+    HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return VFSMS_OK;
 }
@@ -258,23 +263,69 @@ static int kp_capacity(vfsms_ctx *ctx, int h, int w)
     } while (0)
 
 // ---- tiles -------------------------------------------------------------------------------------------------
+static int tile_buffer(vfsms_ctx *ctx, size_t bytes, uint8_t **p)
+{
+    for (size_t k = 0; k < ctx->tile_pool.size(); k++)
+        if (ctx->tile_pool[k].first == bytes) { *p = ctx->tile_pool[k].second; ctx->tile_pool.erase(ctx->tile_pool.begin() + k); return VFSMS_OK; }
+    HIP_TRY(hipMalloc((void **)p, bytes));
+    return VFSMS_OK;
+}
+static int tile_upload_impl(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int64_t *handle, bool async)
+{
+    if (!img || !handle || h <= 0 || w <= 0 || stride < w) { vfsms_set_error("tile_upload: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    TileRec t; t.h = h; t.w = w; t.stride = w; t.owned = true; t.ready = nullptr; t.pending = false;
+    TRY(tile_buffer(ctx, (size_t)h * w, &t.ptr));
+    if (async) {
+        // the copy runs on the context's copy stream; the compute stream waits for it when a batch first names the tile
+        if (!ctx->event_pool.empty()) { t.ready = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+        else HIP_TRY(hipEventCreateWithFlags(&t.ready, hipEventDisableTiming));
+        HIP_TRY(hipMemcpy2DAsync(t.ptr, w, img, stride, w, h, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIP_TRY(hipEventRecord(t.ready, ctx->copy_stream));
+        t.pending = true;
+    } else {
+        HIP_TRY(hipMemcpy2DAsync(t.ptr, w, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    *handle = ctx->next_handle++;
+    ctx->tiles[*handle] = t;
+    return VFSMS_OK;
+}
+// make the compute stream wait for a tile's asynchronous upload (once)
+static int tile_ready(vfsms_ctx *ctx, TileRec &t)
+{
+    if (t.pending) { HIP_TRY(hipStreamWaitEvent(ctx->stream, t.ready, 0)); t.pending = false; }
+    return VFSMS_OK;
+}
 extern "C" int vfsms_tile_upload(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int64_t *handle)
 {
     CTX_ENTER(ctx);
-    if (!img || !handle || h <= 0 || w <= 0 || stride < w) { vfsms_set_error("tile_upload: bad arguments"); return VFSMS_ERR_BAD_ARG; }
-    TileRec t; t.h = h; t.w = w; t.stride = w; t.owned = true;
-    HIP_TRY(hipMalloc((void **)&t.ptr, (size_t)h * w));
-    HIP_TRY(hipMemcpy2DAsync(t.ptr, w, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    *handle = ctx->next_handle++;
-    ctx->tiles[*handle] = t;
+    return tile_upload_impl(ctx, img, h, w, stride, handle, false);
+}
+extern "C" int vfsms_tile_upload_async(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int64_t *handle)
+{
+    CTX_ENTER(ctx);
+    return tile_upload_impl(ctx, img, h, w, stride, handle, true);
+}
+extern "C" int vfsms_host_alloc(vfsms_ctx *ctx, size_t bytes, void **ptr)
+{
+    CTX_ENTER(ctx);
+    if (!ptr || !bytes) { vfsms_set_error("host_alloc: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    HIP_TRY(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    return VFSMS_OK;
+}
+extern "C" int vfsms_host_free(vfsms_ctx *ctx, void *ptr)
+{
+    CTX_ENTER(ctx);
+    if (!ptr) return VFSMS_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
+    HIP_TRY(hipHostFree(ptr));
     return VFSMS_OK;
 }
 extern "C" int vfsms_tile_wrap(vfsms_ctx *ctx, const void *device_ptr, int h, int w, int stride, int64_t *handle)
 {
     CTX_ENTER(ctx);
     if (!device_ptr || !handle || h <= 0 || w <= 0 || stride < w) { vfsms_set_error("tile_wrap: bad arguments"); return VFSMS_ERR_BAD_ARG; }
-    TileRec t; t.ptr = (uint8_t *)device_ptr; t.h = h; t.w = w; t.stride = stride; t.owned = false;
+    TileRec t; t.ptr = (uint8_t *)device_ptr; t.h = h; t.w = w; t.stride = stride; t.owned = false; t.ready = nullptr; t.pending = false;
     *handle = ctx->next_handle++;
     ctx->tiles[*handle] = t;
     return VFSMS_OK;
@@ -284,8 +335,13 @@ extern "C" int vfsms_tile_free(vfsms_ctx *ctx, int64_t handle)
     CTX_ENTER(ctx);
     auto it = ctx->tiles.find(handle);
     if (it == ctx->tiles.end()) { vfsms_set_error("tile_free: unknown handle"); return VFSMS_ERR_BAD_ARG; }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (it->second.owned) HIP_TRY(hipFree(it->second.ptr));
+    // every entry point is synchronous at return, so no compute work on this tile is in flight; an upload may still be
+    if (it->second.pending) HIP_TRY(hipEventSynchronize(it->second.ready));
+    if (it->second.ready) ctx->event_pool.push_back(it->second.ready);
+    if (it->second.owned) {
+        if (ctx->tile_pool.size() < 256) ctx->tile_pool.push_back(std::make_pair((size_t)it->second.h * it->second.w, it->second.ptr));
+        else { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(it->second.ptr)); }
+    }
     ctx->tiles.erase(it);
     return VFSMS_OK;
 }
@@ -309,7 +365,9 @@ static int upload_array(vfsms_ctx *ctx, const T *src, size_t n, T **d)
 
 // small host->device uploads of launch records through one pinned staging buffer (a pageable hipMemcpyAsync is staged by
 // the runtime and costs a synchronisation each); safe to reuse because every entry point is synchronous at return
-static int upload_pinned(vfsms_ctx *ctx, const void *src, size_t bytes, void **d)
+int ctx_upload_small(vfsms_ctx *ctx, const void *src, size_t bytes, void **d);
+static int upload_pinned(vfsms_ctx *ctx, const void *src, size_t bytes, void **d) { return ctx_upload_small(ctx, src, bytes, d); }
+int ctx_upload_small(vfsms_ctx *ctx, const void *src, size_t bytes, void **d)
 {
     *d = ctx_arena_alloc(ctx, bytes ? bytes : 1);
     if (!*d) { vfsms_set_error("arena exhausted (record upload)"); return VFSMS_ERR_CAPACITY; }
@@ -582,7 +640,10 @@ extern "C" int vfsms_phase_correlate_u8(vfsms_ctx *ctx, const uint8_t *a, const 
 {
     CTX_ENTER(ctx);
     if (!a || !b || !out3 || h <= 0 || w <= 0 || stride_a < w || stride_b < w) { vfsms_set_error("phase: bad arguments"); return VFSMS_ERR_BAD_ARG; }
-    TRY(ctx_arena_reserve(ctx, 2 * (size_t)h * w + phase_bytes(h, w) + 65536));
+    size_t pb = 0;
+    TRY(phase_bytes(ctx, h, w, 1, &pb));
+    TRY(ctx_arena_reserve(ctx, 2 * (size_t)h * w + pb + 65536));
+    ctx->pinned_off = 0;
     uint8_t *da, *db;
     TRY(upload_image(ctx, a, h, w, stride_a, &da));
     TRY(upload_image(ctx, b, h, w, stride_b, &db));
@@ -597,7 +658,8 @@ static int resolve_job(vfsms_ctx *ctx, const vfsms_roi_pair &j, const uint8_t **
 {
     auto ia = ctx->tiles.find(j.tile_a), ib = ctx->tiles.find(j.tile_b);
     if (ia == ctx->tiles.end() || ib == ctx->tiles.end()) { vfsms_set_error("attempt: unknown tile handle"); return VFSMS_ERR_BAD_ARG; }
-    const TileRec &A = ia->second, &B = ib->second;
+    TileRec &A = ia->second, &B = ib->second;
+    TRY(tile_ready(ctx, A)); TRY(tile_ready(ctx, B));
     if (j.h <= 0 || j.w <= 0 || j.ay0 < 0 || j.ax0 < 0 || j.by0 < 0 || j.bx0 < 0 || j.ay0 + j.h > A.h || j.ax0 + j.w > A.w ||
         j.by0 + j.h > B.h || j.bx0 + j.w > B.w) { vfsms_set_error("attempt: ROI outside its tile"); return VFSMS_ERR_BAD_ARG; }
     *pa = A.ptr + (size_t)j.ay0 * A.stride + j.ax0; *sa = A.stride;
@@ -610,19 +672,41 @@ extern "C" int vfsms_attempt_phase_batch(vfsms_ctx *ctx, const vfsms_roi_pair *j
     CTX_ENTER(ctx);
     if (n < 0 || (n && (!jobs || !out))) { vfsms_set_error("attempt_phase: bad arguments"); return VFSMS_ERR_BAD_ARG; }
     if (n == 0) return VFSMS_OK;
+    // attempts of one ROI size (all of them, in practice) run as ONE batched transform; other sizes follow group by group
+    std::vector<int> order(n);
+    for (int k = 0; k < n; k++) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+        return jobs[x].h != jobs[y].h ? jobs[x].h < jobs[y].h : jobs[x].w < jobs[y].w; });
     size_t need = 0;
-    for (int k = 0; k < n; k++) need = std::max(need, phase_bytes(jobs[k].h, jobs[k].w));
-    TRY(ctx_arena_reserve(ctx, need + sizeof(double) * 3 * n + 65536));
-    double *d_out = (double *)ctx_arena_alloc(ctx, sizeof(double) * 3 * n);
-    const size_t mark = ctx->arena_off;
-    for (int k = 0; k < n; k++) {
-        const uint8_t *pa, *pb; int sa, sb;
-        TRY(resolve_job(ctx, jobs[k], &pa, &sa, &pb, &sb));
-        ctx->arena_off = mark;                               // stream order makes scratch reuse safe
-        TRY(phase_correlate_device(ctx, pa, sa, pb, sb, jobs[k].h, jobs[k].w, d_out + 3 * k));
+    for (int g0 = 0; g0 < n;) {
+        int g1 = g0;
+        while (g1 < n && jobs[order[g1]].h == jobs[order[g0]].h && jobs[order[g1]].w == jobs[order[g0]].w) g1++;
+        size_t pb = 0;
+        TRY(phase_bytes(ctx, jobs[order[g0]].h, jobs[order[g0]].w, g1 - g0, &pb));
+        need = std::max(need, pb);
+        g0 = g1;
     }
-    HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(ctx_arena_reserve(ctx, need + sizeof(double) * 3 * n + 65536));
+    ctx->pinned_off = 0;
+    double *d_out = (double *)ctx_arena_alloc(ctx, sizeof(double) * 3 * n);   // in group order; un-permuted on the host
+    const size_t mark = ctx->arena_off;
+    std::vector<PhaseJobHost> pj(n);
+    for (int g0 = 0; g0 < n;) {
+        int g1 = g0;
+        while (g1 < n && jobs[order[g1]].h == jobs[order[g0]].h && jobs[order[g1]].w == jobs[order[g0]].w) g1++;
+        for (int k = g0; k < g1; k++) {
+            const uint8_t *pa, *pb; int sa, sb;
+            TRY(resolve_job(ctx, jobs[order[k]], &pa, &sa, &pb, &sb));
+            pj[k].a = pa; pj[k].b = pb; pj[k].sa = sa; pj[k].sb = sb;
+        }
+        ctx->arena_off = mark;                               // stream order makes scratch reuse safe
+        TRY(phase_correlate_batch_device(ctx, pj.data() + g0, g1 - g0, jobs[order[g0]].h, jobs[order[g0]].w, d_out + 3 * g0));
+        g0 = g1;
+    }
+    std::vector<double> tmp((size_t)3 * n);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), d_out, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < n; k++) for (int c = 0; c < 3; c++) out[3 * order[k] + c] = tmp[3 * k + c];
     return VFSMS_OK;
 }
 
@@ -816,6 +900,7 @@ static int canvas_resident_args(vfsms_ctx *ctx, int64_t canvas, int64_t tile, in
     auto jt = ctx->tiles.find(tile);
     if (it == ctx->canvases.end() || jt == ctx->tiles.end()) { vfsms_set_error("canvas: unknown canvas or tile handle"); return VFSMS_ERR_BAD_ARG; }
     *cv = &it->second; *tr = &jt->second;
+    TRY(tile_ready(ctx, jt->second));
     if ((*cv)->ch != 1 || (*tr)->stride != (*tr)->w) {
         vfsms_set_error("canvas: resident tiles must be single-channel and densely packed (stride == w)"); return VFSMS_ERR_BAD_ARG;
     }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <list>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -108,9 +109,10 @@ struct MatchDev {
 };
 
 // ---- context ------------------------------------------------------------------------------------------
-struct TileRec { uint8_t *ptr; int h, w, stride; bool owned; };
+struct TileRec { uint8_t *ptr; int h, w, stride; bool owned; hipEvent_t ready; bool pending; };   // pending: an async upload the compute stream has not yet waited for
 struct CanvasRec { uint8_t *pix; uint8_t *mask; int rows, cols, ch; int *d_err; };   // d_err: sticky "degenerate fuse geometry" flag for calls made without an info readback
-struct FftPlan { int M, N; void *fwd; void *inv; };   // hipfftHandle stored as void* (int in practice)
+struct FftPlan { int M, N, nb; void *fwd, *inv, *fwd_info, *inv_info; size_t fwd_work, inv_work; };   // rocfft_plan / rocfft_execution_info
+struct PhaseJobHost { const uint8_t *a, *b; int sa, sb; };
 struct ProfRec { int id; hipEvent_t a, b; };
 
 struct vfsms_ctx {
@@ -127,9 +129,12 @@ struct vfsms_ctx {
     SurfTables *d_tables;
     vfsms_orb_params cur_orb; bool orb_valid; OrbTables *d_orb_tables;
     std::unordered_map<int64_t, TileRec> tiles;
+    hipStream_t copy_stream;                                  // H2D uploads of tiles, overlapped with compute (vfsms_tile_upload_async)
+    std::vector<std::pair<size_t, uint8_t *>> tile_pool;      // freed tile buffers, reused by size (no hipMalloc / hipFree per step)
+    std::vector<hipEvent_t> event_pool;
     std::unordered_map<int64_t, CanvasRec> canvases;
     int64_t next_handle;
-    std::vector<FftPlan> plans;
+    std::list<FftPlan> plans;            // list: get_plan hands out stable pointers
     // optional per-stage timing with HIP events on this context's stream (vfsms_profile_*)
     bool prof_on;
     std::vector<ProfRec> prof_recs;
@@ -187,6 +192,9 @@ int launch_hamming_mode(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int c
 // phase_kernels.hip
 int phase_correlate_device(vfsms_ctx *ctx, const uint8_t *a, int stride_a, const uint8_t *b, int stride_b,
                            int h, int w, double *d_out3);
+int phase_correlate_batch_device(vfsms_ctx *ctx, const PhaseJobHost *jobs, int nb, int h, int w, double *d_out3);
+int phase_bytes(vfsms_ctx *ctx, int h, int w, int nb, size_t *bytes);
+int ctx_upload_small(vfsms_ctx *ctx, const void *src, size_t bytes, void **d);   // launch records through the pinned staging buffer
 // fuse_kernels.hip
 int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0,
                        int ry0, int rx0, int ry1, int rx1, int dx, int dy, int32_t *info);

@@ -106,6 +106,7 @@ class GridRegistrar:
             except Exception:
                 if not cap:
                     raise
+                self.capacity_retries = getattr(self, "capacity_retries", 0) + 1      # reported by bench.py
                 self._kp_cap = 0
                 self._kp_seen = 0
                 self.eng.set_keypoint_capacity(0)

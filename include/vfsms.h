@@ -97,6 +97,14 @@ int vfsms_profile_read(vfsms_ctx *ctx, char *names, int names_len, double *ms, i
 
 /* ---- device-resident tiles (grayscale u8, row stride in bytes) ----------------------------------- */
 int vfsms_tile_upload(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int64_t *handle);
+/* the same without waiting for the copy: it runs on the context's copy stream, overlapped with whatever the compute stream is doing,
+ * and the first batch / canvas call that names the tile orders itself behind it (the decode loop of Stitcher.py:68-69 feeding the
+ * GPU while earlier pairs are being registered).  img must stay valid and unchanged until vfsms_ctx_sync or the first synchronous
+ * call that used the tile has returned; copies from pinned memory (vfsms_host_alloc) run at PCIe rate and truly overlap.          */
+int vfsms_tile_upload_async(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int64_t *handle);
+/* pinned host staging memory for tiles (decoders write into it; uploads from it are asynchronous DMA)                          */
+int vfsms_host_alloc(vfsms_ctx *ctx, size_t bytes, void **ptr);
+int vfsms_host_free(vfsms_ctx *ctx, void *ptr);
 /* adopt memory already on this device (e.g. a framework tensor); not freed by vfsms_tile_free     */
 int vfsms_tile_wrap(vfsms_ctx *ctx, const void *device_ptr, int h, int w, int stride, int64_t *handle);
 int vfsms_tile_free(vfsms_ctx *ctx, int64_t handle);

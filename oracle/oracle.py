@@ -31,6 +31,22 @@ KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"),
                      ("response", "f4"), ("octave", "i4"), ("class_id", "i4")])
 
 _lib = None
+_kind = "portable (-O3)"
+
+
+def use_native():
+    """Switch to the -O3 -march=native build, compiled on THIS machine (oracle/Makefile `native`): bench.py's cpu_baseline leg.
+    Same results bit for bit (no fast-math, no FMA contraction)."""
+    global _lib, _SO, _kind
+    subprocess.check_call(["make", "-C", _HERE, "-s", "native"])
+    _SO = os.path.join(_HERE, "_build", "libvfsms_oracle_native.so")
+    _kind = "native (-O3 -march=native)"
+    _lib = None
+    return lib()
+
+
+def build_kind():
+    return _kind
 
 
 def lib():
