@@ -81,6 +81,14 @@ _SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     "vfsms_attempt_surf_batch": (C.c_int, [C.c_void_p, C.POINTER(RoiPair), C.c_int, C.POINTER(SurfParams), C.c_double,
                                            C.c_int, C.c_void_p]),
+    "vfsms_attempt_surf_batch_enhanced": (C.c_int, [C.c_void_p, C.POINTER(RoiPair), C.c_int, C.POINTER(SurfParams), C.c_double,
+                                                    C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]),
+    "vfsms_features_surf": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(SurfParams), C.c_int, C.c_double,
+                                      C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "vfsms_features_match_offset": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_int, C.c_void_p]),
+    "vfsms_features_download": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vfsms_features_free": (C.c_int, [C.c_void_p, C.c_int64]),
+    "vfsms_enhance_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]),
     "vfsms_attempt_phase_batch": (C.c_int, [C.c_void_p, C.POINTER(RoiPair), C.c_int, C.c_void_p]),
     "vfsms_canvas_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "vfsms_canvas_free": (C.c_int, [C.c_void_p, C.c_int64]),
@@ -378,6 +386,52 @@ class Engine:
         arr = jobs if isinstance(jobs, C.Array) else self.make_jobs(jobs)
         params = params or self.surf_params()
         self._check(self.lib.vfsms_attempt_surf_batch(self.ctx, arr, n, C.byref(params), float(ratio), int(offset_evaluate), _ptr(out)))
+        return out
+
+    def attempt_surf_batch_enhanced(self, jobs, params=None, ratio=0.75, offset_evaluate=3, enhance=(0, 0.0, 0)):
+        """attempt_surf_batch with every ROI strip equalised (enhance = (1, 0, 0)) or CLAHE'd (enhance = (2, clipLimit, tileSize))
+        first, as Stitcher.py:327-334 does when Method.isEnhance is set."""
+        n = len(jobs)
+        out = np.zeros((n, ATTEMPT_INTS), np.int32)
+        if n == 0:
+            return out
+        arr = jobs if isinstance(jobs, C.Array) else self.make_jobs(jobs)
+        params = params or self.surf_params()
+        self._check(self.lib.vfsms_attempt_surf_batch_enhanced(self.ctx, arr, n, C.byref(params), float(ratio), int(offset_evaluate),
+                                                               int(enhance[0]), float(enhance[1]), int(enhance[2]), _ptr(out)))
+        return out
+
+    # -- resident feature sets (Stitcher.tempImageFeature's payload kept in HBM) -----------------------------------------------
+    def features_surf(self, tile_handle, rect, params=None, enhance=(0, 0.0, 0)):
+        """SURF of rect = (y0, x0, h, w) of a resident tile -> (feature handle, n keypoints); nothing returns to the host."""
+        params = params or self.surf_params()
+        f, n = C.c_int64(), C.c_int()
+        y0, x0, h, w = [int(v) for v in rect]
+        self._check(self.lib.vfsms_features_surf(self.ctx, C.c_int64(tile_handle), y0, x0, h, w, C.byref(params), int(enhance[0]),
+                                                 float(enhance[1]), int(enhance[2]), C.byref(f), C.byref(n)))
+        return f.value, n.value
+
+    def features_match_offset(self, feat_a, feat_b, ratio=0.75, offset_evaluate=3):
+        """matchDescriptors + getOffsetByMode on two resident sets -> int32[8] = status, dx, dy, votes, nA, nB, nMatches, 0."""
+        out = np.zeros(ATTEMPT_INTS, np.int32)
+        self._check(self.lib.vfsms_features_match_offset(self.ctx, C.c_int64(feat_a), C.c_int64(feat_b), float(ratio), int(offset_evaluate), _ptr(out)))
+        return out
+
+    def features_download(self, feat, n, dim=64):
+        kxy = np.empty((max(n, 1), 2), np.float32); desc = np.empty((max(n, 1), dim), np.float32)
+        nn, dd = C.c_int(), C.c_int()
+        self._check(self.lib.vfsms_features_download(self.ctx, C.c_int64(feat), _ptr(kxy), _ptr(desc), max(n, 1), C.byref(nn), C.byref(dd)))
+        return kxy[:nn.value].copy(), desc[:nn.value].copy()
+
+    def features_free(self, feat):
+        self._check(self.lib.vfsms_features_free(self.ctx, C.c_int64(feat)))
+
+    def enhance(self, img, mode, clip_limit=20.0, tile_size=5):
+        """mode 1: cv2.equalizeHist(img); mode 2: cv2.createCLAHE(clip_limit, (tile_size, tile_size)).apply(img)."""
+        img = _u8_2d(img)
+        out = np.empty(img.shape, np.uint8)
+        self._check(self.lib.vfsms_enhance_u8(self.ctx, _ptr(img), img.shape[0], img.shape[1], img.strides[0], int(mode), float(clip_limit),
+                                              int(tile_size), _ptr(out)))
         return out
 
     def attempt_phase_batch(self, jobs):

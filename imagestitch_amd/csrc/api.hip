@@ -228,6 +228,7 @@ extern "C" int vfsms_ctx_destroy(vfsms_ctx *ctx)
     for (hipEvent_t ev : ctx->event_pool) hipEventDestroy(ev);
     hipStreamDestroy(ctx->copy_stream);
     for (auto &kv : ctx->canvases) { hipFree(kv.second.pix); hipFree(kv.second.mask); }
+    for (auto &kv : ctx->feats) { if (kv.second.kps_xy) hipFree(kv.second.kps_xy); if (kv.second.desc) hipFree(kv.second.desc); }
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->d_layers) hipFree(ctx->d_layers);
@@ -711,8 +712,8 @@ extern "C" int vfsms_attempt_phase_batch(vfsms_ctx *ctx, const vfsms_roi_pair *j
 }
 
 // ---- fused SURF + BF + ratio + mode attempts --------------------------------------------------------------------------------
-extern "C" int vfsms_attempt_surf_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n,
-                                        const vfsms_surf_params *params, double ratio, int offset_evaluate, int32_t *out)
+static int attempt_surf_impl(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, const vfsms_surf_params *params, double ratio,
+                             int offset_evaluate, int enh_mode, double clip_limit, int tile_grid, int32_t *out)
 {
     CTX_ENTER(ctx);
     if (n < 0 || (n && (!jobs || !out)) || !params) { vfsms_set_error("attempt_surf: bad arguments"); return VFSMS_ERR_BAD_ARG; }
@@ -734,8 +735,11 @@ extern "C" int vfsms_attempt_surf_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jo
         need += 2 * surf_roi_bytes(jobs[k].h, jobs[k].w, caps[k], ctx->n_layers, params->n_octaves, dim) + match_bytes(caps[k], ns) +
                 (filtered ? match_filter_bytes(caps[k], cns) : 0);
     need += (sizeof(RoiDev) * 2 + sizeof(MatchDev)) * n + 64 * 3 * n + 65536;
+    if (enh_mode) for (int k = 0; k < n; k++) need += 2 * enhance_scratch_bytes(jobs[k].h, jobs[k].w, enh_mode, tile_grid) + 2 * sizeof(EnhJob) + 512;
     TRY(ctx_arena_reserve(ctx, need));
+    ctx->pinned_off = 0;
     std::vector<RoiDev> R(2 * n);
+    std::vector<EnhJob> E(enh_mode ? 2 * n : 0);
     std::vector<MatchDev> M(n);
     // counters of all ROIs and results of all jobs live in two contiguous blocks: one memset, two D2H copies per batch
     int *cblock = (int *)ctx_arena_alloc(ctx, sizeof(int) * 16 * 2 * n);
@@ -743,6 +747,11 @@ extern "C" int vfsms_attempt_surf_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jo
     for (int k = 0; k < n; k++) {
         const uint8_t *pa, *pb; int sa, sb;
         TRY(resolve_job(ctx, jobs[k], &pa, &sa, &pb, &sb));
+        if (enh_mode) {            // Stitcher.py:327-334: the ROI strips are equalised / CLAHE'd before detectAndDescribe
+            TRY(enhance_carve(ctx, &E[2 * k], pa, sa, jobs[k].h, jobs[k].w, enh_mode, tile_grid));
+            TRY(enhance_carve(ctx, &E[2 * k + 1], pb, sb, jobs[k].h, jobs[k].w, enh_mode, tile_grid));
+            pa = E[2 * k].dst; sa = jobs[k].w; pb = E[2 * k + 1].dst; sb = jobs[k].w;
+        }
         TRY(surf_roi_carve(ctx, &R[2 * k], pa, sa, jobs[k].h, jobs[k].w, caps[k], params));
         TRY(surf_roi_carve(ctx, &R[2 * k + 1], pb, sb, jobs[k].h, jobs[k].w, caps[k], params));
         R[2 * k].counters = cblock + 16 * (2 * k); R[2 * k + 1].counters = cblock + 16 * (2 * k + 1);
@@ -754,10 +763,14 @@ extern "C" int vfsms_attempt_surf_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jo
         M[k].nq_ptr = R[2 * k].counters + 1; M[k].nt_ptr = R[2 * k + 1].counters + 1;
         M[k].kq = R[2 * k].kps_xy; M[k].kt = R[2 * k + 1].kps_xy;
     }
-    ctx->pinned_off = 0;
     RoiDev *dR; MatchDev *dM;
     TRY(upload_pinned(ctx, R.data(), sizeof(RoiDev) * 2 * n, (void **)&dR));
     TRY(upload_pinned(ctx, M.data(), sizeof(MatchDev) * n, (void **)&dM));
+    if (enh_mode) {
+        EnhJob *dE;
+        TRY(upload_pinned(ctx, E.data(), sizeof(EnhJob) * 2 * n, (void **)&dE));
+        TRY(launch_enhance(ctx, dE, E.data(), 2 * n, enh_mode, clip_limit, tile_grid));
+    }
     HIP_TRY(hipMemsetAsync(cblock, 0, sizeof(int) * 16 * 2 * n, ctx->stream));
     TRY(launch_surf_detect(ctx, dR, R.data(), 2 * n, params));
     TRY(launch_surf_describe(ctx, dR, R.data(), 2 * n, params));
@@ -773,6 +786,153 @@ extern "C" int vfsms_attempt_surf_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jo
             vfsms_set_error("attempt_surf: ROI %d exceeded %d keypoint candidates (vfsms_ctx_set_keypoint_capacity)", k, R[k].cap);
             return VFSMS_ERR_CAPACITY;
         }
+    return VFSMS_OK;
+}
+
+extern "C" int vfsms_attempt_surf_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n,
+                                        const vfsms_surf_params *params, double ratio, int offset_evaluate, int32_t *out)
+{
+    return attempt_surf_impl(ctx, jobs, n, params, ratio, offset_evaluate, 0, 0.0, 0, out);
+}
+extern "C" int vfsms_attempt_surf_batch_enhanced(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, const vfsms_surf_params *params,
+                                                 double ratio, int offset_evaluate, int enhance_mode, double clip_limit, int tile_grid,
+                                                 int32_t *out)
+{
+    if (enhance_mode < 0 || enhance_mode > 2) { vfsms_set_error("attempt_surf: enhance_mode must be 0, 1 or 2"); return VFSMS_ERR_BAD_ARG; }
+    return attempt_surf_impl(ctx, jobs, n, params, ratio, offset_evaluate, enhance_mode, clip_limit, tile_grid, out);
+}
+
+// ---- enhancement (host buffers) ---------------------------------------------------------------------------------------------------
+extern "C" int vfsms_enhance_u8(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int mode, double clip_limit, int tile_grid,
+                                uint8_t *out)
+{
+    CTX_ENTER(ctx);
+    if (!img || !out || h <= 0 || w <= 0 || stride < w || mode < 1 || mode > 2) { vfsms_set_error("enhance: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    TRY(ctx_arena_reserve(ctx, (size_t)h * w + enhance_scratch_bytes(h, w, mode, tile_grid) + 65536));
+    ctx->pinned_off = 0;
+    uint8_t *d_img;
+    TRY(upload_image(ctx, img, h, w, stride, &d_img));
+    EnhJob J, *dJ;
+    TRY(enhance_carve(ctx, &J, d_img, w, h, w, mode, tile_grid));
+    TRY(upload_pinned(ctx, &J, sizeof(J), (void **)&dJ));
+    TRY(launch_enhance(ctx, dJ, &J, 1, mode, clip_limit, tile_grid));
+    HIP_TRY(hipMemcpyAsync(out, J.dst, (size_t)h * w, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VFSMS_OK;
+}
+
+// ---- device-resident feature sets: the payload of Stitcher.tempImageFeature (Stitcher.py:14-18, 278-290) -----------------------------
+extern "C" int vfsms_features_surf(vfsms_ctx *ctx, int64_t tile, int y0, int x0, int h, int w, const vfsms_surf_params *params,
+                                   int enhance_mode, double clip_limit, int tile_grid, int64_t *feat, int *n_out)
+{
+    CTX_ENTER(ctx);
+    auto it = ctx->tiles.find(tile);
+    if (it == ctx->tiles.end() || !params || !feat || !n_out) { vfsms_set_error("features_surf: bad arguments / unknown tile"); return VFSMS_ERR_BAD_ARG; }
+    TileRec &T = it->second;
+    TRY(tile_ready(ctx, T));
+    if (h <= 0 || w <= 0 || y0 < 0 || x0 < 0 || y0 + h > T.h || x0 + w > T.w) { vfsms_set_error("features_surf: ROI outside the tile"); return VFSMS_ERR_BAD_ARG; }
+    if (enhance_mode < 0 || enhance_mode > 2) { vfsms_set_error("features_surf: enhance_mode must be 0, 1 or 2"); return VFSMS_ERR_BAD_ARG; }
+    TRY(ctx_prepare_surf(ctx, params));
+    const int dim = params->extended ? 128 : 64;
+    const int dcap = kp_capacity(ctx, h, w);
+    TRY(ctx_arena_reserve(ctx, surf_roi_bytes(h, w, dcap, ctx->n_layers, params->n_octaves, dim) +
+                               (enhance_mode ? enhance_scratch_bytes(h, w, enhance_mode, tile_grid) : 0) + 65536));
+    ctx->pinned_off = 0;
+    const uint8_t *src = T.ptr + (size_t)y0 * T.stride + x0;
+    int sstride = T.stride;
+    if (enhance_mode) {
+        EnhJob J, *dJ;
+        TRY(enhance_carve(ctx, &J, src, sstride, h, w, enhance_mode, tile_grid));
+        TRY(upload_pinned(ctx, &J, sizeof(J), (void **)&dJ));
+        TRY(launch_enhance(ctx, dJ, &J, 1, enhance_mode, clip_limit, tile_grid));
+        src = J.dst; sstride = w;
+    }
+    RoiDev R, *d_R;
+    TRY(surf_roi_carve(ctx, &R, src, sstride, h, w, dcap, params));
+    TRY(upload_pinned(ctx, &R, sizeof(R), (void **)&d_R));
+    HIP_TRY(hipMemsetAsync(R.counters, 0, 16 * sizeof(int), ctx->stream));
+    TRY(launch_surf_detect(ctx, d_R, &R, 1, params));
+    TRY(launch_surf_describe(ctx, d_R, &R, 1, params));
+    int counters[16];
+    HIP_TRY(hipMemcpyAsync(counters, R.counters, sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (counters[2] || counters[0] > dcap) {
+        vfsms_set_error("features_surf: more than %d keypoint candidates (raise with vfsms_ctx_set_keypoint_capacity)", dcap);
+        return VFSMS_ERR_CAPACITY;
+    }
+    FeatRec F; F.n = counters[1]; F.dim = dim; F.is_orb = 0; F.kps_xy = nullptr; F.desc = nullptr;
+    if (F.n > 0) {
+        HIP_TRY(hipMalloc((void **)&F.kps_xy, sizeof(float) * 2 * F.n));
+        HIP_TRY(hipMalloc(&F.desc, sizeof(float) * (size_t)F.n * dim));
+        HIP_TRY(hipMemcpyAsync(F.kps_xy, R.kps_xy, sizeof(float) * 2 * F.n, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(F.desc, R.desc, sizeof(float) * (size_t)F.n * dim, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    *feat = ctx->next_handle++;
+    ctx->feats[*feat] = F;
+    *n_out = F.n;
+    return VFSMS_OK;
+}
+
+extern "C" int vfsms_features_free(vfsms_ctx *ctx, int64_t feat)
+{
+    CTX_ENTER(ctx);
+    auto it = ctx->feats.find(feat);
+    if (it == ctx->feats.end()) { vfsms_set_error("features_free: unknown handle"); return VFSMS_ERR_BAD_ARG; }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (it->second.kps_xy) HIP_TRY(hipFree(it->second.kps_xy));
+    if (it->second.desc) HIP_TRY(hipFree(it->second.desc));
+    ctx->feats.erase(it);
+    return VFSMS_OK;
+}
+
+extern "C" int vfsms_features_download(vfsms_ctx *ctx, int64_t feat, float *kps_xy, float *desc, int cap, int *n_out, int *dim_out)
+{
+    CTX_ENTER(ctx);
+    auto it = ctx->feats.find(feat);
+    if (it == ctx->feats.end() || !n_out) { vfsms_set_error("features_download: unknown handle"); return VFSMS_ERR_BAD_ARG; }
+    const FeatRec &F = it->second;
+    *n_out = F.n;
+    if (dim_out) *dim_out = F.dim;
+    if (F.n > cap) { vfsms_set_error("features_download: %d keypoints exceed the caller's capacity %d", F.n, cap); return VFSMS_ERR_CAPACITY; }
+    if (F.n > 0) {
+        if (kps_xy) HIP_TRY(hipMemcpyAsync(kps_xy, F.kps_xy, sizeof(float) * 2 * F.n, hipMemcpyDeviceToHost, ctx->stream));
+        if (desc) HIP_TRY(hipMemcpyAsync(desc, F.desc, sizeof(float) * (size_t)F.n * F.dim, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return VFSMS_OK;
+}
+
+// matchDescriptors + getOffsetByMode on two resident sets (query = A, train = B): out[8] as in vfsms_attempt_surf_batch
+extern "C" int vfsms_features_match_offset(vfsms_ctx *ctx, int64_t feat_a, int64_t feat_b, double ratio, int offset_evaluate, int32_t *out)
+{
+    CTX_ENTER(ctx);
+    auto ia = ctx->feats.find(feat_a), ib = ctx->feats.find(feat_b);
+    if (ia == ctx->feats.end() || ib == ctx->feats.end() || !out) { vfsms_set_error("features_match: unknown handle"); return VFSMS_ERR_BAD_ARG; }
+    const FeatRec &A = ia->second, &B = ib->second;
+    if (A.dim != B.dim || A.is_orb != B.is_orb) { vfsms_set_error("features_match: descriptor kinds differ"); return VFSMS_ERR_BAD_ARG; }
+    for (int k = 0; k < VFSMS_ATTEMPT_INTS; k++) out[k] = 0;
+    out[4] = A.n; out[5] = B.n;
+    if (A.n == 0 || B.n == 0) return VFSMS_OK;
+    const int dim = A.dim, capq = A.n;
+    const bool filtered = dim == 64 && !bf_force_exact();          // SURF descriptors are L2-normalised by construction
+    const int cns = pick_filter_nsplit(A.n, 1);
+    const int ns = filtered ? 1 : pick_nsplit(A.n, B.n, 1, dim);
+    TRY(ctx_arena_reserve(ctx, match_bytes(capq, ns) + (filtered ? match_filter_bytes(capq, cns) : 0) + 65536));
+    ctx->pinned_off = 0;
+    MatchDev M; memset(&M, 0, sizeof(M));
+    TRY(match_carve(ctx, &M, capq, dim, ns));
+    if (filtered) TRY(match_filter_carve(ctx, &M, capq, cns));
+    int cnt[2] = {A.n, B.n}; int *dcnt;
+    TRY(upload_pinned(ctx, cnt, sizeof(cnt), (void **)&dcnt));
+    M.q = (const float *)A.desc; M.t = (const float *)B.desc; M.kq = A.kps_xy; M.kt = B.kps_xy; M.nq_ptr = dcnt; M.nt_ptr = dcnt + 1;
+    MatchDev *dM;
+    TRY(upload_pinned(ctx, &M, sizeof(M), (void **)&dM));
+    if (filtered) { TRY(launch_bf_l2_filtered(ctx, dM, 1, capq, cns)); }
+    else { TRY(launch_bf_l2(ctx, dM, 1, capq, ns, dim)); }
+    TRY(launch_ratio_mode(ctx, dM, 1, capq, ratio, offset_evaluate));
+    HIP_TRY(hipMemcpyAsync(out, M.result, sizeof(int32_t) * VFSMS_ATTEMPT_INTS, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return VFSMS_OK;
 }
 

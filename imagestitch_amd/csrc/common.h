@@ -87,6 +87,12 @@ struct OrbDev {
 };
 struct OrbTables { int nfeat[VFSMS_ORB_MAX_LEVELS]; int umax[34]; int half_patch; int patch_size; int kf[7]; int pattern[1024]; };
 
+// ---- one image of an enhancement batch (equalizeHist / CLAHE before detectAndDescribe) --------------------------------------
+struct EnhJob { const uint8_t *src; int stride, h, w, eh, ew; uint8_t *dst; int *hist; uint8_t *lut; };   // eh, ew: size extended to the CLAHE grid
+
+// ---- device-resident feature set (keypoints + descriptors of one image; Stitcher.tempImageFeature's payload) ---------------
+struct FeatRec { float *kps_xy; void *desc; int n, dim, is_orb; };
+
 // ---- one (query ROI, train ROI) matching job --------------------------------------------------------
 struct MatchDev {
     const float *q; const float *t;   // descriptors
@@ -133,6 +139,7 @@ struct vfsms_ctx {
     std::vector<std::pair<size_t, uint8_t *>> tile_pool;      // freed tile buffers, reused by size (no hipMalloc / hipFree per step)
     std::vector<hipEvent_t> event_pool;
     std::unordered_map<int64_t, CanvasRec> canvases;
+    std::unordered_map<int64_t, FeatRec> feats;
     int64_t next_handle;
     std::list<FftPlan> plans;            // list: get_plan hands out stable pointers
     // optional per-stage timing with HIP events on this context's stream (vfsms_profile_*)
@@ -195,6 +202,10 @@ int phase_correlate_device(vfsms_ctx *ctx, const uint8_t *a, int stride_a, const
 int phase_correlate_batch_device(vfsms_ctx *ctx, const PhaseJobHost *jobs, int nb, int h, int w, double *d_out3);
 int phase_bytes(vfsms_ctx *ctx, int h, int w, int nb, size_t *bytes);
 int ctx_upload_small(vfsms_ctx *ctx, const void *src, size_t bytes, void **d);   // launch records through the pinned staging buffer
+// enhance_kernels.hip
+size_t enhance_scratch_bytes(int h, int w, int mode, int tiles);
+int enhance_carve(vfsms_ctx *ctx, EnhJob *J, const uint8_t *src, int stride, int h, int w, int mode, int tiles);
+int launch_enhance(vfsms_ctx *ctx, const EnhJob *d_jobs, const EnhJob *h_jobs, int n, int mode, double clip_limit, int tiles);
 // fuse_kernels.hip
 int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0,
                        int ry0, int rx0, int ry1, int rx1, int dx, int dy, int32_t *info);

@@ -33,7 +33,7 @@ def _rotate(direction, incre):
 
 class GridRegistrar:
     def __init__(self, engine, method="surf", roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3, directIncre=1,
-                 surfParams=None, phaseResponseThreshold=0.15, window=16):
+                 surfParams=None, phaseResponseThreshold=0.15, window=16, enhance=(0, 0.0, 0)):
         self.eng = engine
         self.method = method
         self.roiRatio = roiRatio
@@ -43,6 +43,7 @@ class GridRegistrar:
         self.params = surfParams
         self.phaseThr = phaseResponseThreshold
         self.window = max(1, int(window))
+        self.enhance = tuple(enhance)                     # (mode, clipLimit, tileSize) of Method.isEnhance (Stitcher.py:327-334)
         self.stats = dict(attempts=0, batches=0, sum_nq_nt=0, sum_nq_plus_nt=0, sum_nq=0, roi_px=0)
 
     # -- candidate order of Stitcher.py:319-351 --------------------------------------------------------------
@@ -102,7 +103,7 @@ class GridRegistrar:
             if adaptive and cap:
                 self.eng.set_keypoint_capacity(cap)
             try:
-                rows = self.eng.attempt_surf_batch(jobs, self.params, self.searchRatio, self.offsetEvaluate)
+                rows = self._surf_call(jobs)
             except Exception:
                 if not cap:
                     raise
@@ -110,7 +111,7 @@ class GridRegistrar:
                 self._kp_cap = 0
                 self._kp_seen = 0
                 self.eng.set_keypoint_capacity(0)
-                rows = self.eng.attempt_surf_batch(jobs, self.params, self.searchRatio, self.offsetEvaluate)
+                rows = self._surf_call(jobs)
         finally:
             if adaptive and cap:
                 self.eng.set_keypoint_capacity(0)
@@ -122,6 +123,11 @@ class GridRegistrar:
             if seen > 0 and want != cap and (cap == 0 or want > cap or want < cap * 0.6):
                 self._kp_cap = want
         return rows
+
+    def _surf_call(self, jobs):
+        if self.enhance[0]:
+            return self.eng.attempt_surf_batch_enhanced(jobs, self.params, self.searchRatio, self.offsetEvaluate, self.enhance)
+        return self.eng.attempt_surf_batch(jobs, self.params, self.searchRatio, self.offsetEvaluate)
 
     def _correct(self, raw, d, i, shapeA, shapeB):
         """Stitcher.py:352-360: ROI-relative vote -> full-tile offset."""

@@ -28,6 +28,38 @@ class ImageFeature():
     feature = None
 
 
+class ResidentFeatures:
+    """What Stitcher.tempImageFeature holds when the stock operators run: the keypoints + descriptors of a tile stay in HBM under
+    an engine handle (vfsms_features_*); `kps` and `feature` of the cache point at this object, which downloads the arrays only if
+    somebody actually reads them (np.asarray(obj.kps) / obj.descriptors())."""
+
+    def __init__(self, engine, handle, n, dim):
+        self.engine, self.handle, self.n, self.dim = engine, handle, n, dim
+        self._host = None
+
+    def __len__(self):
+        return self.n
+
+    def arrays(self):
+        if self._host is None:
+            self._host = self.engine.features_download(self.handle, self.n, self.dim)
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        return self.arrays()[0]
+
+    def descriptors(self):
+        return self.arrays()[1]
+
+    def release(self):
+        if self.handle is not None:
+            try:
+                self.engine.features_free(self.handle)
+            except Exception:
+                pass
+            self.handle = None
+
+
 def _imread(path, color):
     """cv2.imdecode(np.fromfile(path), IMREAD_COLOR | IMREAD_GRAYSCALE) stand-in (Stitcher.py:68-69,382-384).
     Grayscale asks libjpeg for the luma plane directly like OpenCV does; colour is BGR."""
@@ -153,7 +185,8 @@ class Stitcher(Utility.Method):
         params = None if method == "phase" else (self._orbParams() if method == "orb" else self._surfParams())
         reg = GridRegistrar(eng, method=method, roiRatio=self.roiRatio, searchRatio=self.searchRatio, offsetEvaluate=self.offsetEvaluate,
                             directIncre=self.directIncre, surfParams=params,
-                            phaseResponseThreshold=self.phaseResponseThreshold, window=24)
+                            phaseResponseThreshold=self.phaseResponseThreshold, window=24,
+                            enhance=self._enhanceSpec() if method == "surf" else (0, 0.0, 0))
         reg.orbMaxDistance = self.orbMaxDistance if self.isGPUAvailable else -1
         handles = [eng.tile_upload(im) for im in images]
         keep = (not self.isColorMode) and self.fuseMethod in ("notFuse", "fadeInAndFadeOut") and hasattr(eng, "canvas_fuse_tile_resident")
@@ -278,12 +311,29 @@ class Stitcher(Utility.Method):
                 self.engine.tile_free(h)
             except Exception:
                 pass
+        if isinstance(self.tempImageFeature.feature, ResidentFeatures):
+            # the device copy goes with the tiles; the cache keeps the (downloaded) arrays so that it still reads like the reference's
+            rf = self.tempImageFeature.feature
+            if rf.handle is not None:
+                kps, desc = rf.arrays()
+                rf.release()
+                self.tempImageFeature.kps, self.tempImageFeature.feature = kps, desc
 
     def _usesStockOperators(self):
         c = type(self)
         return (c.detectAndDescribe is Utility.Method.detectAndDescribe and c.matchDescriptors is Utility.Method.matchDescriptors
-                and c.getOffsetByMode is Utility.Method.getOffsetByMode and not self.isEnhance
+                and c.getOffsetByMode is Utility.Method.getOffsetByMode and (not self.isEnhance or self.featureMethod == "surf")
                 and self.featureMethod in ("surf", "orb") and self.offsetCaculate == "mode")
+
+    def _enhanceSpec(self):
+        """(mode, clipLimit, tileSize) of Stitcher.py:269-276 / 327-334: 0 none, 1 cv2.equalizeHist, 2 cv2.createCLAHE(...).apply."""
+        if not self.isEnhance:
+            return (0, 0.0, 0)
+        return (2, float(self.clipLimit), int(self.tileSize)) if self.isClahe else (1, 0.0, 0)
+
+    def _enhance(self, image):
+        mode, clip, tiles = self._enhanceSpec()
+        return image if mode == 0 else self.engine.enhance(np.asarray(image), mode, clip, tiles)
 
     def _featureAttempt(self, imageA, imageB, direction, searchRatio):
         """One pass of the loop body at Stitcher.py:322-345 -> (status, [dx, dy]) or None when an image has no features."""
@@ -296,6 +346,8 @@ class Stitcher(Utility.Method):
                 if self.featureMethod == "orb":
                     max_dist = self.orbMaxDistance if self.isGPUAvailable else -1
                     row = self.engine.attempt_orb_batch([job], self._orbParams(), max_dist, self.offsetEvaluate)[0]
+                elif self.isEnhance:
+                    row = self.engine.attempt_surf_batch_enhanced([job], self._surfParams(), self.searchRatio, self.offsetEvaluate, self._enhanceSpec())[0]
                 else:
                     row = self.engine.attempt_surf_batch([job], self._surfParams(), self.searchRatio, self.offsetEvaluate)[0]
                 if row[4] == 0 or row[5] == 0:
@@ -303,8 +355,9 @@ class Stitcher(Utility.Method):
                 return (bool(row[0]), [int(row[1]), int(row[2])])
         roiImageA = self.getROIRegionForIncreMethod(imageA, direction=direction, order="first", searchRatio=searchRatio)
         roiImageB = self.getROIRegionForIncreMethod(imageB, direction=direction, order="second", searchRatio=searchRatio)
-        if self.isEnhance:
-            raise NotImplementedError("isEnhance (CLAHE / equalizeHist, Stitcher.py:327-334) is outside the hot-path scope")
+        if self.isEnhance:                                     # Stitcher.py:327-334
+            roiImageA = self._enhance(roiImageA)
+            roiImageB = self._enhance(roiImageB)
         kpsA, featuresA = self.detectAndDescribe(roiImageA, featureMethod=self.featureMethod)
         kpsB, featuresB = self.detectAndDescribe(roiImageB, featureMethod=self.featureMethod)
         if featuresA is not None and featuresB is not None:
@@ -373,8 +426,11 @@ class Stitcher(Utility.Method):
         (imageA, imageB) = images
         offset = [0, 0]
         status = False
-        if self.isEnhance == True:
-            raise NotImplementedError("isEnhance (CLAHE / equalizeHist, Stitcher.py:269-276) is outside the hot-path scope")
+        if self._usesStockOperators() and self.featureMethod == "surf" and hasattr(self.engine, "features_surf"):
+            return self._featureSearchResident(imageA, imageB)
+        if self.isEnhance == True:                              # Stitcher.py:269-276
+            imageA = self._enhance(imageA)
+            imageB = self._enhance(imageB)
         if self.tempImageFeature.isBreak == True:
             (kpsA, featuresA) = self.detectAndDescribe(imageA, featureMethod=self.featureMethod)
             (kpsB, featuresB) = self.detectAndDescribe(imageB, featureMethod=self.featureMethod)
@@ -395,6 +451,46 @@ class Stitcher(Utility.Method):
             self.tempImageFeature.isBreak = True
             return (status, CANNOT_MATCH)
         self.tempImageFeature.isBreak = False
+        self.printAndWrite("  The offset of stitching: dx is " + str(offset[0]) + " dy is " + str(offset[1]))
+        return (status, offset)
+
+    def _featureSearchResident(self, imageA, imageB):
+        """calculateOffsetForFeatureSearch with the stock SURF operators, device resident: tile B's keypoints + descriptors stay in
+        HBM and become tile A's of the next pair (Stitcher.py:278-290), the optional enhancement (Stitcher.py:269-276) runs on the
+        device in front of the detector, and matching + mode vote read both sets where they are -- eight ints return per pair."""
+        eng = self.engine
+        tf = self.tempImageFeature
+        params, enh = self._surfParams(), self._enhanceSpec()
+        dim = 128 if params.extended else 64
+
+        def describe(image):
+            (h,) = self._tileHandles([image])
+            f, n = eng.features_surf(h, (0, 0, image.shape[0], image.shape[1]), params, enh)
+            return ResidentFeatures(eng, f, n, dim)
+        prev = tf.feature if isinstance(tf.feature, ResidentFeatures) and tf.feature.handle is not None else None
+        if tf.isBreak == True or prev is None:
+            if prev is not None:
+                prev.release()
+            featA = describe(imageA)
+        else:
+            featA = prev
+        featB = describe(imageB)
+        tf.isBreak = False
+        tf.kps = featB if featB.n else np.float32([])
+        tf.feature = featB if featB.n else None            # cv2 returns (kps, None) for an image without keypoints
+        status, offset = False, [0, 0]
+        try:
+            if featA.n and featB.n:
+                row = eng.features_match_offset(featA.handle, featB.handle, self.searchRatio, self.offsetEvaluate)
+                status, offset = bool(row[0]), [int(row[1]), int(row[2])]
+        finally:
+            featA.release()                                     # A's set is never needed again (B's lives on in the cache)
+            if not featB.n:
+                featB.release()
+        if status == False:
+            tf.isBreak = True
+            return (status, CANNOT_MATCH)
+        tf.isBreak = False
         self.printAndWrite("  The offset of stitching: dx is " + str(offset[0]) + " dy is " + str(offset[1]))
         return (status, offset)
 

@@ -174,11 +174,31 @@ int vfsms_fuse_ramps_i64(vfsms_ctx *ctx, const int64_t *A, int r, int c, int ch,
 int vfsms_attempt_surf_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n,
                              const vfsms_surf_params *params, double ratio, int offset_evaluate,
                              int32_t *out);
+/* the same with the reference's pre-enhancement of every ROI strip (Method.isEnhance, Stitcher.py:327-334):
+ * enhance_mode 1 = cv2.equalizeHist, 2 = cv2.createCLAHE(clip_limit, (tile_grid, tile_grid)).apply, 0 = none                  */
+int vfsms_attempt_surf_batch_enhanced(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, const vfsms_surf_params *params,
+                                      double ratio, int offset_evaluate, int enhance_mode, double clip_limit, int tile_grid,
+                                      int32_t *out);
 /* same with ORB + BF-Hamming 1-NN (max_dist < 0: no distance threshold, the cv2 path; else distance < max_dist, the DLL path) */
 int vfsms_attempt_orb_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n,
                             const vfsms_orb_params *params, int max_dist, int offset_evaluate, int32_t *out);
 /* same for phase correlation (Stitcher.py:224-235): out: double[n][3] = {x, y, response}           */
 int vfsms_attempt_phase_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, double *out);
+
+/* ---- whole-tile feature search with the reference's feature cache (Stitcher.calculateOffsetForFeatureSearch, Stitcher.py:260-304) --
+ * Stitcher.tempImageFeature (Stitcher.py:14-18,278-290) keeps tile B's keypoints + descriptors so that they become tile A's of the
+ * next pair; here that payload stays in HBM under a handle: SURF (+ optional enhancement, Stitcher.py:269-276) of a rectangle of a
+ * resident tile -> feature handle; two handles -> BF-L2 2-NN + ratio + mode vote, only out[8] = {status, dx, dy, votes, nA, nB,
+ * nMatches, 0} returns to the host.  vfsms_features_download gives the arrays Method.detectAndDescribe would have returned.      */
+int vfsms_features_surf(vfsms_ctx *ctx, int64_t tile, int y0, int x0, int h, int w, const vfsms_surf_params *params,
+                        int enhance_mode, double clip_limit, int tile_grid, int64_t *feat, int *n_out);
+int vfsms_features_match_offset(vfsms_ctx *ctx, int64_t feat_a, int64_t feat_b, double ratio, int offset_evaluate, int32_t *out);
+int vfsms_features_download(vfsms_ctx *ctx, int64_t feat, float *kps_xy, float *desc, int cap, int *n_out, int *dim_out);
+int vfsms_features_free(vfsms_ctx *ctx, int64_t feat);
+/* cv2.equalizeHist(img) (mode 1) / cv2.createCLAHE(clip_limit, (tile_grid, tile_grid)).apply(img) (mode 2), Stitcher.py:269-276;
+ * out: uint8 [h][w] contiguous                                                                                                     */
+int vfsms_enhance_u8(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int mode, double clip_limit, int tile_grid,
+                     uint8_t *out);
 
 /* ---- device-resident mosaic canvas (Stitcher.getStitchByOffset, Stitcher.py:369-486) -------------- */
 /* u8 canvas + validity plane instead of the reference's int64 / -1 sentinel                         */

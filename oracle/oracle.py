@@ -73,6 +73,8 @@ def lib():
         L.orc_orb_pattern.argtypes = [i32, i32, vp]; L.orc_orb_pattern.restype = None
         L.orc_corner_ramps.argtypes = [vp, i32, i32, i32, vp, vp, vp]; L.orc_corner_ramps.restype = i32
         L.orc_det_sincos.argtypes = [vp, i32, vp]; L.orc_det_sincos.restype = None
+        L.orc_equalize_hist.argtypes = [vp, i32, i32, i32, vp]; L.orc_equalize_hist.restype = None
+        L.orc_clahe.argtypes = [vp, i32, i32, i32, f64, i32, i32, vp]; L.orc_clahe.restype = None
         _lib = L
     return _lib
 
@@ -107,6 +109,22 @@ def det_sincos(x):
     out = np.empty((len(x), 2), np.float64)
     lib().orc_det_sincos(_p(x), len(x), _p(out))
     return out[:, 0].copy(), out[:, 1].copy()
+
+
+def equalize_hist(img):
+    """cv2.equalizeHist(img) (Stitcher.py:275-276)."""
+    img = _u8_2d(img)
+    out = np.empty(img.shape, np.uint8)
+    lib().orc_equalize_hist(_p(img), img.shape[0], img.shape[1], img.strides[0], _p(out))
+    return out
+
+
+def clahe(img, clip_limit=20.0, tile_size=5):
+    """cv2.createCLAHE(clipLimit, (tileSize, tileSize)).apply(img) (Stitcher.py:271-273)."""
+    img = _u8_2d(img)
+    out = np.empty(img.shape, np.uint8)
+    lib().orc_clahe(_p(img), img.shape[0], img.shape[1], img.strides[0], float(clip_limit), int(tile_size), int(tile_size), _p(out))
+    return out
 
 
 def optimal_dft_size(n):

@@ -1048,3 +1048,92 @@ void orc_det_sincos(const double *x, int n, double *out)
 {
     for (int i = 0; i < n; i++) det_sincos(x[i], &out[2 * i], &out[2 * i + 1]);
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Pre-enhancement of Stitcher.py:269-276 / 327-334 (Method.isEnhance): cv2.equalizeHist and cv2.createCLAHE(clipLimit,
+ * (tileSize, tileSize)).apply on 8-bit images -- OpenCV 3.3.1 imgproc/src/histogram.cpp (equalizeHist) and clahe.cpp, restated
+ * from the published algorithm (sources not under /root/reference: parity unpinned against cv2).
+ * ------------------------------------------------------------------------------------------------------------------------- */
+static inline uint8_t sat_u8_f(float v) { int iv = (int)lrintf(v); return (uint8_t)(iv < 0 ? 0 : iv > 255 ? 255 : iv); }
+
+/* equalizeHist: hist -> first non-empty bin i0 -> lut[i] = saturate(round((sum_{i0 < j <= i} hist[j]) * 255.f / (total - hist[i0]))) */
+void orc_equalize_hist(const uint8_t *src, int h, int w, int stride, uint8_t *dst)
+{
+    int hist[256] = {0};
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) hist[src[(size_t)y * stride + x]]++;
+    int i = 0;
+    while (!hist[i]) ++i;
+    const int total = h * w;
+    if (hist[i] == total) { for (int y = 0; y < h; y++) memset(dst + (size_t)y * w, i, (size_t)w); return; }
+    const float scale = (256 - 1.f) / (total - hist[i]);
+    uint8_t lut[256];
+    memset(lut, 0, sizeof(lut));
+    int sum = 0;
+    for (lut[i++] = 0; i < 256; ++i) { sum += hist[i]; lut[i] = sat_u8_f(sum * scale); }
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) dst[(size_t)y * w + x] = lut[src[(size_t)y * stride + x]];
+}
+
+static inline int reflect101_i(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * len - 2 - p; }
+    return p;
+}
+
+/* CLAHE_Impl::apply for CV_8UC1: tiles x tiles grid (image extended bottom / right with BORDER_REFLECT_101 to a multiple of the
+ * grid when it is not one), per-tile clipped histogram -> LUT, bilinear interpolation of the four neighbouring tile LUTs. */
+void orc_clahe(const uint8_t *src, int h, int w, int stride, double clipLimitD, int tilesX, int tilesY, uint8_t *dst)
+{
+    const int histSize = 256;
+    int eh = h, ew = w;
+    if (!(w % tilesX == 0 && h % tilesY == 0)) { eh = h + (tilesY - (h % tilesY)); ew = w + (tilesX - (w % tilesX)); }
+    const int tw = ew / tilesX, th = eh / tilesY;
+    const int tileSizeTotal = tw * th;
+    const float lutScale = (float)(histSize - 1) / tileSizeTotal;
+    int clipLimit = 0;
+    if (clipLimitD > 0.0) {
+        clipLimit = (int)(clipLimitD * tileSizeTotal / histSize);
+        if (clipLimit < 1) clipLimit = 1;
+    }
+    uint8_t *lut = (uint8_t *)malloc((size_t)tilesX * tilesY * histSize);
+    for (int k = 0; k < tilesX * tilesY; k++) {
+        const int ty = k / tilesX, tx = k % tilesX;
+        int tileHist[256] = {0};
+        for (int y = ty * th; y < (ty + 1) * th; y++)
+            for (int x = tx * tw; x < (tx + 1) * tw; x++)
+                tileHist[src[(size_t)reflect101_i(y, h) * stride + reflect101_i(x, w)]]++;
+        if (clipLimit > 0) {
+            int clipped = 0;
+            for (int i = 0; i < histSize; ++i)
+                if (tileHist[i] > clipLimit) { clipped += tileHist[i] - clipLimit; tileHist[i] = clipLimit; }
+            const int redistBatch = clipped / histSize;
+            const int residual = clipped - redistBatch * histSize;
+            for (int i = 0; i < histSize; ++i) tileHist[i] += redistBatch;
+            for (int i = 0; i < residual; ++i) tileHist[i]++;          /* 3.3.1: the first `residual` bins (3.4.2+ strides them) */
+        }
+        int sum = 0;
+        uint8_t *tileLut = lut + (size_t)k * histSize;
+        for (int i = 0; i < histSize; ++i) { sum += tileHist[i]; tileLut[i] = sat_u8_f(sum * lutScale); }
+    }
+    const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+    for (int y = 0; y < h; y++) {
+        const float tyf = y * inv_th - 0.5f;
+        int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+        const float ya = tyf - ty1, ya1 = 1.0f - ya;
+        if (ty1 < 0) ty1 = 0;
+        if (ty2 > tilesY - 1) ty2 = tilesY - 1;
+        const uint8_t *lutPlane1 = lut + (size_t)ty1 * tilesX * histSize, *lutPlane2 = lut + (size_t)ty2 * tilesX * histSize;
+        for (int x = 0; x < w; x++) {
+            const float txf = x * inv_tw - 0.5f;
+            int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+            const float xa = txf - tx1, xa1 = 1.0f - xa;
+            if (tx1 < 0) tx1 = 0;
+            if (tx2 > tilesX - 1) tx2 = tilesX - 1;
+            const int srcVal = src[(size_t)y * stride + x];
+            const int ind1 = tx1 * histSize + srcVal, ind2 = tx2 * histSize + srcVal;
+            const float res = (lutPlane1[ind1] * xa1 + lutPlane1[ind2] * xa) * ya1 + (lutPlane2[ind1] * xa1 + lutPlane2[ind2] * xa) * ya;
+            dst[(size_t)y * w + x] = sat_u8_f(res);
+        }
+    }
+    free(lut);
+}

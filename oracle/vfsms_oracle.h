@@ -65,6 +65,11 @@ static inline void det_sincos(double x, double *s_out, double *c_out)
     }
     *s_out = s; *c_out = c;
 }
+/* cv2.equalizeHist(img) and cv2.createCLAHE(clipLimit, (tilesX, tilesY)).apply(img) on 8-bit images (Stitcher.py:269-276,327-334);
+ * dst is contiguous h x w.  OpenCV 3.3.1 histogram.cpp / clahe.cpp restated; parity unpinned against cv2. */
+void orc_equalize_hist(const uint8_t *src, int h, int w, int stride, uint8_t *dst);
+void orc_clahe(const uint8_t *src, int h, int w, int stride, double clipLimit, int tilesX, int tilesY, uint8_t *dst);
+
 /* exported for tests: out[2n] = sin(x[n]), out[2n+1] = cos(x[n]) */
 void orc_det_sincos(const double *x, int n, double *out);
 

@@ -559,3 +559,99 @@ def test_real_dendritic_path_through_grid_registrar(engine, golden_dir):
             finally:
                 isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate = old
     assert n == 25
+
+
+def test_enhancement_bit_exact(engine, oracle, strips):
+    """cv2.equalizeHist / cv2.createCLAHE(clipLimit, (tileSize, tileSize)).apply as Stitcher.py:269-276 calls them: device bytes equal
+    the oracle's on micrograph-like and random images, sizes that are and are not multiples of the CLAHE grid (the extension is
+    BORDER_REFLECT_101), a one-grey-level image, other clip limits / grids."""
+    g, tiles = strips
+    low = (np.random.default_rng(3).normal(110, 12, (203, 317))).clip(0, 255).astype(np.uint8)
+    imgs = [tiles[0], np.ascontiguousarray(tiles[1][:409, :]), low, _rand_img(5, (100, 250)), np.full((64, 80), 77, np.uint8), tiles[2][:, 100:357]]
+    for img in imgs:
+        assert np.array_equal(engine.enhance(img, 1), oracle.equalize_hist(img)), ("equalizeHist", img.shape)
+        for clip, ts in ((20.0, 5), (2.0, 8), (40.0, 3), (0.0, 4)):
+            assert np.array_equal(engine.enhance(img, 2, clip, ts), oracle.clahe(img, clip, ts)), ("clahe", img.shape, clip, ts)
+
+
+def _line_scan(n=4, h=1024, w=1280, bar=48):
+    """a zircon-like line scan (Main.py:29-51): n tiles of h x w, tile k+1 to the LEFT of tile k (direction 4, full-image search),
+    with a static data bar burned into the bottom rows of every tile (pixel-identical between tiles, like zirconCL's)."""
+    from imagestitch_amd.synthetic import texture_window
+    rng = np.random.default_rng(77)
+    step = w - int(0.2 * w)
+    bar_px = rng.integers(0, 256, (bar, w), dtype=np.uint8)
+    bar_px[:, ::7] = 255
+    tiles, offs = [], []
+    x = 5000
+    for k in range(n):
+        jy, jx = int(rng.integers(-6, 7)), int(rng.integers(-6, 7))
+        y0, x0 = 300 + jy, x - k * step + jx
+        t = texture_window(y0, x0, h, w)
+        img = np.clip(np.rint(128.0 + 45.0 * t + rng.normal(0, 2.0, t.shape)), 0, 255).astype(np.uint8)
+        img[h - bar:, :] = bar_px
+        tiles.append(img); offs.append((y0, x0))
+    truth = [[offs[k + 1][0] - offs[k][0], offs[k + 1][1] - offs[k][1]] for k in range(n - 1)]
+    return tiles, truth
+
+
+def test_full_image_feature_search_resident_cache(engine, oracle):
+    """Stitcher.calculateOffsetForFeatureSearch (the method Main.py runs on its four zircon sets, Stitcher.py:260-304) on a line scan
+    with a burned-in data bar: whole-tile SURF, tile B's features kept in HBM and reused as tile A's (each tile described once),
+    (0, 0) votes of the static bar dropped (ImageUtility.py:158-159).  Every pair must equal the oracle's operator chain on the whole
+    tiles (status, offset) and the ground truth within 1 px; with isEnhance (equalizeHist, then CLAHE) the same against the oracle
+    chain on the enhanced tiles."""
+    tiles, truth = _line_scan()
+    old = (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate, isa.Stitcher.isEnhance,
+           isa.Stitcher.isClahe)
+    calls = []
+    real = engine.features_surf
+    try:
+        isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate = 4, 0, "surf", 3
+        for enh, clahe in ((False, False), (True, False), (True, True)):
+            isa.Stitcher.isEnhance, isa.Stitcher.isClahe = enh, clahe
+            st = isa.Stitcher(); st._engine = engine; st.isPrintLog = False
+            st.tempImageFeature.isBreak = True
+            del calls[:]
+            engine.features_surf = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+            pre = (lambda im: im) if not enh else (lambda im: oracle.clahe(im, 20.0, 5)) if clahe else oracle.equalize_hist
+            prevB = None
+            for k in range(len(tiles) - 1):
+                got = st.calculateOffsetForFeatureSearch([tiles[k], tiles[k + 1]])
+                ka, da = prevB if prevB is not None else oracle.surf_detect_describe(pre(tiles[k]))
+                kb, db = oracle.surf_detect_describe(pre(tiles[k + 1]))
+                prevB = (kb, db)
+                pairs = oracle.bf_l2_ratio_matches(da, db, 0.75)
+                ost, ooff, _v = oracle.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, 3)
+                assert got == ((True, ooff) if ost else (False, "  The two images can not match")), (enh, clahe, k, got, ooff)
+                assert got[0] and abs(got[1][0] - truth[k][0]) <= 1 and abs(got[1][1] - truth[k][1]) <= 1, (k, got, truth[k])
+            assert len(calls) == len(tiles)                      # the cache: every tile described exactly once
+            assert isinstance(st.tempImageFeature.feature, isa.stitcher.ResidentFeatures)
+            kxy = np.asarray(st.tempImageFeature.kps)            # reading the cache downloads what detectAndDescribe would have returned
+            assert kxy.shape == (len(prevB[0]), 2) and np.array_equal(kxy, np.stack([prevB[0]["x"], prevB[0]["y"]], 1))
+            assert np.array_equal(st.tempImageFeature.feature.descriptors(), prevB[1])
+            st.releaseTiles()
+    finally:
+        engine.features_surf = real
+        (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate, isa.Stitcher.isEnhance,
+         isa.Stitcher.isClahe) = old
+        isa.Stitcher.tempImageFeature.isBreak = True
+
+
+def test_incremental_search_with_enhancement(engine, oracle, strips):
+    """Method.isEnhance inside the incremental ROI search (Stitcher.py:327-334): fused attempts on equalised / CLAHE'd strips equal
+    the oracle chain on the oracle-enhanced strips."""
+    g, tiles = strips
+    offs, dirs = g.true_offsets(), g.true_directions()
+    k = 0
+    A, B, d = tiles[k], tiles[k + 1], dirs[k]
+    ra = isa.roi_rect(A.shape, d, "first", 0.2); rb = isa.roi_rect(B.shape, d, "second", 0.2)
+    ha, hb = engine.tile_upload(A), engine.tile_upload(B)
+    roiA = np.ascontiguousarray(A[ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]]); roiB = np.ascontiguousarray(B[rb[0]:rb[0] + rb[2], rb[1]:rb[1] + rb[3]])
+    for spec, pre in (((1, 0.0, 0), oracle.equalize_hist), ((2, 20.0, 5), lambda im: oracle.clahe(im, 20.0, 5))):
+        row = engine.attempt_surf_batch_enhanced([(ha, hb, ra[0], ra[1], rb[0], rb[1], ra[2], ra[3])], None, 0.75, 3, spec)[0]
+        ka, da = oracle.surf_detect_describe(pre(roiA)); kb, db = oracle.surf_detect_describe(pre(roiB))
+        pairs = oracle.bf_l2_ratio_matches(da, db, 0.75)
+        st, off, votes = oracle.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, 3)
+        assert list(row[:7]) == [int(st), off[0], off[1], votes, len(ka), len(kb), len(pairs)], (spec, row)
+    engine.tile_free(ha); engine.tile_free(hb)
