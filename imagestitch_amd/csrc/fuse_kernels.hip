@@ -38,81 +38,168 @@ struct I64View {
     __device__ long long b_val(int i, int j, int k) const { return B[((size_t)i * c + j) * ch + k]; }
 };
 
-// one workgroup per ROI row: occupancy + quadrant counts + first/last valid column of the row
+// occupancy + quadrant counts + first/last valid column of every ROI row.  A workgroup owns FUSE_RBAND rows (one wave-sized
+// reduction per row for first / last; the counts stay in registers across the band) and issues ONE set of global atomics -- a set
+// per row put 3 x r same-address 64-bit atomics behind each other: 70 us of an 2048-row ROI's 73 us.
+#define FUSE_RBAND 8
+typedef uint32_t u32u1 __attribute__((aligned(1)));
 __global__ __launch_bounds__(256) void k_fuse_stats_rows(CanvasView V, int r, int c, FuseStats *st, int *rowFirst, int *rowLast)
 {
-    const int i = blockIdx.x;
-    int first = 0x7fffffff, last = -1;
-    unsigned valid = 0, qlo = 0, qhi = 0;          // > 0 counts left / right half
-    const int c2 = c / 2;
-    for (int j = threadIdx.x; j < c; j += 256) {
-        if (V.a_valid(i, j)) {
-            first = min(first, j); last = max(last, j);
-            valid += V.ch;
-            int pos = 0;
-            for (int k = 0; k < V.ch; k++) pos += V.a_val(i, j, k) > 0;
-            if (j < c2) qlo += pos; else qhi += pos;
-        }
-    }
     __shared__ int sf[256], sl[256];
-    __shared__ unsigned sv[256], s0[256], s1[256];
-    sf[threadIdx.x] = first; sl[threadIdx.x] = last; sv[threadIdx.x] = valid; s0[threadIdx.x] = qlo; s1[threadIdx.x] = qhi;
+    __shared__ unsigned sv[256], s0[256], s1[256], s2[256], s3[256];
+    const int c2 = c / 2, r2 = r / 2;
+    unsigned valid = 0, q_tl = 0, q_bl = 0, q_br = 0, q_tr = 0;
+    const int i0 = blockIdx.x * FUSE_RBAND, i1 = min(i0 + FUSE_RBAND, r);
+    for (int i = i0; i < i1; i++) {
+        int first = 0x7fffffff, last = -1;
+        unsigned qlo = 0, qhi = 0;
+        if (V.ch == 1) {
+            // four pixels per lane and trip: the validity bytes and the grey values as (unaligned) dwords
+            const uint8_t *mrow = V.mask + (size_t)(V.ry0 + i) * V.ccols + V.rx0, *prow = V.pix + (size_t)(V.ry0 + i) * V.ccols + V.rx0;
+            for (int j = threadIdx.x * 4; j < c; j += 1024) {
+                uint32_t m, p;
+                if (j + 3 < c) { m = *(const u32u1 *)(mrow + j); p = *(const u32u1 *)(prow + j); }
+                else { m = 0; p = 0; for (int k = 0; j + k < c; k++) { m |= (uint32_t)mrow[j + k] << (8 * k); p |= (uint32_t)prow[j + k] << (8 * k); } }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if ((m >> (8 * k)) & 0xff) {
+                        first = min(first, j + k); last = max(last, j + k);
+                        valid += 1;
+                        const unsigned pos = ((p >> (8 * k)) & 0xff) != 0;
+                        if (j + k < c2) qlo += pos; else qhi += pos;
+                    }
+            }
+        } else {
+            for (int j = threadIdx.x; j < c; j += 256)
+                if (V.a_valid(i, j)) {
+                    first = min(first, j); last = max(last, j);
+                    valid += V.ch;
+                    int pos = 0;
+                    for (int k = 0; k < V.ch; k++) pos += V.a_val(i, j, k) > 0;
+                    if (j < c2) qlo += pos; else qhi += pos;
+                }
+        }
+        if (i < r2) { q_tl += qlo; q_tr += qhi; } else { q_bl += qlo; q_br += qhi; }
+        sf[threadIdx.x] = first; sl[threadIdx.x] = last;
+        __syncthreads();
+        for (int d = 128; d > 0; d >>= 1) {
+            if ((int)threadIdx.x < d) {
+                sf[threadIdx.x] = min(sf[threadIdx.x], sf[threadIdx.x + d]);
+                sl[threadIdx.x] = max(sl[threadIdx.x], sl[threadIdx.x + d]);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { rowFirst[i] = sf[0] == 0x7fffffff ? -1 : sf[0]; rowLast[i] = sl[0]; }
+        __syncthreads();
+    }
+    sv[threadIdx.x] = valid; s0[threadIdx.x] = q_tl; s1[threadIdx.x] = q_bl; s2[threadIdx.x] = q_br; s3[threadIdx.x] = q_tr;
     __syncthreads();
     for (int d = 128; d > 0; d >>= 1) {
         if ((int)threadIdx.x < d) {
-            sf[threadIdx.x] = min(sf[threadIdx.x], sf[threadIdx.x + d]);
-            sl[threadIdx.x] = max(sl[threadIdx.x], sl[threadIdx.x + d]);
             sv[threadIdx.x] += sv[threadIdx.x + d]; s0[threadIdx.x] += s0[threadIdx.x + d]; s1[threadIdx.x] += s1[threadIdx.x + d];
+            s2[threadIdx.x] += s2[threadIdx.x + d]; s3[threadIdx.x] += s3[threadIdx.x + d];
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        rowFirst[i] = sf[0] == 0x7fffffff ? -1 : sf[0];
-        rowLast[i] = sl[0];
-        atomicAdd(&st->valid, (unsigned long long)sv[0]);
-        const bool top = i < r / 2;
-        atomicAdd(&st->quad[top ? 0 : 1], (unsigned long long)s0[0]);   // TL / BL
-        atomicAdd(&st->quad[top ? 3 : 2], (unsigned long long)s1[0]);   // TR / BR
+        if (sv[0]) atomicAdd(&st->valid, (unsigned long long)sv[0]);
+        if (s0[0]) atomicAdd(&st->quad[0], (unsigned long long)s0[0]);   // TL
+        if (s1[0]) atomicAdd(&st->quad[1], (unsigned long long)s1[0]);   // BL
+        if (s2[0]) atomicAdd(&st->quad[2], (unsigned long long)s2[0]);   // BR
+        if (s3[0]) atomicAdd(&st->quad[3], (unsigned long long)s3[0]);   // TR
     }
 }
 
-// one lane per ROI column: first/last valid row
-__global__ __launch_bounds__(256) void k_fuse_stats_cols(CanvasView V, int r, int c, int *colFirst, int *colLast)
+// first / last valid row of every ROI column.  A workgroup owns 256 columns x FUSE_CBAND rows (one lane per column walks the band:
+// row-major reads, coalesced across lanes) and folds its band into the column records with one atomicMax each.  Encoding:
+// colLast[j] = last valid row (or -1); colFirstEnc[j] = r - 1 - first valid row (or -1), so both start at -1 (one memset) and
+// both are maxima.  (The single-lane-per-column loop this replaces walked all r rows sequentially: 0.3 ms per 2048-row ROI.)
+#define FUSE_CBAND 64
+__global__ __launch_bounds__(256) void k_fuse_stats_cols(CanvasView V, int r, int c, int *colFirstEnc, int *colLast)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;                 // four adjacent columns per lane: validity bytes as one dword
     if (j >= c) return;
-    int first = -1, last = -1;
-    for (int i = 0; i < r; i++)
-        if (V.a_valid(i, j)) { if (first < 0) first = i; last = i; }
-    colFirst[j] = first; colLast[j] = last;
+    const int i0 = blockIdx.y * FUSE_CBAND, i1 = min(i0 + FUSE_CBAND, r);
+    int first[4] = {-1, -1, -1, -1}, last[4] = {-1, -1, -1, -1};
+    const uint8_t *mcol = V.mask + (size_t)V.ry0 * V.ccols + V.rx0 + j;
+    const int nk = min(4, c - j);
+    for (int i = i0; i < i1; i++) {
+        const uint8_t *mp = mcol + (size_t)i * V.ccols;
+        uint32_t m;
+        if (nk == 4) m = *(const u32u1 *)mp;
+        else { m = 0; for (int k = 0; k < nk; k++) m |= (uint32_t)mp[k] << (8 * k); }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if ((m >> (8 * k)) & 0xff) { if (first[k] < 0) first[k] = i; last[k] = i; }
+    }
+    for (int k = 0; k < nk; k++)
+        if (last[k] >= 0) { atomicMax(&colLast[j + k], last[k]); atomicMax(&colFirstEnc[j + k], r - 1 - first[k]); }
 }
 
 // the blend: writes the whole tile rectangle (outside the ROI: plain paste) and marks it valid
+__device__ __forceinline__ uint8_t fade_px(float wA, float wB, bool av, int a0, int b)
+{
+    const int a = av ? a0 : b;                                         // imageA[imageA < 0] = imageB[imageA < 0]
+    double res = (double)wA * (double)a + (double)wB * (double)b;
+    res = res < 0 ? 0 : res;
+    res = res > 255 ? 255 : res;
+    return (uint8_t)res;                                               // np.uint8(): truncation
+}
 __global__ __launch_bounds__(256) void k_fuse_apply(uint8_t *pix, uint8_t *mask, int ccols, int ch,
                                                     const uint8_t *tile, int th, int tw, int y0, int x0,
                                                     int ry0, int rx0, int r, int c, const int *mode,
                                                     const float *wAr, const float *wAc, const float *wBr, const float *wBc)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
+    const int cy = y0 + y;
+    const int i = cy - ry0;
+    const bool row_in = i >= 0 && i < r;
+    const int corner = mode[0];
+    if (ch == 1) {
+        // four pixels per lane: tile, canvas and validity bytes move as (unaligned) dwords
+        const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+        if (x >= tw) return;
+        const size_t co = (size_t)cy * ccols + x0 + x;
+        const uint8_t *tp = tile + (size_t)y * tw + x;
+        const int nk = min(4, tw - x);
+        uint32_t tb, pb = 0, mb = 0;
+        if (nk == 4) { tb = *(const u32u1 *)tp; if (row_in) { pb = *(const u32u1 *)(pix + co); mb = *(const u32u1 *)(mask + co); } }
+        else { tb = 0; for (int k = 0; k < nk; k++) { tb |= (uint32_t)tp[k] << (8 * k); if (row_in) { pb |= (uint32_t)pix[co + k] << (8 * k); mb |= (uint32_t)mask[co + k] << (8 * k); } } }
+        uint32_t ob = tb;
+        if (row_in) {
+            const float war = wAr[i], wbr = wBr[i];
+            ob = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = x0 + x + k - rx0;
+                const int b = (tb >> (8 * k)) & 0xff;
+                uint32_t o = (uint32_t)b;
+                if (k < nk && j >= 0 && j < c) {
+                    float wA, wB;
+                    if (corner) { wB = wbr * wBc[j]; wA = 1 - wB; }
+                    else { wA = war * wAc[j]; wB = wbr * wBc[j]; }
+                    o = fade_px(wA, wB, ((mb >> (8 * k)) & 0xff) != 0, (pb >> (8 * k)) & 0xff, b);
+                }
+                ob |= o << (8 * k);
+            }
+        }
+        if (nk == 4) { *(u32u1 *)(pix + co) = ob; *(u32u1 *)(mask + co) = 0x01010101u; }
+        else for (int k = 0; k < nk; k++) { pix[co + k] = (uint8_t)(ob >> (8 * k)); mask[co + k] = 1; }
+        return;
+    }
+    const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= tw) return;
-    const int cy = y0 + y, cx = x0 + x;
+    const int cx = x0 + x;
     const size_t co = (size_t)cy * ccols + cx;
-    const int i = cy - ry0, j = cx - rx0;
-    const bool in_roi = (i >= 0 && i < r && j >= 0 && j < c);
+    const int j = cx - rx0;
+    const bool in_roi = (row_in && j >= 0 && j < c);
     if (in_roi) {
         float wA, wB;
-        if (mode[0]) { wB = wBr[i] * wBc[j]; wA = 1 - wB; }
+        if (corner) { wB = wBr[i] * wBc[j]; wA = 1 - wB; }
         else { wA = wAr[i] * wAc[j]; wB = wBr[i] * wBc[j]; }
         const bool av = mask[co] != 0;
-        for (int k = 0; k < ch; k++) {
-            const int b = tile[((size_t)y * tw + x) * ch + k];
-            const int a = av ? (int)pix[co * ch + k] : b;          // imageA[imageA < 0] = imageB[imageA < 0]
-            double res = (double)wA * (double)a + (double)wB * (double)b;
-            res = res < 0 ? 0 : res;
-            res = res > 255 ? 255 : res;
-            pix[co * ch + k] = (uint8_t)res;                       // np.uint8(): truncation
-        }
+        for (int k = 0; k < ch; k++)
+            pix[co * ch + k] = fade_px(wA, wB, av, (int)pix[co * ch + k], tile[((size_t)y * tw + x) * ch + k]);
     } else {
         for (int k = 0; k < ch; k++) pix[co * ch + k] = tile[((size_t)y * tw + x) * ch + k];
     }
@@ -206,9 +293,12 @@ __global__ __launch_bounds__(256) void k_i64_apply(I64View V, int r, int c, cons
 __device__ __forceinline__ int pywrap(int i, int n) { return i < 0 ? i + n : i; }
 
 __global__ __launch_bounds__(256) void k_fuse_weights(int r, int c, int ch, int dx, int dy, int force_corner, const FuseStats *st,
-                                                      const int *rowFirst, const int *rowLast, const int *colFirst, const int *colLast,
-                                                      float *wAr, float *wAc, float *wBr, float *wBc, int *out, int *sticky_err)
+                                                      const int *rowFirst, const int *rowLast, const int *colFirstRaw, const int *colLast,
+                                                      float *wAr, float *wAc, float *wBr, float *wBc, int *out, int *sticky_err, int first_encoded)
 {
+    // colFirst: first valid row of a column, or -1 (the canvas path stores it as r - 1 - first so that one memset initialises it)
+    struct ColFirst { const int *p; int r, enc; __device__ int operator[](int j) const { const int v = p[j]; return (enc && v >= 0) ? r - 1 - v : v; } };
+    const ColFirst colFirst = {colFirstRaw, r, first_encoded};
     const int t = threadIdx.x;
     __shared__ int s_first, s_geom[4];          // first scan position with a non-zero candidate; index,rowIndex,colIndex,err
     for (int i = t; i < r; i += 256) { wAr[i] = 1.f; wBr[i] = 1.f; }
@@ -314,11 +404,12 @@ static int fuse_scratch(vfsms_ctx *ctx, int r, int c, FuseScratch *S)
 }
 
 // launch the ramp kernel; `finish_weights` later brings back its 6 status ints (and the ramps when a caller wants them) in one sync
-static int launch_weights(vfsms_ctx *ctx, const FuseScratch &S, int r, int c, int ch, int dx, int dy, int force_corner = 0, int *sticky_err = nullptr)
+static int launch_weights(vfsms_ctx *ctx, const FuseScratch &S, int r, int c, int ch, int dx, int dy, int force_corner = 0, int *sticky_err = nullptr,
+                          int first_encoded = 0, bool out_cleared = false)
 {
-    HIP_TRY(hipMemsetAsync(S.out, 0, sizeof(int) * 8, ctx->stream));
+    if (!out_cleared) HIP_TRY(hipMemsetAsync(S.out, 0, sizeof(int) * 8, ctx->stream));
     hipLaunchKernelGGL(k_fuse_weights, dim3(1), dim3(256), 0, ctx->stream, r, c, ch, dx, dy, force_corner, S.st, S.rowFirst, S.rowLast,
-                       S.colFirst, S.colLast, S.wAr, S.wAc, S.wBr, S.wBc, S.out, sticky_err);
+                       S.colFirst, S.colLast, S.wAr, S.wAc, S.wBr, S.wBc, S.out, sticky_err, first_encoded);
     HIP_TRY(hipGetLastError());
     return VFSMS_OK;
 }
@@ -393,16 +484,25 @@ int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int
     const int r = ry1 - ry0, c = rx1 - rx0;
     if (r <= 0 || c <= 0) return canvas_paste_device(ctx, cv, d_tile, h, w, y0, x0);
     ProfScope ps(ctx, "fuse");
+    // scratch: [stats | status out] cleared to 0 and [colFirstEnc | colLast] preset to -1 -- two memsets for the whole tile
     FuseScratch S;
-    TRY(fuse_scratch(ctx, r, c, &S));
-    HIP_TRY(hipMemsetAsync(S.st, 0, sizeof(FuseStats), ctx->stream));
+    char *zero = (char *)ctx_arena_alloc(ctx, 256);
+    S.st = (FuseStats *)zero; S.out = (int *)(zero + 128);
+    int *cols = (int *)ctx_arena_alloc(ctx, sizeof(int) * 2 * (size_t)c);
+    S.colFirst = cols; S.colLast = cols + c;
+    S.rowFirst = (int *)ctx_arena_alloc(ctx, sizeof(int) * r); S.rowLast = (int *)ctx_arena_alloc(ctx, sizeof(int) * r);
+    S.wAr = (float *)ctx_arena_alloc(ctx, sizeof(float) * r); S.wBr = (float *)ctx_arena_alloc(ctx, sizeof(float) * r);
+    S.wAc = (float *)ctx_arena_alloc(ctx, sizeof(float) * c); S.wBc = (float *)ctx_arena_alloc(ctx, sizeof(float) * c);
+    if (!zero || !cols || !S.wBc) { vfsms_set_error("arena exhausted in fuse"); return VFSMS_ERR_CAPACITY; }
+    HIP_TRY(hipMemsetAsync(zero, 0, 256, ctx->stream));
+    HIP_TRY(hipMemsetAsync(cols, 0xff, sizeof(int) * 2 * (size_t)c, ctx->stream));
     CanvasView V;
     V.pix = cv->pix; V.mask = cv->mask; V.ccols = cv->cols; V.ch = cv->ch; V.ry0 = ry0; V.rx0 = rx0;
     V.tile = d_tile; V.tw = w; V.ty0 = ry0 - y0; V.tx0 = rx0 - x0;
-    hipLaunchKernelGGL(k_fuse_stats_rows, dim3(r), dim3(256), 0, ctx->stream, V, r, c, S.st, S.rowFirst, S.rowLast);
-    hipLaunchKernelGGL(k_fuse_stats_cols, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, V, r, c, S.colFirst, S.colLast);
-    TRY(launch_weights(ctx, S, r, c, cv->ch, dx, dy, 0, cv->d_err));
-    hipLaunchKernelGGL(k_fuse_apply, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, cv->pix, cv->mask, cv->cols, cv->ch,
+    hipLaunchKernelGGL(k_fuse_stats_rows, dim3((r + FUSE_RBAND - 1) / FUSE_RBAND), dim3(256), 0, ctx->stream, V, r, c, S.st, S.rowFirst, S.rowLast);
+    hipLaunchKernelGGL(k_fuse_stats_cols, dim3((c + 1023) / 1024, (r + FUSE_CBAND - 1) / FUSE_CBAND), dim3(256), 0, ctx->stream, V, r, c, S.colFirst, S.colLast);
+    TRY(launch_weights(ctx, S, r, c, cv->ch, dx, dy, 0, cv->d_err, 1, true));
+    hipLaunchKernelGGL(k_fuse_apply, dim3(cv->ch == 1 ? (w + 1023) / 1024 : (w + 255) / 256, h), dim3(256), 0, ctx->stream, cv->pix, cv->mask, cv->cols, cv->ch,
                        d_tile, h, w, y0, x0, ry0, rx0, r, c, S.out, S.wAr, S.wAc, S.wBr, S.wBc);
     HIP_TRY(hipGetLastError());
     if (!info) return VFSMS_OK;          // no readback wanted: a degenerate geometry is latched in the canvas and reported by the download

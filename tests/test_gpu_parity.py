@@ -655,3 +655,32 @@ def test_incremental_search_with_enhancement(engine, oracle, strips):
         st, off, votes = oracle.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, 3)
         assert list(row[:7]) == [int(st), off[0], off[1], votes, len(ka), len(kb), len(pairs)], (spec, row)
     engine.tile_free(ha); engine.tile_free(hb)
+
+
+def test_fuse_at_production_size_vs_oracle(engine, oracle, tmp_path):
+    """fadeInAndFadeOut at the BASELINE tile size: a 2 x 2 serpentine of 2048 x 2048 tiles assembled by Stitcher.getStitchByOffset
+    on the device canvas (a 204 x 2048 strip ROI in the column, then whole-tile corner-mode ROIs after the turn) must equal, byte
+    for byte, the reference's int64 / -1 canvas walk with the oracle's fuseByFadeInAndFadeOut (tests/fakes.OracleEngine) -- and the
+    same with the tiles resident in HBM (the path flowStitch takes after a batched registration)."""
+    from fakes import OracleEngine
+    from test_host_logic import _write_tiles
+    g = SyntheticGrid(2, 2, 2048)
+    tiles = g.tiles(threads=4)
+    offs = [list(map(int, o)) for o in g.true_offsets()]
+    files = _write_tiles(tmp_path, tiles, "prod")
+    old = isa.Stitcher.isColorMode
+    try:
+        isa.Stitcher.isColorMode = False
+        outs = []
+        for eng in (engine, OracleEngine(oracle)):
+            s = isa.Stitcher(); s._engine = eng; s.isPrintLog = False; s.isColorMode = False
+            s.fuseMethod = "fadeInAndFadeOut"
+            outs.append(s.getStitchByOffset(files, [list(o) for o in offs]))
+        assert outs[0].shape == outs[1].shape and outs[0].shape[0] > 3800 and np.array_equal(outs[0], outs[1])
+        # resident tiles: the handles of a registration phase handed to the fuse
+        s = isa.Stitcher(); s._engine = engine; s.isPrintLog = False; s.isColorMode = False; s.fuseMethod = "fadeInAndFadeOut"
+        s._resident = {f: (engine.tile_upload(t), t.shape) for f, t in zip(files, tiles)}
+        res = s.getStitchByOffset(files, [list(o) for o in offs])
+        assert np.array_equal(res, outs[1])
+    finally:
+        isa.Stitcher.isColorMode = old
