@@ -1,7 +1,7 @@
 """Synthetic micrograph grids with exact integer ground-truth offsets (SURVEY section 8d "Synthetic inputs").
 
 The texture is a pure function of GLOBAL canvas coordinates (hashed-lattice value noise over several
-octaves), so any tile of any grid size can be produced on its own -- per rank, on the fly, without ever
+octaves plus one Gaussian dot or short line segment per 400 px^2 cell), so any tile of any grid size can be produced on its own -- per rank, on the fly, without ever
 materialising the canvas (a 32x32 grid of 4096^2 tiles would be 16 GB).  Tiles follow the column-major
 serpentine shooting path of the reference's dendriticCrystal demo set (down, step right, up, ...), with a
 nominal 10 % overlap, integer jitter U{-8..8} on both axes, per-tile gain U(0.97, 1.03) and additive
@@ -41,20 +41,83 @@ def _octave(gy0, gx0, h, w, cell, salt):
 _OCTAVES = ((192, 0.9), (48, 0.8), (14, 1.0), (7, 1.1), (4, 0.9))
 
 
-def texture_window(gy0, gx0, h, w, seed=DEFAULT_SEED):
-    """float32 texture (roughly mean 0, unit variance) over a window of the infinite canvas."""
+_BLOB_CELL = 20          # one blob per 20 x 20 px cell = one per 400 px^2
+_BLOB_REACH = 48         # no blob reaches further than this from its cell
+_BLOB_GAIN = 1.1         # blob layer amplitude relative to the unit-variance noise
+_BLOB_NORM = 0.898       # std of (noise + _BLOB_GAIN x blob layer), measured once (noise alone: 0.734): the sum gets unit variance
+
+
+def _gauss_kernel(sigma):
+    r = int(np.ceil(3 * sigma))
+    y, x = np.mgrid[-r:r + 1, -r:r + 1].astype(np.float32)
+    return np.exp(-(x * x + y * y) / np.float32(2 * sigma * sigma)).astype(np.float32)
+
+
+_KERNELS = {}
+
+
+def blob_window(gy0, gx0, h, w, seed=DEFAULT_SEED):
+    """The dendrite-like layer of SURVEY 8d: per 20 x 20 px cell of the infinite canvas one feature, a pure function of the cell's
+    GLOBAL index -- a Gaussian dot of radius 2..12 px (sigma = radius / 2.5) or a short line segment (a chain of narrow dots along
+    a random direction), bright or dark.  Gives SURF / FAST the blob and ridge structure micrographs have (value noise alone yields
+    a third fewer keypoints than the real dendriticCrystal strips)."""
+    acc = np.zeros((h + 2 * _BLOB_REACH, w + 2 * _BLOB_REACH), np.float32)
+    cy0, cy1 = (gy0 - _BLOB_REACH) // _BLOB_CELL, (gy0 + h + _BLOB_REACH) // _BLOB_CELL
+    cx0, cx1 = (gx0 - _BLOB_REACH) // _BLOB_CELL, (gx0 + w + _BLOB_REACH) // _BLOB_CELL
+    cy, cx = np.meshgrid(np.arange(cy0, cy1 + 1), np.arange(cx0, cx1 + 1), indexing="ij")
+    cy, cx = cy.ravel(), cx.ravel()
+    with np.errstate(over="ignore"):
+        hsh = [_hash_u32(cx + (1 << 20), cy + (1 << 20), seed * 977 + 31 * k) for k in range(6)]
+    u = [hh.astype(np.float64) / 4294967296.0 for hh in hsh]
+    py = cy * _BLOB_CELL + (u[0] * _BLOB_CELL).astype(np.int64) - gy0 + _BLOB_REACH       # feature centre in the padded window
+    px = cx * _BLOB_CELL + (u[1] * _BLOB_CELL).astype(np.int64) - gx0 + _BLOB_REACH
+    radius = 2 + (u[2] * 11).astype(np.int64)                                              # 2 .. 12
+    sign = np.where(u[3] < 0.5, -1.0, 1.0).astype(np.float32)
+    is_line = u[4] < 0.5
+    theta = u[5] * np.pi
+    H, W = acc.shape
+
+    def stamp(y, x, key, amp):
+        k = _KERNELS.get(key)
+        if k is None:
+            k = _KERNELS[key] = _gauss_kernel(key / 10.0)
+        r = k.shape[0] // 2
+        y0, y1, x0, x1 = y - r, y + r + 1, x - r, x + r + 1
+        if y1 <= 0 or x1 <= 0 or y0 >= H or x0 >= W:
+            return
+        ky0, kx0 = max(0, -y0), max(0, -x0)
+        ky1, kx1 = k.shape[0] - max(0, y1 - H), k.shape[1] - max(0, x1 - W)
+        acc[max(y0, 0):min(y1, H), max(x0, 0):min(x1, W)] += amp * k[ky0:ky1, kx0:kx1]
+    for n in range(len(cy)):
+        if is_line[n]:
+            L = 6 + 2 * int(radius[n])                           # 10 .. 30 px long, sigma 1.4
+            dy, dx = np.sin(theta[n]), np.cos(theta[n])
+            for t in range(-L // 2, L // 2 + 1, 2):
+                stamp(int(py[n] + round(t * dy)), int(px[n] + round(t * dx)), 14, sign[n] * np.float32(0.8))
+        else:
+            stamp(int(py[n]), int(px[n]), int(radius[n]) * 4, sign[n] * np.float32(1.6))     # sigma = radius / 2.5
+    return acc[_BLOB_REACH:_BLOB_REACH + h, _BLOB_REACH:_BLOB_REACH + w]
+
+
+def texture_window(gy0, gx0, h, w, seed=DEFAULT_SEED, blobs=True):
+    """float32 texture (roughly mean 0, unit variance) over a window of the infinite canvas: (a) multi-octave value noise +
+    (b) the blob / line-segment layer of SURVEY 8d (blobs=False gives round 1's noise-only texture)."""
     acc = np.zeros((h, w), np.float32)
     tot = 0.0
     for k, (cell, amp) in enumerate(_OCTAVES):
         acc += np.float32(amp) * (_octave(gy0, gx0, h, w, cell, seed * 131 + k) - np.float32(0.5))
         tot += amp * amp / 12.0
-    return acc / np.float32(np.sqrt(tot))
+    acc /= np.float32(np.sqrt(tot))
+    if not blobs:
+        return acc
+    return (acc + np.float32(_BLOB_GAIN) * blob_window(gy0, gx0, h, w, seed)) / np.float32(_BLOB_NORM)
 
 
 class SyntheticGrid:
     """rows x cols tiles of tile_h x tile_w on a column-major serpentine path."""
 
-    def __init__(self, rows, cols, tile_h, tile_w=None, overlap=0.10, jitter=8, seed=DEFAULT_SEED):
+    def __init__(self, rows, cols, tile_h, tile_w=None, overlap=0.10, jitter=8, seed=DEFAULT_SEED, blobs=True):
+        self.blobs = bool(blobs)
         self.rows, self.cols = int(rows), int(cols)
         self.th, self.tw = int(tile_h), int(tile_w or tile_h)
         self.seed = int(seed)
@@ -98,7 +161,7 @@ class SyntheticGrid:
     def tile(self, k):
         """uint8 tile k of the path (mean 128, sigma ~45, per-tile gain and noise)."""
         y0, x0 = self.origin(k)
-        t = texture_window(y0, x0, self.th, self.tw, self.seed)
+        t = texture_window(y0, x0, self.th, self.tw, self.seed, self.blobs)
         rng = np.random.default_rng(1000 + k + self.seed % 1000)
         gain = rng.uniform(0.97, 1.03)
         img = 128.0 + 45.0 * gain * t + rng.normal(0.0, 2.0, t.shape).astype(np.float32)
