@@ -41,7 +41,7 @@ VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # 2 v_cvt_i32_f64, 3 address, 2 v_fract_f64, 2 v_cvt_f32_f64, 2 v_sub, 4 v_cvt_f32_ubyte, 4 v_pk_mul (+2 moves), 3 v_add, v_rndne,
 # v_cvt, 2 loop / index) -- the ALGORITHMIC work of one sample as this kernel formulates it
 DESC_VALU_PER_SAMPLE = 32
-MIN_WARM_S = 1.5
+MIN_WARM_S = float(os.environ.get("VFSMS_BENCH_MIN_WARM", "1.5"))     # 0 under rocprofv3 --pmc (serialised kernels make every step slow)
 
 
 def pmc_value(kernel, key):
@@ -294,10 +294,15 @@ def main():
     # The MI355X needs about a second of sustained load to reach its steady clocks (and the first touches of the arena to
     # settle): measured here, the step right after a short warmup runs 5-100 % slower than the steady state.  More untimed
     # steps are run until the warmup has lasted MIN_WARM_S; they are reported, and the K timed steps below are exactly K.
-    warm_extra = 0
-    while time.perf_counter() - t_w < MIN_WARM_S:
+    dt_w = time.perf_counter() - t_w
+    warm_extra = int(np.ceil(max(MIN_WARM_S - dt_w, 0.0) / max(dt_w / max(args.warmup, 1), 1e-4)))
+    if dist is not None:                                    # the same count on every rank: a step contains the collective
+        tw = torch.tensor([warm_extra], dtype=torch.int64, device=coll_device)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        warm_extra = int(tw.item())
+    warm_extra = min(warm_extra, 400)
+    for _ in range(warm_extra):
         step()
-        warm_extra += 1
     ok = res[:, 0] == 1
     err = np.abs(res[:, 1:3].astype(np.int64) - truth)
     max_err = int(err[ok].max()) if ok.any() else -1
@@ -327,7 +332,12 @@ def main():
             step_from_host()
         fence()
         elapsed_host = time.perf_counter() - t0
+    per_rank = None
     if dist is not None:
+        mine = dict(rank=rank, pairs=hi - lo, attempts_per_step=st["attempts"] / max(args.steps, 1), batches_per_step=st["batches"] / max(args.steps, 1),
+                    gpu_ms_per_step=round(sum(v[0] for v in prof.values()) / max(args.steps, 1), 3), wall_ms_per_step=round(elapsed / args.steps * 1e3, 3))
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         t = torch.tensor([elapsed, elapsed_host or 0.0], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0].item())
@@ -440,6 +450,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "stages": stages,
+            "per_rank": per_rank,
         }
         out.update(extra)
         print(json.dumps(out))

@@ -12,16 +12,24 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 from imagestitch_amd.grid import GridRegistrar  # noqa: E402
 from imagestitch_amd.distributed import make_all_gather  # noqa: E402
-from scripted import ScriptedAttemptEngine, random_truth  # noqa: E402
+from scripted import ScriptedAttemptEngine, random_truth, serpentine_truth  # noqa: E402
 
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-rng = np.random.default_rng(77)
-accept = random_truth(rng, 23, 0.2)
+n_pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 23
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 77
+window = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+rng = np.random.default_rng(seed)
+accept = random_truth(rng, n_pairs, 0.2) if n_pairs < 100 else serpentine_truth(32, 32, 0.2)
 SHAPE = (1000, 1400)
-reg = GridRegistrar(ScriptedAttemptEngine(SHAPE, 0.2, accept), roiRatio=0.2, directIncre=1, window=4)
-full, d = reg.register_sharded(list(range(24)), [SHAPE] * 24, 1, rank, world, make_all_gather(torch.device("cpu")))
+eng = ScriptedAttemptEngine(SHAPE, 0.2, accept)
+reg = GridRegistrar(eng, roiRatio=0.2, directIncre=1, window=window)
+full, d = reg.register_sharded(list(range(len(accept) + 1)), [SHAPE] * (len(accept) + 1), 1, rank, world, make_all_gather(torch.device("cpu")))
+stats = torch.tensor([reg.stats["attempts"], reg.stats["batches"]], dtype=torch.int64)
+allstats = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+dist.all_gather(allstats, stats)
 if rank == 0:
-    json.dump(dict(rows=full.tolist(), direction=int(d)), open(sys.argv[1], "w"))
+    json.dump(dict(rows=full.tolist(), direction=int(d), attempts=[int(s[0]) for s in allstats], batches=[int(s[1]) for s in allstats]),
+              open(sys.argv[1], "w"))
 dist.barrier()
 dist.destroy_process_group()

@@ -55,3 +55,19 @@ def random_truth(rng, n_pairs, roiRatio, p_fail=0.05, p_false=0.2):
             acc[(int(rng.integers(1, 5)), int(rng.integers(1, maxI)))] = (int(rng.integers(-9, 9)), int(rng.integers(-9, 9)))
         accept.append(acc)
     return accept
+
+
+def serpentine_truth(rows, cols, roiRatio, seed=5):
+    """The shooting path of BASELINE configs[4] (32 x 32 tiles, column-major serpentine: rows-1 pairs down, one to the right,
+    rows-1 up, ...): pair k accepts its true direction at i = 1 (every i), plus an occasional late success at i = 2."""
+    rng = np.random.default_rng(seed)
+    maxI = int(np.floor(0.5 / roiRatio) + 1) + 1
+    accept = []
+    for c in range(cols):
+        d_col = 1 if c % 2 == 0 else 3
+        for r in range(rows - 1):
+            i0 = 2 if rng.random() < 0.03 else 1
+            accept.append({(d_col, i): (int(rng.integers(-8, 9)), int(rng.integers(-8, 9))) for i in range(i0, maxI)})
+        if c < cols - 1:
+            accept.append({(2, i): (int(rng.integers(-8, 9)), int(rng.integers(-8, 9))) for i in range(1, maxI)})
+    return accept

@@ -94,3 +94,23 @@ def test_two_process_gloo_all_gather(tmp_path):
     accept = random_truth(rng, 23, 0.2)
     seq, d_end, _ = sequential(accept, 0.2, 1, 1)
     assert got["direction"] == d_end and [r[:4] for r in got["rows"]] == seq
+
+
+def test_eight_process_gloo_config4_path(tmp_path):
+    """BASELINE configs[4]'s registration half on scripted attempts: the 1023 pairs of a 32 x 32 serpentine sharded over world_size 8
+    (gloo, CPU): contiguous chunks, blind chunk starts, ONE all-gather; every rank assembles the sequential result.  Also records how
+    the work spread (attempts / batches per rank) -- the quantity that bounds strong scaling."""
+    from scripted import serpentine_truth
+    out = os.path.join(str(tmp_path), "res8.json")
+    worker = os.path.join(os.path.dirname(__file__), "dist_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", worker, out, "1023", "5", "24"]
+    subprocess.check_call(cmd, env=env, timeout=900)
+    got = json.load(open(out))
+    accept = serpentine_truth(32, 32, 0.2)
+    assert len(accept) == 1023
+    seq, d_end, _ = sequential(accept, 0.2, 1, 1)
+    assert got["direction"] == d_end and [r[:4] for r in got["rows"]] == seq
+    print("attempts per rank", got["attempts"], "batches per rank", got["batches"])
+    assert len(got["attempts"]) == 8 and sum(got["attempts"]) < 1.4 * 1100 and max(got["attempts"]) < 1.35 * sum(got["attempts"]) / 8
