@@ -30,6 +30,20 @@ class OrbParams(C.Structure):
                 ("fast_threshold", C.c_int32)]
 
 
+class AttemptKey(C.Structure):
+    _fields_ = [("pair", C.c_int32), ("direction", C.c_int32), ("i", C.c_int32)]
+
+
+class GridParams(C.Structure):
+    _fields_ = [("method", C.c_int32), ("offset_evaluate", C.c_int32), ("direct_incre", C.c_int32), ("window", C.c_int32),
+                ("orb_max_dist", C.c_int32), ("enhance_mode", C.c_int32), ("tile_grid", C.c_int32), ("reserved", C.c_int32),
+                ("roi_ratio", C.c_double), ("search_ratio", C.c_double), ("phase_threshold", C.c_double), ("clip_limit", C.c_double),
+                ("surf", SurfParams), ("orb", OrbParams)]
+
+
+ATTEMPT_EVAL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(AttemptKey), C.c_int, C.POINTER(C.c_int32))
+
+
 class RoiPair(C.Structure):
     _fields_ = [("tile_a", C.c_int64), ("tile_b", C.c_int64),
                 ("ay0", C.c_int32), ("ax0", C.c_int32), ("by0", C.c_int32), ("bx0", C.c_int32),
@@ -89,6 +103,10 @@ _SIGNATURES = {
     "vfsms_features_download": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vfsms_features_free": (C.c_int, [C.c_void_p, C.c_int64]),
     "vfsms_enhance_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]),
+    "vfsms_pairs_offsets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(GridParams), C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "vfsms_pairs_offsets_eval": (C.c_int, [ATTEMPT_EVAL, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(GridParams), C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "vfsms_attempt_phase_batch": (C.c_int, [C.c_void_p, C.POINTER(RoiPair), C.c_int, C.c_void_p]),
     "vfsms_canvas_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "vfsms_canvas_free": (C.c_int, [C.c_void_p, C.c_int64]),
@@ -401,6 +419,33 @@ class Engine:
                                                                int(enhance[0]), float(enhance[1]), int(enhance[2]), _ptr(out)))
         return out
 
+    # -- whole shooting paths ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def grid_params(method="surf", roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3, directIncre=1, window=24, surf=None, orb=None,
+                    phaseResponseThreshold=0.15, orbMaxDistance=-1, enhance=(0, 0.0, 0)):
+        p = GridParams()
+        p.method = {"surf": 0, "orb": 1, "phase": 2}[method]
+        p.offset_evaluate, p.direct_incre, p.window, p.orb_max_dist = int(offsetEvaluate), int(directIncre), int(window), int(orbMaxDistance)
+        p.enhance_mode, p.clip_limit, p.tile_grid = int(enhance[0]), float(enhance[1]), int(enhance[2])
+        p.roi_ratio, p.search_ratio, p.phase_threshold = float(roiRatio), float(searchRatio), float(phaseResponseThreshold)
+        p.surf = surf or Engine.surf_params()
+        p.orb = orb or Engine.orb_params()
+        return p
+
+    def pairs_offsets(self, handles, shapes, params, first=0, last=None, direction=1, midpath=False, stop_on_fail=False):
+        """vfsms_pairs_offsets: every pair of [first, last) of the path through the library's own candidate state machine.
+        -> (int32[last-first, 6] = status, dx, dy, direction, i, votes; direction out; (attempts, batches, capacity retries))."""
+        n = len(shapes)
+        last = n - 1 if last is None else last
+        hs = np.array([h if h is not None else 0 for h in handles], np.int64)
+        sh = np.ascontiguousarray(np.array([[s[0], s[1]] for s in shapes], np.int32))
+        out = np.zeros((max(last - first, 0), 6), np.int32)
+        d_out = C.c_int32()
+        stats = np.zeros(8, np.int64)
+        self._check(self.lib.vfsms_pairs_offsets(self.ctx, _ptr(hs), _ptr(sh), n, int(first), int(last), int(direction), int(bool(midpath)),
+                                                 int(bool(stop_on_fail)), C.byref(params), _ptr(out), C.byref(d_out), _ptr(stats)))
+        return out, d_out.value, tuple(int(v) for v in stats)
+
     # -- resident feature sets (Stitcher.tempImageFeature's payload kept in HBM) -----------------------------------------------
     def features_surf(self, tile_handle, rect, params=None, enhance=(0, 0.0, 0)):
         """SURF of rect = (y0, x0, h, w) of a resident tile -> (feature handle, n keypoints); nothing returns to the host."""
@@ -503,3 +548,36 @@ def default_engine():
             raise VfsmsError("no HIP device visible: imagestitch_amd needs an MI355X (there is no CPU fallback)")
         _default_engine = Engine(dev % n)
     return _default_engine
+
+
+def pairs_offsets_eval(attempts, shapes, params, first=0, last=None, direction=1, midpath=False, stop_on_fail=False):
+    """vfsms_pairs_offsets_eval: the library's candidate state machine over a Python evaluator of fused batches (needs no GPU).
+    attempts(items) with items = [(pair, direction, i), ...] -> rows [[status, raw dx, raw dy, votes, nA, nB, ...], ...]."""
+    lib = load_library()
+    n = len(shapes)
+    last = n - 1 if last is None else last
+    err = []
+
+    def cb(_user, items, count, rows):
+        try:
+            res = attempts([(items[k].pair, items[k].direction, items[k].i) for k in range(count)])
+            for k, r in enumerate(res):
+                for c in range(min(len(r), ATTEMPT_INTS)):
+                    rows[k * ATTEMPT_INTS + c] = int(r[c])
+            return 0
+        except Exception as e:            # never let an exception cross the C frame
+            err.append(e)
+            return -1
+    sh = np.ascontiguousarray(np.array([[s[0], s[1]] for s in shapes], np.int32))
+    out = np.zeros((max(last - first, 0), 6), np.int32)
+    d_out = C.c_int32()
+    stats = np.zeros(8, np.int64)
+    rc = lib.vfsms_pairs_offsets_eval(ATTEMPT_EVAL(cb), None, _ptr(sh), n, int(first), int(last), int(direction), int(bool(midpath)),
+                                      int(bool(stop_on_fail)), C.byref(params), _ptr(out), C.byref(d_out), _ptr(stats))
+    if err:
+        raise err[0]
+    if rc != VFSMS_OK:
+        buf = C.create_string_buffer(512)
+        lib.vfsms_last_error(buf, 512)
+        raise VfsmsError("libvfsms error %d: %s" % (rc, buf.value.decode(errors="replace")))
+    return out, d_out.value, tuple(int(v) for v in stats)

@@ -143,7 +143,7 @@ class GridRegistrar:
         return dx, dy
 
     # -- sequentially-equivalent chain over pairs [first, last) ------------------------------------------------------
-    def chain(self, handles, shapes, first, last, d_in, memo=None, cache=None, midpath=False):
+    def chain(self, handles, shapes, first, last, d_in, memo=None, cache=None, midpath=False, stop_on_fail=False):
         """-> (int32[last-first, 6], d_out).
 
         An attempt is a pure function of (pair, direction, i), so WHICH attempts are evaluated together is free;
@@ -250,11 +250,31 @@ class GridRegistrar:
             out[k - first] = row
             d = d_next
             k += 1
+            if stop_on_fail and not row[0]:
+                break                             # flowStitch discards everything behind the first break (Stitcher.py:74-76)
         return out, d
 
-    def register(self, handles, shapes, direction=1):
-        """All P = len(handles)-1 consecutive pairs on this GPU.  -> (int32[P, 6], final direction)."""
-        return self.chain(handles, shapes, 0, len(handles) - 1, direction)
+    native = True      # run whole chains inside the library (vfsms_pairs_offsets) when the engine offers it; chain() is the same machine in Python
+
+    def _grid_params(self):
+        return self.eng.grid_params(method=self.method, roiRatio=self.roiRatio, searchRatio=self.searchRatio, offsetEvaluate=self.offsetEvaluate,
+                                    directIncre=self.directIncre, window=self.window, surf=self.params if self.method == "surf" else None,
+                                    orb=self.params if self.method == "orb" else None, phaseResponseThreshold=self.phaseThr,
+                                    orbMaxDistance=getattr(self, "orbMaxDistance", -1), enhance=self.enhance)
+
+    def _native_stats(self, st):
+        self.stats["attempts"] += st[0]; self.stats["batches"] += st[1]
+        self.capacity_retries = getattr(self, "capacity_retries", 0) + st[2]
+        self.stats["sum_nq_nt"] += st[3]; self.stats["sum_nq_plus_nt"] += st[4]; self.stats["roi_px"] += st[5]
+
+    def register(self, handles, shapes, direction=1, stop_on_fail=False):
+        """All P = len(handles)-1 consecutive pairs on this GPU.  -> (int32[P, 6], final direction).
+        stop_on_fail: stop behind the first pair that cannot be registered (rows after it stay zero)."""
+        if self.native and hasattr(self.eng, "pairs_offsets"):
+            out, d, st = self.eng.pairs_offsets(handles, shapes, self._grid_params(), 0, len(handles) - 1, direction, False, stop_on_fail)
+            self._native_stats(st)
+            return out, d
+        return self.chain(handles, shapes, 0, len(handles) - 1, direction, stop_on_fail=stop_on_fail)
 
     # -- pair-sharded ---------------------------------------------------------------------------------------------------
     @staticmethod
@@ -285,7 +305,11 @@ class GridRegistrar:
             for it, r in zip([(lo, d, 1) for d in dirs], self._attempts(handles, shapes, [(lo, d, 1) for d in dirs])):
                 cache[it] = r
         for d_in in dirs:
-            if hi > lo:
+            if hi > lo and len(dirs) == 1 and self.native and hasattr(self.eng, "pairs_offsets"):
+                res, dn, st = self.eng.pairs_offsets(handles, shapes, self._grid_params(), lo, hi, d_in, rank > 0, False)
+                self._native_stats(st)
+                table[d_in - 1, :hi - lo] = res
+            elif hi > lo:
                 res, dn = self.chain(handles, shapes, lo, hi, d_in, memo, cache, midpath=rank > 0)
                 table[d_in - 1, :hi - lo] = res
             else:

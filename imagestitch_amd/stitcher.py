@@ -191,7 +191,7 @@ class Stitcher(Utility.Method):
         handles = [eng.tile_upload(im) for im in images]
         keep = (not self.isColorMode) and self.fuseMethod in ("notFuse", "fadeInAndFadeOut") and hasattr(eng, "canvas_fuse_tile_resident")
         try:
-            table, _d = reg.register(handles, [im.shape for im in images], self.direction)
+            table, _d = reg.register(handles, [im.shape for im in images], self.direction, stop_on_fail=True)
         except BaseException:
             keep = False
             raise

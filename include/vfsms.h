@@ -185,6 +185,44 @@ int vfsms_attempt_orb_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n,
 /* same for phase correlation (Stitcher.py:224-235): out: double[n][3] = {x, y, response}           */
 int vfsms_attempt_phase_batch(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, double *out);
 
+/* ---- whole shooting paths behind one call (the pair loop of Stitcher.flowStitch, Stitcher.py:64-79, around the incremental search of
+ * Stitcher.py:306-367 / 205-258) -------------------------------------------------------------------------------------------------
+ * The candidate state machine runs inside the library: speculative fused batches (a window of consecutive pairs at the inherited
+ * direction, whole candidate rings at predicted turns), results selected in the reference's order
+ *     for i in 1 .. maxI-1 { d = direction; do { attempt(d, i); d = rotate(d) } while (d != direction) },  maxI = floor(0.5 / roiRatio) + 2,
+ * `direction` threaded from pair to pair (Stitcher.py:252,361).  out: int32[last_pair - first_pair][6] = {status, dx, dy, accepted
+ * direction, ROI growth i, votes}, offsets already carried back to full-tile coordinates (Stitcher.py:352-360); direction_out: the
+ * direction the path leaves with; stats (optional, int64[8]): attempts evaluated, fused batches, keypoint-capacity retries, sum nA*nB,
+ * sum nA+nB, ROI pixels processed (workload figures for roofline reports), 2 reserved.
+ * midpath != 0: the chain starts inside a path (a rank of the pair-sharded form): speculation stays short until two runs were seen.
+ * stop_on_fail != 0: stop behind the first pair that cannot be registered (flowStitch breaks there, Stitcher.py:74-76).              */
+typedef struct { int32_t pair, direction, i; } vfsms_attempt_key;
+typedef struct {
+    int32_t method;                  /* 0 SURF + BF-L2 + ratio + mode, 1 ORB + BF-Hamming + mode, 2 FP64 phase correlation        */
+    int32_t offset_evaluate;         /* Method.offsetEvaluate                                                                      */
+    int32_t direct_incre;            /* Stitcher.directIncre: 1, 0 or -1                                                           */
+    int32_t window;                  /* speculation window (attempts per fused batch)                                              */
+    int32_t orb_max_dist;            /* < 0: no Hamming threshold (the cv2 path)                                                   */
+    int32_t enhance_mode;            /* Method.isEnhance: 0 none, 1 equalizeHist, 2 CLAHE (SURF only)                              */
+    int32_t tile_grid;               /* Method.tileSize                                                                            */
+    int32_t reserved;
+    double roi_ratio;                /* Method.roiRatio                                                                            */
+    double search_ratio;             /* Method.searchRatio (ratio test)                                                            */
+    double phase_threshold;          /* Stitcher.phaseResponseThreshold                                                            */
+    double clip_limit;               /* Method.clipLimit                                                                           */
+    vfsms_surf_params surf;
+    vfsms_orb_params orb;
+} vfsms_grid_params;
+int vfsms_pairs_offsets(vfsms_ctx *ctx, const int64_t *tiles, const int32_t *shapes_hw, int n_tiles, int first_pair, int last_pair,
+                        int direction_in, int midpath, int stop_on_fail, const vfsms_grid_params *p, int32_t *out,
+                        int32_t *direction_out, int64_t *stats);
+/* The same state machine over a caller-supplied evaluator of fused batches (other operators; the CPU tests): eval fills
+ * rows[n][VFSMS_ATTEMPT_INTS] = {status, raw dx, raw dy, votes, nA, nB, ...} for n attempts and returns VFSMS_OK.                   */
+typedef int (*vfsms_attempt_eval)(void *user, const vfsms_attempt_key *items, int n, int32_t *rows);
+int vfsms_pairs_offsets_eval(vfsms_attempt_eval eval, void *user, const int32_t *shapes_hw, int n_tiles, int first_pair, int last_pair,
+                             int direction_in, int midpath, int stop_on_fail, const vfsms_grid_params *p, int32_t *out,
+                             int32_t *direction_out, int64_t *stats);
+
 /* ---- whole-tile feature search with the reference's feature cache (Stitcher.calculateOffsetForFeatureSearch, Stitcher.py:260-304) --
  * Stitcher.tempImageFeature (Stitcher.py:14-18,278-290) keeps tile B's keypoints + descriptors so that they become tile A's of the
  * next pair; here that payload stays in HBM under a handle: SURF (+ optional enhancement, Stitcher.py:269-276) of a rectangle of a

@@ -684,3 +684,39 @@ def test_fuse_at_production_size_vs_oracle(engine, oracle, tmp_path):
         assert np.array_equal(res, outs[1])
     finally:
         isa.Stitcher.isColorMode = old
+
+
+def test_orb_at_config2_geometry(engine, oracle):
+    """BASELINE configs[2] geometry: 2048 x 2048 tiles, 10 % overlap, ROI strips 409 x 2048, ORB(5000, 1.2, 8, 31, 0, 2, HARRIS, 31, 20)
+    with upstream's learned sampling table.  Keypoints + descriptor bytes of a full-size strip equal the oracle's; size-independent
+    properties hold (level-major order, per-level quotas, 31 px border in level coordinates, a set matched against itself finds
+    itself at Hamming distance 0); the fused attempt row equals the oracle chain and the voted offset equals the integer ground truth
+    exactly (north_star's bar for ORB)."""
+    g = SyntheticGrid(2, 1, 2048, overlap=0.10)
+    t = g.tiles(threads=2)
+    truth = g.true_offsets()[0]
+    ra = isa.roi_rect(t[0].shape, 1, "first", 0.2); rb = isa.roi_rect(t[1].shape, 1, "second", 0.2)
+    assert ra[2:] == (409, 2048)
+    A = np.ascontiguousarray(t[0][ra[0]:ra[0] + ra[2]]); B = np.ascontiguousarray(t[1][:rb[2]])
+    kxy, da, kf = engine.orb_detect_describe(A, full=True)
+    ko, do = oracle.orb_detect_describe(A)
+    assert len(kf) == len(ko) > 4000
+    for f in ("x", "y", "size", "angle", "response", "octave"):
+        assert np.array_equal(kf[f], ko[f]), f
+    assert np.array_equal(da, do)
+    assert np.all(np.diff(kf["octave"]) >= 0)
+    q = np.bincount(kf["octave"], minlength=8)
+    assert q[0] <= 1085 + 64 and q.sum() <= 5000 + 8 * 64
+    lx = kf["x"] / (1.2 ** kf["octave"]); ly = kf["y"] / (1.2 ** kf["octave"])
+    assert lx.min() >= 30.9 and ly.min() >= 30.9
+    self_pairs = engine.bf_hamming_matches(da, da)
+    assert len(self_pairs) == len(da)
+    assert np.all((da[self_pairs[:, 0]] == da[self_pairs[:, 1]]).all(1))            # distance 0 (ties go to the lower index)
+    _kb, db, kfb = engine.orb_detect_describe(B, full=True)
+    ha, hb = engine.tile_upload(t[0]), engine.tile_upload(t[1])
+    row = engine.attempt_orb_batch([(ha, hb, ra[0], ra[1], rb[0], rb[1], ra[2], ra[3])], engine.orb_params(), -1, 3)[0]
+    engine.tile_free(ha); engine.tile_free(hb)
+    pairs, _ = oracle.bf_hamming_matches(da, db)
+    st, off, votes = oracle.mode_offset(kxy, np.stack([kfb["x"], kfb["y"]], 1), pairs, 3)
+    assert list(row[:7]) == [int(st), off[0], off[1], votes, len(da), len(db), len(pairs)], (row, st, off, votes)
+    assert st and [off[0] + 2048 - int(0.2 * 2048), off[1]] == truth, (off, truth)

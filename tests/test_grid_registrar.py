@@ -114,3 +114,44 @@ def test_eight_process_gloo_config4_path(tmp_path):
     assert got["direction"] == d_end and [r[:4] for r in got["rows"]] == seq
     print("attempts per rank", got["attempts"], "batches per rank", got["batches"])
     assert len(got["attempts"]) == 8 and sum(got["attempts"]) < 1.4 * 1100 and max(got["attempts"]) < 1.35 * sum(got["attempts"]) / 8
+
+
+def test_native_pairs_offsets_state_machine_equals_python_and_sequential():
+    """vfsms_pairs_offsets_eval -- the candidate state machine inside libvfsms.so (csrc/grid.hip), fed by a scripted evaluator through
+    a C callback (no GPU): on random truth tables with failures, late successes and false-positive directions it must return the
+    rows of the sequential search AND evaluate exactly the batches the Python registrar evaluates (same attempts, same order)."""
+    import imagestitch_amd as isa
+    from imagestitch_amd._lib import pairs_offsets_eval, Engine
+    for seed in range(40):
+        rng = np.random.default_rng(1000 + seed)
+        roiRatio = float(rng.choice([0.1, 0.2]))
+        incre = int(rng.choice([-1, 0, 1]))
+        P = int(rng.integers(1, 40))
+        window = int(rng.choice([1, 3, 8, 24]))
+        d0 = int(rng.integers(1, 5))
+        accept = random_truth(rng, P, roiRatio)
+        seq, d_end, _ = sequential(accept, roiRatio, incre, d0)
+        eng = ScriptedAttemptEngine(SHAPE, roiRatio, accept)
+        reg = GridRegistrar(eng, roiRatio=roiRatio, directIncre=incre, window=window)
+        res_py, d_py = reg.chain(list(range(P + 1)), [SHAPE] * (P + 1), 0, P, d0)
+        log = []
+
+        def attempts(items, accept=accept, log=log):
+            rows = []
+            for (k, d, i) in items:
+                log.append((k, d, i))
+                acc = accept[k]
+                ok = (d, i) in acc
+                raw = acc[(d, i)] if ok else (7, -3)
+                rows.append([int(ok), raw[0], raw[1], 5 if ok else 1, 100, 100, 10, 0])
+            return rows
+        params = Engine.grid_params(method="surf", roiRatio=roiRatio, directIncre=incre, window=window)
+        res_c, d_c, st = pairs_offsets_eval(attempts, [SHAPE] * (P + 1), params, 0, P, d0)
+        assert [list(r[:4]) for r in res_c.tolist()] == seq and d_c == d_end, (seed, res_c.tolist(), seq)
+        assert np.array_equal(res_c, res_py) and d_c == d_py
+        assert log == eng.log and st[0] == len(log) == reg.stats["attempts"] and st[1] == reg.stats["batches"], (seed, len(log), len(eng.log))
+    # stop_on_fail: nothing behind the first break is reported
+    accept = [{(1, 1): (3, 3)}, {}, {(1, 1): (4, 4)}]
+    res, d, _st = pairs_offsets_eval(lambda items: [[int((dd, i) in accept[k])] + ([3, 3, 5] if (dd, i) in accept[k] else [0, 0, 0]) + [9, 9, 4, 0] for (k, dd, i) in items],
+                                     [SHAPE] * 4, Engine.grid_params(roiRatio=0.2, directIncre=1, window=8), 0, 3, 1, False, True)
+    assert res[:, 0].tolist() == [1, 0, 0]
