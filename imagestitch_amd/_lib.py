@@ -61,6 +61,7 @@ _SIGNATURES = {
     "vfsms_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "vfsms_ctx_destroy": (C.c_int, [C.c_void_p]),
     "vfsms_ctx_sync": (C.c_int, [C.c_void_p]),
+    "vfsms_ctx_sync_uploads": (C.c_int, [C.c_void_p]),
     "vfsms_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "vfsms_ctx_set_keypoint_capacity": (C.c_int, [C.c_void_p, C.c_int]),
     "vfsms_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
@@ -193,6 +194,11 @@ class Engine:
 
     def sync(self):
         self._check(self.lib.vfsms_ctx_sync(self.ctx))
+        self.__dict__.pop("_inflight", None)
+
+    def sync_uploads(self):
+        """wait for tile_upload_async copies only: their host buffers may be reused"""
+        self._check(self.lib.vfsms_ctx_sync_uploads(self.ctx))
         self.__dict__.pop("_inflight", None)
 
     def stream_handle(self):

@@ -245,6 +245,12 @@ extern "C" int vfsms_ctx_sync(vfsms_ctx *ctx)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return VFSMS_OK;
 }
+extern "C" int vfsms_ctx_sync_uploads(vfsms_ctx *ctx)
+{
+    if (!ctx) return VFSMS_ERR_BAD_ARG;
+    HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
+    return VFSMS_OK;
+}
 extern "C" void *vfsms_ctx_stream(vfsms_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 extern "C" int vfsms_ctx_set_keypoint_capacity(vfsms_ctx *ctx, int cap)
 {

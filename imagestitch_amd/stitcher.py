@@ -177,18 +177,46 @@ class Stitcher(Utility.Method):
             method = "phase"
         else:
             return None
-        images = [_imread(f, False) for f in fileList]
-        if any(im.shape != images[0].shape for im in images):
-            return None
-        from .grid import GridRegistrar
         eng = self.engine
+        handles = []
+        if hasattr(eng, "tile_upload_async") and hasattr(eng, "pinned_empty"):
+            # decode once per tile (the reference decodes each tile three times: Stitcher.py:68-69,382-403) straight into a small
+            # ring of pinned staging buffers; every upload is an asynchronous DMA on the copy stream that overlaps the decode of
+            # the next files, and the first batch that names a tile waits for exactly that tile
+            first = _imread(fileList[0], False)
+            ring = self.__dict__.get("_stage")
+            if ring is None or ring[0].shape != first.shape:
+                ring = self._stage = [eng.pinned_empty(first.shape) for _ in range(4)]
+            images = []
+            ok = True
+            for n, f in enumerate(fileList):
+                im = first if n == 0 else _imread(f, False)
+                if im.shape != first.shape:
+                    ok = False
+                    break
+                if n >= len(ring) and n % len(ring) == 0:
+                    eng.sync_uploads()                       # the ring is about to wrap: its copies have long landed
+                buf = ring[n % len(ring)]
+                buf[...] = im
+                handles.append(eng.tile_upload_async(buf))
+                images.append(im)
+            eng.sync_uploads()
+            if not ok:
+                for h in handles:
+                    eng.tile_free(h)
+                return None
+        else:
+            images = [_imread(f, False) for f in fileList]
+            if any(im.shape != images[0].shape for im in images):
+                return None
+            handles = [eng.tile_upload(im) for im in images]
+        from .grid import GridRegistrar
         params = None if method == "phase" else (self._orbParams() if method == "orb" else self._surfParams())
         reg = GridRegistrar(eng, method=method, roiRatio=self.roiRatio, searchRatio=self.searchRatio, offsetEvaluate=self.offsetEvaluate,
                             directIncre=self.directIncre, surfParams=params,
                             phaseResponseThreshold=self.phaseResponseThreshold, window=24,
                             enhance=self._enhanceSpec() if method == "surf" else (0, 0.0, 0))
         reg.orbMaxDistance = self.orbMaxDistance if self.isGPUAvailable else -1
-        handles = [eng.tile_upload(im) for im in images]
         keep = (not self.isColorMode) and self.fuseMethod in ("notFuse", "fadeInAndFadeOut") and hasattr(eng, "canvas_fuse_tile_resident")
         try:
             table, _d = reg.register(handles, [im.shape for im in images], self.direction, stop_on_fail=True)

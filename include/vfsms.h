@@ -83,6 +83,8 @@ int vfsms_last_error(char *buf, int buflen);           /* copies the calling thr
 int vfsms_ctx_create(int device, vfsms_ctx **out);
 int vfsms_ctx_destroy(vfsms_ctx *ctx);
 int vfsms_ctx_sync(vfsms_ctx *ctx);
+/* wait for the asynchronous tile uploads only (vfsms_tile_upload_async): their host buffers may be reused afterwards             */
+int vfsms_ctx_sync_uploads(vfsms_ctx *ctx);
 /* The context's hipStream_t (as void*), so a host framework can record HIP events on it.          */
 void *vfsms_ctx_stream(vfsms_ctx *ctx);
 /* Max SURF candidates per ROI (default: h*w/24 + 4096).  0 restores the default.                  */

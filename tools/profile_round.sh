@@ -1,44 +1,54 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for one round on the GPU box (run through gpurun); outputs under gpurun_out/prof_$TAG.
-#   bash tools/profile_round.sh r01
-# pass 1: --kernel-trace --stats equivalent (rocpd database -> per-kernel CSV by tools/rocpd_summary.py afterwards)
-# pass 2..4: PMC passes, each in its own run (wave-cycle breakdown; FETCH_SIZE; WRITE_SIZE), kernel-trace only.
-TAG=${1:-r01}
+#   bash tools/profile_round.sh r02 [pmc]
+# pass 1: --kernel-trace --stats of the DEFAULT bench command (rocpd database -> per-kernel CSV by tools/rocpd_summary.py)
+# passes 2..4 (only with "pmc"): PMC passes, each in its own run, kernel-trace only (SQ instruction mix / wave-cycle breakdown;
+#   FETCH_SIZE; WRITE_SIZE).  PMC serialises kernels, so these run ONE step of the same workload without the steady-clock warmup.
+TAG=${1:-r02}; PMC=${2:-}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD="python bench.py --steps 2 --warmup 1 --cpu-sample 0"
-timeout 240 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err
-timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVES -d $OUT/pmc_sq -o pmc --output-format csv -- $CMD > $OUT/pmc_sq_bench.json 2> $OUT/pmc_sq.err
-timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc --output-format csv -- $CMD > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
-timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc --output-format csv -- $CMD > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
+CMD="python bench.py --cpu-sample 0"
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err
 python tools/rocpd_summary.py $(ls $OUT/trace/*results.db | head -1) $OUT/kernel_stats.csv
+for m in orb phase fuse; do
+  timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/trace_$m -o trace -- python bench.py --method $m --cpu-sample 0 > $OUT/trace_bench_$m.json 2> $OUT/trace_$m.err
+  python tools/rocpd_summary.py $(ls $OUT/trace_$m/*results.db | head -1) $OUT/kernel_stats_$m.csv
+done
+rm -rf $OUT/trace $OUT/trace_orb $OUT/trace_phase $OUT/trace_fuse
+[ "$PMC" = "pmc" ] || exit 0
+export VFSMS_BENCH_MIN_WARM=0
+PCMD="python bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-host-leg"
+timeout 500 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc_sq -o pmc --output-format csv -- $PCMD > $OUT/pmc_sq_bench.json 2> $OUT/pmc_sq.err
+timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc --output-format csv -- $PCMD > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
+timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc --output-format csv -- $PCMD > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
 python - <<PY
-import csv, glob, collections, json
-def agg(path):
-    a=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
-    for row in csv.DictReader(open(path)):
+import csv, glob, collections
+def agg(pat):
+    a=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter(); seen=set()
+    f=glob.glob(pat, recursive=True)
+    if not f: return a, n
+    for row in csv.DictReader(open(f[0])):
         k=row['Kernel_Name'].split('(')[0]
         a[k][row['Counter_Name']]+=float(row['Counter_Value'])
-    return a
+        key=(row.get('Dispatch_Id'),k)
+        if key not in seen: seen.add(key); n[k]+=1
+    return a, n
 out=open('$OUT/pmc_summary.txt','w')
-sq=agg(glob.glob('$OUT/pmc_sq/*counter_collection.csv')[0])
-out.write('# wave-cycle breakdown per kernel (rocprofv3 --pmc SQ_*; percentages of SQ_WAVE_CYCLES)\n')
-for k,v in sq.items():
-    if k.startswith('k_'):
-        w=v.get('SQ_WAVE_CYCLES',1)
-        out.write('%-18s waves=%.3g wave_cycles=%.3g ' % (k, v.get('SQ_WAVES',0), w) + ' '.join('%s=%.1f%%'%(c.replace('SQ_',''),100*x/w) for c,x in sorted(v.items()) if c not in ('SQ_WAVE_CYCLES','SQ_WAVES')) + '\n')
-# dispatch counts from the trace
-disp=collections.Counter()
-for row in csv.DictReader(open(glob.glob('$OUT/pmc_fetch/*kernel_trace.csv')[0])):
-    disp[row['Kernel_Name'].split('(')[0]]+=1
-f=agg(glob.glob('$OUT/pmc_fetch/*counter_collection.csv')[0]); w=agg(glob.glob('$OUT/pmc_write/*counter_collection.csv')[0])
-out.write('\n# HBM traffic per launch (MI355X_MICROARCH.md HBM section): bytes = FETCH_SIZE*1024*2 (gfx950 reports half of a wide\n# coalesced read stream; scattered/narrow accesses uncalibrated) + WRITE_SIZE*1024; separate --pmc passes\n')
+sq,nsq=agg('$OUT/pmc_sq/**/*counter_collection.csv')
+out.write('# SQ counters per launch (rocprofv3 --pmc, one step of the default bench workload, kernels serialised); quad-cycle units for\\n# WAVE_CYCLES / WAIT_ANY / ACTIVE_INST_ANY; INSTS_* = wave-instructions (one VALU wave-instruction occupies its SIMD for 4 cycles)\\n')
+for k,v in sorted(sq.items(), key=lambda kv:-kv[1].get('SQ_WAVE_CYCLES',0)):
+    if 'k_' in k:
+        n=max(nsq[k],1)
+        out.write('%-28s launches=%d '%(k[:28],n)+' '.join('%s=%.4g'%(c.replace('SQ_',''),x/n) for c,x in sorted(v.items()))+'\\n')
+f,nf=agg('$OUT/pmc_fetch/**/*counter_collection.csv'); w,nw=agg('$OUT/pmc_write/**/*counter_collection.csv')
+out.write('\\n# HBM traffic per launch (MI355X_MICROARCH.md HBM section): bytes = FETCH_SIZE*1024*2 (gfx950 reports half of a wide\\n# coalesced read stream; scattered/narrow accesses uncalibrated) + WRITE_SIZE*1024; separate --pmc passes\\n')
 for k in sorted(f):
-    if k.startswith('k_'):
-        n=max(disp.get(k,1),1)
-        fb=f[k].get('FETCH_SIZE',0)*1024; wb=w.get(k,{}).get('WRITE_SIZE',0)*1024
-        out.write('%-18s launches=%d fetch_raw=%.4g B/launch fetch_x2=%.4g B/launch write=%.4g B/launch total(x2 rule)=%.4g B/launch\n' % (k,n,fb/n,2*fb/n,wb/n,(2*fb+wb)/n))
+    if 'k_' in k:
+        n=max(nf[k],1)
+        fb=f[k].get('FETCH_SIZE',0)*1024; wb=w.get(k,{}).get('WRITE_SIZE',0)*1024; nn=max(nw.get(k,n),1)
+        out.write('%-28s launches=%d fetch_raw=%.4g B/launch fetch_x2=%.4g B/launch write=%.4g B/launch total(x2 rule)=%.4g B/launch\\n' % (k[:28],n,fb/n,2*fb/n,wb/nn,2*fb/n+wb/nn))
 out.close()
 print(open('$OUT/pmc_summary.txt').read())
 PY
+rm -rf $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write
