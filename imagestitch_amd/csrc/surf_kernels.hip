@@ -630,9 +630,13 @@ __device__ unsigned long long g_desc_cycles[8];
 #define DT_MARK(ph) do { if (threadIdx.x == 0) { unsigned long long _n = clock64(); atomicAdd(&g_desc_cycles[ph], _n - _t0); _t0 = _n; } } while (0)
 #define DT_START unsigned long long _t0 = clock64()
 extern "C" int vfsms_debug_desc_cycles(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_desc_cycles), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -3; }
+__device__ unsigned long long g_desc_trips[4];      // [0] interior-strip trips, [1] border-strip trips that are all inside, [2] border trips (per-sample path), [3] keypoints
+#define DT_TRIP(n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_desc_trips[n], 1ull); } while (0)
+extern "C" int vfsms_debug_desc_trips(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_desc_trips), sizeof(unsigned long long) * 4) == hipSuccess ? 0 : -3; }
 #else
 #define DT_MARK(ph) do {} while (0)
 #define DT_START do {} while (0)
+#define DT_TRIP(n) do {} while (0)
 #endif
 #ifndef VFSMS_EXP
 #define VFSMS_EXP 0
@@ -676,7 +680,7 @@ __device__ __forceinline__ int win_sample_upright(const WinGeom &G, int i, int j
 // changes of tile shape, ILP depth or occupancy beyond that left its time unchanged -- DESIGN.md section 9.)
 #define STAGE_ILP 4
 #ifndef BORDER_ILP
-#define BORDER_ILP 1            // strips that cross the image border (rare): short trips keep the register budget of the hot path
+#define BORDER_ILP 2            // strips that cross the image border: shorter trips keep the register budget of the hot path
 #endif
 __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row, const float *sy_row,
                                            int r0, int nrows, uint8_t *dst)
@@ -719,6 +723,7 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
                 for (int jb = 0; jb < win; jb += 8 * STAGE_ILP) {
                     uint32_t top[STAGE_ILP], bot[STAGE_ILP];
                     double px[STAGE_ILP], py[STAGE_ILP];
+                    DT_TRIP(0);
 #pragma unroll
                     for (int u = 0; u < STAGE_ILP; u++) {
                         // start + j * step: the product is exact in double, so the fused form rounds exactly like mul-then-add
@@ -756,6 +761,7 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
                 inb[u] = px[u] >= 0.0 && py[u] >= 0.0 && (int)px[u] < ncols1 - 2 && (int)py[u] < nrows1;
                 all_in = all_in && (inb[u] || !act[u]);
             }
+            if (__all(all_in)) DT_TRIP(1); else DT_TRIP(2);
             if (__all(all_in)) {                                   // interior (the common case): branch-free gathers
                 // the gather path (one address per lane through the texture-address unit) is what bounds this kernel:
                 // the two horizontally adjacent taps of a row come from ONE unaligned dword load (2 loads / sample, not 4)
@@ -775,10 +781,29 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
                     const float v = t00 * (1.f - a) * (1.f - b) + t01 * a * (1.f - b) + t10 * (1.f - a) * b + t11 * a * b;
                     if (act[u]) drow[jb + u * 8 + lj] = (uint8_t)cv_round_f(v);
                 }
-            } else {                                               // window crosses the image border: per-sample path
+            } else {
+                // The window crosses the image border here (a quarter of all sample slots on 409-row strips: not rare).  No branch
+                // per sample: every lane gathers four bytes at clamped coordinates -- the bilinear taps when (ix, iy) is interior,
+                // the nearest pixel clamp(cvRound(px), cvRound(py)) otherwise -- and selects at the end.
+                uint32_t p00[BORDER_ILP], p01[BORDER_ILP], p10[BORDER_ILP], p11[BORDER_ILP];
+                bool inside[BORDER_ILP];
 #pragma unroll
-                for (int u = 0; u < BORDER_ILP; u++)
-                    if (act[u]) drow[jb + u * 8 + lj] = (uint8_t)win_sample_xy(G, px[u], py[u]);
+                for (int u = 0; u < BORDER_ILP; u++) {
+                    const int ix = (int)px[u], iy = (int)py[u];                       // trunc == floor wherever `inside` holds
+                    inside[u] = px[u] >= 0.0 && py[u] >= 0.0 && ix < ncols1 && iy < nrows1;
+                    const int rx = min(max(cv_round_d(px[u]), 0), ncols1), ry = min(max(cv_round_d(py[u]), 0), nrows1);
+                    const int cx = (inside[u] && act[u]) ? ix : (act[u] ? rx : 0), cy = (inside[u] && act[u]) ? iy : (act[u] ? ry : 0);
+                    const int cx1 = min(cx + 1, ncols1), cy1 = min(cy + 1, nrows1);
+                    const uint32_t o0 = (uint32_t)__umul24((uint32_t)cy, (uint32_t)G.stride), o1 = (uint32_t)__umul24((uint32_t)cy1, (uint32_t)G.stride);
+                    p00[u] = ubase[o0 + (uint32_t)cx]; p01[u] = ubase[o0 + (uint32_t)cx1];
+                    p10[u] = ubase[o1 + (uint32_t)cx]; p11[u] = ubase[o1 + (uint32_t)cx1];
+                }
+#pragma unroll
+                for (int u = 0; u < BORDER_ILP; u++) {
+                    const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
+                    const float v = (uint8_t)p00[u] * (1.f - a) * (1.f - b) + (uint8_t)p01[u] * a * (1.f - b) + (uint8_t)p10[u] * (1.f - a) * b + (uint8_t)p11[u] * a * b;
+                    if (act[u]) drow[jb + u * 8 + lj] = inside[u] ? (uint8_t)cv_round_f(v) : (uint8_t)p00[u];
+                }
             }
         }
     }

@@ -22,3 +22,6 @@ names = ["prologue", "stageA", "outputsA", "stageB", "outputsB", "descriptor", "
 print("keypoints", nk, "total block-cycles %.3g (clock64 ticks)" % d.sum())
 for n, v in zip(names, d[:7]):
     print("  %-10s %6.1f %%   %.0f ticks/keypoint" % (n, 100 * v / d.sum(), v / nk))
+
+tr = np.zeros(4, np.uint64); eng.lib.vfsms_debug_desc_trips(tr.ctypes.data_as(ctypes.c_void_p))
+print("wave trips (both runs): interior strips %d (x4 samples/lane), border strips all-in %d (x%d), border per-sample %d" % (tr[0], tr[1], 1, tr[2]))
