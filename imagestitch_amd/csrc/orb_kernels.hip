@@ -121,34 +121,52 @@ __global__ __launch_bounds__(256) void k_orb_fast_nms(const OrbDev *rois, int nl
         img[r][c] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? src[(size_t)gy * st + gx] : (uint8_t)0;
     }
     __syncthreads();
+    // Pass A: the 9-of-16 segment test for every pixel of the tile + its 1 px halo; pixels that pass are queued.  Pass B: cornerScore
+    // for the queue only, all lanes busy.  (Evaluated inline, a wave ran the ~150-instruction score whenever ONE of its 64 pixels
+    // was a corner candidate -- nearly always -- although only about one pixel in ten is.)
+    __shared__ unsigned short cq[(FT_H + 2) * (FT_W + 2)];
+    __shared__ int cqn;
+    if (tid == 0) cqn = 0;
+    const int ox[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    const int oy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+    __syncthreads();
     for (int idx = tid; idx < (FT_H + 2) * (FT_W + 2); idx += 256) {
         const int r = idx / (FT_W + 2), c = idx - r * (FT_W + 2);
         const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-        int s = 0;
+        bool cand = false;
         if (gy >= 3 && gy < h - 3 && gx >= 3 && gx < w - 3) {
             const uint8_t *p = &img[r + 3][c + 3];
             const int v = p[0];
-            const int ox[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-            const int oy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-            int d[25];
             unsigned dark = 0, bright = 0;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const int x = p[oy[k] * (FT_W + 8) + ox[k]];
-                d[k] = v - x;
                 dark |= (unsigned)(x < v - threshold) << k;
                 bright |= (unsigned)(x > v + threshold) << k;
             }
-#pragma unroll
-            for (int k = 16; k < 25; k++) d[k] = d[k - 16];
             // a circular run of >= 9: AND of the mask with its 8 rotations
             unsigned md = dark | (dark << 16), mb = bright | (bright << 16);
             unsigned rd = md, rb = mb;
 #pragma unroll
             for (int q = 1; q < 9; q++) { rd &= md >> q; rb &= mb >> q; }
-            if ((rd & 0xffffu) | (rb & 0xffffu)) s = corner_score16(d, threshold) & 0xff;
+            cand = ((rd & 0xffffu) | (rb & 0xffffu)) != 0;
         }
-        sc[r][c] = (uint8_t)s;
+        sc[r][c] = 0;
+        if (cand) cq[atomicAdd(&cqn, 1)] = (unsigned short)idx;
+    }
+    __syncthreads();
+    const int ncand = cqn;
+    for (int e = tid; e < ncand; e += 256) {
+        const int idx = cq[e];
+        const int r = idx / (FT_W + 2), c = idx - r * (FT_W + 2);
+        const uint8_t *p = &img[r + 3][c + 3];
+        const int v = p[0];
+        int d[25];
+#pragma unroll
+        for (int k = 0; k < 16; k++) d[k] = v - (int)p[oy[k] * (FT_W + 8) + ox[k]];
+#pragma unroll
+        for (int k = 16; k < 25; k++) d[k] = d[k - 16];
+        sc[r][c] = (uint8_t)(corner_score16(d, threshold) & 0xff);
     }
     __syncthreads();
     g_u8 nm = (g_u8)R.nms[level];
@@ -337,8 +355,6 @@ __global__ __launch_bounds__(1024) void k_orb_select2(const OrbDev *rois, int nl
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int *o_xy = R.k2_xy + (size_t)level * R.cap2 * 2;
     float *o_r = R.k2_resp + (size_t)level * R.cap2;
-    float *o_a = R.k2_angle + (size_t)level * R.cap2;
-    const int hp = T->half_patch;
     for (int base = 0; base < n1; base += 1024) {
         const int idx = base + threadIdx.x;
         const float me = idx < n1 ? resp[idx] : 0.f;
@@ -362,32 +378,7 @@ __global__ __launch_bounds__(1024) void k_orb_select2(const OrbDev *rois, int nl
         if (keep) {
             const int x = xy[2 * idx], y = xy[2 * idx + 1];
             if (off < R.cap2) {
-                // ICAngles: intensity centroid over the circular patch (umax table), integer moments
-                g_cu8 center = (g_cu8)R.lv[level] + (size_t)y * R.ls[level] + x;
-                const int st = R.ls[level];
-                int m_01 = 0, m_10 = 0;
-                for (int u = -hp; u <= hp; ++u) m_10 += u * center[u];
-                for (int v = 1; v <= hp; ++v) {
-                    int v_sum = 0;
-                    const int d = T->umax[v];
-                    for (int u = -d; u <= d; ++u) {
-                        const int vp = center[u + v * st], vm = center[u - v * st];
-                        v_sum += (vp - vm);
-                        m_10 += u * (vp + vm);
-                    }
-                    m_01 += v * v_sum;
-                }
-                // fastAtan2((float)m_01, (float)m_10)
-                const float yy = (float)m_01, xx = (float)m_10;
-                const float sc = (float)(180 / 3.1415926535897932384626433832795);
-                const float p1 = 0.9997878412794807f * sc, p3 = -0.3258083974640975f * sc, p5 = 0.1555786518463281f * sc, p7 = -0.04432655554792128f * sc;
-                const float ax = fabsf(xx), ay = fabsf(yy);
-                float a, c, c2;
-                if (ax >= ay) { c = ay / (ax + (float)DBL_EPSILON); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
-                else { c = ax / (ay + (float)DBL_EPSILON); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
-                if (xx < 0) a = 180.f - a;
-                if (yy < 0) a = 360.f - a;
-                o_xy[2 * off] = x; o_xy[2 * off + 1] = y; o_r[off] = me; o_a[off] = a;
+                o_xy[2 * off] = x; o_xy[2 * off + 1] = y; o_r[off] = me;         // the angle follows in k_orb_angle
             } else R.counters[2] = 1;
         }
         __syncthreads();
@@ -396,6 +387,48 @@ __global__ __launch_bounds__(1024) void k_orb_select2(const OrbDev *rois, int nl
     }
     if (threadIdx.x == 0) R.n2[level] = min(carry, R.cap2);
 }
+
+// ---- ICAngles: intensity centroid over the circular patch (umax table), one WAVE per keypoint ---------------------------------------
+// The moments are integer sums, so any summation order gives upstream's bits: lanes 0-31 / 32-63 take two rows of the disc per
+// trip (rows are at most 31 pixels wide), one byte gather each, and a wave reduction finishes.  (Inside k_orb_select2 one lane
+// walked the ~700 pixels of a disc with a dependent wait per load: 0.5 ms per launch.)
+__global__ __launch_bounds__(256) void k_orb_angle(const OrbDev *rois, int nlevels, const OrbTables *T)
+{
+    const OrbDev &R = rois[blockIdx.y / nlevels];
+    const int level = blockIdx.y % nlevels;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= R.n2[level]) return;
+    const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+    const int *xy = R.k2_xy + (size_t)level * R.cap2 * 2;
+    const int x = xy[2 * idx], y = xy[2 * idx + 1];
+    const int st = R.ls[level], hp = T->half_patch;
+    g_cu8 center = (g_cu8)R.lv[level] + (size_t)y * st + x;
+    int m_01 = 0, m_10 = 0;
+    for (int v0 = -hp; v0 <= hp; v0 += 2) {
+        const int v = v0 + half;
+        if (v > hp) continue;
+        const int d = T->umax[v < 0 ? -v : v];
+        const int u = l32 - d;
+        if (u > d) continue;
+        const int val = center[u + v * st];
+        m_10 += u * val; m_01 += v * val;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m_10 += __shfl_xor(m_10, o, 64); m_01 += __shfl_xor(m_01, o, 64); }
+    if (lane != 0) return;
+    // fastAtan2((float)m_01, (float)m_10)
+    const float yy = (float)m_01, xx = (float)m_10;
+    const float sc = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * sc, p3 = -0.3258083974640975f * sc, p5 = 0.1555786518463281f * sc, p7 = -0.04432655554792128f * sc;
+    const float ax = fabsf(xx), ay = fabsf(yy);
+    float a, c, c2;
+    if (ax >= ay) { c = ay / (ax + (float)DBL_EPSILON); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else { c = ax / (ay + (float)DBL_EPSILON); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (xx < 0) a = 180.f - a;
+    if (yy < 0) a = 360.f - a;
+    (R.k2_angle + (size_t)level * R.cap2)[idx] = a;
+}
+
 
 // ---- GaussianBlur(7x7, sigma 2, REFLECT_101) as the 8-bit fixed-point separable filter: 32x32 tile + 3 px halo in LDS ---------------
 __global__ __launch_bounds__(256) void k_orb_blur(const OrbDev *rois, int nlevels, const OrbTables *T)
@@ -626,6 +659,7 @@ int launch_orb(vfsms_ctx *ctx, const OrbDev *d_rois, const OrbDev *h_rois, int n
         hipLaunchKernelGGL(k_orb_scatter, dim3(ORB_CHUNKS, nrois * nl), dim3(1024), 0, ctx->stream, d_rois, nl);
         hipLaunchKernelGGL(k_orb_harris, dim3((maxcap1 + 255) / 256, nrois * nl), dim3(256), 0, ctx->stream, d_rois, nl);
         hipLaunchKernelGGL(k_orb_select2, dim3(nrois * nl), dim3(1024), 0, ctx->stream, d_rois, nl, ctx->d_orb_tables);
+        hipLaunchKernelGGL(k_orb_angle, dim3((maxcap2 + 3) / 4, nrois * nl), dim3(256), 0, ctx->stream, d_rois, nl, ctx->d_orb_tables);
     }
     {
         ProfScope ps(ctx, "orb_describe");
