@@ -662,9 +662,18 @@ def test_fuse_at_production_size_vs_oracle(engine, oracle, tmp_path):
     on the device canvas (a 204 x 2048 strip ROI in the column, then whole-tile corner-mode ROIs after the turn) must equal, byte
     for byte, the reference's int64 / -1 canvas walk with the oracle's fuseByFadeInAndFadeOut (tests/fakes.OracleEngine) -- and the
     same with the tiles resident in HBM (the path flowStitch takes after a batched registration)."""
+    _fuse_production(engine, oracle, tmp_path, 2048)
+
+
+def test_fuse_at_config4_tile_size_vs_oracle(engine, oracle, tmp_path):
+    """the same at BASELINE configs[4]'s tile size: 4096 x 4096 tiles (819 x 4096 strip ROI, 16 Mpx corner-mode ROIs)."""
+    _fuse_production(engine, oracle, tmp_path, 4096)
+
+
+def _fuse_production(engine, oracle, tmp_path, tile):
     from fakes import OracleEngine
     from test_host_logic import _write_tiles
-    g = SyntheticGrid(2, 2, 2048)
+    g = SyntheticGrid(2, 2, tile, blobs=tile <= 2048)
     tiles = g.tiles(threads=4)
     offs = [list(map(int, o)) for o in g.true_offsets()]
     files = _write_tiles(tmp_path, tiles, "prod")
@@ -676,7 +685,7 @@ def test_fuse_at_production_size_vs_oracle(engine, oracle, tmp_path):
             s = isa.Stitcher(); s._engine = eng; s.isPrintLog = False; s.isColorMode = False
             s.fuseMethod = "fadeInAndFadeOut"
             outs.append(s.getStitchByOffset(files, [list(o) for o in offs]))
-        assert outs[0].shape == outs[1].shape and outs[0].shape[0] > 3800 and np.array_equal(outs[0], outs[1])
+        assert outs[0].shape == outs[1].shape and outs[0].shape[0] > 1.85 * tile and np.array_equal(outs[0], outs[1])
         # resident tiles: the handles of a registration phase handed to the fuse
         s = isa.Stitcher(); s._engine = engine; s.isPrintLog = False; s.isColorMode = False; s.fuseMethod = "fadeInAndFadeOut"
         s._resident = {f: (engine.tile_upload(t), t.shape) for f, t in zip(files, tiles)}
