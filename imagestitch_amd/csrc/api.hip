@@ -504,7 +504,7 @@ static int bf_l2_host(vfsms_ctx *ctx, const float *q, int nq, const float *t, in
     const int cns = pick_filter_nsplit(nq, 1);
     const bool try_filter = dim == 64 && nq > 0 && nt > 0 && !bf_force_exact();
     TRY(ctx_arena_reserve(ctx, sizeof(float) * ((size_t)nq + nt) * dim + match_bytes(capq, ns_exact) +
-                               (try_filter ? match_filter_bytes(capq, cns) : 0) + 65536));
+                               (try_filter ? match_filter_bytes(capq, std::max(nt, 1), cns) : 0) + 65536));
     memset(M, 0, sizeof(*M));
     float *dq, *dt;
     TRY(upload_array(ctx, q, (size_t)nq * dim, &dq));
@@ -527,11 +527,11 @@ static int bf_l2_host(vfsms_ctx *ctx, const float *q, int nq, const float *t, in
     }
     const int ns = filtered ? 1 : ns_exact;
     TRY(match_carve(ctx, M, capq, dim, ns));
-    if (filtered) TRY(match_filter_carve(ctx, M, capq, cns));
+    if (filtered) TRY(match_filter_carve(ctx, M, capq, std::max(nt, 1), cns));
     M->q = dq; M->t = dt; M->nq_ptr = dcnt; M->nt_ptr = dcnt + 1; M->kq = nullptr; M->kt = nullptr;
     MatchDev *dM;
     TRY(upload_array(ctx, M, 1, &dM));
-    if (filtered) { TRY(launch_bf_l2_filtered(ctx, dM, 1, capq, cns)); }
+    if (filtered) { TRY(launch_bf_l2_filtered(ctx, dM, 1, capq, std::max(nt, 1), cns)); }
     else { TRY(launch_bf_l2(ctx, dM, 1, capq, ns, dim)); }
     if (with_ratio) {
         TRY(launch_ratio_only(ctx, dM, 1, capq, ratio));
@@ -739,7 +739,7 @@ static int attempt_surf_impl(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, 
     const int ns = filtered ? 1 : pick_nsplit(maxcap / 3, maxcap / 3, n, dim);   // typical occupancy of the capacity
     for (int k = 0; k < n; k++)
         need += 2 * surf_roi_bytes(jobs[k].h, jobs[k].w, caps[k], ctx->n_layers, params->n_octaves, dim) + match_bytes(caps[k], ns) +
-                (filtered ? match_filter_bytes(caps[k], cns) : 0);
+                (filtered ? match_filter_bytes(caps[k], caps[k], cns) : 0);
     need += (sizeof(RoiDev) * 2 + sizeof(MatchDev)) * n + 64 * 3 * n + 65536;
     if (enh_mode) for (int k = 0; k < n; k++) need += 2 * enhance_scratch_bytes(jobs[k].h, jobs[k].w, enh_mode, tile_grid) + 2 * sizeof(EnhJob) + 512;
     TRY(ctx_arena_reserve(ctx, need));
@@ -763,7 +763,7 @@ static int attempt_surf_impl(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, 
         R[2 * k].counters = cblock + 16 * (2 * k); R[2 * k + 1].counters = cblock + 16 * (2 * k + 1);
         memset(&M[k], 0, sizeof(MatchDev));
         TRY(match_carve(ctx, &M[k], caps[k], dim, ns));
-        if (filtered) TRY(match_filter_carve(ctx, &M[k], caps[k], cns));
+        if (filtered) TRY(match_filter_carve(ctx, &M[k], caps[k], caps[k], cns));
         M[k].result = rblock + VFSMS_ATTEMPT_INTS * k;
         M[k].q = R[2 * k].desc; M[k].t = R[2 * k + 1].desc;
         M[k].nq_ptr = R[2 * k].counters + 1; M[k].nt_ptr = R[2 * k + 1].counters + 1;
@@ -780,7 +780,7 @@ static int attempt_surf_impl(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, 
     HIP_TRY(hipMemsetAsync(cblock, 0, sizeof(int) * 16 * 2 * n, ctx->stream));
     TRY(launch_surf_detect(ctx, dR, R.data(), 2 * n, params));
     TRY(launch_surf_describe(ctx, dR, R.data(), 2 * n, params));
-    if (filtered) { TRY(launch_bf_l2_filtered(ctx, dM, n, maxcap, cns)); }
+    if (filtered) { TRY(launch_bf_l2_filtered(ctx, dM, n, maxcap, maxcap, cns)); }
     else { TRY(launch_bf_l2(ctx, dM, n, maxcap, ns, dim)); }
     TRY(launch_ratio_mode(ctx, dM, n, maxcap, ratio, offset_evaluate));
     std::vector<int> counters((size_t)16 * 2 * n);
@@ -924,17 +924,17 @@ extern "C" int vfsms_features_match_offset(vfsms_ctx *ctx, int64_t feat_a, int64
     const bool filtered = dim == 64 && !bf_force_exact();          // SURF descriptors are L2-normalised by construction
     const int cns = pick_filter_nsplit(A.n, 1);
     const int ns = filtered ? 1 : pick_nsplit(A.n, B.n, 1, dim);
-    TRY(ctx_arena_reserve(ctx, match_bytes(capq, ns) + (filtered ? match_filter_bytes(capq, cns) : 0) + 65536));
+    TRY(ctx_arena_reserve(ctx, match_bytes(capq, ns) + (filtered ? match_filter_bytes(capq, B.n, cns) : 0) + 65536));
     ctx->pinned_off = 0;
     MatchDev M; memset(&M, 0, sizeof(M));
     TRY(match_carve(ctx, &M, capq, dim, ns));
-    if (filtered) TRY(match_filter_carve(ctx, &M, capq, cns));
+    if (filtered) TRY(match_filter_carve(ctx, &M, capq, B.n, cns));
     int cnt[2] = {A.n, B.n}; int *dcnt;
     TRY(upload_pinned(ctx, cnt, sizeof(cnt), (void **)&dcnt));
     M.q = (const float *)A.desc; M.t = (const float *)B.desc; M.kq = A.kps_xy; M.kt = B.kps_xy; M.nq_ptr = dcnt; M.nt_ptr = dcnt + 1;
     MatchDev *dM;
     TRY(upload_pinned(ctx, &M, sizeof(M), (void **)&dM));
-    if (filtered) { TRY(launch_bf_l2_filtered(ctx, dM, 1, capq, cns)); }
+    if (filtered) { TRY(launch_bf_l2_filtered(ctx, dM, 1, capq, B.n, cns)); }
     else { TRY(launch_bf_l2(ctx, dM, 1, capq, ns, dim)); }
     TRY(launch_ratio_mode(ctx, dM, 1, capq, ratio, offset_evaluate));
     HIP_TRY(hipMemcpyAsync(out, M.result, sizeof(int32_t) * VFSMS_ATTEMPT_INTS, hipMemcpyDeviceToHost, ctx->stream));

@@ -104,6 +104,7 @@ struct MatchDev {
     float *p_d1; float *p_d2; int *p_i1; int nsplit;
     // MFMA candidate filter (fused SURF path): per (query, split, lane half) lists of (score bits, train index) + their counts
     uint2 *c_ent; int *c_cnt;
+    unsigned short *q16, *t16;        // split-bf16 operands of the filter (k_bf_split16): BF16_ROW uint16 per descriptor row
     // merged
     float *d1; float *d2; int *i1;
     int *match_flag; int *match_pos;
@@ -178,9 +179,9 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
 size_t match_bytes(int capq, int nsplit);
 int match_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int dim, int nsplit);
 int launch_max_norm2_d64(vfsms_ctx *ctx, const float *a, int n, unsigned *d_out);
-size_t match_filter_bytes(int capq, int cns);
-int match_filter_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int cns);
-int launch_bf_l2_filtered(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int cns);
+size_t match_filter_bytes(int capq, int capt, int cns);
+int match_filter_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int capt, int cns);
+int launch_bf_l2_filtered(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int capt, int cns);
 int launch_bf_l2(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int nsplit, int dim);
 int launch_merge_only(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq);
 int launch_ratio_only(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, double ratio);

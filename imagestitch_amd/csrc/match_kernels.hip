@@ -13,6 +13,8 @@
 // Distances: float accumulation in the 4-wide order of normL2Sqr_, sqrt per candidate exactly when the
 // squared distance can still change the top-2 (comparisons happen in the sqrt domain like OpenCV's).
 #include "common.h"
+#include <algorithm>
+#include <stdlib.h>
 #include <math.h>
 
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -250,6 +252,145 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma_d64(const MatchDev *jobs)
             } else {
                 const int row0 = tl * 32 + 4 * half;
                 // the seed tile is already part of the running statistics: list its candidates without counting them twice
+                bfm_scan(acc0, Sa, row0, lista, pitch, tl != tile0); bfm_scan(acc1, Sb, row0, listb, pitch, tl != tile0);
+            }
+        }
+        if (pass == 0) {
+            Sa.thr = va ? Sa.m2 + BFM_MARGIN : -INFINITY;      // lanes of queries beyond nq never append
+            Sb.thr = vb ? Sb.m2 + BFM_MARGIN : -INFINITY;
+        }
+    }
+    if (va) J.c_cnt[(size_t)lst * pitch + q0 + col] = Sa.cnt;
+    if (vb) J.c_cnt[(size_t)lst * pitch + q0 + 32 + col] = Sb.cnt;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same filter on the bf16 matrix pipe (16x the f32-MFMA rate) with SPLIT operands: every descriptor element x is stored as
+// hi = bf16(x) and lo = bf16(x - hi), and q.t is taken as hi.hi + hi.lo + lo.hi (three v_mfma_f32_32x32x16_bf16 products per 16
+// dims, f32 accumulation).  What is dropped is lo.lo (<= 2^-16 |q_i t_i| per term) and the rounding of lo (2^-17 relative): for
+// norms <= 1 the score is within ~3e-5 of the f32 score -- BFM_MARGIN is 30x that -- and the scores only select WHICH distances the
+// verifier computes exactly.  |t|^2 rides along as one more k-slot (its own hi + lo against 1.0 on the query side).
+// k_bf_split16 writes the operands once per ROI: row = [dims 0-31: hi x 32 | lo x 32 | dims 32-63: hi x 32 | lo x 32 | |x|^2 hi, lo, 0...]
+// so that a lane (row, half) reads its 128 bytes contiguously.
+// ---------------------------------------------------------------------------------------------------
+#define BF16_ROW 144                 // uint16 per descriptor row: 2 x (32 hi + 32 lo) + 16 for the norm slot
+typedef short s8v __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_rne(float x)
+{
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+// one thread per (descriptor row, 32-dim half); grid (ceil(cap / 128), 2 [q | t], jobs)
+__global__ __launch_bounds__(256) void k_bf_split16(const MatchDev *jobs, float scale_q)
+{
+    const MatchDev &J = jobs[blockIdx.z];
+    const bool is_t = blockIdx.y == 1;
+    const int n = is_t ? *J.nt_ptr : *J.nq_ptr;
+    const int row = blockIdx.x * 128 + (threadIdx.x >> 1), half = threadIdx.x & 1;
+    if (row >= n) return;
+    const float *src = (is_t ? J.t : J.q) + (size_t)row * 64 + 32 * half;
+    unsigned short *dst = (is_t ? J.t16 : J.q16) + (size_t)row * BF16_ROW + 64 * half;
+    const float sc = is_t ? 1.f : scale_q;                      // queries carry the factor -2 (exact in bf16)
+    float part = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < 32; d++) {
+        const float x = src[d];
+        part += x * x;
+        const float xs = x * sc;
+        const unsigned short hi = bf16_rne(xs);
+        dst[d] = hi;
+        dst[32 + d] = bf16_rne(xs - bf16_to_f32(hi));
+    }
+    // norm slot (trains: |t|^2 as hi + lo; queries: 1, 1): k-slots 0 and 1 of the fifth MFMA step, lane half 0 only
+    const float tot = part + __shfl_xor(part, 1, 64);
+    if (half == 0) {
+        unsigned short *ns = (is_t ? J.t16 : J.q16) + (size_t)row * BF16_ROW + 128;
+        unsigned short a = 0x3f80, b = 0x3f80;                    // 1.0
+        if (is_t) { a = bf16_rne(tot); b = bf16_rne(tot - bf16_to_f32(a)); }
+        ns[0] = a; ns[1] = b;
+        for (int k = 2; k < 16; k++) ns[k] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_bf_mfma16_d64(const MatchDev *jobs)
+{
+    const MatchDev &J = jobs[blockIdx.z];
+    const int nq = __builtin_amdgcn_readfirstlane(*J.nq_ptr), nt = __builtin_amdgcn_readfirstlane(*J.nt_ptr);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q0 = (blockIdx.x * 4 + wave) * 64;
+    if (q0 >= nq) return;
+    const int nsplit = gridDim.y, sp = blockIdx.y;
+    const int ntiles = (nt + 31) >> 5;
+    const int tchunk = (ntiles + nsplit - 1) / nsplit;
+    const int tile0 = sp * tchunk, tile1 = min(ntiles, tile0 + tchunk);
+    const int col = lane & 31, half = lane >> 5;
+    // B operands (queries, resident): per 16-dim step s the lane's 8 hi and 8 lo values of dims 32*half + 8*s .. + 7
+    s8v bh0[4], bl0[4], bh1[4], bl1[4], bn0, bn1;
+    {
+        const s8v *p0 = reinterpret_cast<const s8v *>(J.q16 + (size_t)min(q0 + col, nq - 1) * BF16_ROW + 64 * half);
+        const s8v *p1 = reinterpret_cast<const s8v *>(J.q16 + (size_t)min(q0 + 32 + col, nq - 1) * BF16_ROW + 64 * half);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) { bh0[s4] = p0[s4]; bl0[s4] = p0[4 + s4]; bh1[s4] = p1[s4]; bl1[s4] = p1[4 + s4]; }
+        const s8v zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        bn0 = half == 0 ? *reinterpret_cast<const s8v *>(J.q16 + (size_t)min(q0 + col, nq - 1) * BF16_ROW + 128) : zero;
+        bn1 = half == 0 ? *reinterpret_cast<const s8v *>(J.q16 + (size_t)min(q0 + 32 + col, nq - 1) * BF16_ROW + 128) : zero;
+    }
+    const bool va = q0 + col < nq, vb = q0 + 32 + col < nq;
+    BfmState Sa = {INFINITY, INFINITY, INFINITY, 0}, Sb = {INFINITY, INFINITY, INFINITY, 0};
+    const size_t pitch = (size_t)J.capq;
+    const int lst = sp * 2 + half;
+    uint2 *lista = J.c_ent + (size_t)lst * BFM_CAPL * pitch + (q0 + col), *listb = lista + 32;
+    const unsigned short *T = J.t16;
+    const s8v zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int pass = 0; pass < 2; pass++) {          // pass 0: first tile only, to seed the running second best
+        const int tend = pass == 0 ? min(tile0 + 1, tile1) : tile1;
+        s8v an[8], nn = zero;
+        if (tile0 < tend) {
+            const int trow = min(tile0 * 32 + col, nt - 1);
+            const s8v *pn = reinterpret_cast<const s8v *>(T + (size_t)trow * BF16_ROW + 64 * half);
+#pragma unroll
+            for (int s = 0; s < 8; s++) an[s] = pn[s];
+            if (half == 0) nn = *reinterpret_cast<const s8v *>(T + (size_t)trow * BF16_ROW + 128);
+        }
+        for (int tl = tile0; tl < tend; tl++) {
+            s8v a[8], na = nn;
+#pragma unroll
+            for (int s = 0; s < 8; s++) a[s] = an[s];
+            if (tl + 1 < tend) {                    // prefetch the next train tile behind this tile's MFMAs
+                const int trow = min((tl + 1) * 32 + col, nt - 1);
+                const s8v *pn = reinterpret_cast<const s8v *>(T + (size_t)trow * BF16_ROW + 64 * half);
+#pragma unroll
+                for (int s = 0; s < 8; s++) an[s] = pn[s];
+                if (half == 0) nn = *reinterpret_cast<const s8v *>(T + (size_t)trow * BF16_ROW + 128);
+            }
+            f16v acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {            // a[s] = hi, a[4 + s] = lo of the lane's dims 8s .. 8s + 7
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bh0[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bh1[s], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bl0[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bl1[s], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[4 + s], bh0[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[4 + s], bh1[s], acc1, 0, 0, 0);
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na, bn0, acc0, 0, 0, 0);      // + |t|^2
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na, bn1, acc1, 0, 0, 0);
+            // train rows beyond nt never qualify (the f32 filter pushed them out through the norm slot)
+            if (tl * 32 + 31 >= nt) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const bool past = tl * 32 + 4 * half + (i & 3) + 8 * (i >> 2) >= nt;
+                    acc0[i] = past ? BFM_FAR : acc0[i]; acc1[i] = past ? BFM_FAR : acc1[i];
+                }
+            }
+            if (pass == 0) {
+                bfm_warm(acc0, Sa); bfm_warm(acc1, Sb);
+            } else {
+                const int row0 = tl * 32 + 4 * half;
                 bfm_scan(acc0, Sa, row0, lista, pitch, tl != tile0); bfm_scan(acc1, Sb, row0, listb, pitch, tl != tile0);
             }
         }
@@ -587,26 +728,41 @@ int launch_max_norm2_d64(vfsms_ctx *ctx, const float *a, int n, unsigned *d_out)
     return VFSMS_OK;
 }
 
-size_t match_filter_bytes(int capq, int cns)
+size_t match_filter_bytes(int capq, int capt, int cns)
 {
-    return al(sizeof(uint2) * (size_t)capq * cns * 2 * BFM_CAPL) + al(sizeof(int) * (size_t)capq * cns * 2) + 1024;
+    return al(sizeof(uint2) * (size_t)capq * cns * 2 * BFM_CAPL) + al(sizeof(int) * (size_t)capq * cns * 2) +
+           al(sizeof(unsigned short) * BF16_ROW * (size_t)capq) + al(sizeof(unsigned short) * BF16_ROW * (size_t)capt) + 1024;
 }
 
-int match_filter_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int cns)
+int match_filter_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int capt, int cns)
 {
     m->c_ent = (uint2 *)ctx_arena_alloc(ctx, sizeof(uint2) * (size_t)capq * cns * 2 * BFM_CAPL);
     m->c_cnt = (int *)ctx_arena_alloc(ctx, sizeof(int) * (size_t)capq * cns * 2);
-    if (!m->c_cnt) { vfsms_set_error("arena exhausted while carving a match filter"); return VFSMS_ERR_CAPACITY; }
+    m->q16 = (unsigned short *)ctx_arena_alloc(ctx, sizeof(unsigned short) * BF16_ROW * (size_t)capq);
+    m->t16 = (unsigned short *)ctx_arena_alloc(ctx, sizeof(unsigned short) * BF16_ROW * (size_t)capt);
+    if (!m->c_cnt || !m->t16) { vfsms_set_error("arena exhausted while carving a match filter"); return VFSMS_ERR_CAPACITY; }
     return VFSMS_OK;
 }
 
-// MFMA-filtered exact 2-NN for 64-d descriptors of norm <= 1 (jobs carved with nsplit == 1 plus match_filter_carve)
-int launch_bf_l2_filtered(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int cns)
+static bool bf_f32_filter()
+{
+    static const bool v = getenv("VFSMS_BF_F32FILTER") && atoi(getenv("VFSMS_BF_F32FILTER")) != 0;
+    return v;
+}
+
+// MFMA-filtered exact 2-NN for 64-d descriptors of norm <= 1 (jobs carved with nsplit == 1 plus match_filter_carve).
+// Default: split-bf16 filter on the bf16 matrix pipe; VFSMS_BF_F32FILTER=1 keeps round 1's f32-MFMA filter.
+int launch_bf_l2_filtered(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int capq, int capt, int cns)
 {
     if (njobs <= 0 || capq <= 0) return VFSMS_OK;
     {
         ProfScope ps(ctx, "bf_mfma");
-        hipLaunchKernelGGL(k_bf_mfma_d64, dim3((capq + 255) / 256, cns, njobs), dim3(256), 0, ctx->stream, d_jobs);
+        if (bf_f32_filter())
+            hipLaunchKernelGGL(k_bf_mfma_d64, dim3((capq + 255) / 256, cns, njobs), dim3(256), 0, ctx->stream, d_jobs);
+        else {
+            hipLaunchKernelGGL(k_bf_split16, dim3((std::max(capq, capt) + 127) / 128, 2, njobs), dim3(256), 0, ctx->stream, d_jobs, -2.f);
+            hipLaunchKernelGGL(k_bf_mfma16_d64, dim3((capq + 255) / 256, cns, njobs), dim3(256), 0, ctx->stream, d_jobs);
+        }
     }
     {
         ProfScope ps(ctx, "bf_verify");
