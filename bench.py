@@ -33,6 +33,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak of gfx950 (v_mfma_f32_32x32x16_bf16), MI355X_MICROARCH.md
 FP32_PEAK_TFLOPS = 157.3       # dense FP32 MFMA peak of gfx950 (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md
 # VALU issue peak in lane-operations: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.  (157.3 TFLOP/s = this x 2 flop per FMA x 2 for packed
 # FP32; SQ_INSTS_VALU == SQ_ACTIVE_INST_VALU quad-cycles in profiles/r02_pmc_describe.txt: one wave64 VALU instruction = 4 cycles.)
@@ -378,11 +379,17 @@ def main():
         dur = bf_ms / bf_n * 1e-3
         flops = 2.0 * 64 * st["sum_nq_nt"] / bf_n                         # one 64-d dot product per (query, train)
         bytes_ = (st["sum_nq_plus_nt"] * 64 * 4) / bf_n
-        extra["bf_l2_mfma"] = dict(kernel="k_bf_mfma_d64", bound="mfma", achieved=round(flops / dur / 1e12, 3), peak=FP32_PEAK_TFLOPS,
-                                   unit="TFLOP/s", frac=round(flops / dur / 1e12 / FP32_PEAK_TFLOPS, 4), traffic=pmc_traffic("k_bf_mfma_d64")[0],
+        f32_filter = os.environ.get("VFSMS_BF_F32FILTER", "0") not in ("", "0")
+        peak = FP32_PEAK_TFLOPS if f32_filter else BF16_PEAK_TFLOPS
+        kname = "k_bf_mfma_d64" if f32_filter else "k_bf_split16+k_bf_mfma16_d64"
+        extra["bf_l2_mfma"] = dict(kernel=kname, bound="mfma", achieved=round(flops / dur / 1e12, 3), peak=peak,
+                                   unit="TFLOP/s", frac=round(flops / dur / 1e12 / peak, 4), traffic=pmc_traffic(kname.split("+")[-1])[0],
                                    avg_launch_ms=round(dur * 1e3, 4), flops_per_launch=flops, launches=bf_n,
-                                   note="v_mfma_f32_32x32x2_f32 candidate filter (peak = dense f32 MFMA); the exact distances are "
-                                        "evaluated by k_bf_verify_d64 for the few surviving candidates")
+                                   issued_mfma_flops_per_launch=flops if f32_filter else flops * 3.25,
+                                   note=("v_mfma_f32_32x32x2_f32 candidate filter (peak = dense f32 MFMA)" if f32_filter else
+                                         "split-bf16 candidate filter: q.t = hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 (3.25x the algorithmic "
+                                         "flops are issued; peak = dense bf16 MFMA); achieved counts one 64-d dot product per pair") +
+                                        "; the exact distances are evaluated by k_bf_verify_d64 for the few surviving candidates")
         extra["bf_l2_hbm"] = dict(bound="hbm", achieved=round(bytes_ / dur / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                                   frac=round(bytes_ / dur / 1e9 / HBM_PEAK_GBS, 5), bytes_per_launch=bytes_)
     in_ms, in_n = prof.get("integral", (0.0, 0))
@@ -394,7 +401,7 @@ def main():
     he_ms, he_n = prof.get("hessian", (0.0, 0))
     if he_n:
         # reads S once per octave pass 4 (h+1)(w+1) x 4 + writes det + trace 8 x sum_o 5 (h/2^o)(w/2^o) = 69.1 B/px
-        extra["hessian_hbm"] = hbm_roofline("k_hessian_lds<1,64>+k_hessian_lds<2,32>+k_hessian", st["roi_px"] / he_n * 69.1, he_ms / he_n, he_n)
+        extra["hessian_hbm"] = hbm_roofline("k_hessian_lds<1,64>+k_hessian_lds<2,32>+k_hessian(octaves 2..)", st["roi_px"] / he_n * 69.1, he_ms / he_n, he_n)
     if args.method == "phase":
         ph_ms, ph_n = prof.get("phase", (0.0, 0))
         if ph_n:

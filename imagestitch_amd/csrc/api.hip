@@ -162,6 +162,11 @@ int ctx_prepare_surf(vfsms_ctx *ctx, const vfsms_surf_params *p)
                 const int x1 = (int)lrintf(ratio * src[0]), y1 = (int)lrintf(ratio * src[1]);
                 const int x2 = (int)lrintf(ratio * src[2]), y2 = (int)lrintf(ratio * src[3]);
                 P.box[k][0] = x1; P.box[k][1] = y1; P.box[k][2] = x2; P.box[k][3] = y2;
+                for (int c = 0; c < 4; c++)
+                    if (P.box[k][c] != vfsms_haar_corner(P.size, k, c)) {       // the LDS Hessian kernels bake these in
+                        vfsms_set_error("internal: Haar pattern corner mismatch (size %d box %d)", P.size, k);
+                        return VFSMS_ERR_UNSUPPORTED;
+                    }
                 P.w[k] = src[4] / ((float)(x2 - x1) * (y2 - y1));
             }
         }

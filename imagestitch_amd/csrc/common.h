@@ -28,6 +28,19 @@ void vfsms_set_error(const char *fmt, ...);
     } while (0)
 
 // ---- fast-Hessian layer description (host-built, device-resident table) ---------------------------
+#define VFSMS_MAX_OCTAVES 8
+// resizeHaarPattern: corner c (x1, y1, x2, y2) of box k (Dx 0-2, Dy 3-5, Dxy 6-9) of the 9 x 9 pattern scaled to `size`:
+// cvRound(size / 9.f * v) == (2 size v + 9) / 18 -- 2 size v is never an odd multiple of 9, so there are no ties to break
+// (ctx_prepare_surf checks the table it builds with the float expression against this one).
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+constexpr int vfsms_haar_corner(int size, int k, int c)
+{
+    constexpr int src[10][4] = { {0, 2, 3, 7}, {3, 2, 6, 7}, {6, 2, 9, 7}, {2, 0, 7, 3}, {2, 3, 7, 6}, {2, 6, 7, 9},
+                                 {1, 1, 4, 4}, {5, 1, 8, 4}, {1, 5, 4, 8}, {5, 5, 8, 8} };
+    return (2 * size * src[k][c] + 9) / 18;
+}
 struct LayerPat {
     int size, step, margin, octave;   // margin = (size/2)/step
     int box[10][4];                   // dx1, dy1, dx2, dy2 for Dx[3], Dy[3], Dxy[4]  (resizeHaarPattern)
@@ -104,6 +117,7 @@ struct MatchDev {
     float *p_d1; float *p_d2; int *p_i1; int nsplit;
     // MFMA candidate filter (fused SURF path): per (query, split, lane half) lists of (score bits, train index) + their counts
     uint2 *c_ent; int *c_cnt;
+    float2 *c_m12;                    // per (list, query): best / second-best hi-only score of the bounds pass
     unsigned short *q16, *t16;        // split-bf16 operands of the filter (k_bf_split16): BF16_ROW uint16 per descriptor row
     // merged
     float *d1; float *d2; int *i1;
@@ -213,3 +227,17 @@ int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int
 int canvas_blend_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0,
                         int ry0, int rx0, int ry1, int rx1, int mode);
 int canvas_paste_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0);
+
+#ifdef __HIPCC__
+// Speed only (placement is not a contract): workgroups are observed to land on XCD (linear block id % 8), each XCD with a private
+// 4 MB L2.  Gather-heavy kernels whose slowest grid index is a unit with its own working set (an ROI and its 3.4 MB integral
+// image; a (match job, train chunk) and its descriptors) hand every XCD WHOLE units, so that a unit's data is pulled into one L2
+// once instead of into all eight.  L = linear block id, per_unit blocks per unit; the units beyond the last multiple of 8 keep
+// the plain order.
+__device__ __forceinline__ void xcd_roi_map(unsigned L, unsigned per_unit, unsigned nunits, unsigned &unit, unsigned &inner)
+{
+    const unsigned nfull = nunits & ~7u;
+    if (L < per_unit * nfull) { const unsigned x = L & 7u, slot = L >> 3; unit = x + 8u * (slot / per_unit); inner = slot % per_unit; }
+    else { unit = L / per_unit; inner = L % per_unit; }
+}
+#endif

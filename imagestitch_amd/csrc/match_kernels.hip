@@ -270,10 +270,14 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma_d64(const MatchDev *jobs)
 // dims, f32 accumulation).  What is dropped is lo.lo (<= 2^-16 |q_i t_i| per term) and the rounding of lo (2^-17 relative): for
 // norms <= 1 the score is within ~3e-5 of the f32 score -- BFM_MARGIN is 30x that -- and the scores only select WHICH distances the
 // verifier computes exactly.  |t|^2 rides along as one more k-slot (its own hi + lo against 1.0 on the query side).
-// k_bf_split16 writes the operands once per ROI: row = [dims 0-31: hi x 32 | lo x 32 | dims 32-63: hi x 32 | lo x 32 | |x|^2 hi, lo, 0...]
-// so that a lane (row, half) reads its 128 bytes contiguously.
+// k_bf_split16 writes the operands once per ROI.  Queries (each wave loads its 64 once): row = [dims 0-31: hi x 32 | lo x 32 |
+// dims 32-63: hi x 32 | lo x 32 | 1, 1, 0...].  Trains (every wave streams all of them) are stored in MFMA FRAGMENT order: per
+// 32-train tile nine 1 KB fragments -- hi of k-steps 0..3, lo of k-steps 0..3, the |t|^2 slot -- each holding the 16 bytes of lane 0,
+// lane 1, ... lane 63, so that one load instruction of a wave reads 8 consecutive cache lines instead of one line per lane (the
+// row-major layout kept the texture-address path, not the matrix pipe, busy: 64 lines per load).
 // ---------------------------------------------------------------------------------------------------
 #define BF16_ROW 144                 // uint16 per descriptor row: 2 x (32 hi + 32 lo) + 16 for the norm slot
+#define BF16_FRAGS 9                 // per train tile: 4 hi + 4 lo + norm fragments of 64 lanes x 8 uint16
 typedef short s8v __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ unsigned short bf16_rne(float x)
@@ -293,114 +297,178 @@ __global__ __launch_bounds__(256) void k_bf_split16(const MatchDev *jobs, float 
     const int row = blockIdx.x * 128 + (threadIdx.x >> 1), half = threadIdx.x & 1;
     if (row >= n) return;
     const float *src = (is_t ? J.t : J.q) + (size_t)row * 64 + 32 * half;
-    unsigned short *dst = (is_t ? J.t16 : J.q16) + (size_t)row * BF16_ROW + 64 * half;
     const float sc = is_t ? 1.f : scale_q;                      // queries carry the factor -2 (exact in bf16)
     float part = 0.f;
-#pragma unroll 8
+    s8v hi[4], lo[4];
+#pragma unroll
     for (int d = 0; d < 32; d++) {
         const float x = src[d];
         part += x * x;
         const float xs = x * sc;
-        const unsigned short hi = bf16_rne(xs);
-        dst[d] = hi;
-        dst[32 + d] = bf16_rne(xs - bf16_to_f32(hi));
+        const unsigned short h = bf16_rne(xs);
+        hi[d >> 3][d & 7] = (short)h;
+        lo[d >> 3][d & 7] = (short)bf16_rne(xs - bf16_to_f32(h));
     }
     // norm slot (trains: |t|^2 as hi + lo; queries: 1, 1): k-slots 0 and 1 of the fifth MFMA step, lane half 0 only
     const float tot = part + __shfl_xor(part, 1, 64);
+    s8v ns = {0, 0, 0, 0, 0, 0, 0, 0};
     if (half == 0) {
-        unsigned short *ns = (is_t ? J.t16 : J.q16) + (size_t)row * BF16_ROW + 128;
         unsigned short a = 0x3f80, b = 0x3f80;                    // 1.0
         if (is_t) { a = bf16_rne(tot); b = bf16_rne(tot - bf16_to_f32(a)); }
-        ns[0] = a; ns[1] = b;
-        for (int k = 2; k < 16; k++) ns[k] = 0;
+        ns[0] = (short)a; ns[1] = (short)b;
+    }
+    if (is_t) {
+        s8v *dst = reinterpret_cast<s8v *>(J.t16) + (size_t)(row >> 5) * (BF16_FRAGS * 64) + (row & 31) + 32 * half;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) { dst[s4 * 64] = hi[s4]; dst[(4 + s4) * 64] = lo[s4]; }
+        dst[8 * 64] = ns;
+    } else {
+        s8v *dst = reinterpret_cast<s8v *>(J.q16 + (size_t)row * BF16_ROW + 64 * half);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) { dst[s4] = hi[s4]; dst[4 + s4] = lo[s4]; }
+        if (half == 0) *reinterpret_cast<s8v *>(J.q16 + (size_t)row * BF16_ROW + 128) = ns;
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_bf_mfma16_d64(const MatchDev *jobs)
+// Two launches.  PASS 0 (bounds): hi.hi products only (5 MFMAs per accumulator and tile) and a branch-free running (best, second
+// best) per lane, written per (list, query).  Its scores are within BFM_HI_ERR of the split scores, so
+//     thr(q) = second best over all lists + BFM_HI_ERR + BFM_MARGIN
+// is an upper bound of the true second-best score plus the margin, known BEFORE the second sweep.  PASS 1 (candidates): full split
+// products; a train is listed when its score is <= thr(q) -- a handful per query instead of the ~2 ln(n) records per list that a
+// running threshold admits, so the append branch is almost never taken (one min3 tree + one ballot per accumulator decides) and
+// the verifier has a few distances to evaluate instead of ~200.
+#define BFM_HI_ERR 9e-3f             // >= 2 * ((1 + 2^-9)^2 - 1) * |q||t| + the split filter's own 3e-5
+#define GASM __attribute__((address_space(1)))
+typedef GASM const s8v *g_cs8v;
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+template <int PASS>
+__global__ __launch_bounds__(256, 2) void k_bf_mfma16_d64(const MatchDev *jobs, int qblocks, int nsplit, int njobs)
 {
-    const MatchDev &J = jobs[blockIdx.z];
+    // a (job, train chunk) and its 0.3 MB of split descriptors stay on one XCD (xcd_roi_map): every query block of the unit re-reads them
+    unsigned unit, qb;
+    xcd_roi_map(blockIdx.x, (unsigned)qblocks, (unsigned)(nsplit * njobs), unit, qb);
+    const int sp = (int)(unit % (unsigned)nsplit);
+    const MatchDev &J = jobs[unit / (unsigned)nsplit];
     const int nq = __builtin_amdgcn_readfirstlane(*J.nq_ptr), nt = __builtin_amdgcn_readfirstlane(*J.nt_ptr);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q0 = (blockIdx.x * 4 + wave) * 64;
+    const int q0 = ((int)qb * 4 + wave) * 64;
     if (q0 >= nq) return;
-    const int nsplit = gridDim.y, sp = blockIdx.y;
     const int ntiles = (nt + 31) >> 5;
     const int tchunk = (ntiles + nsplit - 1) / nsplit;
     const int tile0 = sp * tchunk, tile1 = min(ntiles, tile0 + tchunk);
     const int col = lane & 31, half = lane >> 5;
+    constexpr int NA = PASS == 0 ? 4 : 8;            // s8v per train row and lane: hi only | hi and lo
+    const s8v zero = {0, 0, 0, 0, 0, 0, 0, 0};
     // B operands (queries, resident): per 16-dim step s the lane's 8 hi and 8 lo values of dims 32*half + 8*s .. + 7
     s8v bh0[4], bl0[4], bh1[4], bl1[4], bn0, bn1;
     {
-        const s8v *p0 = reinterpret_cast<const s8v *>(J.q16 + (size_t)min(q0 + col, nq - 1) * BF16_ROW + 64 * half);
-        const s8v *p1 = reinterpret_cast<const s8v *>(J.q16 + (size_t)min(q0 + 32 + col, nq - 1) * BF16_ROW + 64 * half);
+        g_cs8v p0 = (g_cs8v)(J.q16 + (size_t)min(q0 + col, nq - 1) * BF16_ROW + 64 * half);
+        g_cs8v p1 = (g_cs8v)(J.q16 + (size_t)min(q0 + 32 + col, nq - 1) * BF16_ROW + 64 * half);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) { bh0[s4] = p0[s4]; bl0[s4] = p0[4 + s4]; bh1[s4] = p1[s4]; bl1[s4] = p1[4 + s4]; }
-        const s8v zero = {0, 0, 0, 0, 0, 0, 0, 0};
-        bn0 = half == 0 ? *reinterpret_cast<const s8v *>(J.q16 + (size_t)min(q0 + col, nq - 1) * BF16_ROW + 128) : zero;
-        bn1 = half == 0 ? *reinterpret_cast<const s8v *>(J.q16 + (size_t)min(q0 + 32 + col, nq - 1) * BF16_ROW + 128) : zero;
+        for (int s4 = 0; s4 < 4; s4++) {
+            bh0[s4] = p0[s4]; bh1[s4] = p1[s4];
+            if (PASS == 1) { bl0[s4] = p0[4 + s4]; bl1[s4] = p1[4 + s4]; } else { bl0[s4] = zero; bl1[s4] = zero; }
+        }
+        bn0 = half == 0 ? *(g_cs8v)(J.q16 + (size_t)min(q0 + col, nq - 1) * BF16_ROW + 128) : zero;
+        bn1 = half == 0 ? *(g_cs8v)(J.q16 + (size_t)min(q0 + 32 + col, nq - 1) * BF16_ROW + 128) : zero;
     }
     const bool va = q0 + col < nq, vb = q0 + 32 + col < nq;
-    BfmState Sa = {INFINITY, INFINITY, INFINITY, 0}, Sb = {INFINITY, INFINITY, INFINITY, 0};
     const size_t pitch = (size_t)J.capq;
-    const int lst = sp * 2 + half;
-    uint2 *lista = J.c_ent + (size_t)lst * BFM_CAPL * pitch + (q0 + col), *listb = lista + 32;
-    const unsigned short *T = J.t16;
-    const s8v zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int pass = 0; pass < 2; pass++) {          // pass 0: first tile only, to seed the running second best
-        const int tend = pass == 0 ? min(tile0 + 1, tile1) : tile1;
-        s8v an[8], nn = zero;
-        if (tile0 < tend) {
-            const int trow = min(tile0 * 32 + col, nt - 1);
-            const s8v *pn = reinterpret_cast<const s8v *>(T + (size_t)trow * BF16_ROW + 64 * half);
-#pragma unroll
-            for (int s = 0; s < 8; s++) an[s] = pn[s];
-            if (half == 0) nn = *reinterpret_cast<const s8v *>(T + (size_t)trow * BF16_ROW + 128);
+    const int lst = sp * 2 + half, nl = 2 * nsplit;
+    float m1a = INFINITY, m2a = INFINITY, m1b = INFINITY, m2b = INFINITY;       // PASS 0: running best / second best
+    float thra = -INFINITY, thrb = -INFINITY;                                  // PASS 1: fixed thresholds (lanes beyond nq never append)
+    int cnta = 0, cntb = 0;
+    if (PASS == 1) {
+        GASM const f2v *B = (GASM const f2v *)J.c_m12;
+        float a1 = INFINITY, a2 = INFINITY, b1 = INFINITY, b2 = INFINITY;
+        for (int L = 0; L < nl; L++) {
+            const f2v ua = B[(size_t)L * pitch + min(q0 + col, nq - 1)], ub = B[(size_t)L * pitch + min(q0 + 32 + col, nq - 1)];
+            a2 = fminf(fminf(a2, ua.y), fmaxf(a1, ua.x)); a1 = fminf(a1, ua.x);
+            b2 = fminf(fminf(b2, ub.y), fmaxf(b1, ub.x)); b1 = fminf(b1, ub.x);
         }
-        for (int tl = tile0; tl < tend; tl++) {
-            s8v a[8], na = nn;
+        if (va) thra = a2 + (BFM_HI_ERR + BFM_MARGIN);
+        if (vb) thrb = b2 + (BFM_HI_ERR + BFM_MARGIN);
+    }
+    uint2 *lista = J.c_ent + (size_t)lst * BFM_CAPL * pitch + (q0 + col), *listb = lista + 32;
+    g_cs8v T = (g_cs8v)J.t16 + lane;                     // fragment order: tile * 9 fragments * 64 lanes (k_bf_split16)
+    s8v an[NA], nn = zero;
+    if (tile0 < tile1) {
+        g_cs8v pn = T + (size_t)tile0 * (BF16_FRAGS * 64);
 #pragma unroll
-            for (int s = 0; s < 8; s++) a[s] = an[s];
-            if (tl + 1 < tend) {                    // prefetch the next train tile behind this tile's MFMAs
-                const int trow = min((tl + 1) * 32 + col, nt - 1);
-                const s8v *pn = reinterpret_cast<const s8v *>(T + (size_t)trow * BF16_ROW + 64 * half);
+        for (int s = 0; s < NA; s++) an[s] = pn[s * 64];
+        nn = pn[8 * 64];
+    }
+    for (int tl = tile0; tl < tile1; tl++) {
+        s8v a[NA], na = nn;
 #pragma unroll
-                for (int s = 0; s < 8; s++) an[s] = pn[s];
-                if (half == 0) nn = *reinterpret_cast<const s8v *>(T + (size_t)trow * BF16_ROW + 128);
-            }
-            f16v acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+        for (int s = 0; s < NA; s++) a[s] = an[s];
+        if (tl + 1 < tile1) {                    // prefetch the next train tile behind this tile's MFMAs
+            g_cs8v pn = T + (size_t)(tl + 1) * (BF16_FRAGS * 64);
 #pragma unroll
-            for (int s = 0; s < 4; s++) {            // a[s] = hi, a[4 + s] = lo of the lane's dims 8s .. 8s + 7
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bh0[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bh1[s], acc1, 0, 0, 0);
+            for (int s = 0; s < NA; s++) an[s] = pn[s * 64];
+            nn = pn[8 * 64];
+        }
+        f16v acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {            // a[s] = hi, a[4 + s] = lo of the lane's dims 8s .. 8s + 7
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bh0[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bh1[s], acc1, 0, 0, 0);
+            if (PASS == 1) {
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bl0[s], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bl1[s], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[4 + s], bh0[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[4 + s], bh1[s], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NA - 4 + s], bh0[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NA - 4 + s], bh1[s], acc1, 0, 0, 0);
             }
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na, bn0, acc0, 0, 0, 0);      // + |t|^2
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na, bn1, acc1, 0, 0, 0);
-            // train rows beyond nt never qualify (the f32 filter pushed them out through the norm slot)
-            if (tl * 32 + 31 >= nt) {
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na, bn0, acc0, 0, 0, 0);      // + |t|^2 (hi + lo in both passes)
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na, bn1, acc1, 0, 0, 0);
+        if (tl * 32 + 31 >= nt) {                // train rows beyond nt never qualify
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const bool past = tl * 32 + 4 * half + (i & 3) + 8 * (i >> 2) >= nt;
-                    acc0[i] = past ? BFM_FAR : acc0[i]; acc1[i] = past ? BFM_FAR : acc1[i];
+            for (int i = 0; i < 16; i++) {
+                const bool past = tl * 32 + 4 * half + (i & 3) + 8 * (i >> 2) >= nt;
+                acc0[i] = past ? BFM_FAR : acc0[i]; acc1[i] = past ? BFM_FAR : acc1[i];
+            }
+        }
+        if (PASS == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                m2a = fminf(m2a, fmaxf(m1a, acc0[i])); m1a = fminf(m1a, acc0[i]);
+                m2b = fminf(m2b, fmaxf(m1b, acc1[i])); m1b = fminf(m1b, acc1[i]);
+            }
+        } else {
+            const int row0 = tl * 32 + 4 * half;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const f16v &acc = h == 0 ? acc0 : acc1;
+                const float thr = h == 0 ? thra : thrb;
+                float mn = fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3]));
+#pragma unroll
+                for (int i = 4; i < 16; i += 3) mn = fminf(mn, fminf(acc[i], fminf(acc[i + 1], acc[i + 2])));
+                if (__any(mn <= thr)) {
+                    uint2 *list = h == 0 ? lista : listb;
+                    int cnt = h == 0 ? cnta : cntb;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const float v = acc[i];
+                        if (v <= thr && v < 1e29f) {
+                            if (cnt < BFM_CAPL) list[cnt * pitch] = make_uint2(__float_as_uint(v), (unsigned)(row0 + (i & 3) + 8 * (i >> 2)));
+                            cnt++;
+                        }
+                    }
+                    if (h == 0) cnta = cnt; else cntb = cnt;
                 }
             }
-            if (pass == 0) {
-                bfm_warm(acc0, Sa); bfm_warm(acc1, Sb);
-            } else {
-                const int row0 = tl * 32 + 4 * half;
-                bfm_scan(acc0, Sa, row0, lista, pitch, tl != tile0); bfm_scan(acc1, Sb, row0, listb, pitch, tl != tile0);
-            }
-        }
-        if (pass == 0) {
-            Sa.thr = va ? Sa.m2 + BFM_MARGIN : -INFINITY;      // lanes of queries beyond nq never append
-            Sb.thr = vb ? Sb.m2 + BFM_MARGIN : -INFINITY;
         }
     }
-    if (va) J.c_cnt[(size_t)lst * pitch + q0 + col] = Sa.cnt;
-    if (vb) J.c_cnt[(size_t)lst * pitch + q0 + 32 + col] = Sb.cnt;
+    if (PASS == 0) {
+        GASM f2v *B = (GASM f2v *)J.c_m12;
+        if (va) B[(size_t)lst * pitch + q0 + col] = f2v{m1a, m2a};
+        if (vb) B[(size_t)lst * pitch + q0 + 32 + col] = f2v{m1b, m2b};
+    } else {
+        if (va) J.c_cnt[(size_t)lst * pitch + q0 + col] = cnta;
+        if (vb) J.c_cnt[(size_t)lst * pitch + q0 + 32 + col] = cntb;
+    }
 }
 
 // One THREAD per query (no cross-lane traffic; list reads are coalesced across the queries of a wave).  Sweep 1 takes
@@ -731,7 +799,8 @@ int launch_max_norm2_d64(vfsms_ctx *ctx, const float *a, int n, unsigned *d_out)
 size_t match_filter_bytes(int capq, int capt, int cns)
 {
     return al(sizeof(uint2) * (size_t)capq * cns * 2 * BFM_CAPL) + al(sizeof(int) * (size_t)capq * cns * 2) +
-           al(sizeof(unsigned short) * BF16_ROW * (size_t)capq) + al(sizeof(unsigned short) * BF16_ROW * (size_t)capt) + 1024;
+           al(sizeof(unsigned short) * BF16_ROW * (size_t)capq) + al(sizeof(unsigned short) * BF16_ROW * ((size_t)capt + 32)) +
+           al(sizeof(float2) * (size_t)capq * cns * 2) + 1024;
 }
 
 int match_filter_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int capt, int cns)
@@ -739,8 +808,9 @@ int match_filter_carve(vfsms_ctx *ctx, MatchDev *m, int capq, int capt, int cns)
     m->c_ent = (uint2 *)ctx_arena_alloc(ctx, sizeof(uint2) * (size_t)capq * cns * 2 * BFM_CAPL);
     m->c_cnt = (int *)ctx_arena_alloc(ctx, sizeof(int) * (size_t)capq * cns * 2);
     m->q16 = (unsigned short *)ctx_arena_alloc(ctx, sizeof(unsigned short) * BF16_ROW * (size_t)capq);
-    m->t16 = (unsigned short *)ctx_arena_alloc(ctx, sizeof(unsigned short) * BF16_ROW * (size_t)capt);
-    if (!m->c_cnt || !m->t16) { vfsms_set_error("arena exhausted while carving a match filter"); return VFSMS_ERR_CAPACITY; }
+    m->t16 = (unsigned short *)ctx_arena_alloc(ctx, sizeof(unsigned short) * BF16_ROW * ((size_t)capt + 32));   // whole 32-train tiles
+    m->c_m12 = (float2 *)ctx_arena_alloc(ctx, sizeof(float2) * (size_t)capq * cns * 2);
+    if (!m->c_cnt || !m->t16 || !m->c_m12) { vfsms_set_error("arena exhausted while carving a match filter"); return VFSMS_ERR_CAPACITY; }
     return VFSMS_OK;
 }
 
@@ -761,7 +831,9 @@ int launch_bf_l2_filtered(vfsms_ctx *ctx, const MatchDev *d_jobs, int njobs, int
             hipLaunchKernelGGL(k_bf_mfma_d64, dim3((capq + 255) / 256, cns, njobs), dim3(256), 0, ctx->stream, d_jobs);
         else {
             hipLaunchKernelGGL(k_bf_split16, dim3((std::max(capq, capt) + 127) / 128, 2, njobs), dim3(256), 0, ctx->stream, d_jobs, -2.f);
-            hipLaunchKernelGGL(k_bf_mfma16_d64, dim3((capq + 255) / 256, cns, njobs), dim3(256), 0, ctx->stream, d_jobs);
+            const int qblocks = (capq + 255) / 256;
+            hipLaunchKernelGGL(k_bf_mfma16_d64<0>, dim3((unsigned)qblocks * cns * njobs), dim3(256), 0, ctx->stream, d_jobs, qblocks, cns, njobs);
+            hipLaunchKernelGGL(k_bf_mfma16_d64<1>, dim3((unsigned)qblocks * cns * njobs), dim3(256), 0, ctx->stream, d_jobs, qblocks, cns, njobs);
         }
     }
     {

@@ -226,19 +226,28 @@ __device__ __forceinline__ float haar_box(g_ci32 sp, int sw, const LayerPat &P, 
     return (float)d;
 }
 
-__global__ __launch_bounds__(256) void k_hessian(const RoiDev *rois, const LayerPat *pats, int layers_per_octave, int octave)
+// Gather variant (coarse octaves; every octave when n_octave_layers != 3): ONE launch for all its octaves -- first[q] counts the
+// 64 x 4-sample tiles of the octaves before o0 + q -- so the small octaves share a launch and fill each other's tails.
+struct HessPlan { int o0, noct; int first[VFSMS_MAX_OCTAVES + 1]; int tiles_x[VFSMS_MAX_OCTAVES]; };
+
+__global__ __launch_bounds__(256) void k_hessian(const RoiDev *rois, const LayerPat *pats, int layers_per_octave, HessPlan plan, int nrois)
 {
-    const int roi = blockIdx.z / layers_per_octave;
-    const int l = blockIdx.z % layers_per_octave;
-    const int li = octave * layers_per_octave + l;
+    unsigned roi, inner;
+    xcd_roi_map(blockIdx.x, (unsigned)(plan.first[plan.noct] * layers_per_octave), (unsigned)nrois, roi, inner);
+    const int l = (int)(inner % (unsigned)layers_per_octave);
+    int t = (int)(inner / (unsigned)layers_per_octave);
+    int q = 0;
+    while (q + 1 < plan.noct && t >= plan.first[q + 1]) q++;
+    t -= plan.first[q];
+    const int li = (plan.o0 + q) * layers_per_octave + l;
     const RoiDev &R = rois[roi];
     const LayerPat &P = pats[li];
     const int step = P.step, size = P.size;
     if (size > R.h || size > R.w) return;
     const int samples_i = 1 + (R.h - size) / step;
     const int samples_j = 1 + (R.w - size) / step;
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    const int i = blockIdx.y * 4 + threadIdx.y;
+    const int j = (t % plan.tiles_x[q]) * 64 + threadIdx.x;
+    const int i = (t / plan.tiles_x[q]) * 4 + threadIdx.y;
     if (i >= samples_i || j >= samples_j) return;
     const int sw = R.w + 1;
     const int lcols = R.w / step;
@@ -255,10 +264,13 @@ __global__ __launch_bounds__(256) void k_hessian(const RoiDev *rois, const Layer
 // same integral-image neighbourhood, so one workgroup stages the (tile + largest wavelet) window of the integral once
 // and evaluates all 5 x 40 taps of its TW x 16 samples from LDS -- 200 L2 gathers per sample become ~5 coalesced loads.
 // Arithmetic and its order are those of k_hessian.
+// The box corners of a layer depend on its size alone ((9 + 6 l) << octave; vfsms_haar_corner), so with the five layers and ten boxes
+// unrolled every LDS tap is `ds_read_b32 base offset:imm` -- no address arithmetic per tap; the weights stay the host's floats.
 template <int STEP, int TW>
 __global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const LayerPat *pats, int layers_per_octave, int octave)
 {
     constexpr int TH = 16;
+    constexpr int OCT = STEP == 1 ? 0 : 1;
     constexpr int MAXSZ = 33 * STEP;                              // size of the octave's coarsest layer: (9 + 6*4) << o
     constexpr int LW = (TW - 1) * STEP + MAXSZ + 1, LH = (TH - 1) * STEP + MAXSZ + 1;
     __shared__ int32_t tile[LH * LW];
@@ -275,13 +287,18 @@ __global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const L
     }
     __syncthreads();
     const int lcols = R.w / STEP;
-    for (int l = 0; l < layers_per_octave; l++) {
+#pragma unroll
+    for (int l = 0; l < 5; l++) {
         const int li = octave * layers_per_octave + l;
         const LayerPat &P = pats[li];
-        const int size = P.size;
+        const int size = (9 + 6 * l) << OCT;                      // == P.size (checked by ctx_prepare_surf)
         if (size > R.h || size > R.w) continue;
         const int samples_i = 1 + (R.h - size) / STEP, samples_j = 1 + (R.w - size) / STEP;
         g_f32 det = (g_f32)R.det[li], trace = (g_f32)R.trace[li];
+        const int margin = (size / 2) / STEP;
+        float w[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) w[k] = P.w[k];
         for (int e = tid; e < TW * TH; e += 256) {
             const int ly = e / TW, lx = e - ly * TW;
             const int i = i0 + ly, j = j0 + lx;
@@ -292,14 +309,16 @@ __global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const L
             for (int g = 0; g < 3; g++) {
                 const int k0 = g == 0 ? 0 : g == 1 ? 3 : 6, n = g == 2 ? 4 : 3;
                 double d = 0;
+#pragma unroll
                 for (int k = k0; k < k0 + n; k++) {
-                    const int dx1 = P.box[k][0], dy1 = P.box[k][1], dx2 = P.box[k][2], dy2 = P.box[k][3];
+                    const int dx1 = vfsms_haar_corner(size, k, 0), dy1 = vfsms_haar_corner(size, k, 1);
+                    const int dx2 = vfsms_haar_corner(size, k, 2), dy2 = vfsms_haar_corner(size, k, 3);
                     const int v = sp[dy1 * LW + dx1] + sp[dy2 * LW + dx2] - sp[dy2 * LW + dx1] - sp[dy1 * LW + dx2];
-                    d += (double)((float)v * P.w[k]);
+                    d += (double)((float)v * w[k]);
                 }
                 d3[g] = (float)d;
             }
-            const size_t o = (size_t)(i + P.margin) * lcols + (j + P.margin);
+            const size_t o = (size_t)(i + margin) * lcols + (j + margin);
             det[o] = d3[0] * d3[1] - 0.81f * d3[2] * d3[2];
             trace[o] = d3[0] + d3[1];
         }
@@ -342,13 +361,26 @@ __device__ __forceinline__ bool interpolate_keypoint(const float N9[3][9], int d
     return ok;
 }
 
-#define NMS_ROWS 4
-#define NMS_LOCAL 96
+// One launch covers every octave: blockIdx.x walks the 64 x 64-cell tiles of octave 0, then those of octave 1, ... (NmsPlan), so
+// the small coarse octaves fill the tail of the fine one instead of paying a launch each; blockIdx.y = roi * n_middle + middle layer.
+// A wave streams NMS_RW rows of a 64-column strip with the three rows it needs in registers (the +-1 column taps are unaligned
+// loads of the same lines, L1 hits): no LDS tile, no barrier in the scan.  A cell above the threshold that beats its 8 own-layer
+// neighbours -- a fraction of a per cent of the cells -- is queued in the wave's LDS queue (ballot + prefix count); afterwards the
+// queue is examined one cell per lane against the layers below and above, so the 18 extra taps and the 3 x 3 solve run on full waves.
+#define NMS_RW 16
+#define NMS_TH (4 * NMS_RW)
+#define NMS_LOCAL 192
+struct NmsPlan { int noct; int first[VFSMS_MAX_OCTAVES + 1]; int tiles_x[VFSMS_MAX_OCTAVES]; };
+
 __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat *pats, int layers_per_octave,
-                                             int n_middle, int octave, float hessianThreshold)
+                                             int n_middle, NmsPlan plan, float hessianThreshold)
 {
-    const int roi = blockIdx.z / n_middle;
-    const int l = 1 + blockIdx.z % n_middle;
+    int octave = 0;
+    while (octave + 1 < plan.noct && (int)blockIdx.x >= plan.first[octave + 1]) octave++;
+    const int tix = (int)blockIdx.x - plan.first[octave];
+    const int bx = tix % plan.tiles_x[octave], by = tix / plan.tiles_x[octave];
+    const int roi = blockIdx.y / n_middle;
+    const int l = 1 + blockIdx.y % n_middle;
     const int li = octave * layers_per_octave + l;
     const RoiDev &R = rois[roi];
     const LayerPat &P = pats[li];
@@ -356,65 +388,75 @@ __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat 
     const int lrows = R.h / ss, lcols = R.w / ss;
     const int margin = (pats[li + 1].size / 2) / ss + 1;
     if (pats[li + 1].size > R.h || pats[li + 1].size > R.w) return;   // upper layer not computed: nothing readable
-    // A workgroup owns 64 columns x 16 rows of one middle layer.  Its (16+2) x (64+2) halo tile of the layer is read
-    // into LDS with every load of a lane in flight at once; the threshold and the 8 own-layer neighbours are tested
-    // from LDS; the few 2-D maxima (a few per cent of the cells) are queued in LDS and then examined one per lane
-    // against the layers below and above, so a wave pays two global round trips in total.
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    const int j0 = margin + blockIdx.x * 64, i0 = margin + blockIdx.y * (4 * NMS_ROWS);
-    if (j0 >= lcols - margin || i0 >= lrows - margin) return;
-    __shared__ float tile[4 * NMS_ROWS + 2][64 + 2];
-    __shared__ int queue[64 * 4 * NMS_ROWS];
-    __shared__ int qn, cn, cbase;
+    const int lane = threadIdx.x, wave = threadIdx.y, tid = wave * 64 + lane;
+    const int j0 = margin + bx * 64, i0 = margin + by * NMS_TH;
+    if (j0 >= lcols - margin || i0 >= lrows - margin) return;        // (whole workgroup)
+    __shared__ unsigned short queue[4][NMS_RW * 64];
+    __shared__ int cn, cbase;
     __shared__ Cand local[NMS_LOCAL];
-    if (tid == 0) { qn = 0; cn = 0; }
-    {
-        g_cf32 d2 = (g_cf32)R.det[li];
-        for (int idx = tid; idx < (4 * NMS_ROWS + 2) * 66; idx += 256) {
-            const int r = idx / 66, c = idx - r * 66;
-            const int gi = i0 - 1 + r, gj = j0 - 1 + c;
-            tile[r][c] = (gi < lrows && gj < lcols) ? d2[(size_t)gi * lcols + gj] : 0.f;
+    if (tid == 0) cn = 0;
+    __syncthreads();
+    g_cf32 d2 = (g_cf32)R.det[li];
+    const int st = lcols;
+    const int j = j0 + lane;
+    const int ia = i0 + wave * NMS_RW;
+    int nq = 0;
+    if (ia < lrows - margin) {
+        // evaluated cells have all 8 neighbours inside the layer; the clamps only keep the loads of the other lanes in bounds
+        const int jl = min(j - 1, lcols - 1), jc = min(j, lcols - 1), jr = min(j + 1, lcols - 1);
+        const bool jev = j < lcols - margin;
+        float up[3], mid[3], dn[3];
+        {
+            g_cf32 r0 = d2 + (size_t)min(ia - 1, lrows - 1) * st, r1 = d2 + (size_t)min(ia, lrows - 1) * st;
+            up[0] = r0[jl]; up[1] = r0[jc]; up[2] = r0[jr];
+            mid[0] = r1[jl]; mid[1] = r1[jc]; mid[2] = r1[jr];
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int r = 0; r < NMS_RW; r++) {
+            const int i = ia + r;
+            g_cf32 r2 = d2 + (size_t)min(i + 1, lrows - 1) * st;
+            dn[0] = r2[jl]; dn[1] = r2[jc]; dn[2] = r2[jr];
+            const float v = mid[1];
+            const bool c2 = jev && i < lrows - margin && v > hessianThreshold &&
+                            v > up[0] && v > up[1] && v > up[2] && v > mid[0] && v > mid[2] && v > dn[0] && v > dn[1] && v > dn[2];
+            const unsigned long long m = __ballot(c2);
+            if (m) {
+                if (c2) queue[wave][nq + __popcll(m & below)] = (unsigned short)((r << 8) | lane);
+                nq += __popcll(m);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { up[k] = mid[k]; mid[k] = dn[k]; }
         }
     }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < NMS_ROWS; it++) {
-        const int r = threadIdx.y + 4 * it, c = threadIdx.x;
-        const int i = i0 + r, j = j0 + c;
-        const float val0 = tile[r + 1][c + 1];
-        if (i >= lrows - margin || j >= lcols - margin || !(val0 > hessianThreshold)) continue;
-        if (val0 > tile[r][c] && val0 > tile[r][c + 1] && val0 > tile[r][c + 2] && val0 > tile[r + 1][c] && val0 > tile[r + 1][c + 2] &&
-            val0 > tile[r + 2][c] && val0 > tile[r + 2][c + 1] && val0 > tile[r + 2][c + 2])
-            queue[atomicAdd(&qn, 1)] = (r << 8) | c;
-    }
-    __syncthreads();
-    const int nq = qn;
-    const int st = lcols;
-    for (int e = tid; e < nq; e += 256) {
-        const int r = queue[e] >> 8, c = queue[e] & 255;
-        const int i = i0 + r, j = j0 + c;
-        const float val0 = tile[r + 1][c + 1];
-        g_cf32 d1 = (g_cf32)R.det[li - 1] + (size_t)i * lcols + j;
-        g_cf32 d3 = (g_cf32)R.det[li + 1] + (size_t)i * lcols + j;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < nq; e += 64) {
+        const int qe = queue[wave][e];
+        const int i = ia + (qe >> 8), jj = j0 + (qe & 255);
+        g_cf32 d1 = (g_cf32)R.det[li - 1] + (size_t)i * lcols + jj;
+        g_cf32 dm = d2 + (size_t)i * lcols + jj;
+        g_cf32 d3 = (g_cf32)R.det[li + 1] + (size_t)i * lcols + jj;
+        const float val0 = dm[0];
         float N9[3][9] = {
             { d1[-st - 1], d1[-st], d1[-st + 1], d1[-1], d1[0], d1[1], d1[st - 1], d1[st], d1[st + 1] },
-            { tile[r][c], tile[r][c + 1], tile[r][c + 2], tile[r + 1][c], val0, tile[r + 1][c + 2], tile[r + 2][c], tile[r + 2][c + 1], tile[r + 2][c + 2] },
+            { dm[-st - 1], dm[-st], dm[-st + 1], dm[-1], val0, dm[1], dm[st - 1], dm[st], dm[st + 1] },
             { d3[-st - 1], d3[-st], d3[-st + 1], d3[-1], d3[0], d3[1], d3[st - 1], d3[st], d3[st + 1] } };
         bool is_max = true;
 #pragma unroll
         for (int b = 0; b < 9; b++) is_max = is_max && (val0 > N9[0][b]) && (val0 > N9[2][b]);
         if (!is_max) continue;
         const int sum_i = ss * (i - (size / 2) / ss);
-        const int sum_j = ss * (j - (size / 2) / ss);
+        const int sum_j = ss * (jj - (size / 2) / ss);
         Cand cd;
         cd.y = sum_i + (size - 1) * 0.5f;
         cd.x = sum_j + (size - 1) * 0.5f;
         cd.size = (float)size;
         cd.response = val0;
         cd.octave = octave;
-        const float tr = ((g_cf32)R.trace[li])[(size_t)i * lcols + j];
+        const float tr = ((g_cf32)R.trace[li])[(size_t)i * lcols + jj];
         cd.class_id = (tr > 0) - (tr < 0);
-        cd.layer = li; cd.i = i; cd.j = j;
+        cd.layer = li; cd.i = i; cd.j = jj;
         const int ds = size - pats[li - 1].size;
         if (!interpolate_keypoint(N9, ss, ss, ds, cd)) continue;
         const int slot = atomicAdd(&cn, 1);
@@ -550,71 +592,102 @@ __device__ __forceinline__ float grad_haar(g_ci32 ptr, int sw, int gws, bool is_
     return (float)d;
 }
 
-__device__ void orientation_one(const RoiDev &R, const SurfTables *T, const int k, int upright)
+// K4 dominant orientation, EIGHT keypoints per 1024-thread workgroup.  The three phases have different widths -- 113 gradient
+// samples, 72 sliding windows, one argmax per keypoint -- and a workgroup per keypoint left most lanes of its second wave idle in the
+// window phase (72 windows = one wave + 8 lanes) and one lane walking the 72 moduli.  Here phase 1 gives every keypoint 128 lanes
+// (sample = lane), phase 2 packs the 8 x 72 windows into nine full waves, phase 3 reduces each keypoint's 72 moduli in one wave
+// (first maximum in window order, as the reference's strict `>` scan keeps it).  The sums visit the samples in index order.
+#define ORI_KP 8
+__device__ __forceinline__ void orientation_block(const RoiDev &R, const SurfTables *T, const int k0, const int n, int upright)
 {
-    __shared__ __attribute__((aligned(16))) float X[128], Y[128];
-    __shared__ __attribute__((aligned(16))) int A[128];
-    __shared__ float mod_s[72], sx_s[72], sy_s[72];
-    vfsms_keypoint kp = R.kps[k];
-    const float s = kp.size * 1.2f / 9.0f;
-    const int gws = 2 * cv_round_f(2 * s);
-    const int srows = R.h + 1, scols = R.w + 1, sw = R.w + 1;
-    if (srows < gws || scols < gws) {                  // gradient wavelet larger than the image: delete
-        if (threadIdx.x == 0) R.kps[k].size = -1.f;
-        return;
-    }
-    if (upright) {
-        if (threadIdx.x == 0) R.kps[k].angle = 270.f;
-        return;
-    }
-    const int nori = T->nOriSamples;
-    const int t = threadIdx.x;
-    int valid = 0;
-    if (t < nori) {
-        int x = cv_round_f(kp.x + T->aptx[t] * s - (float)(gws - 1) / 2);
-        int y = cv_round_f(kp.y + T->apty[t] * s - (float)(gws - 1) / 2);
-        if (!(y < 0 || y >= srows - gws || x < 0 || x >= scols - gws)) {
-            g_ci32 ptr = (g_ci32)R.sum + (size_t)y * sw + x;
-            float vx = grad_haar(ptr, sw, gws, true);
-            float vy = grad_haar(ptr, sw, gws, false);
-            float xx = vx * T->aptw[t], yy = vy * T->aptw[t];
-            X[t] = xx; Y[t] = yy;
-            A[t] = cv_round_f(fast_atan2_deg(yy, xx));     // cv::phase(X, Y, angle, true) then cvRound
-            valid = 1;
-        }
-    }
-    if (t < 128 && !valid) A[t] = -100000;
-    int nangle = __syncthreads_count(valid);
-    if (nangle == 0) {
-        if (threadIdx.x == 0) R.kps[k].size = -1.f;
-        return;
-    }
-    if (t < 72) {
-        const int i = t * 5;
-        float sumx = 0, sumy = 0;
-        // four rounded angles per LDS read (entries past nOriSamples hold the sentinel); the sums still visit the samples in index order
-        for (int j = 0; j < nori; j += 4) {
-            const int4 a4 = *reinterpret_cast<const int4 *>(&A[j]);
-            const float4 x4 = *reinterpret_cast<const float4 *>(&X[j]), y4 = *reinterpret_cast<const float4 *>(&Y[j]);
-            const int aa[4] = {a4.x, a4.y, a4.z, a4.w};
-            const float xx[4] = {x4.x, x4.y, x4.z, x4.w}, yy[4] = {y4.x, y4.y, y4.z, y4.w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int d = abs(aa[q] - i);
-                const bool m = aa[q] != -100000 && (d < 30 || d > 330);
-                sumx = m ? sumx + xx[q] : sumx;
-                sumy = m ? sumy + yy[q] : sumy;
+    __shared__ __attribute__((aligned(16))) float X[ORI_KP][128], Y[ORI_KP][128];
+    __shared__ __attribute__((aligned(16))) int A[ORI_KP][128];
+    __shared__ float mod_s[ORI_KP][72], sx_s[ORI_KP][72], sy_s[ORI_KP][72];
+    __shared__ int nvalid[ORI_KP], state[ORI_KP];              // state: 0 compute, 1 done (deleted / upright / beyond n)
+    const int tid = threadIdx.x;
+    const int kq = tid >> 7, t = tid & 127;
+    if (tid < ORI_KP) { nvalid[tid] = 0; state[tid] = 0; }
+    __syncthreads();
+    {
+        const int k = k0 + kq;
+        int valid = 0;
+        if (k < n) {
+            const vfsms_keypoint kp = R.kps[k];
+            const float s = kp.size * 1.2f / 9.0f;
+            const int gws = 2 * cv_round_f(2 * s);
+            const int srows = R.h + 1, scols = R.w + 1, sw = R.w + 1;
+            if (srows < gws || scols < gws) {                  // gradient wavelet larger than the image: delete
+                if (t == 0) { R.kps[k].size = -1.f; state[kq] = 1; }
+            } else if (upright) {
+                if (t == 0) { R.kps[k].angle = 270.f; state[kq] = 1; }
+            } else if (t < T->nOriSamples) {
+                int x = cv_round_f(kp.x + T->aptx[t] * s - (float)(gws - 1) / 2);
+                int y = cv_round_f(kp.y + T->apty[t] * s - (float)(gws - 1) / 2);
+                if (!(y < 0 || y >= srows - gws || x < 0 || x >= scols - gws)) {
+                    g_ci32 ptr = (g_ci32)R.sum + (size_t)y * sw + x;
+                    float vx = grad_haar(ptr, sw, gws, true);
+                    float vy = grad_haar(ptr, sw, gws, false);
+                    float xx = vx * T->aptw[t], yy = vy * T->aptw[t];
+                    X[kq][t] = xx; Y[kq][t] = yy;
+                    A[kq][t] = cv_round_f(fast_atan2_deg(yy, xx));     // cv::phase(X, Y, angle, true) then cvRound
+                    valid = 1;
+                }
             }
-        }
-        mod_s[t] = sumx * sumx + sumy * sumy;
-        sx_s[t] = sumx; sy_s[t] = sumy;
+        } else if (t == 0) state[kq] = 1;
+        if (!valid) A[kq][t] = -100000;
+        const unsigned long long m = __ballot(valid);
+        if ((tid & 63) == 0 && m) atomicAdd(&nvalid[kq], __popcll(m));
     }
     __syncthreads();
-    if (t == 0) {
-        float bestx = 0, besty = 0, best = 0;
-        for (int i = 0; i < 72; i++)
-            if (mod_s[i] > best) { best = mod_s[i]; bestx = sx_s[i]; besty = sy_s[i]; }
-        R.kps[k].angle = fast_atan2_deg(-besty, bestx);
+    if (tid < ORI_KP * 72) {
+        const int q = tid / 72, w = tid - q * 72;
+        if (state[q] == 0 && nvalid[q] > 0) {
+            const int nori = T->nOriSamples;
+            const int i = w * 5;
+            float sumx = 0, sumy = 0;
+            // four rounded angles per LDS read (entries past nOriSamples hold the sentinel); the sums still visit the samples in index order
+            for (int j = 0; j < nori; j += 4) {
+                const int4 a4 = *reinterpret_cast<const int4 *>(&A[q][j]);
+                const float4 x4 = *reinterpret_cast<const float4 *>(&X[q][j]), y4 = *reinterpret_cast<const float4 *>(&Y[q][j]);
+                const int aa[4] = {a4.x, a4.y, a4.z, a4.w};
+                const float xx[4] = {x4.x, x4.y, x4.z, x4.w}, yy[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int d = abs(aa[u] - i);
+                    const bool m = aa[u] != -100000 && (d < 30 || d > 330);
+                    sumx = m ? sumx + xx[u] : sumx;
+                    sumy = m ? sumy + yy[u] : sumy;
+                }
+            }
+            mod_s[q][w] = sumx * sumx + sumy * sumy;
+            sx_s[q][w] = sumx; sy_s[q][w] = sumy;
+        }
+    }
+    __syncthreads();
+    {
+        const int q = tid >> 6, lane = tid & 63;
+        if (q < ORI_KP && state[q] == 0) {
+            const int k = k0 + q;
+            if (nvalid[q] == 0) {
+                if (lane == 0) R.kps[k].size = -1.f;
+            } else {
+                // the reference keeps the FIRST window whose modulus exceeds every earlier one, starting from 0: a modulus that is
+                // not > 0 (zero or NaN) never wins; ties go to the lower window index
+                float bm = mod_s[q][lane]; int bi = lane;
+                if (!(bm > 0.f)) bm = 0.f;
+                if (lane < 8) { float m2 = mod_s[q][64 + lane]; if (m2 > bm) { bm = m2; bi = 64 + lane; } }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const float om = __shfl_xor(bm, off, 64); const int oi = __shfl_xor(bi, off, 64);
+                    if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
+                }
+                if (lane == 0) {
+                    float bestx = 0, besty = 0;
+                    if (bm > 0.f) { bestx = sx_s[q][bi]; besty = sy_s[q][bi]; }
+                    R.kps[k].angle = fast_atan2_deg(-besty, bestx);
+                }
+            }
+        }
     }
 }
 
@@ -1119,12 +1192,13 @@ __device__ __forceinline__ bool ticket_next(const RoiDev *rois, int *counter, in
     return true;
 }
 
-__global__ __launch_bounds__(128) void k_orientation(const RoiDev *rois, const SurfTables *T, int upright)
+__global__ __launch_bounds__(1024) void k_orientation(const RoiDev *rois, const SurfTables *T, int upright)
 {
     const RoiDev &R = rois[blockIdx.y];
-    const int k = blockIdx.x;
-    if (k >= min(R.counters[0], R.cap)) return;
-    orientation_one(R, T, k, upright);
+    const int n = min(R.counters[0], R.cap);
+    const int k0 = blockIdx.x * ORI_KP;
+    if (k0 >= n) return;
+    orientation_block(R, T, k0, n, upright);
 }
 
 #ifndef DESC_WGS
@@ -1318,34 +1392,46 @@ int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_roi
     TRY(launch_integral(ctx, d_rois, nrois, maxh, maxw));
     {
         ProfScope ps(ctx, "hessian");
-        int step = 1;
-        for (int o = 0; o < p->n_octaves; o++) {
-            int lrows = maxh / step, lcols = maxw / step;
-            if (lrows > 0 && lcols > 0) {
-                if (o == 0 && lpo == 5)
-                    hipLaunchKernelGGL((k_hessian_lds<1, 64>), dim3((lcols + 63) / 64, (lrows + 15) / 16, nrois), dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo, o);
-                else if (o == 1 && lpo == 5)
-                    hipLaunchKernelGGL((k_hessian_lds<2, 32>), dim3((lcols + 31) / 32, (lrows + 15) / 16, nrois), dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo, o);
-                else {
-                    dim3 grid((lcols + 63) / 64, (lrows + 3) / 4, nrois * lpo);
-                    hipLaunchKernelGGL(k_hessian, grid, dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo, o);
+        int step = 1, o = 0;
+        if (lpo == 5) {                                                // the two fine octaves: LDS-tiled
+            for (; o < p->n_octaves && o < 2; o++) {
+                const int lrows = maxh / step, lcols = maxw / step;
+                if (lrows > 0 && lcols > 0) {
+                    if (o == 0)
+                        hipLaunchKernelGGL((k_hessian_lds<1, 64>), dim3((lcols + 63) / 64, (lrows + 15) / 16, nrois), dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo, o);
+                    else
+                        hipLaunchKernelGGL((k_hessian_lds<2, 32>), dim3((lcols + 31) / 32, (lrows + 15) / 16, nrois), dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo, o);
                 }
+                step *= 2;
             }
+        }
+        HessPlan plan; plan.o0 = o; plan.noct = 0; plan.first[0] = 0;
+        for (; o < p->n_octaves && plan.noct < VFSMS_MAX_OCTAVES; o++) {
+            const int lrows = maxh / step, lcols = maxw / step;
+            const int tx = (lcols + 63) / 64, ty = (lrows + 3) / 4;
+            plan.tiles_x[plan.noct] = tx > 0 ? tx : 1;
+            plan.first[plan.noct + 1] = plan.first[plan.noct] + tx * ty;
+            plan.noct++;
             step *= 2;
         }
+        if (plan.noct > 0 && plan.first[plan.noct] > 0)
+            hipLaunchKernelGGL(k_hessian, dim3((unsigned)plan.first[plan.noct] * lpo * nrois), dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo, plan, nrois);
     }
     {
         ProfScope ps(ctx, "nms");
+        NmsPlan plan; plan.noct = 0; plan.first[0] = 0;
         int step = 1;
-        for (int o = 0; o < p->n_octaves; o++) {
-            int lrows = maxh / step, lcols = maxw / step;
-            if (lrows > 0 && lcols > 0) {
-                dim3 grid((lcols + 63) / 64, (lrows + 4 * NMS_ROWS - 1) / (4 * NMS_ROWS), nrois * p->n_octave_layers);
-                hipLaunchKernelGGL(k_nms, grid, dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo,
-                                   p->n_octave_layers, o, p->hessian_threshold);
-            }
+        for (int o = 0; o < p->n_octaves && o < VFSMS_MAX_OCTAVES; o++) {
+            const int lrows = maxh / step, lcols = maxw / step;
+            const int tx = (lcols + 63) / 64, ty = (lrows + NMS_TH - 1) / NMS_TH;
+            plan.tiles_x[o] = tx > 0 ? tx : 1;
+            plan.first[o + 1] = plan.first[o] + tx * ty;
+            plan.noct = o + 1;
             step *= 2;
         }
+        if (plan.noct > 0 && plan.first[plan.noct] > 0)
+            hipLaunchKernelGGL(k_nms, dim3(plan.first[plan.noct], nrois * p->n_octave_layers), dim3(64, 4), 0, ctx->stream, d_rois,
+                               ctx->d_layers, lpo, p->n_octave_layers, plan, p->hessian_threshold);
     }
     {
         ProfScope ps(ctx, "sort");
@@ -1364,7 +1450,7 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
     for (int r = 0; r < nrois; r++) maxcap = h_rois[r].cap > maxcap ? h_rois[r].cap : maxcap;
     {
         ProfScope ps(ctx, "orientation");
-        hipLaunchKernelGGL(k_orientation, dim3(maxcap, nrois), dim3(128), 0, ctx->stream, d_rois, ctx->d_tables, p->upright);
+        hipLaunchKernelGGL(k_orientation, dim3((maxcap + ORI_KP - 1) / ORI_KP, nrois), dim3(1024), 0, ctx->stream, d_rois, ctx->d_tables, p->upright);
     }
     {
         ProfScope ps(ctx, "compact");
