@@ -343,7 +343,7 @@ typedef GASM const s8v *g_cs8v;
 typedef float f2v __attribute__((ext_vector_type(2)));
 
 template <int PASS>
-__global__ __launch_bounds__(256, 2) void k_bf_mfma16_d64(const MatchDev *jobs, int qblocks, int nsplit, int njobs)
+__global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, int qblocks, int nsplit, int njobs)
 {
     // a (job, train chunk) and its 0.3 MB of split descriptors stay on one XCD (xcd_roi_map): every query block of the unit re-reads them
     unsigned unit, qb;
@@ -352,13 +352,13 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma16_d64(const MatchDev *jobs, 
     const MatchDev &J = jobs[unit / (unsigned)nsplit];
     const int nq = __builtin_amdgcn_readfirstlane(*J.nq_ptr), nt = __builtin_amdgcn_readfirstlane(*J.nt_ptr);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)qb * 256 >= nq) return;                    // (whole workgroup)
     const int q0 = ((int)qb * 4 + wave) * 64;
-    if (q0 >= nq) return;
+    const bool live = q0 < nq;                           // a wave beyond nq still stages train tiles and keeps the barriers
     const int ntiles = (nt + 31) >> 5;
     const int tchunk = (ntiles + nsplit - 1) / nsplit;
     const int tile0 = sp * tchunk, tile1 = min(ntiles, tile0 + tchunk);
     const int col = lane & 31, half = lane >> 5;
-    constexpr int NA = PASS == 0 ? 4 : 8;            // s8v per train row and lane: hi only | hi and lo
     const s8v zero = {0, 0, 0, 0, 0, 0, 0, 0};
     // B operands (queries, resident): per 16-dim step s the lane's 8 hi and 8 lo values of dims 32*half + 8*s .. + 7
     s8v bh0[4], bl0[4], bh1[4], bl1[4], bn0, bn1;
@@ -373,6 +373,14 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma16_d64(const MatchDev *jobs, 
         bn0 = half == 0 ? *(g_cs8v)(J.q16 + (size_t)min(q0 + col, nq - 1) * BF16_ROW + 128) : zero;
         bn1 = half == 0 ? *(g_cs8v)(J.q16 + (size_t)min(q0 + 32 + col, nq - 1) * BF16_ROW + 128) : zero;
     }
+    // Pin the query operands as "defined here": the compiler otherwise carries their load waits into the tile loop as in-order
+    // vmcnt counts, which also drain the train prefetch issued at the top of every iteration (a full L2 round trip per tile).
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+        asm volatile("" : "+v"(bh0[s4]), "+v"(bh1[s4]));
+        if (PASS == 1) asm volatile("" : "+v"(bl0[s4]), "+v"(bl1[s4]));
+    }
+    asm volatile("" : "+v"(bn0), "+v"(bn1));
     const bool va = q0 + col < nq, vb = q0 + 32 + col < nq;
     const size_t pitch = (size_t)J.capq;
     const int lst = sp * 2 + half, nl = 2 * nsplit;
@@ -391,36 +399,49 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma16_d64(const MatchDev *jobs, 
         if (vb) thrb = b2 + (BFM_HI_ERR + BFM_MARGIN);
     }
     uint2 *lista = J.c_ent + (size_t)lst * BFM_CAPL * pitch + (q0 + col), *listb = lista + 32;
-    g_cs8v T = (g_cs8v)J.t16 + lane;                     // fragment order: tile * 9 fragments * 64 lanes (k_bf_split16)
-    s8v an[NA], nn = zero;
-    if (tile0 < tile1) {
-        g_cs8v pn = T + (size_t)tile0 * (BF16_FRAGS * 64);
-#pragma unroll
-        for (int s = 0; s < NA; s++) an[s] = pn[s * 64];
-        nn = pn[8 * 64];
-    }
+    // Train tiles go through LDS: the four waves of a workgroup sweep the SAME tiles (for different queries), so one cooperative
+    // copy per tile (2.25 x 16 B per thread, straight in fragment order) replaces four sets of per-wave loads, and the operands
+    // arrive by ds_read_b128 instead of waiting on L2.  Three buffers, one barrier per tile: tile t + 2 is fetched into registers
+    // before the MFMAs of tile t and stored after them into the buffer that tile t - 1 vacated.
+    constexpr int NFR = PASS == 0 ? 5 : BF16_FRAGS;      // fragments staged: hi x 4 (+ lo x 4) + norm
+    __shared__ s8v stage[3][NFR * 64];
+    g_cs8v T = (g_cs8v)J.t16;                            // fragment order: tile * 9 fragments * 64 lanes (k_bf_split16)
+    const int tid = threadIdx.x;
+    s8v g0 = zero, g1 = zero, g2 = zero;
+    auto fetch = [&](int tl) {
+        g_cs8v pn = T + (size_t)tl * (BF16_FRAGS * 64);
+        g0 = pn[tid];
+        if (PASS == 1) { g1 = pn[256 + tid]; if (tid < 64) g2 = pn[512 + tid]; }
+        else if (tid < 64) g1 = pn[512 + tid];
+    };
+    auto put = [&](int b) {
+        stage[b][tid] = g0;
+        if (PASS == 1) { stage[b][256 + tid] = g1; if (tid < 64) stage[b][512 + tid] = g2; }
+        else if (tid < 64) stage[b][256 + tid] = g1;
+    };
+    if (tile0 < tile1) { fetch(tile0); put(0); }
+    if (tile0 + 1 < tile1) { fetch(tile0 + 1); put(1); }
     for (int tl = tile0; tl < tile1; tl++) {
-        s8v a[NA], na = nn;
-#pragma unroll
-        for (int s = 0; s < NA; s++) a[s] = an[s];
-        if (tl + 1 < tile1) {                    // prefetch the next train tile behind this tile's MFMAs
-            g_cs8v pn = T + (size_t)(tl + 1) * (BF16_FRAGS * 64);
-#pragma unroll
-            for (int s = 0; s < NA; s++) an[s] = pn[s * 64];
-            nn = pn[8 * 64];
-        }
+        const int b = (tl - tile0) % 3;
+        __syncthreads();
+        const bool more = tl + 2 < tile1;
+        if (more) fetch(tl + 2);
+        if (!live) { if (more) put((b + 2) % 3); continue; }
         f16v acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
 #pragma unroll
-        for (int s = 0; s < 4; s++) {            // a[s] = hi, a[4 + s] = lo of the lane's dims 8s .. 8s + 7
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bh0[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bh1[s], acc1, 0, 0, 0);
+        for (int s = 0; s < 4; s++) {            // fragment s = hi, 4 + s = lo of the lane's dims 8s .. 8s + 7
+            const s8v ah = stage[b][s * 64 + lane];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1[s], acc1, 0, 0, 0);
             if (PASS == 1) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bl0[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bl1[s], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NA - 4 + s], bh0[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NA - 4 + s], bh1[s], acc1, 0, 0, 0);
+                const s8v al = stage[b][(4 + s) * 64 + lane];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1[s], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1[s], acc1, 0, 0, 0);
             }
         }
+        const s8v na = stage[b][(NFR - 1) * 64 + lane];
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na, bn0, acc0, 0, 0, 0);      // + |t|^2 (hi + lo in both passes)
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na, bn1, acc1, 0, 0, 0);
         if (tl * 32 + 31 >= nt) {                // train rows beyond nt never qualify
@@ -460,6 +481,7 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma16_d64(const MatchDev *jobs, 
                 }
             }
         }
+        if (more) put((b + 2) % 3);
     }
     if (PASS == 0) {
         GASM f2v *B = (GASM f2v *)J.c_m12;

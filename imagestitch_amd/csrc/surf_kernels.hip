@@ -755,11 +755,12 @@ __device__ __forceinline__ int win_sample_upright(const WinGeom &G, int i, int j
 #ifndef BORDER_ILP
 #define BORDER_ILP 2            // strips that cross the image border: shorter trips keep the register budget of the hot path
 #endif
+template <int NW>                                              // NW waves share the strips (4: the workgroup; 1: one wave on its own)
 __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row, const float *sy_row,
                                            int r0, int nrows, uint8_t *dst)
 {
     const int win = G.win;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = NW == 1 ? 0 : (int)(threadIdx.x >> 6);
     const int li = lane >> 3, lj = lane & 7;
     const int strips = (nrows + 7) >> 3;
     const double c = (double)G.cos_dir, sn = (double)G.sin_dir;
@@ -769,7 +770,7 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
     // (readfirstlane returns int: widen through uint32_t, or a low half with bit 31 set sign-extends into the high half)
     g_cu8 ubase = (g_cu8)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32)) << 32) |
                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)bp));
-    for (int ty = wv; ty < strips; ty += 4) {
+    for (int ty = wv; ty < strips; ty += NW) {
         const int r = ty * 8 + li;
         const bool rok = r < nrows;
         const int i = min(r0 + r, VFSMS_MAX_WIN - 1);
@@ -973,7 +974,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
     // window when it fits (win <= 169), otherwise one band of source rows per row of output cells.  The INTER_AREA
     // reduction then reads bytes from LDS in exactly the accumulation order of cv::resize's three area paths.
     if (win * win <= DESC_WBUF) {
-        stage_rows(G, sx_row, sy_row, 0, win, WINBUF);
+        stage_rows<4>(G, sx_row, sy_row, 0, win, WINBUF);
         __syncthreads();
         DT_MARK(1);
         for (int o = threadIdx.x; o < dsz * dsz; o += 256) {
@@ -1019,7 +1020,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
             const int crows = max(DESC_WBUF / win, 1);             // band rows staged per chunk (>= 22 for win <= 739)
             for (int c0 = 0; c0 < nrows; c0 += crows) {
                 const int cn = min(crows, nrows - c0);
-                stage_rows(G, sx_row, sy_row, rlo + c0, cn, WINBUF);
+                stage_rows<4>(G, sx_row, sy_row, rlo + c0, cn, WINBUF);
                 __syncthreads();
                 DT_MARK(3);
                 for (int t = threadIdx.x; t < dsz * cn; t += 256) { // horizontal sums, one (cell column, source row) per lane
@@ -1154,7 +1155,9 @@ __device__ __forceinline__ void ticket_init(const RoiDev *rois, int nrois, Ticke
         for (int e = 0; e < DESC_NCLS * nrois; e++) total += S.prefix[e + 1];
         S.split = total < (int)gridDim.x * 48 ? 21 : 1;
         S.prefix[0] = 0;
-        for (int e = 0; e < DESC_NCLS * nrois; e++) S.prefix[e + 1] = S.prefix[e] + S.prefix[e + 1] * (e < nrois ? S.split : 1);
+        // class 3 (windows <= 64 px) is k_describe_small's: no tickets for it here
+        for (int e = 0; e < DESC_NCLS * nrois; e++)
+            S.prefix[e + 1] = S.prefix[e] + (e >= 3 * nrois ? 0 : S.prefix[e + 1] * (e < nrois ? S.split : 1));
         S.head = 0;
     }
     __syncthreads();
@@ -1199,6 +1202,125 @@ __global__ __launch_bounds__(1024) void k_orientation(const RoiDev *rois, const 
     const int k0 = blockIdx.x * ORI_KP;
     if (k0 >= n) return;
     orientation_block(R, T, k0, n, upright);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Windows of <= 64 px (class 3: two thirds of the keypoints, a quarter of the samples) are described by ONE WAVE each: a 42 px
+// window is 7 samples per thread of a 256-thread workgroup, so the workgroup form spends its time in the five barriers, the
+// two-barrier ticket draw and the single-lane row-origin chains.  Here the four waves of a workgroup run independently -- own ticket
+// (lane 0 draws, the wave shares it by shuffle), own 64 x 64 LDS window, no workgroup barrier after the prefix table is built -- with
+// the sampling and INTER_AREA arithmetic of describe_one (stage_rows<1>, the same cell code).
+// ---------------------------------------------------------------------------------------------------
+#define DESC_SMALL_WIN 64
+struct SmallLds { uint8_t win[DESC_SMALL_WIN * DESC_SMALL_WIN]; float sx[DESC_SMALL_WIN + 8], sy[DESC_SMALL_WIN + 8]; AreaSpan span[21]; };
+
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ void describe_small(const RoiDev &R, const int k, int upright, SmallLds &L)
+{
+    const int lane = threadIdx.x & 63;
+    const vfsms_keypoint kp = R.kps[k];
+    if (!(kp.size > 0)) return;                            // deleted by the orientation stage (wave-uniform)
+    const float s = kp.size * 1.2f / 9.0f;
+    WinGeom G;
+    G.win = min((int)((20 + 1) * s), DESC_SMALL_WIN);      // (class 3 means <= 64 already)
+    G.h = R.h; G.w = R.w; G.stride = R.stride; G.img = (g_cu8)R.img;
+    G.upright = upright; G.usx = 0; G.usy = 0; G.sin_dir = 0.f; G.cos_dir = 0.f;
+    const int win = G.win;
+    const int dsz = 21;
+    const double inv_scale = (double)dsz / win;
+    const double scale = 1. / inv_scale;
+    const int iscale = cv_round_d(scale);
+    const bool is_area_fast = fabs(scale - iscale) < DBL_EPSILON;
+    if (!upright) {
+        const float sin_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[0];
+        const float cos_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[1];
+        G.sin_dir = sin_dir; G.cos_dir = cos_dir;
+        if (lane < 2) {                                    // running float sums of the reference: lane 0 walks x, lane 1 walks y
+            const float win_offset = -(float)(win - 1) / 2;
+            if (lane == 0) {
+                float start_x = kp.x + win_offset * cos_dir + win_offset * sin_dir;
+                for (int i = 0; i < win; i++, start_x += sin_dir) L.sx[i] = start_x;
+            } else {
+                float start_y = kp.y - win_offset * sin_dir + win_offset * cos_dir;
+                for (int i = 0; i < win; i++, start_y += cos_dir) L.sy[i] = start_y;
+            }
+        }
+    } else {
+        const float win_offset = -(float)(win - 1) / 2;
+        G.usx = cv_round_f(kp.x + win_offset);
+        G.usy = cv_round_f(kp.y - win_offset);
+    }
+    if (!is_area_fast && lane >= 32 && lane < 32 + dsz) L.span[lane - 32] = area_span(lane - 32, win, scale);
+    wave_sync_lds();
+    stage_rows<1>(G, L.sx, L.sy, 0, win, L.win);
+    wave_sync_lds();
+    uint8_t *prow = R.patch + (size_t)k * VFSMS_PATCH_ROW;
+    for (int o = lane; o < dsz * dsz; o += 64) {
+        const int dy = o / dsz, dx = o % dsz;
+        uint8_t outv;
+        if (is_area_fast && iscale == 2) {
+            const uint8_t *S = L.win + (dy * 2) * win + dx * 2;
+            outv = (uint8_t)((S[0] + S[1] + S[win] + S[win + 1] + 2) >> 2);
+        } else if (is_area_fast) {
+            int sum = 0;
+            for (int sy = 0; sy < iscale; sy++)
+                for (int sx = 0; sx < iscale; sx++) sum += L.win[(dy * iscale + sy) * win + dx * iscale + sx];
+            outv = sat_u8(sum * (1.f / (iscale * iscale)));
+        } else {
+            const AreaSpan Sy = L.span[dy], Sx = L.span[dx];
+            float sum = 0; bool first = true;
+            for (int pass = 0; pass < 3; pass++) {
+                int r0 = pass == 0 ? Sy.s_left : pass == 1 ? Sy.sx1 : Sy.s_right;
+                int r1 = pass == 1 ? Sy.sx2 : r0 + 1;
+                float beta = pass == 0 ? Sy.a_left : pass == 1 ? Sy.a_full : Sy.a_right;
+                if (pass != 1 && r0 < 0) continue;
+                for (int sy = r0; sy < r1; sy++) {
+                    const float buf = area_row(L.win + sy * win, Sx);
+                    if (first) { sum = beta * buf; first = false; } else sum += beta * buf;
+                }
+            }
+            outv = sat_u8(sum);
+        }
+        prow[o] = outv;                                    // the 21 x 21 patch for k_desc_tail
+    }
+    wave_sync_lds();                                       // the next keypoint of this wave overwrites L
+}
+
+#define DESC_SMALL_WGS 5
+__global__ __launch_bounds__(256, DESC_SMALL_WGS) void k_describe_small(const RoiDev *rois, int nrois, int *counter, int upright)
+{
+    __shared__ int prefix[VFSMS_MAX_ROIS + 1];            // class-3 keypoints of the ROIs before each ROI
+    __shared__ SmallLds L[4];
+    for (int e = threadIdx.x; e < nrois; e += 256) prefix[e + 1] = rois[e].counters[12 + 3];
+    __syncthreads();
+    if (threadIdx.x == 0) { prefix[0] = 0; for (int e = 0; e < nrois; e++) prefix[e + 1] += prefix[e]; }
+    __syncthreads();
+    const int total = prefix[nrois];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int head = 0;
+    for (;;) {
+        int t = total;
+        if (lane == 0)
+            while (head < DESC_HEADS) {
+                const int q = (blockIdx.x + head) & (DESC_HEADS - 1);
+                t = atomicAdd(counter + q * DESC_HEAD_STRIDE, 1) * DESC_HEADS + q;
+                if (t < total) break;
+                head++;                                      // this head is exhausted (it stays exhausted): steal from the next
+                t = total;
+            }
+        t = __shfl(t, 0, 64);
+        if (t >= total) break;
+        int lo = 0, hi = nrois;                               // prefix[lo] <= t < prefix[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= t) lo = mid; else hi = mid; }
+        const RoiDev &R = rois[lo];
+        const int within = t - prefix[lo] + R.counters[12] + R.counters[13] + R.counters[14];   // the ROI's list is class-major
+        describe_small(R, R.order[within], upright, L[wave]);
+    }
 }
 
 #ifndef DESC_WGS
@@ -1459,13 +1581,15 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
     {
         ProfScope ps(ctx, "describe");
         // ticket heads: 8 counters, 256 B apart, out of the call's arena (callers reserve 64 KB of slack)
-        int *tickets = (int *)ctx_arena_alloc(ctx, sizeof(int) * DESC_HEADS * DESC_HEAD_STRIDE);
+        int *tickets = (int *)ctx_arena_alloc(ctx, sizeof(int) * 2 * DESC_HEADS * DESC_HEAD_STRIDE);
         if (!tickets) { vfsms_set_error("arena exhausted (descriptor tickets)"); return VFSMS_ERR_CAPACITY; }
-        HIP_TRY(hipMemsetAsync(tickets, 0, sizeof(int) * DESC_HEADS * DESC_HEAD_STRIDE, ctx->stream));
+        HIP_TRY(hipMemsetAsync(tickets, 0, sizeof(int) * 2 * DESC_HEADS * DESC_HEAD_STRIDE, ctx->stream));
         hipLaunchKernelGGL(k_desc_order, dim3(nrois), dim3(1024), 0, ctx->stream, d_rois);
         if (!p->upright) hipLaunchKernelGGL(k_desc_trig, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
         hipLaunchKernelGGL(k_describe, dim3(256 * DESC_WGS), dim3(256), 0, ctx->stream, d_rois, nrois, tickets,
                            ctx->d_tables, p->extended, p->upright);
+        hipLaunchKernelGGL(k_describe_small, dim3(256 * DESC_SMALL_WGS), dim3(256), 0, ctx->stream, d_rois, nrois,
+                           tickets + DESC_HEADS * DESC_HEAD_STRIDE, p->upright);
         hipLaunchKernelGGL(k_desc_tail, dim3((maxcap + 15) / 16, nrois), dim3(256), 0, ctx->stream, d_rois, ctx->d_tables, p->extended);
     }
     HIP_TRY(hipGetLastError());
