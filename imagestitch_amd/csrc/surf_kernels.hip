@@ -770,58 +770,65 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
     // (readfirstlane returns int: widen through uint32_t, or a low half with bit 31 set sign-extends into the high half)
     g_cu8 ubase = (g_cu8)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32)) << 32) |
                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)bp));
-    for (int ty = wv; ty < strips; ty += NW) {
+    // Work unit = (strip of 8 rows, block of 32 columns); each wave takes a contiguous run of units.  (Strips alone left waves idle:
+    // a band of a large window is only 1-5 strips tall, so one to three of the four waves of the workgroup had nothing to sample.)
+    const int ncb = (win + 31) >> 5;
+    const int total = strips * ncb;
+    const int chunk = (total + NW - 1) / NW;
+    const int u_end = min(total, (wv + 1) * chunk);
+    int cur_ty = -1; bool strip_in = false;
+    for (int unit = wv * chunk; unit < u_end; unit++) {
+        const int ty = unit / ncb, cb0 = (unit - ty * ncb) * 32;
+        const int cb1 = min(win, cb0 + 32);
         const int r = ty * 8 + li;
         const bool rok = r < nrows;
         const int i = min(r0 + r, VFSMS_MAX_WIN - 1);
         const double sxi = (double)sx_row[i], syi = (double)sy_row[i];
         uint8_t *drow = dst + r * win;
         if (G.upright) {
-            for (int j = lj; j < win; j += 8)
+            for (int j = cb0 + lj; j < cb1; j += 8)
                 if (rok) drow[j] = (uint8_t)win_sample_upright(G, r0 + r, j);
             continue;
         }
         // Strip-level interior test: the samples of rows [r0 + 8 ty, +8) x [0, win) are linear in j and monotone in i, so
         // their extremes sit at the four corners.  A strip that lies inside the image (with the 2 px of slack the dword
         // taps need) runs without any per-sample bounds logic; other strips keep the per-trip test below.
-        {
+        if (ty != cur_ty) {
+            cur_ty = ty;
             const int ia = min(r0 + ty * 8, VFSMS_MAX_WIN - 1), ib = min(min(r0 + ty * 8 + 7, r0 + nrows - 1), VFSMS_MAX_WIN - 1);
             const double e = (double)(win - 1);
             const double xa = (double)sx_row[ia], xb = (double)sx_row[ib], ya = (double)sy_row[ia], yb = (double)sy_row[ib];
             const double xmin = fmin(fmin(xa, xa + e * c), fmin(xb, xb + e * c)), xmax = fmax(fmax(xa, xa + e * c), fmax(xb, xb + e * c));
             const double ymin = fmin(fmin(ya, ya - e * sn), fmin(yb, yb - e * sn)), ymax = fmax(fmax(ya, ya - e * sn), fmax(yb, yb - e * sn));
-            if (xmin >= 0.0 && ymin >= 0.0 && xmax < (double)(ncols1 - 2) && ymax < (double)nrows1) {
-                double jd[STAGE_ILP];
-#pragma unroll
-                for (int u = 0; u < STAGE_ILP; u++) jd[u] = (double)(u * 8 + lj);
-                for (int jb = 0; jb < win; jb += 8 * STAGE_ILP) {
-                    uint32_t top[STAGE_ILP], bot[STAGE_ILP];
-                    double px[STAGE_ILP], py[STAGE_ILP];
-                    DT_TRIP(0);
-#pragma unroll
-                    for (int u = 0; u < STAGE_ILP; u++) {
-                        // start + j * step: the product is exact in double, so the fused form rounds exactly like mul-then-add
-                        px[u] = __builtin_fma(jd[u], c, sxi);
-                        py[u] = __builtin_fma(jd[u], -sn, syi);
-                        jd[u] += (double)(8 * STAGE_ILP);
-                        const bool act = rok && jb + u * 8 + lj < win;
-                        const uint32_t off = act ? (uint32_t)__umul24((uint32_t)(int)py[u], (uint32_t)G.stride) + (uint32_t)(int)px[u] : 0u;
-                        top[u] = *(GAS const uint32_t *)(ubase + off);      // unaligned dword gathers, uniform base + 32-bit offset
-                        bot[u] = *(GAS const uint32_t *)(ubase + off + (uint32_t)G.stride);
-                    }
-#pragma unroll
-                    for (int u = 0; u < STAGE_ILP; u++) {
-                        const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
-                        const uint8_t t00 = (uint8_t)(top[u] & 0xff), t01 = (uint8_t)((top[u] >> 8) & 0xff);
-                        const uint8_t t10 = (uint8_t)(bot[u] & 0xff), t11 = (uint8_t)((bot[u] >> 8) & 0xff);
-                        const float v = t00 * (1.f - a) * (1.f - b) + t01 * a * (1.f - b) + t10 * (1.f - a) * b + t11 * a * b;
-                        if (rok && jb + u * 8 + lj < win) drow[jb + u * 8 + lj] = (uint8_t)cv_round_f(v);
-                    }
-                }
-                continue;
-            }
+            strip_in = xmin >= 0.0 && ymin >= 0.0 && xmax < (double)(ncols1 - 2) && ymax < (double)nrows1;
         }
-        for (int jb = 0; jb < win; jb += 8 * BORDER_ILP) {
+        if (strip_in) {
+            const int jb = cb0;
+            uint32_t top[STAGE_ILP], bot[STAGE_ILP];
+            double px[STAGE_ILP], py[STAGE_ILP];
+            DT_TRIP(0);
+#pragma unroll
+            for (int u = 0; u < STAGE_ILP; u++) {
+                // start + j * step: the product is exact in double, so the fused form rounds exactly like mul-then-add
+                const double jd = (double)(jb + u * 8 + lj);
+                px[u] = __builtin_fma(jd, c, sxi);
+                py[u] = __builtin_fma(jd, -sn, syi);
+                const bool act = rok && jb + u * 8 + lj < win;
+                const uint32_t off = act ? (uint32_t)__umul24((uint32_t)(int)py[u], (uint32_t)G.stride) + (uint32_t)(int)px[u] : 0u;
+                top[u] = *(GAS const uint32_t *)(ubase + off);      // unaligned dword gathers, uniform base + 32-bit offset
+                bot[u] = *(GAS const uint32_t *)(ubase + off + (uint32_t)G.stride);
+            }
+#pragma unroll
+            for (int u = 0; u < STAGE_ILP; u++) {
+                const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
+                const uint8_t t00 = (uint8_t)(top[u] & 0xff), t01 = (uint8_t)((top[u] >> 8) & 0xff);
+                const uint8_t t10 = (uint8_t)(bot[u] & 0xff), t11 = (uint8_t)((bot[u] >> 8) & 0xff);
+                const float v = t00 * (1.f - a) * (1.f - b) + t01 * a * (1.f - b) + t10 * (1.f - a) * b + t11 * a * b;
+                if (rok && jb + u * 8 + lj < win) drow[jb + u * 8 + lj] = (uint8_t)cv_round_f(v);
+            }
+            continue;
+        }
+        for (int jb = cb0; jb < cb1; jb += 8 * BORDER_ILP) {
             double px[BORDER_ILP], py[BORDER_ILP];
             bool act[BORDER_ILP], inb[BORDER_ILP];
             bool all_in = true;
