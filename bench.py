@@ -295,15 +295,18 @@ def main():
     # The MI355X needs about a second of sustained load to reach its steady clocks (and the first touches of the arena to
     # settle): measured here, the step right after a short warmup runs 5-100 % slower than the steady state.  More untimed
     # steps are run until the warmup has lasted MIN_WARM_S; they are reported, and the K timed steps below are exactly K.
-    dt_w = time.perf_counter() - t_w
-    warm_extra = int(np.ceil(max(MIN_WARM_S - dt_w, 0.0) / max(dt_w / max(args.warmup, 1), 1e-4)))
-    if dist is not None:                                    # the same count on every rank: a step contains the collective
-        tw = torch.tensor([warm_extra], dtype=torch.int64, device=coll_device)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        warm_extra = int(tw.item())
-    warm_extra = min(warm_extra, 400)
-    for _ in range(warm_extra):
+    # The decision to run one more warm step is taken jointly (a step contains the collective): MAX over ranks of "not warm yet".
+    warm_extra = 0
+    while warm_extra < 400:
+        need = 1 if time.perf_counter() - t_w < MIN_WARM_S else 0
+        if dist is not None:
+            tw = torch.tensor([need], dtype=torch.int64, device=coll_device)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            need = int(tw.item())
+        if not need:
+            break
         step()
+        warm_extra += 1
     ok = res[:, 0] == 1
     err = np.abs(res[:, 1:3].astype(np.int64) - truth)
     max_err = int(err[ok].max()) if ok.any() else -1
