@@ -1015,33 +1015,73 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
         DT_MARK(2);
     } else {
         int *irow = reinterpret_cast<int *>(&rowbuf[0][0]);
-        for (int dy = band >= 0 ? band : 0; dy < (band >= 0 ? band + 1 : dsz); dy++) {
-            int rlo, rhi;
-            if (is_area_fast) { rlo = dy * iscale; rhi = rlo + iscale - 1; }
+        // source rows [rlo, rhi] of output row d (computeResizeAreaTab: left partial, full cells, right partial)
+        auto band_rows = [&](int d, int &lo, int &hi) {
+            if (is_area_fast) { lo = d * iscale; hi = lo + iscale - 1; }
             else {
-                const AreaSpan Sy = span_s[dy];
-                rlo = Sy.s_left >= 0 ? Sy.s_left : Sy.sx1;
-                rhi = Sy.s_right >= 0 ? Sy.s_right : Sy.sx2 - 1;
+                const volatile AreaSpan *vs = &span_s[d];
+                const int sl = vs->s_left, sr = vs->s_right;
+                lo = sl >= 0 ? sl : vs->sx1;
+                hi = sr >= 0 ? sr : vs->sx2 - 1;
             }
+        };
+        const int dy_end = band >= 0 ? band + 1 : dsz;
+        const int crows = max(DESC_WBUF / win, 1);                 // window rows the LDS buffer holds (>= 22 for win <= 739)
+        int st_lo = 0, st_hi = -1;                                 // window rows currently staged (SUPER-BAND, see below)
+        for (int dy = band >= 0 ? band : 0; dy < dy_end; dy++) {
+            int rlo, rhi;
+            band_rows(dy, rlo, rhi);
             const int nrows = rhi - rlo + 1;                       // <= scale + 2 <= 38
-            const int crows = max(DESC_WBUF / win, 1);             // band rows staged per chunk (>= 22 for win <= 739)
-            for (int c0 = 0; c0 < nrows; c0 += crows) {
-                const int cn = min(crows, nrows - c0);
-                stage_rows<4>(G, sx_row, sy_row, rlo + c0, cn, WINBUF);
-                __syncthreads();
-                DT_MARK(3);
-                for (int t = threadIdx.x; t < dsz * cn; t += 256) { // horizontal sums, one (cell column, source row) per lane
-                    const int dx = t / cn, r = t - dx * cn;
-                    const uint8_t *S = WINBUF + r * win;
+            if (nrows <= crows) {
+                // Super-band: the buffer is filled with the source rows of as many consecutive output rows as fit.  A band on
+                // its own is only scale + 2 (8-38) rows tall -- one or two 8-row strips, a third of their lanes idle, and every row
+                // shared by two bands sampled twice; a full buffer is sampled in whole strips and its shared rows once.
+                if (rlo < st_lo || rhi > st_hi) {
+                    int end = rhi;
+                    for (int d2 = dy + 1; d2 < dy_end; d2++) {
+                        int l2, h2;
+                        band_rows(d2, l2, h2);
+                        if (h2 - rlo + 1 > crows) break;
+                        end = h2;
+                    }
+                    __syncthreads();                               // (the previous band's sums have been consumed)
+                    stage_rows<4>(G, sx_row, sy_row, rlo, end - rlo + 1, WINBUF);
+                    st_lo = rlo; st_hi = end;
+                    __syncthreads();
+                    DT_MARK(3);
+                }
+                for (int t = threadIdx.x; t < dsz * nrows; t += 256) { // horizontal sums, one (cell column, source row) per lane
+                    const int dx = t / nrows, r = t - dx * nrows;
+                    const uint8_t *S = WINBUF + (rlo - st_lo + r) * win;
                     if (is_area_fast) {
                         int sum = 0;
                         for (int sx = 0; sx < iscale; sx++) sum += S[dx * iscale + sx];
-                        irow[dx * 40 + c0 + r] = sum;
+                        irow[dx * 40 + r] = sum;
                     } else {
-                        rowbuf[dx][c0 + r] = area_row(S, span_s[dx]);
+                        rowbuf[dx][r] = area_row(S, span_s[dx]);
                     }
                 }
                 __syncthreads();
+            } else {
+                st_hi = -1;                                        // (a band taller than the buffer: staged in chunks of its own)
+                for (int c0 = 0; c0 < nrows; c0 += crows) {
+                    const int cn = min(crows, nrows - c0);
+                    stage_rows<4>(G, sx_row, sy_row, rlo + c0, cn, WINBUF);
+                    __syncthreads();
+                    DT_MARK(3);
+                    for (int t = threadIdx.x; t < dsz * cn; t += 256) {
+                        const int dx = t / cn, r = t - dx * cn;
+                        const uint8_t *S = WINBUF + r * win;
+                        if (is_area_fast) {
+                            int sum = 0;
+                            for (int sx = 0; sx < iscale; sx++) sum += S[dx * iscale + sx];
+                            irow[dx * 40 + c0 + r] = sum;
+                        } else {
+                            rowbuf[dx][c0 + r] = area_row(S, span_s[dx]);
+                        }
+                    }
+                    __syncthreads();
+                }
             }
             if (threadIdx.x < dsz) {                                // vertical combine in source-row order
                 const int dx = threadIdx.x;
