@@ -718,6 +718,7 @@ extern "C" int vfsms_debug_desc_trips(unsigned long long *out) { return hipMemcp
 struct WinGeom {
     int win; float sin_dir, cos_dir;
     int h, w, stride; g_cu8 img;
+    g_cu8 pair;                       // RoiDev::pair as bytes: the 2 x 2 taps of a sample are ONE dword at 2 * (y * w + x)
     int upright, usx, usy;            // upright: integer lattice origin (start_x, start_y)
 };
 
@@ -765,11 +766,16 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
     const int strips = (nrows + 7) >> 3;
     const double c = (double)G.cos_dir, sn = (double)G.sin_dir;
     const int ncols1 = G.w - 1, nrows1 = G.h - 1;
-    // the image base is the same for the whole workgroup: pinned to SGPRs so gathers use scalar-base + 32-bit-offset addressing
-    const uint64_t bp = (uint64_t)G.img;
+    // Samples read the ROW-PAIR image (k_pair_rows): element (y, x) = pixel (y, x) | pixel (y + 1, x) << 8, so the four taps of a
+    // bilinear sample are ONE dword at element (iy, ix) -- bytes t00, t10, t01, t11.  The descriptor kernels are bound by the
+    // texture-address path (PMC: TA busy 73 % of the launch, ~24 cycles per 64-lane gather whatever its width), so one gather per
+    // sample instead of two (rows y and y + 1 of the byte image) is what counts.  Its base is the same for the whole workgroup: pinned
+    // to SGPRs so gathers use scalar-base + 32-bit-offset addressing.
+    const uint64_t bp = (uint64_t)G.pair;
     // (readfirstlane returns int: widen through uint32_t, or a low half with bit 31 set sign-extends into the high half)
     g_cu8 ubase = (g_cu8)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32)) << 32) |
                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)bp));
+    const uint32_t pw = (uint32_t)G.w;                           // pitch of the pair image in elements
     // Work unit = (strip of 8 rows, block of 32 columns); each wave takes a contiguous run of units.  (Strips alone left waves idle:
     // a band of a large window is only 1-5 strips tall, so one to three of the four waves of the workgroup had nothing to sample.)
     const int ncb = (win + 31) >> 5;
@@ -804,7 +810,7 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
         }
         if (strip_in) {
             const int jb = cb0;
-            uint32_t top[STAGE_ILP], bot[STAGE_ILP];
+            uint32_t top[STAGE_ILP];
             double px[STAGE_ILP], py[STAGE_ILP];
             DT_TRIP(0);
 #pragma unroll
@@ -814,15 +820,14 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
                 px[u] = __builtin_fma(jd, c, sxi);
                 py[u] = __builtin_fma(jd, -sn, syi);
                 const bool act = rok && jb + u * 8 + lj < win;
-                const uint32_t off = act ? (uint32_t)__umul24((uint32_t)(int)py[u], (uint32_t)G.stride) + (uint32_t)(int)px[u] : 0u;
-                top[u] = *(GAS const uint32_t *)(ubase + off);      // unaligned dword gathers, uniform base + 32-bit offset
-                bot[u] = *(GAS const uint32_t *)(ubase + off + (uint32_t)G.stride);
+                const uint32_t off = act ? ((uint32_t)__umul24((uint32_t)(int)py[u], pw) + (uint32_t)(int)px[u]) << 1 : 0u;
+                top[u] = *(GAS const uint32_t *)(ubase + off);      // 2-byte-aligned dword gather, uniform base + 32-bit offset
             }
 #pragma unroll
             for (int u = 0; u < STAGE_ILP; u++) {
                 const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
-                const uint8_t t00 = (uint8_t)(top[u] & 0xff), t01 = (uint8_t)((top[u] >> 8) & 0xff);
-                const uint8_t t10 = (uint8_t)(bot[u] & 0xff), t11 = (uint8_t)((bot[u] >> 8) & 0xff);
+                const uint8_t t00 = (uint8_t)(top[u] & 0xff), t10 = (uint8_t)((top[u] >> 8) & 0xff);
+                const uint8_t t01 = (uint8_t)((top[u] >> 16) & 0xff), t11 = (uint8_t)(top[u] >> 24);
                 const float v = t00 * (1.f - a) * (1.f - b) + t01 * a * (1.f - b) + t10 * (1.f - a) * b + t11 * a * b;
                 if (rok && jb + u * 8 + lj < win) drow[jb + u * 8 + lj] = (uint8_t)cv_round_f(v);
             }
@@ -846,19 +851,17 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
             if (__all(all_in)) {                                   // interior (the common case): branch-free gathers
                 // the gather path (one address per lane through the texture-address unit) is what bounds this kernel:
                 // the two horizontally adjacent taps of a row come from ONE unaligned dword load (2 loads / sample, not 4)
-                uint32_t top[BORDER_ILP], bot[BORDER_ILP];
+                uint32_t top[BORDER_ILP];
 #pragma unroll
                 for (int u = 0; u < BORDER_ILP; u++) {
                     const int ix = act[u] ? (int)px[u] : 0, iy = act[u] ? (int)py[u] : 0;
-                    g_cu8 p = G.img + (size_t)iy * G.stride + ix;
-                    top[u] = *(GAS const uint32_t *)p;          // unaligned dword gather (gfx950 global memory allows it)
-                    bot[u] = *(GAS const uint32_t *)(p + G.stride);
+                    top[u] = *(GAS const uint32_t *)(ubase + (((uint32_t)__umul24((uint32_t)iy, pw) + (uint32_t)ix) << 1));
                 }
 #pragma unroll
                 for (int u = 0; u < BORDER_ILP; u++) {
                     const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
-                    const uint8_t t00 = (uint8_t)(top[u] & 0xff), t01 = (uint8_t)((top[u] >> 8) & 0xff);
-                    const uint8_t t10 = (uint8_t)(bot[u] & 0xff), t11 = (uint8_t)((bot[u] >> 8) & 0xff);
+                    const uint8_t t00 = (uint8_t)(top[u] & 0xff), t10 = (uint8_t)((top[u] >> 8) & 0xff);
+                    const uint8_t t01 = (uint8_t)((top[u] >> 16) & 0xff), t11 = (uint8_t)(top[u] >> 24);
                     const float v = t00 * (1.f - a) * (1.f - b) + t01 * a * (1.f - b) + t10 * (1.f - a) * b + t11 * a * b;
                     if (act[u]) drow[jb + u * 8 + lj] = (uint8_t)cv_round_f(v);
                 }
@@ -866,7 +869,7 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
                 // The window crosses the image border here (a quarter of all sample slots on 409-row strips: not rare).  No branch
                 // per sample: every lane gathers four bytes at clamped coordinates -- the bilinear taps when (ix, iy) is interior,
                 // the nearest pixel clamp(cvRound(px), cvRound(py)) otherwise -- and selects at the end.
-                uint32_t p00[BORDER_ILP], p01[BORDER_ILP], p10[BORDER_ILP], p11[BORDER_ILP];
+                uint32_t q0[BORDER_ILP], q1[BORDER_ILP];          // pair elements (cy, cx) and (cy, cx1): two 16-bit gathers, not four bytes
                 bool inside[BORDER_ILP];
 #pragma unroll
                 for (int u = 0; u < BORDER_ILP; u++) {
@@ -874,16 +877,18 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
                     inside[u] = px[u] >= 0.0 && py[u] >= 0.0 && ix < ncols1 && iy < nrows1;
                     const int rx = min(max(cv_round_d(px[u]), 0), ncols1), ry = min(max(cv_round_d(py[u]), 0), nrows1);
                     const int cx = (inside[u] && act[u]) ? ix : (act[u] ? rx : 0), cy = (inside[u] && act[u]) ? iy : (act[u] ? ry : 0);
-                    const int cx1 = min(cx + 1, ncols1), cy1 = min(cy + 1, nrows1);
-                    const uint32_t o0 = (uint32_t)__umul24((uint32_t)cy, (uint32_t)G.stride), o1 = (uint32_t)__umul24((uint32_t)cy1, (uint32_t)G.stride);
-                    p00[u] = ubase[o0 + (uint32_t)cx]; p01[u] = ubase[o0 + (uint32_t)cx1];
-                    p10[u] = ubase[o1 + (uint32_t)cx]; p11[u] = ubase[o1 + (uint32_t)cx1];
+                    const int cx1 = min(cx + 1, ncols1);
+                    const uint32_t o0 = (uint32_t)__umul24((uint32_t)cy, pw);
+                    q0[u] = *(GAS const uint16_t *)(ubase + ((o0 + (uint32_t)cx) << 1));
+                    q1[u] = *(GAS const uint16_t *)(ubase + ((o0 + (uint32_t)cx1) << 1));
                 }
 #pragma unroll
                 for (int u = 0; u < BORDER_ILP; u++) {
                     const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
-                    const float v = (uint8_t)p00[u] * (1.f - a) * (1.f - b) + (uint8_t)p01[u] * a * (1.f - b) + (uint8_t)p10[u] * (1.f - a) * b + (uint8_t)p11[u] * a * b;
-                    if (act[u]) drow[jb + u * 8 + lj] = inside[u] ? (uint8_t)cv_round_f(v) : (uint8_t)p00[u];
+                    // the high bytes are row min(cy + 1, h - 1): the clamped lower taps
+                    const float v = (uint8_t)(q0[u] & 0xff) * (1.f - a) * (1.f - b) + (uint8_t)(q1[u] & 0xff) * a * (1.f - b) +
+                                    (uint8_t)(q0[u] >> 8) * (1.f - a) * b + (uint8_t)(q1[u] >> 8) * a * b;
+                    if (act[u]) drow[jb + u * 8 + lj] = inside[u] ? (uint8_t)cv_round_f(v) : (uint8_t)(q0[u] & 0xff);
                 }
             }
         }
@@ -939,7 +944,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
     const float s = kp.size * 1.2f / 9.0f;
     WinGeom G;
     G.win = min((int)((20 + 1) * s), VFSMS_MAX_WIN);
-    G.h = R.h; G.w = R.w; G.stride = R.stride; G.img = (g_cu8)R.img;
+    G.h = R.h; G.w = R.w; G.stride = R.stride; G.img = (g_cu8)R.img; G.pair = (g_cu8)R.pair;
     G.upright = upright; G.usx = 0; G.usy = 0; G.sin_dir = 0.f; G.cos_dir = 0.f;
     const int win = G.win;
     const int dsz = 21;
@@ -1275,7 +1280,7 @@ __device__ void describe_small(const RoiDev &R, const int k, int upright, SmallL
     const float s = kp.size * 1.2f / 9.0f;
     WinGeom G;
     G.win = min((int)((20 + 1) * s), DESC_SMALL_WIN);      // (class 3 means <= 64 already)
-    G.h = R.h; G.w = R.w; G.stride = R.stride; G.img = (g_cu8)R.img;
+    G.h = R.h; G.w = R.w; G.stride = R.stride; G.img = (g_cu8)R.img; G.pair = (g_cu8)R.pair;
     G.upright = upright; G.usx = 0; G.usy = 0; G.sin_dir = 0.f; G.cos_dir = 0.f;
     const int win = G.win;
     const int dsz = 21;
@@ -1338,7 +1343,7 @@ __device__ void describe_small(const RoiDev &R, const int k, int upright, SmallL
     wave_sync_lds();                                       // the next keypoint of this wave overwrites L
 }
 
-#define DESC_SMALL_WGS 5
+#define DESC_SMALL_WGS 6
 __global__ __launch_bounds__(256, DESC_SMALL_WGS) void k_describe_small(const RoiDev *rois, int nrois, int *counter, int upright)
 {
     __shared__ int prefix[VFSMS_MAX_ROIS + 1];            // class-3 keypoints of the ROIs before each ROI
@@ -1367,6 +1372,24 @@ __global__ __launch_bounds__(256, DESC_SMALL_WGS) void k_describe_small(const Ro
         const RoiDev &R = rois[lo];
         const int within = t - prefix[lo] + R.counters[12] + R.counters[13] + R.counters[14];   // the ROI's list is class-major
         describe_small(R, R.order[within], upright, L[wave]);
+    }
+}
+
+// Row-pair image for the descriptor sampling (see stage_rows): element (y, x) = pixel (y, x) | pixel (min(y + 1, h - 1), x) << 8.
+// One thread per four pixels; grid (ceil(w / 1024), h, rois).
+__global__ __launch_bounds__(256) void k_pair_rows(const RoiDev *rois)
+{
+    const RoiDev &R = rois[blockIdx.z];
+    const int y = blockIdx.y, x = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (y >= R.h || x >= R.w) return;
+    g_cu8 r0 = (g_cu8)R.img + (size_t)y * R.stride + x, r1 = (g_cu8)R.img + (size_t)min(y + 1, R.h - 1) * R.stride + x;
+    GAS uint16_t *dst = (GAS uint16_t *)R.pair + (size_t)y * R.w + x;
+    if (x + 4 <= R.w) {
+        const uint32_t a = *(GAS const u32u *)r0, b = *(GAS const u32u *)r1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) dst[k] = (uint16_t)(((a >> (8 * k)) & 0xff) | (((b >> (8 * k)) & 0xff) << 8));
+    } else {
+        for (int k = 0; x + k < R.w; k++) dst[k] = (uint16_t)(r0[k] | (r1[k] << 8));
     }
 }
 
@@ -1503,7 +1526,7 @@ static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 size_t surf_roi_bytes(int h, int w, int cap, int nlayers_total, int noctaves, int dim)
 {
-    size_t b = al(sizeof(int32_t) * (size_t)(h + 1) * (w + 1)) + al(integral_carry_bytes(h, w));
+    size_t b = al(sizeof(int32_t) * (size_t)(h + 1) * (w + 1)) + al(integral_carry_bytes(h, w)) + al(sizeof(uint16_t) * (size_t)h * w + 8);
     int lpo = nlayers_total / noctaves;
     for (int o = 0; o < noctaves; o++) {
         size_t n = (size_t)(h >> o) * (w >> o);
@@ -1523,6 +1546,7 @@ int surf_roi_carve(vfsms_ctx *ctx, RoiDev *r, const uint8_t *img, int stride, in
     r->sum = (int32_t *)ctx_arena_alloc(ctx, sizeof(int32_t) * (size_t)(h + 1) * (w + 1));
     r->ipitch = (w + 3) & ~3;
     r->icarry = (int32_t *)ctx_arena_alloc(ctx, integral_carry_bytes(h, w));
+    r->pair = (uint16_t *)ctx_arena_alloc(ctx, sizeof(uint16_t) * (size_t)h * w + 8);
     int step = 1;
     for (int o = 0; o < p->n_octaves; o++) {
         size_t n = (size_t)(h / step) * (w / step);
@@ -1631,6 +1655,9 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
         int *tickets = (int *)ctx_arena_alloc(ctx, sizeof(int) * 2 * DESC_HEADS * DESC_HEAD_STRIDE);
         if (!tickets) { vfsms_set_error("arena exhausted (descriptor tickets)"); return VFSMS_ERR_CAPACITY; }
         HIP_TRY(hipMemsetAsync(tickets, 0, sizeof(int) * 2 * DESC_HEADS * DESC_HEAD_STRIDE, ctx->stream));
+        int maxh = 0, maxw = 0;
+        for (int r = 0; r < nrois; r++) { maxh = std::max(maxh, h_rois[r].h); maxw = std::max(maxw, h_rois[r].w); }
+        hipLaunchKernelGGL(k_pair_rows, dim3((maxw + 1023) / 1024, maxh, nrois), dim3(256), 0, ctx->stream, d_rois);
         hipLaunchKernelGGL(k_desc_order, dim3(nrois), dim3(1024), 0, ctx->stream, d_rois);
         if (!p->upright) hipLaunchKernelGGL(k_desc_trig, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
         hipLaunchKernelGGL(k_describe, dim3(256 * DESC_WGS), dim3(256), 0, ctx->stream, d_rois, nrois, tickets,
