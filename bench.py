@@ -38,10 +38,10 @@ FP32_PEAK_TFLOPS = 157.3       # dense FP32 MFMA peak of gfx950 (v_mfma_f32_32x3
 # VALU issue peak in lane-operations: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.  (157.3 TFLOP/s = this x 2 flop per FMA x 2 for packed
 # FP32; SQ_INSTS_VALU == SQ_ACTIVE_INST_VALU quad-cycles in profiles/r02_pmc_describe.txt: one wave64 VALU instruction = 4 cycles.)
 VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
-# VALU instructions per bilinear sample of k_describe's staging loop, counted in its gfx950 assembly (interior path: 2 v_fma_f64,
-# 2 v_cvt_i32_f64, 3 address, 2 v_fract_f64, 2 v_cvt_f32_f64, 2 v_sub, 4 v_cvt_f32_ubyte, 4 v_pk_mul (+2 moves), 3 v_add, v_rndne,
-# v_cvt, 2 loop / index) -- the ALGORITHMIC work of one sample as this kernel formulates it
-DESC_VALU_PER_SAMPLE = 32
+# VALU instructions per bilinear sample of k_describe's staging loop, counted in its gfx950 assembly (interior path: index + v_cvt_f64,
+# 2 v_fma_f64, 2 v_cvt_i32_f64, 2 address, 2 v_fract_f64, 2 v_cvt_f32_f64, 2 v_sub, 4 v_cvt_f32_ubyte, 4 v_pk_mul (+2 moves), 3 v_add,
+# v_rndne, v_cvt, LDS address) -- the ALGORITHMIC work of one sample as this kernel formulates it
+DESC_VALU_PER_SAMPLE = 30
 MIN_WARM_S = float(os.environ.get("VFSMS_BENCH_MIN_WARM", "1.5"))     # 0 under rocprofv3 --pmc (serialised kernels make every step slow)
 
 
@@ -298,12 +298,12 @@ def main():
     # The decision to run one more warm step is taken jointly (a step contains the collective): MAX over ranks of "not warm yet".
     warm_extra = 0
     while warm_extra < 400:
-        need = 1 if time.perf_counter() - t_w < MIN_WARM_S else 0
+        more_warm = 1 if time.perf_counter() - t_w < MIN_WARM_S else 0
         if dist is not None:
-            tw = torch.tensor([need], dtype=torch.int64, device=coll_device)
+            tw = torch.tensor([more_warm], dtype=torch.int64, device=coll_device)
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-            need = int(tw.item())
-        if not need:
+            more_warm = int(tw.item())
+        if not more_warm:
             break
         step()
         warm_extra += 1
@@ -354,8 +354,10 @@ def main():
     roi_h, roi_w = isa.roi_rect((grid.th, grid.tw), 1, "first", 0.2)[2:]
     de_ms, de_n = prof.get("describe", (0.0, 0))
     if de_n and args.method == "surf":
-        # dominant kernel: k_describe (descriptor windows), bound by VALU issue (profiles/r02_pmc_describe.txt: SQ_INSTS_VALU x 4
-        # cycles = 60 % of the SIMD cycles of the launch; HBM traffic is a few per cent of what 8 TB/s would move in that time).
+        # dominant kernels: k_describe + k_describe_small (descriptor windows).  Until the row-pair image they were bound by the
+        # texture-address path (TA busy 73 % of the launch: two gathers per sample); with one gather per sample the VALU is the
+        # busiest unit (PMC: SQ_INSTS_VALU x 4 cycles = ~94 % of the SIMD cycles of k_describe, TA ~60 %); HBM traffic is a few per
+        # cent of what 8 TB/s would move in that time.
         # Algorithmic work per launch = bilinear samples (win x win per keypoint, win = int(21 * size * 1.2 / 9)) x the VALU
         # instructions one sample takes in the kernel's own inner loop; samples/keypoint is measured outside the timed region.
         k0 = need[0]
@@ -368,15 +370,19 @@ def main():
         laneops = kps * spk * DESC_VALU_PER_SAMPLE
         traffic, traffic_src = pmc_traffic("k_describe")
         valu_insts, _src = pmc_value("k_describe", "INSTS_VALU")
-        roofline = dict(kernel="k_describe", bound="valu", achieved=round(laneops / dur / 1e12, 3), peak=round(VALU_PEAK_TLANEOPS, 2),
+        busy, _src2 = pmc_value("k_describe", "BUSY_CYCLES")            # summed over the 32 shader engines: / 32 = cycles of the launch
+        valu_busy = round(valu_insts * 4.0 / (busy / 32.0 * 1024.0), 3) if valu_insts and busy else None
+        roofline = dict(kernel="k_describe+k_describe_small", bound="valu", achieved=round(laneops / dur / 1e12, 3), peak=round(VALU_PEAK_TLANEOPS, 2),
                         unit="Tlane-op/s", frac=round(laneops / dur / 1e12 / VALU_PEAK_TLANEOPS, 4), traffic=traffic, traffic_source=traffic_src,
                         compulsory_bytes_per_launch=round(kps / max(len(kf), 1) * (roi_h * roi_w) + kps * 441.0), avg_launch_ms=round(dur * 1e3, 4),
                         lane_ops_per_launch=laneops, valu_ops_per_sample=DESC_VALU_PER_SAMPLE, keypoints_per_launch=kps,
                         samples_per_keypoint=round(spk, 1), launches=de_n,
-                        note="dominant kernel by time (%.0f %% of the GPU time of a step); VALU-issue bound: achieved counts only the inner-loop "
-                             "instructions of the samples; all VALU instructions the kernel issues (PMC SQ_INSTS_VALU, profiles/) occupy "
-                             "~60 %% of the SIMD cycles" % (100.0 * de_ms / max(sum(v[0] for v in prof.values()), 1e-9)),
-                        valu_insts_per_launch_pmc=valu_insts)
+                        note="dominant stage by time (%.0f %% of the GPU time of a step; the timed scope also holds k_pair_rows, k_desc_order, "
+                             "k_desc_trig and k_desc_tail); achieved counts only the inner-loop instructions of the samples; all VALU "
+                             "instructions k_describe issues (PMC SQ_INSTS_VALU, profiles/) keep its SIMDs busy for valu_busy_frac_pmc of the "
+                             "launch (lane padding of 8 x 32-sample units, INTER_AREA reduction, row-origin chains, tickets)"
+                             % (100.0 * de_ms / max(sum(v[0] for v in prof.values()), 1e-9)),
+                        valu_insts_per_launch_pmc=valu_insts, valu_busy_frac_pmc=valu_busy)
     bf_ms, bf_n = prof.get("bf_mfma", (0.0, 0))
     if bf_n:
         dur = bf_ms / bf_n * 1e-3

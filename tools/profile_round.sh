@@ -22,6 +22,8 @@ PCMD="python bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-host-leg"
 timeout 500 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc_sq -o pmc --output-format csv -- $PCMD > $OUT/pmc_sq_bench.json 2> $OUT/pmc_sq.err
 timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc --output-format csv -- $PCMD > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
 timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc --output-format csv -- $PCMD > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
+timeout 500 rocprofv3 --kernel-trace --pmc TA_TA_BUSY TA_FLAT_READ_WAVEFRONTS_sum -d $OUT/pmc_ta -o pmc --output-format csv -- $PCMD > $OUT/pmc_ta_bench.json 2> $OUT/pmc_ta.err
+timeout 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $OUT/pmc_mfma -o pmc --output-format csv -- $PCMD > $OUT/pmc_mfma_bench.json 2> $OUT/pmc_mfma.err
 python - <<PY
 import csv, glob, collections
 def agg(pat):
@@ -48,7 +50,17 @@ for k in sorted(f):
         n=max(nf[k],1)
         fb=f[k].get('FETCH_SIZE',0)*1024; wb=w.get(k,{}).get('WRITE_SIZE',0)*1024; nn=max(nw.get(k,n),1)
         out.write('%-28s launches=%d fetch_raw=%.4g B/launch fetch_x2=%.4g B/launch write=%.4g B/launch total(x2 rule)=%.4g B/launch\\n' % (k[:28],n,fb/n,2*fb/n,wb/nn,2*fb/n+wb/nn))
+ta,nta=agg('$OUT/pmc_ta/**/*counter_collection.csv'); mf,nmf=agg('$OUT/pmc_mfma/**/*counter_collection.csv')
+out.write('\n# texture-address path and matrix pipe per launch (separate passes): TA_TA_BUSY summed over the 256 CUs (/256 = busy cycles of one\n# TA; the launch lasts SQ_BUSY_CYCLES/32 cycles); SQ_VALU_MFMA_BUSY_CYCLES summed over the 1024 SIMDs\n')
+for k in sorted(ta, key=lambda k:-ta[k].get('TA_TA_BUSY',0)):
+    if 'k_' in k:
+        n=max(nta[k],1); m=mf.get(k,{}); nm=max(nmf.get(k,n),1)
+        busy=m.get('SQ_BUSY_CYCLES',0)/nm/32.0
+        out.write('%-28s launches=%d TA_BUSY=%.4g TA_READ_WAVEFRONTS=%.4g ta_busy_frac=%.3f MFMA_BUSY_CYCLES=%.4g mfma_busy_frac=%.3f WAIT_INST_ANY=%.4g ACTIVE_INST_VALU=%.4g\n' % (
+            k[:28],n,ta[k].get('TA_TA_BUSY',0)/n,ta[k].get('TA_FLAT_READ_WAVEFRONTS_sum',ta[k].get('TA_FLAT_READ_WAVEFRONTS',0))/n,
+            (ta[k].get('TA_TA_BUSY',0)/n/256.0)/busy if busy else 0, m.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/nm,
+            (m.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/nm/1024.0)/busy if busy else 0, m.get('SQ_WAIT_INST_ANY',0)/nm, m.get('SQ_ACTIVE_INST_VALU',0)/nm))
 out.close()
 print(open('$OUT/pmc_summary.txt').read())
 PY
-rm -rf $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write
+rm -rf $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_ta $OUT/pmc_mfma
