@@ -182,6 +182,11 @@ int ctx_prepare_surf(vfsms_ctx *ctx, const vfsms_surf_params *p)
                 T.aptx[T.nOriSamples] = i; T.apty[T.nOriSamples] = j;
                 T.aptw[T.nOriSamples++] = G_ori[i + 6] * G_ori[j + 6];
             }
+    for (int ang = 0; ang <= 360; ang++)
+        for (int w = 0; w < 72; w++) {
+            const int d = abs(ang - 5 * w);
+            if (d < 30 || d > 330) T.oriMask[ang][w >> 5] |= 1u << (w & 31);
+        }
     gaussian_kernel_f32(20, 3.3f, G_desc);
     for (int i = 0; i < 20; i++)
         for (int j = 0; j < 20; j++) T.DW[i * 20 + j] = G_desc[i] * G_desc[j];

@@ -52,6 +52,9 @@ struct SurfTables {                   // orientation lattice + descriptor Gaussi
     int aptx[128], apty[128];
     float aptw[128];
     float DW[400];
+    // sliding-window membership of a rounded gradient angle a (0..360): bit w of the 72-bit row a is set when the ORI_WIN = 60 degree
+    // window starting at 5 w holds it, i.e. |a - 5 w| < 30 or > 330 (SURFInvoker's test, evaluated once per angle on the host)
+    uint32_t oriMask[361][3];
 };
 
 struct Cand {                         // NMS survivor before sorting

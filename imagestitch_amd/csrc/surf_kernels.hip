@@ -601,7 +601,7 @@ __device__ __forceinline__ float grad_haar(g_ci32 ptr, int sw, int gws, bool is_
 __device__ __forceinline__ void orientation_block(const RoiDev &R, const SurfTables *T, const int k0, const int n, int upright)
 {
     __shared__ __attribute__((aligned(16))) float X[ORI_KP][128], Y[ORI_KP][128];
-    __shared__ __attribute__((aligned(16))) int A[ORI_KP][128];
+    __shared__ __attribute__((aligned(16))) uint32_t M[ORI_KP][3][128];   // window membership of every sample (SurfTables::oriMask rows)
     __shared__ float mod_s[ORI_KP][72], sx_s[ORI_KP][72], sy_s[ORI_KP][72];
     __shared__ int nvalid[ORI_KP], state[ORI_KP];              // state: 0 compute, 1 done (deleted / upright / beyond n)
     const int tid = threadIdx.x;
@@ -629,12 +629,15 @@ __device__ __forceinline__ void orientation_block(const RoiDev &R, const SurfTab
                     float vy = grad_haar(ptr, sw, gws, false);
                     float xx = vx * T->aptw[t], yy = vy * T->aptw[t];
                     X[kq][t] = xx; Y[kq][t] = yy;
-                    A[kq][t] = cv_round_f(fast_atan2_deg(yy, xx));     // cv::phase(X, Y, angle, true) then cvRound
+                    const int ang = cv_round_f(fast_atan2_deg(yy, xx));     // cv::phase(X, Y, angle, true) then cvRound
+                    const uint32_t *mrow = T->oriMask[min(max(ang, 0), 360)];
+                    M[kq][0][t] = mrow[0]; M[kq][1][t] = mrow[1]; M[kq][2][t] = mrow[2];
                     valid = 1;
                 }
             }
         } else if (t == 0) state[kq] = 1;
-        if (!valid) A[kq][t] = -100000;
+        // a sample outside the image (or past nOriSamples) belongs to no window and carries a zero gradient
+        if (!valid) { X[kq][t] = 0.f; Y[kq][t] = 0.f; M[kq][0][t] = 0; M[kq][1][t] = 0; M[kq][2][t] = 0; }
         const unsigned long long m = __ballot(valid);
         if ((tid & 63) == 0 && m) atomicAdd(&nvalid[kq], __popcll(m));
     }
@@ -643,20 +646,23 @@ __device__ __forceinline__ void orientation_block(const RoiDev &R, const SurfTab
         const int q = tid / 72, w = tid - q * 72;
         if (state[q] == 0 && nvalid[q] > 0) {
             const int nori = T->nOriSamples;
-            const int i = w * 5;
+            // sum += m ? v : 0 written as sum += v * (float)m: v * 1 is v, v * 0 is a signed zero, and adding a zero of either sign
+            // leaves the running sum as it is (the sum is never -0: it starts at +0 and x + (-x) rounds to +0) -- so the membership
+            // bit costs one bit-field extract and one convert instead of the angle arithmetic and two selects per sample.
+            // Four samples per LDS read; the sums still visit the samples in index order.
+            const uint32_t *mw = M[q][w >> 5];
+            const int bit = w & 31;
             float sumx = 0, sumy = 0;
-            // four rounded angles per LDS read (entries past nOriSamples hold the sentinel); the sums still visit the samples in index order
             for (int j = 0; j < nori; j += 4) {
-                const int4 a4 = *reinterpret_cast<const int4 *>(&A[q][j]);
+                const uint4 m4 = *reinterpret_cast<const uint4 *>(&mw[j]);
                 const float4 x4 = *reinterpret_cast<const float4 *>(&X[q][j]), y4 = *reinterpret_cast<const float4 *>(&Y[q][j]);
-                const int aa[4] = {a4.x, a4.y, a4.z, a4.w};
+                const uint32_t mm[4] = {m4.x, m4.y, m4.z, m4.w};
                 const float xx[4] = {x4.x, x4.y, x4.z, x4.w}, yy[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const int d = abs(aa[u] - i);
-                    const bool m = aa[u] != -100000 && (d < 30 || d > 330);
-                    sumx = m ? sumx + xx[u] : sumx;
-                    sumy = m ? sumy + yy[u] : sumy;
+                    const float mf = (float)((mm[u] >> bit) & 1u);
+                    sumx += xx[u] * mf;
+                    sumy += yy[u] * mf;
                 }
             }
             mod_s[q][w] = sumx * sumx + sumy * sumy;
@@ -1247,7 +1253,7 @@ __device__ __forceinline__ bool ticket_next(const RoiDev *rois, int *counter, in
     return true;
 }
 
-__global__ __launch_bounds__(1024) void k_orientation(const RoiDev *rois, const SurfTables *T, int upright)
+__global__ __launch_bounds__(1024, 8) void k_orientation(const RoiDev *rois, const SurfTables *T, int upright)
 {
     const RoiDev &R = rois[blockIdx.y];
     const int n = min(R.counters[0], R.cap);
