@@ -405,26 +405,28 @@ __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat 
         // evaluated cells have all 8 neighbours inside the layer; the clamps only keep the loads of the other lanes in bounds
         const int jl = min(j - 1, lcols - 1), jc = min(j, lcols - 1), jr = min(j + 1, lcols - 1);
         const bool jev = j < lcols - margin;
-        // all NMS_RW + 2 rows of the strip are requested before the first compare: 54 loads in flight per lane, one round trip
-        float v[NMS_RW + 2][3];
-#pragma unroll
-        for (int r = 0; r < NMS_RW + 2; r++) {
-            g_cf32 row = d2 + (size_t)min(ia - 1 + r, lrows - 1) * st;
-            v[r][0] = row[jl]; v[r][1] = row[jc]; v[r][2] = row[jr];
+        float up[3], mid[3], dn[3];
+        {
+            g_cf32 r0 = d2 + (size_t)min(ia - 1, lrows - 1) * st, r1 = d2 + (size_t)min(ia, lrows - 1) * st;
+            up[0] = r0[jl]; up[1] = r0[jc]; up[2] = r0[jr];
+            mid[0] = r1[jl]; mid[1] = r1[jc]; mid[2] = r1[jr];
         }
         const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
         for (int r = 0; r < NMS_RW; r++) {
             const int i = ia + r;
-            const float c0 = v[r + 1][1];
-            const bool c2 = jev && i < lrows - margin && c0 > hessianThreshold &&
-                            c0 > v[r][0] && c0 > v[r][1] && c0 > v[r][2] && c0 > v[r + 1][0] && c0 > v[r + 1][2] &&
-                            c0 > v[r + 2][0] && c0 > v[r + 2][1] && c0 > v[r + 2][2];
+            g_cf32 r2 = d2 + (size_t)min(i + 1, lrows - 1) * st;
+            dn[0] = r2[jl]; dn[1] = r2[jc]; dn[2] = r2[jr];
+            const float v = mid[1];
+            const bool c2 = jev && i < lrows - margin && v > hessianThreshold &&
+                            v > up[0] && v > up[1] && v > up[2] && v > mid[0] && v > mid[2] && v > dn[0] && v > dn[1] && v > dn[2];
             const unsigned long long m = __ballot(c2);
             if (m) {
                 if (c2) queue[wave][nq + __popcll(m & below)] = (unsigned short)((r << 8) | lane);
                 nq += __popcll(m);
             }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { up[k] = mid[k]; mid[k] = dn[k]; }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
