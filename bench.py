@@ -287,11 +287,11 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
-    t_w = time.perf_counter()
     for _ in range(args.warmup):
         res, _d = step()
     if args.warmup == 0:
         res, _d = step()
+    t_w = time.perf_counter()                               # the clock of the steady-state warm-up starts AFTER the first (slow) steps
     # The MI355X needs about a second of sustained load to reach its steady clocks (and the first touches of the arena to
     # settle): measured here, the step right after a short warmup runs 5-100 % slower than the steady state.  More untimed
     # steps are run until the warmup has lasted MIN_WARM_S; they are reported, and the K timed steps below are exactly K.
