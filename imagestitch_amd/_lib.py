@@ -120,6 +120,8 @@ _SIGNATURES = {
     "vfsms_canvas_fuse_tile": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vfsms_canvas_download": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "vfsms_canvas_download_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "vfsms_tile_upload_ch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
 }
 
 _lib = None
@@ -233,6 +235,18 @@ class Engine:
         h = C.c_int64()
         self._check(self.lib.vfsms_tile_upload_async(self.ctx, _ptr(img), img.shape[0], img.shape[1], img.strides[0], C.byref(h)))
         self.__dict__.setdefault("_inflight", []).append(img)
+        return h.value
+
+    def tile_upload_color(self, img, asynchronous=False):
+        """Interleaved colour tile (h, w, ch) u8 for the mosaic canvas (vfsms_tile_upload_ch); asynchronous like tile_upload_async."""
+        img = np.ascontiguousarray(img, np.uint8)
+        if img.ndim != 3:
+            raise ValueError("tile_upload_color takes an (h, w, ch) array")
+        h = C.c_int64()
+        self._check(self.lib.vfsms_tile_upload_ch(self.ctx, _ptr(img), img.shape[0], img.shape[1], img.shape[2], img.strides[0],
+                                                  1 if asynchronous else 0, C.byref(h)))
+        if asynchronous:
+            self.__dict__.setdefault("_inflight", []).append(img)
         return h.value
 
     def pinned_empty(self, shape, dtype=np.uint8):
@@ -538,6 +552,21 @@ class Engine:
         out = np.empty((rows, cols, ch) if ch > 1 else (rows, cols), np.uint8)
         self._check(self.lib.vfsms_canvas_download(self.ctx, C.c_int64(handle), _ptr(out)))
         return out
+
+    def canvas_download_rows(self, handle, row0, nrows, cols, ch, out=None):
+        """Rows [row0, row0 + nrows) of the mosaic (vfsms_canvas_download_rows); `out` may be a preallocated band buffer."""
+        shape = (nrows, cols, ch) if ch > 1 else (nrows, cols)
+        if out is None:
+            out = np.empty(shape, np.uint8)
+        if out.shape != shape or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError("canvas_download_rows: `out` must be a C-contiguous u8 array of shape %r" % (shape,))
+        self._check(self.lib.vfsms_canvas_download_rows(self.ctx, C.c_int64(handle), int(row0), int(nrows), _ptr(out)))
+        return out
+
+    def canvas_download_bands(self, handle, rows, cols, ch, band_rows=4096):
+        """Generator of (row0, band) over the whole mosaic, `band_rows` rows at a time (streamed write-out of large mosaics)."""
+        for r0 in range(0, rows, band_rows):
+            yield r0, self.canvas_download_rows(handle, r0, min(band_rows, rows - r0), cols, ch)
 
 
 _default_engine = None

@@ -287,10 +287,12 @@ static int tile_buffer(vfsms_ctx *ctx, size_t bytes, uint8_t **p)
     HIP_TRY(hipMalloc((void **)p, bytes));
     return VFSMS_OK;
 }
-static int tile_upload_impl(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int64_t *handle, bool async)
+// ch > 1: an interleaved colour tile for the mosaic canvas (rows of w * ch bytes; `stride` in bytes); registration takes ch == 1 only
+static int tile_upload_impl(vfsms_ctx *ctx, const uint8_t *img, int h, int w_px, int stride, int64_t *handle, bool async, int ch = 1)
 {
-    if (!img || !handle || h <= 0 || w <= 0 || stride < w) { vfsms_set_error("tile_upload: bad arguments"); return VFSMS_ERR_BAD_ARG; }
-    TileRec t; t.h = h; t.w = w; t.stride = w; t.owned = true; t.ready = nullptr; t.pending = false;
+    const int w = w_px * ch;                                 // bytes per row
+    if (!img || !handle || h <= 0 || w_px <= 0 || ch < 1 || ch > 4 || stride < w) { vfsms_set_error("tile_upload: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    TileRec t; t.h = h; t.w = w_px; t.stride = w; t.owned = true; t.ready = nullptr; t.pending = false; t.ch = ch;
     TRY(tile_buffer(ctx, (size_t)h * w, &t.ptr));
     if (async) {
         // the copy runs on the context's copy stream; the compute stream waits for it when a batch first names the tile
@@ -322,6 +324,11 @@ extern "C" int vfsms_tile_upload_async(vfsms_ctx *ctx, const uint8_t *img, int h
 {
     CTX_ENTER(ctx);
     return tile_upload_impl(ctx, img, h, w, stride, handle, true);
+}
+extern "C" int vfsms_tile_upload_ch(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int ch, int stride_bytes, int async, int64_t *handle)
+{
+    CTX_ENTER(ctx);
+    return tile_upload_impl(ctx, img, h, w, stride_bytes, handle, async != 0, ch);
 }
 extern "C" int vfsms_host_alloc(vfsms_ctx *ctx, size_t bytes, void **ptr)
 {
@@ -676,6 +683,7 @@ static int resolve_job(vfsms_ctx *ctx, const vfsms_roi_pair &j, const uint8_t **
     auto ia = ctx->tiles.find(j.tile_a), ib = ctx->tiles.find(j.tile_b);
     if (ia == ctx->tiles.end() || ib == ctx->tiles.end()) { vfsms_set_error("attempt: unknown tile handle"); return VFSMS_ERR_BAD_ARG; }
     TileRec &A = ia->second, &B = ib->second;
+    if (A.ch != 1 || B.ch != 1) { vfsms_set_error("attempt: registration takes single-channel tiles"); return VFSMS_ERR_BAD_ARG; }
     TRY(tile_ready(ctx, A)); TRY(tile_ready(ctx, B));
     if (j.h <= 0 || j.w <= 0 || j.ay0 < 0 || j.ax0 < 0 || j.by0 < 0 || j.bx0 < 0 || j.ay0 + j.h > A.h || j.ax0 + j.w > A.w ||
         j.by0 + j.h > B.h || j.bx0 + j.w > B.w) { vfsms_set_error("attempt: ROI outside its tile"); return VFSMS_ERR_BAD_ARG; }
@@ -845,6 +853,7 @@ extern "C" int vfsms_features_surf(vfsms_ctx *ctx, int64_t tile, int y0, int x0,
     auto it = ctx->tiles.find(tile);
     if (it == ctx->tiles.end() || !params || !feat || !n_out) { vfsms_set_error("features_surf: bad arguments / unknown tile"); return VFSMS_ERR_BAD_ARG; }
     TileRec &T = it->second;
+    if (T.ch != 1) { vfsms_set_error("features_surf: registration takes single-channel tiles"); return VFSMS_ERR_BAD_ARG; }
     TRY(tile_ready(ctx, T));
     if (h <= 0 || w <= 0 || y0 < 0 || x0 < 0 || y0 + h > T.h || x0 + w > T.w) { vfsms_set_error("features_surf: ROI outside the tile"); return VFSMS_ERR_BAD_ARG; }
     if (enhance_mode < 0 || enhance_mode > 2) { vfsms_set_error("features_surf: enhance_mode must be 0, 1 or 2"); return VFSMS_ERR_BAD_ARG; }
@@ -1077,8 +1086,8 @@ static int canvas_resident_args(vfsms_ctx *ctx, int64_t canvas, int64_t tile, in
     if (it == ctx->canvases.end() || jt == ctx->tiles.end()) { vfsms_set_error("canvas: unknown canvas or tile handle"); return VFSMS_ERR_BAD_ARG; }
     *cv = &it->second; *tr = &jt->second;
     TRY(tile_ready(ctx, jt->second));
-    if ((*cv)->ch != 1 || (*tr)->stride != (*tr)->w) {
-        vfsms_set_error("canvas: resident tiles must be single-channel and densely packed (stride == w)"); return VFSMS_ERR_BAD_ARG;
+    if ((*cv)->ch != (*tr)->ch || (*tr)->stride != (*tr)->w * (*tr)->ch) {
+        vfsms_set_error("canvas: a resident tile must have the canvas's channel count and be densely packed (stride == w * ch)"); return VFSMS_ERR_BAD_ARG;
     }
     if (y0 < 0 || x0 < 0 || y0 + (*tr)->h > (*cv)->rows || x0 + (*tr)->w > (*cv)->cols) {
         vfsms_set_error("canvas: tile rectangle outside the canvas"); return VFSMS_ERR_BAD_ARG;
@@ -1119,6 +1128,27 @@ extern "C" int vfsms_canvas_download(vfsms_ctx *ctx, int64_t canvas, uint8_t *ou
     int err = 0;
     HIP_TRY(hipMemcpyAsync(&err, cv.d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(out, cv.pix, (size_t)cv.rows * cv.cols * cv.ch, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (err) {
+        vfsms_set_error("fuse: degenerate corner geometry in one of the fused tiles (the reference's getWeightsMatrix raises there)");
+        return VFSMS_ERR_BAD_ARG;
+    }
+    return VFSMS_OK;
+}
+
+// rows [row0, row0 + nrows) of the canvas: a multi-GB mosaic leaves the device band by band (streamed write-out, Stitcher.py:174-179)
+extern "C" int vfsms_canvas_download_rows(vfsms_ctx *ctx, int64_t canvas, int row0, int nrows, uint8_t *out)
+{
+    CTX_ENTER(ctx);
+    auto it = ctx->canvases.find(canvas);
+    if (it == ctx->canvases.end() || !out || row0 < 0 || nrows <= 0 || row0 + nrows > it->second.rows) {
+        vfsms_set_error("canvas_download_rows: bad arguments"); return VFSMS_ERR_BAD_ARG;
+    }
+    const CanvasRec &cv = it->second;
+    const size_t pitch = (size_t)cv.cols * cv.ch;
+    int err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, cv.d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, cv.pix + (size_t)row0 * pitch, (size_t)nrows * pitch, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (err) {
         vfsms_set_error("fuse: degenerate corner geometry in one of the fused tiles (the reference's getWeightsMatrix raises there)");

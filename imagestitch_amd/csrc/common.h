@@ -134,7 +134,7 @@ struct MatchDev {
 };
 
 // ---- context ------------------------------------------------------------------------------------------
-struct TileRec { uint8_t *ptr; int h, w, stride; bool owned; hipEvent_t ready; bool pending; };   // pending: an async upload the compute stream has not yet waited for
+struct TileRec { uint8_t *ptr; int h, w, stride; bool owned; hipEvent_t ready; bool pending; int ch = 1; };   // pending: an async upload the compute stream has not yet waited for
 struct CanvasRec { uint8_t *pix; uint8_t *mask; int rows, cols, ch; int *d_err; };   // d_err: sticky "degenerate fuse geometry" flag for calls made without an info readback
 struct FftPlan { int M, N, nb; void *fwd, *inv, *fwd_info, *inv_info; size_t fwd_work, inv_work; };   // rocfft_plan / rocfft_execution_info
 struct PhaseJobHost { const uint8_t *a, *b; int sa, sb; };

@@ -72,6 +72,8 @@ def _imread(path, color):
 
 
 def _imwrite(path, img):
+    if img is None:                                          # streamed to Stitcher.mosaicSink instead
+        return
     from PIL import Image
     img = np.asarray(img)
     if img.ndim == 3:
@@ -81,6 +83,25 @@ def _imwrite(path, img):
         os.makedirs(d)
     kw = {"quality": 95} if path.lower().endswith((".jpg", ".jpeg")) else {}     # cv2.imwrite's JPEG default (Pillow's is 75)
     Image.fromarray(np.ascontiguousarray(img)).save(path, **kw)
+
+
+class NpyBandWriter:
+    """A `Stitcher.mosaicSink`: writes the bands of a mosaic into one .npy file through a memory map, so a mosaic larger than host
+    memory can be assembled (set `stitcher.mosaicSink = NpyBandWriter(path)`; getStitchByOffset then returns None)."""
+
+    def __init__(self, path):
+        self.path, self._mm = path, None
+
+    def __call__(self, row0, band, full_shape):
+        if self._mm is None:
+            d = os.path.dirname(self.path)
+            if d and not os.path.exists(d):
+                os.makedirs(d)
+            self._mm = np.lib.format.open_memmap(self.path, mode="w+", dtype=np.uint8, shape=tuple(full_shape))
+        self._mm[row0:row0 + band.shape[0]] = band
+        if row0 + band.shape[0] >= full_shape[0]:
+            self._mm.flush()
+            self._mm = None
 
 
 def _list_images(folder, extension):
@@ -600,7 +621,9 @@ class Stitcher(Utility.Method):
         eng = self.engine
         # tiles the batched registration left in HBM (gray mosaics only): fused from where they are, no second decode / upload
         resident = self.__dict__.pop("_resident", None) or {}
-        use_res = (not color) and self.fuseMethod in ("notFuse", "fadeInAndFadeOut") and all(fileList[i] in resident for i in range(n))
+        device_fuse = self.fuseMethod in ("notFuse", "fadeInAndFadeOut")
+        handles = None
+        use_res = (not color) and device_fuse and all(fileList[i] in resident for i in range(n))
         try:
             if use_res:
                 shapes = [resident[fileList[i]][1] for i in range(n)]
@@ -609,6 +632,20 @@ class Stitcher(Utility.Method):
                 for i in range(1, n):
                     imageList.append(_imread(fileList[i], Stitcher.isColorMode))
                 shapes = [im.shape for im in imageList]
+                if device_fuse and hasattr(eng, "tile_upload_color") and len({im.ndim for im in imageList}) == 1:
+                    # colour (or not yet resident) tiles: all uploads are queued on the copy stream up front and the per-tile canvas
+                    # calls below only enqueue work behind them -- no host synchronisation per tile (Stitcher.py:174-179, 434-483)
+                    for h, _shape in resident.values():
+                        eng.tile_free(h)
+                    resident = {}
+                    for i in range(n):
+                        im = np.ascontiguousarray(imageList[i])
+                        hnd = eng.tile_upload_color(im, asynchronous=True) if im.ndim == 3 else eng.tile_upload_async(im)
+                        resident[(i, fileList[i])] = (hnd, im.shape)
+                    handles = [resident[(i, fileList[i])][0] for i in range(n)]
+                    use_res = True
+            if use_res and handles is None:
+                handles = [resident[fileList[i]][0] for i in range(n)]
             offsetList, rangeX, rangeY, resultRow, resultCol = self._layout(shapes, originOffsetList)
             self.printAndWrite("  The rectified offsetList is " + str(offsetList))
             simple = {"average": 0, "maximum": 1, "minimum": 2}.get(self.fuseMethod)
@@ -625,7 +662,7 @@ class Stitcher(Utility.Method):
                     oy, ox = offsetList[i][0], offsetList[i][1]
                     if i == 0 or self.fuseMethod == "notFuse":
                         if use_res:
-                            eng.canvas_paste_tile(canvas, resident[fileList[i]][0], oy, ox)
+                            eng.canvas_paste_tile(canvas, handles[i], oy, ox)
                         else:
                             eng.canvas_paste(canvas, imageList[i], oy, ox)
                         continue
@@ -634,9 +671,15 @@ class Stitcher(Utility.Method):
                     if simple is not None:
                         eng.canvas_blend_tile(canvas, imageList[i], oy, ox, roi, simple)
                     elif use_res:
-                        eng.canvas_fuse_tile_resident(canvas, resident[fileList[i]][0], oy, ox, roi, originOffsetList[i][0], originOffsetList[i][1])
+                        eng.canvas_fuse_tile_resident(canvas, handles[i], oy, ox, roi, originOffsetList[i][0], originOffsetList[i][1])
                     else:
                         eng.canvas_fuse_tile(canvas, imageList[i], oy, ox, roi, originOffsetList[i][0], originOffsetList[i][1])
+                sink = getattr(self, "mosaicSink", None)
+                if sink is not None and hasattr(eng, "canvas_download_bands"):
+                    # streamed write-out: the mosaic leaves the device band by band and is never whole in host memory
+                    for r0, band in eng.canvas_download_bands(canvas, resultRow, resultCol, ch, int(getattr(self, "mosaicBandRows", 4096))):
+                        sink(r0, band, (resultRow, resultCol, ch) if ch > 1 else (resultRow, resultCol))
+                    return None
                 return eng.canvas_download(canvas, resultRow, resultCol, ch)
             finally:
                 eng.canvas_free(canvas)

@@ -104,6 +104,10 @@ int vfsms_tile_upload(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stri
  * GPU while earlier pairs are being registered).  img must stay valid and unchanged until vfsms_ctx_sync or the first synchronous
  * call that used the tile has returned; copies from pinned memory (vfsms_host_alloc) run at PCIe rate and truly overlap.          */
 int vfsms_tile_upload_async(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int64_t *handle);
+/* an interleaved colour tile (ch = 3: the isColorMode = True default of Main.py, Stitcher.py:174-179) for the mosaic canvas only:
+ * rows of w * ch bytes, stride_bytes between rows, synchronous or (async != 0) on the copy stream like vfsms_tile_upload_async.
+ * Registration entry points reject tiles with ch != 1.                                                                          */
+int vfsms_tile_upload_ch(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int ch, int stride_bytes, int async, int64_t *handle);
 /* pinned host staging memory for tiles (decoders write into it; uploads from it are asynchronous DMA)                          */
 int vfsms_host_alloc(vfsms_ctx *ctx, size_t bytes, void **ptr);
 int vfsms_host_free(vfsms_ctx *ctx, void *ptr);
@@ -255,8 +259,9 @@ int vfsms_canvas_fuse_tile(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, 
  * behind the zero / empty filling of Stitcher.fuseImage (Stitcher.py:498-504).                                              */
 int vfsms_canvas_blend_tile(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w,
                             int y0, int x0, int ry0, int rx0, int ry1, int rx1, int mode);
-/* the same two operations for a single-channel tile that is already resident in HBM (a handle from vfsms_tile_upload /
- * vfsms_tile_wrap with stride == w, e.g. the tiles the registration phase uploaded): no host copy, canvas ch must be 1.
+/* the same two operations for a tile that is already resident in HBM (a handle from vfsms_tile_upload / vfsms_tile_wrap with
+ * stride == w, e.g. the tiles the registration phase uploaded, or a colour tile from vfsms_tile_upload_ch): no host copy; the
+ * tile's channel count must be the canvas's.
  * With info == NULL the fuse only enqueues work (no host synchronisation per tile); a degenerate corner geometry -- where the
  * reference's getWeightsMatrix raises -- is then latched in the canvas and reported by vfsms_canvas_download.               */
 int vfsms_canvas_paste_tile(vfsms_ctx *ctx, int64_t canvas, int64_t tile, int y0, int x0);
@@ -265,6 +270,9 @@ int vfsms_canvas_fuse_tile_resident(vfsms_ctx *ctx, int64_t canvas, int64_t tile
                                     int dx, int dy, int32_t *info);
 /* final image: empty -> 0 (Stitcher.py:485-486).  out: u8 [rows][cols][ch]                           */
 int vfsms_canvas_download(vfsms_ctx *ctx, int64_t canvas, uint8_t *out);
+/* rows [row0, row0 + nrows) of the same image: a multi-GB mosaic leaves the device band by band and can be handed to an
+ * incremental writer (the reference holds the whole int64 canvas and the u8 copy in host memory, Stitcher.py:434-436, 485-486) */
+int vfsms_canvas_download_rows(vfsms_ctx *ctx, int64_t canvas, int row0, int nrows, uint8_t *out);
 
 #ifdef __cplusplus
 }

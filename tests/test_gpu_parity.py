@@ -165,7 +165,24 @@ def test_get_stitch_by_offset_golden_bit_exact(engine, golden_dir, tmp_path):
         s.fuseMethod = FUSE_NAMES[fm]
         res = s.getStitchByOffset(files, [list(map(int, o)) for o in g["s%d_offsets" % n]])
         assert np.array_equal(res, g["s%d_out" % n]), (n, FUSE_NAMES[fm], color)
+        if s.fuseMethod in ("notFuse", "fadeInAndFadeOut"):
+            # streamed write-out (vfsms_canvas_download_rows): the bands of the same mosaic, 7 rows at a time, through NpyBandWriter
+            path = os.path.join(str(tmp_path), "mosaic%d.npy" % n)
+            s.mosaicSink = isa.NpyBandWriter(path); s.mosaicBandRows = 7
+            assert s.getStitchByOffset(files, [list(map(int, o)) for o in g["s%d_offsets" % n]]) is None
+            assert np.array_equal(np.load(path), g["s%d_out" % n]), (n, "streamed")
     isa.Stitcher.isColorMode = True
+
+
+def test_colour_tiles_are_rejected_by_registration(engine):
+    """vfsms_tile_upload_ch handles are for the mosaic canvas; the registration entry points take single-channel tiles only."""
+    rng = np.random.default_rng(5)
+    c = rng.integers(0, 255, (64, 80, 3), dtype=np.uint8)
+    hc = engine.tile_upload_color(c)
+    hg = engine.tile_upload(np.ascontiguousarray(c[:, :, 0]))
+    with pytest.raises(isa.VfsmsError):
+        engine.attempt_surf_batch([(hc, hg, 0, 0, 0, 0, 32, 80)])
+    engine.tile_free(hc); engine.tile_free(hg)
 
 
 def test_fused_attempt_equals_operator_chain_and_oracle(engine, oracle, strips):
