@@ -600,7 +600,7 @@ __device__ __forceinline__ float grad_haar(g_ci32 ptr, int sw, int gws, bool is_
 #define ORI_KP 8
 __device__ __forceinline__ void orientation_block(const RoiDev &R, const SurfTables *T, const int k0, const int n, int upright)
 {
-    __shared__ __attribute__((aligned(16))) float X[ORI_KP][128], Y[ORI_KP][128];
+    __shared__ __attribute__((aligned(16))) float2 XY[ORI_KP][128];      // weighted gradient (x, y) of every sample, interleaved: phase 2 reads pairs
     __shared__ __attribute__((aligned(16))) uint32_t M[ORI_KP][3][128];   // window membership of every sample (SurfTables::oriMask rows)
     __shared__ float mod_s[ORI_KP][72], sx_s[ORI_KP][72], sy_s[ORI_KP][72];
     __shared__ int nvalid[ORI_KP], state[ORI_KP];              // state: 0 compute, 1 done (deleted / upright / beyond n)
@@ -628,7 +628,7 @@ __device__ __forceinline__ void orientation_block(const RoiDev &R, const SurfTab
                     float vx = grad_haar(ptr, sw, gws, true);
                     float vy = grad_haar(ptr, sw, gws, false);
                     float xx = vx * T->aptw[t], yy = vy * T->aptw[t];
-                    X[kq][t] = xx; Y[kq][t] = yy;
+                    XY[kq][t] = make_float2(xx, yy);
                     const int ang = cv_round_f(fast_atan2_deg(yy, xx));     // cv::phase(X, Y, angle, true) then cvRound
                     const uint32_t *mrow = T->oriMask[min(max(ang, 0), 360)];
                     M[kq][0][t] = mrow[0]; M[kq][1][t] = mrow[1]; M[kq][2][t] = mrow[2];
@@ -637,7 +637,7 @@ __device__ __forceinline__ void orientation_block(const RoiDev &R, const SurfTab
             }
         } else if (t == 0) state[kq] = 1;
         // a sample outside the image (or past nOriSamples) belongs to no window and carries a zero gradient
-        if (!valid) { X[kq][t] = 0.f; Y[kq][t] = 0.f; M[kq][0][t] = 0; M[kq][1][t] = 0; M[kq][2][t] = 0; }
+        if (!valid) { XY[kq][t] = make_float2(0.f, 0.f); M[kq][0][t] = 0; M[kq][1][t] = 0; M[kq][2][t] = 0; }
         const unsigned long long m = __ballot(valid);
         if ((tid & 63) == 0 && m) atomicAdd(&nvalid[kq], __popcll(m));
     }
@@ -655,9 +655,9 @@ __device__ __forceinline__ void orientation_block(const RoiDev &R, const SurfTab
             float sumx = 0, sumy = 0;
             for (int j = 0; j < nori; j += 4) {
                 const uint4 m4 = *reinterpret_cast<const uint4 *>(&mw[j]);
-                const float4 x4 = *reinterpret_cast<const float4 *>(&X[q][j]), y4 = *reinterpret_cast<const float4 *>(&Y[q][j]);
+                const float4 p01 = *reinterpret_cast<const float4 *>(&XY[q][j]), p23 = *reinterpret_cast<const float4 *>(&XY[q][j + 2]);
                 const uint32_t mm[4] = {m4.x, m4.y, m4.z, m4.w};
-                const float xx[4] = {x4.x, x4.y, x4.z, x4.w}, yy[4] = {y4.x, y4.y, y4.z, y4.w};
+                const float xx[4] = {p01.x, p01.z, p23.x, p23.z}, yy[4] = {p01.y, p01.w, p23.y, p23.w};
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const float mf = (float)((mm[u] >> bit) & 1u);
