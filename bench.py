@@ -64,6 +64,10 @@ def pmc_traffic(kernel):
     return pmc_value(kernel, "total(x2 rule)")
 
 
+def sum_or_none(vals):
+    return sum(vals) if all(v is not None for v in vals) else None
+
+
 def hbm_roofline(kernel, bytes_per_launch, ms_per_launch, launches, note=None, **extra):
     dur = ms_per_launch * 1e-3
     gbs = bytes_per_launch / dur / 1e9 if dur > 0 else 0.0
@@ -188,7 +192,7 @@ def cpu_baseline_surf(args, grid, tiles, isa):
             O.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pr, 3)
         return time.perf_counter() - t1
     dt_all = run(range(S), cores)
-    S1 = max(1, min(S, 2))
+    S1 = max(1, min(S, 6))
     dt_one = run(range(S1), 1)
     return dict(value=round(S / dt_all, 4), unit="image-pairs/s", cores=cores, kind="port",
                 sample="first %d pairs of the same grid, one ROI attempt each at the true direction (oracle SURF+BF-L2+mode built -O3 "
@@ -211,7 +215,7 @@ def main():
                          " secondary metric of SURVEY 8d (mosaic assembly with fadeInAndFadeOut blending, N = 1 only)")
     ap.add_argument("--overlap", type=float, default=0.10, help="nominal tile overlap of the synthetic grid (SURVEY 8d: 10 %%)")
     ap.add_argument("--offset-evaluate", type=int, default=3, help="Method.offsetEvaluate (Main.py:12: 3)")
-    ap.add_argument("--cpu-sample", type=int, default=4, help="pairs timed on the host cores for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=12, help="pairs timed on the host cores for cpu_baseline (0 = skip)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-resident-tiles measurement")
     args = ap.parse_args()
 
@@ -374,7 +378,7 @@ def main():
         valu_busy = round(valu_insts * 4.0 / (busy / 32.0 * 1024.0), 3) if valu_insts and busy else None
         roofline = dict(kernel="k_describe+k_describe_small", bound="valu", achieved=round(laneops / dur / 1e12, 3), peak=round(VALU_PEAK_TLANEOPS, 2),
                         unit="Tlane-op/s", frac=round(laneops / dur / 1e12 / VALU_PEAK_TLANEOPS, 4), traffic=traffic, traffic_source=traffic_src,
-                        compulsory_bytes_per_launch=round(kps / max(len(kf), 1) * (roi_h * roi_w) + kps * 441.0), avg_launch_ms=round(dur * 1e3, 4),
+                        compulsory_bytes_per_launch=round(kps / max(len(kf), 1) * (2.0 * roi_h * roi_w) + kps * 441.0), avg_launch_ms=round(dur * 1e3, 4),
                         lane_ops_per_launch=laneops, valu_ops_per_sample=DESC_VALU_PER_SAMPLE, keypoints_per_launch=kps,
                         samples_per_keypoint=round(spk, 1), launches=de_n,
                         note="dominant stage by time (%.0f %% of the GPU time of a step; the timed scope also holds k_pair_rows, k_desc_order, "
@@ -392,7 +396,9 @@ def main():
         peak = FP32_PEAK_TFLOPS if f32_filter else BF16_PEAK_TFLOPS
         kname = "k_bf_mfma_d64" if f32_filter else "k_bf_split16+k_bf_mfma16_d64"
         extra["bf_l2_mfma"] = dict(kernel=kname, bound="mfma", achieved=round(flops / dur / 1e12, 3), peak=peak,
-                                   unit="TFLOP/s", frac=round(flops / dur / 1e12 / peak, 4), traffic=pmc_traffic(kname.split("+")[-1])[0],
+                                   unit="TFLOP/s", frac=round(flops / dur / 1e12 / peak, 4),
+                                   traffic=(pmc_traffic("k_bf_mfma_d64")[0] if f32_filter else
+                                            sum_or_none([pmc_traffic("void k_bf_mfma16_d64<%d>" % q)[0] for q in (0, 1)])),
                                    avg_launch_ms=round(dur * 1e3, 4), flops_per_launch=flops, launches=bf_n,
                                    issued_mfma_flops_per_launch=flops if f32_filter else flops * 3.25,
                                    note=("v_mfma_f32_32x32x2_f32 candidate filter (peak = dense f32 MFMA)" if f32_filter else
