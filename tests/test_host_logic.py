@@ -323,3 +323,17 @@ def test_tile_cache_is_lru_and_never_evicts_the_current_job():
     assert st.calculateOffsetForFeatureSearchIncre([others[0], anchor])[0] is True      # evicted long ago: uploaded again
     st.releaseTiles()
     assert not eng.live
+
+
+def test_npy_band_writer_reassembles_the_mosaic(tmp_path):
+    """Stitcher.mosaicSink protocol: (row0, band, full_shape) calls in row order -> one .npy equal to the whole image (gray and colour)."""
+    import os
+    import imagestitch_amd as isa
+    rng = np.random.default_rng(9)
+    for shape in ((53, 40), (31, 17, 3)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        path = os.path.join(str(tmp_path), "sub", "m%d.npy" % len(shape))
+        sink = isa.NpyBandWriter(path)
+        for r0 in range(0, shape[0], 7):
+            sink(r0, img[r0:r0 + 7], shape)
+        assert np.array_equal(np.load(path), img)
