@@ -766,12 +766,16 @@ template <int NW>                                              // NW waves share
 __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row, const float *sy_row,
                                            int r0, int nrows, uint8_t *dst)
 {
-    const int win = G.win;
-    const int lane = threadIdx.x & 63, wv = NW == 1 ? 0 : (int)(threadIdx.x >> 6);
+    // everything that is the same for the whole wave is pinned to SGPRs (the compiler cannot know that a keypoint read through a
+    // ticket index, or threadIdx.x >> 6, is wave-uniform): the unit bookkeeping below then runs on the scalar unit, not on the VALU
+    // that bounds this kernel
+    const int win = __builtin_amdgcn_readfirstlane(G.win);
+    r0 = __builtin_amdgcn_readfirstlane(r0); nrows = __builtin_amdgcn_readfirstlane(nrows);
+    const int lane = threadIdx.x & 63, wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int li = lane >> 3, lj = lane & 7;
     const int strips = (nrows + 7) >> 3;
     const double c = (double)G.cos_dir, sn = (double)G.sin_dir;
-    const int ncols1 = G.w - 1, nrows1 = G.h - 1;
+    const int ncols1 = __builtin_amdgcn_readfirstlane(G.w) - 1, nrows1 = __builtin_amdgcn_readfirstlane(G.h) - 1;
     // Samples read the ROW-PAIR image (k_pair_rows): element (y, x) = pixel (y, x) | pixel (y + 1, x) << 8, so the four taps of a
     // bilinear sample are ONE dword at element (iy, ix) -- bytes t00, t10, t01, t11.  The descriptor kernels are bound by the
     // texture-address path (PMC: TA busy 73 % of the launch, ~24 cycles per 64-lane gather whatever its width), so one gather per
@@ -781,7 +785,7 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
     // (readfirstlane returns int: widen through uint32_t, or a low half with bit 31 set sign-extends into the high half)
     g_cu8 ubase = (g_cu8)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32)) << 32) |
                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)bp));
-    const uint32_t pw = (uint32_t)G.w;                           // pitch of the pair image in elements
+    const uint32_t pw = (uint32_t)(ncols1 + 1);                  // pitch of the pair image in elements
     // Work unit = (strip of 8 rows, block of 32 columns); each wave takes a contiguous run of units.  (Strips alone left waves idle:
     // a band of a large window is only 1-5 strips tall, so one to three of the four waves of the workgroup had nothing to sample.)
     const int ncb = (win + 31) >> 5;
@@ -789,8 +793,10 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
     const int chunk = (total + NW - 1) / NW;
     const int u_end = min(total, (wv + 1) * chunk);
     int cur_ty = -1; bool strip_in = false;
-    for (int unit = wv * chunk; unit < u_end; unit++) {
-        const int ty = unit / ncb, cb0 = (unit - ty * ncb) * 32;
+    int ty = (wv * chunk) / ncb, cbi = wv * chunk - ty * ncb;    // (strip, column block) of the wave's first unit; stepped, not divided
+    for (int unit = wv * chunk; unit < u_end; unit++, cbi++) {
+        if (cbi == ncb) { cbi = 0; ty++; }
+        const int cb0 = cbi * 32;
         const int cb1 = min(win, cb0 + 32);
         const int r = ty * 8 + li;
         const bool rok = r < nrows;
@@ -949,7 +955,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
     __shared__ float rowbuf[21][40];
     const float s = kp.size * 1.2f / 9.0f;
     WinGeom G;
-    G.win = min((int)((20 + 1) * s), VFSMS_MAX_WIN);
+    G.win = __builtin_amdgcn_readfirstlane(min((int)((20 + 1) * s), VFSMS_MAX_WIN));     // wave-uniform: keep it (and what derives from it) scalar
     G.h = R.h; G.w = R.w; G.stride = R.stride; G.img = (g_cu8)R.img; G.pair = (g_cu8)R.pair;
     G.upright = upright; G.usx = 0; G.usy = 0; G.sin_dir = 0.f; G.cos_dir = 0.f;
     const int win = G.win;
@@ -1061,8 +1067,10 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
                     __syncthreads();
                     DT_MARK(3);
                 }
+                // t / nrows as a multiply-shift: exact for t < 21 * 127 and nrows <= 127 (t * (inv * nrows - 2^20) < 2^20)
+                const uint32_t inv_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((1u << 20) + (uint32_t)nrows - 1u) / (uint32_t)nrows));
                 for (int t = threadIdx.x; t < dsz * nrows; t += 256) { // horizontal sums, one (cell column, source row) per lane
-                    const int dx = t / nrows, r = t - dx * nrows;
+                    const int dx = (int)(((uint32_t)t * inv_n) >> 20), r = t - dx * nrows;
                     const uint8_t *S = WINBUF + (rlo - st_lo + r) * win;
                     if (is_area_fast) {
                         int sum = 0;
@@ -1080,8 +1088,9 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
                     stage_rows<4>(G, sx_row, sy_row, rlo + c0, cn, WINBUF);
                     __syncthreads();
                     DT_MARK(3);
+                    const uint32_t inv_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((1u << 20) + (uint32_t)cn - 1u) / (uint32_t)cn));
                     for (int t = threadIdx.x; t < dsz * cn; t += 256) {
-                        const int dx = t / cn, r = t - dx * cn;
+                        const int dx = (int)(((uint32_t)t * inv_c) >> 20), r = t - dx * cn;
                         const uint8_t *S = WINBUF + r * win;
                         if (is_area_fast) {
                             int sum = 0;
