@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat 
     const int lrows = R.h / ss, lcols = R.w / ss;
     const int margin = (pats[li + 1].size / 2) / ss + 1;
     if (pats[li + 1].size > R.h || pats[li + 1].size > R.w) return;   // upper layer not computed: nothing readable
-    const int lane = threadIdx.x, wave = threadIdx.y, tid = wave * 64 + lane;
+    const int lane = threadIdx.x, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.y), tid = wave * 64 + lane;
     const int j0 = margin + bx * 64, i0 = margin + by * NMS_TH;
     if (j0 >= lcols - margin || i0 >= lrows - margin) return;        // (whole workgroup)
     __shared__ unsigned short queue[4][NMS_RW * 64];
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void k_rank_sort(const RoiDev *rois)
     const RoiDev &R = rois[blockIdx.y];
     const int n = min(R.counters[0], R.cap);
     if ((int)(blockIdx.x * 64) >= n) return;
-    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int idx = blockIdx.x * 64 + lane;
     __shared__ unsigned long long t1[256], t2[256], t3[256];
     __shared__ int partial[4][64];
@@ -605,7 +605,7 @@ __device__ __forceinline__ void orientation_block(const RoiDev &R, const SurfTab
     __shared__ float mod_s[ORI_KP][72], sx_s[ORI_KP][72], sy_s[ORI_KP][72];
     __shared__ int nvalid[ORI_KP], state[ORI_KP];              // state: 0 compute, 1 done (deleted / upright / beyond n)
     const int tid = threadIdx.x;
-    const int kq = tid >> 7, t = tid & 127;
+    const int kq = __builtin_amdgcn_readfirstlane(tid >> 7), t = tid & 127;      // keypoint slot: wave-uniform, kept scalar
     if (tid < ORI_KP) { nvalid[tid] = 0; state[tid] = 0; }
     __syncthreads();
     {
@@ -671,7 +671,7 @@ __device__ __forceinline__ void orientation_block(const RoiDev &R, const SurfTab
     }
     __syncthreads();
     {
-        const int q = tid >> 6, lane = tid & 63;
+        const int q = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         if (q < ORI_KP && state[q] == 0) {
             const int k = k0 + q;
             if (nvalid[q] == 0) {
@@ -1294,7 +1294,7 @@ __device__ void describe_small(const RoiDev &R, const int k, int upright, SmallL
     if (!(kp.size > 0)) return;                            // deleted by the orientation stage (wave-uniform)
     const float s = kp.size * 1.2f / 9.0f;
     WinGeom G;
-    G.win = min((int)((20 + 1) * s), DESC_SMALL_WIN);      // (class 3 means <= 64 already)
+    G.win = __builtin_amdgcn_readfirstlane(min((int)((20 + 1) * s), DESC_SMALL_WIN));      // (class 3 means <= 64 already)
     G.h = R.h; G.w = R.w; G.stride = R.stride; G.img = (g_cu8)R.img; G.pair = (g_cu8)R.pair;
     G.upright = upright; G.usx = 0; G.usy = 0; G.sin_dir = 0.f; G.cos_dir = 0.f;
     const int win = G.win;
@@ -1368,7 +1368,7 @@ __global__ __launch_bounds__(256, DESC_SMALL_WGS) void k_describe_small(const Ro
     if (threadIdx.x == 0) { prefix[0] = 0; for (int e = 0; e < nrois; e++) prefix[e + 1] += prefix[e]; }
     __syncthreads();
     const int total = prefix[nrois];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int head = 0;
     for (;;) {
         int t = total;
@@ -1380,13 +1380,13 @@ __global__ __launch_bounds__(256, DESC_SMALL_WGS) void k_describe_small(const Ro
                 head++;                                      // this head is exhausted (it stays exhausted): steal from the next
                 t = total;
             }
-        t = __shfl(t, 0, 64);
+        t = __builtin_amdgcn_readfirstlane(t);               // lane 0's ticket, as an SGPR: the ROI record and keypoint index below are scalar
         if (t >= total) break;
         int lo = 0, hi = nrois;                               // prefix[lo] <= t < prefix[hi]
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= t) lo = mid; else hi = mid; }
         const RoiDev &R = rois[lo];
         const int within = t - prefix[lo] + R.counters[12] + R.counters[13] + R.counters[14];   // the ROI's list is class-major
-        describe_small(R, R.order[within], upright, L[wave]);
+        describe_small(R, __builtin_amdgcn_readfirstlane(R.order[within]), upright, L[wave]);
     }
 }
 
@@ -1425,7 +1425,11 @@ __global__ __launch_bounds__(256, DESC_WGS) void k_describe(const RoiDev *rois, 
         tq = clock64();
     }
 #else
-    while (ticket_next(rois, counter, nrois, S, roi, k, band)) describe_one(rois[roi], T, k, extended, upright, band);
+    // (roi, k, band) come out of LDS, i.e. in VGPRs; they are the same for the whole workgroup: as SGPRs the ROI record and the
+    // keypoint are fetched by scalar loads and everything derived from them stays off the VALU
+    while (ticket_next(rois, counter, nrois, S, roi, k, band))
+        describe_one(rois[__builtin_amdgcn_readfirstlane(roi)], T, __builtin_amdgcn_readfirstlane(k), extended, upright,
+                     __builtin_amdgcn_readfirstlane(band));
 #endif
 }
 
