@@ -684,6 +684,8 @@ class Stitcher(Utility.Method):
             finally:
                 eng.canvas_free(canvas)
         finally:
+            if hasattr(eng, "sync_uploads"):
+                eng.sync_uploads()                           # the host tiles of asynchronous uploads may be released now
             for h, _shape in resident.values():
                 eng.tile_free(h)
 
