@@ -32,7 +32,7 @@ extern "C" {
 #define VFSMS_ERR_BAD_ARG (-1)
 #define VFSMS_ERR_CAPACITY (-2)   /* an output or internal capacity was exceeded            */
 #define VFSMS_ERR_HIP (-3)        /* a HIP runtime call failed (message has hipGetErrorString) */
-#define VFSMS_ERR_FFT (-4)        /* hipFFT plan/exec failure                                  */
+#define VFSMS_ERR_FFT (-4)        /* rocFFT plan / execution failure                           */
 #define VFSMS_ERR_NO_DEVICE (-5)
 #define VFSMS_ERR_UNSUPPORTED (-6)
 
