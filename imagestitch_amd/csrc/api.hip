@@ -243,6 +243,7 @@ extern "C" int vfsms_ctx_destroy(vfsms_ctx *ctx)
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->d_layers) hipFree(ctx->d_layers);
     if (ctx->d_tables) hipFree(ctx->d_tables);
+    if (ctx->d_area_tab) hipFree(ctx->d_area_tab);
     if (ctx->d_orb_tables) hipFree(ctx->d_orb_tables);
     hipStreamDestroy(ctx->stream);
     delete ctx;

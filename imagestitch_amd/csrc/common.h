@@ -152,6 +152,7 @@ struct vfsms_ctx {
     vfsms_surf_params cur_params; bool tables_valid;
     LayerPat *d_layers; int n_layers;
     SurfTables *d_tables;
+    void *d_area_tab = nullptr;          // INTER_AREA tables of every descriptor-window size (ctx_prepare_area_tab)
     vfsms_orb_params cur_orb; bool orb_valid; OrbTables *d_orb_tables;
     std::unordered_map<int64_t, TileRec> tiles;
     hipStream_t copy_stream;                                  // H2D uploads of tiles, overlapped with compute (vfsms_tile_upload_async)

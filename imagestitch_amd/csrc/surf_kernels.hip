@@ -13,6 +13,8 @@
 #include <float.h>
 #include <string.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 
 // ---------------------------------------------------------------------------------------------------
 // small helpers
@@ -941,8 +943,36 @@ __device__ __forceinline__ float area_row(const uint8_t *S, const AreaSpan &Sx) 
     return buf;
 }
 
+// computeResizeAreaTab per window size, built ONCE per context on the host (ctx_prepare_area_tab): record dx < 21 of window `win` = the run of
+// source pixels [j0, j0 + n) of cell dx with alpha a0 for the first, af for the middle ones, al for the last (left partial / full / right
+// partial); record 21 = { min n, max n, 1 / iscale^2, -, -, mode } with mode 0: float table, 1: integer scale, 2: scale == 2.
+// The same records serve the rows.  For integer scales every alpha is 1: the float sums are the exact integer sums of the fast paths.
+struct AreaRec { int j0, n; float a0, af, al; int mode, r1, r2; };
+#define AREA_RECS 22
+
+// buf[dx] of one source row: S[j0] * a0 + S[j0 + 1] * af + ... + S[j0 + n - 1] * al, left to right.  The trip count is the same for every
+// lane (nmax); steps past a cell's own run add S * 0 (x + 0 == x: the sum is never -0), so there is no per-lane loop bound.
+__device__ __forceinline__ float area_row_tab(const uint8_t *S, const AreaRec &c, const int nmin, const int nmax)
+{
+    const uint8_t *p = S + c.j0;
+    float buf = (float)p[0] * c.a0;
+    int t = 1;
+    for (; t < nmin - 1; t++) buf += (float)p[t] * c.af;
+    for (; t < nmax; t++) buf += (float)p[t] * (t < c.n - 1 ? c.af : (t == c.n - 1 ? c.al : 0.f));
+    return buf;
+}
+// one output pixel from the row sums rb[0], rb[21], ... of its n source rows (sum = beta * buf, then sum += beta * buf)
+__device__ __forceinline__ uint8_t area_col_tab(const float *rb, const AreaRec &c, const int mode, const float inv_area)
+{
+    float sum = c.a0 * rb[0];
+    for (int t = 1; t < c.n; t++) sum += (t < c.n - 1 ? c.af : c.al) * rb[t * 21];
+    if (mode == 2) return (uint8_t)(((int)sum + 2) >> 2);
+    if (mode == 1) return sat_u8(sum * inv_area);
+    return sat_u8(sum);
+}
+
 // band >= 0: only row `band` of the 21 x 21 patch (tickets of the largest windows are split by output row, see ticket_next)
-__device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, int extended, int upright, const int band)
+__device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec *area_tab, const int k, int extended, int upright, const int band)
 {
     DT_START;
     vfsms_keypoint kp = R.kps[k];
@@ -950,20 +980,21 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
     __shared__ float sx_row[VFSMS_MAX_WIN], sy_row[VFSMS_MAX_WIN];
     __shared__ uint8_t PATCH[21][21 + 3];
     __shared__ float trig_s[2];
-    __shared__ AreaSpan span_s[21];                        // computeResizeAreaTab entries: same table for x and y
+    __shared__ AreaRec REC[AREA_RECS];                     // computeResizeAreaTab of this window size: same records for x and y
     __shared__ uint8_t WINBUF[DESC_WBUF];
-    __shared__ float rowbuf[21][40];
+    __shared__ float rowsum[40 * 21];                      // buf[dx] of up to 40 source rows
     const float s = kp.size * 1.2f / 9.0f;
     WinGeom G;
-    G.win = __builtin_amdgcn_readfirstlane(min((int)((20 + 1) * s), VFSMS_MAX_WIN));     // wave-uniform: keep it (and what derives from it) scalar
+    G.win = __builtin_amdgcn_readfirstlane(max(21, min((int)((20 + 1) * s), VFSMS_MAX_WIN)));     // wave-uniform: keep it (and what derives from it) scalar
     G.h = R.h; G.w = R.w; G.stride = R.stride; G.img = (g_cu8)R.img; G.pair = (g_cu8)R.pair;
     G.upright = upright; G.usx = 0; G.usy = 0; G.sin_dir = 0.f; G.cos_dir = 0.f;
     const int win = G.win;
     const int dsz = 21;
-    const double inv_scale = (double)dsz / win;
-    const double scale = 1. / inv_scale;
-    const int iscale = cv_round_d(scale);
-    const bool is_area_fast = fabs(scale - iscale) < DBL_EPSILON;
+    if (threadIdx.x < AREA_RECS * 8) ((int *)REC)[threadIdx.x] = ((const int *)(area_tab + (size_t)win * AREA_RECS))[threadIdx.x];
+    __syncthreads();
+    const int nmin = __builtin_amdgcn_readfirstlane(REC[21].j0), nmax = __builtin_amdgcn_readfirstlane(REC[21].n);
+    const int mode = __builtin_amdgcn_readfirstlane(REC[21].mode);
+    const float inv_area = REC[21].a0;
     if (!upright) {
         // Row origins are running float sums in the reference (start_x += sin_dir per row): inherently sequential,
         // so one lane of wave 0 walks x while one lane of wave 1 walks y.
@@ -973,8 +1004,8 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
             const float sin_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[0];
             const float cos_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[1];
             const float win_offset = -(float)(win - 1) / 2;
-            // a band ticket only needs the origins up to the last source row of its band (<= floor((band + 1) * scale))
-            const int need = band >= 0 ? min(win, (int)((band + 1) * scale) + 2) : win;
+            // a band ticket only needs the origins up to the last source row of its band
+            const int need = band >= 0 ? min(win, REC[band].j0 + REC[band].n) : win;
             if (threadIdx.x == 0) {
                 trig_s[0] = sin_dir; trig_s[1] = cos_dir;
                 float start_x = kp.x + win_offset * cos_dir + win_offset * sin_dir;
@@ -989,144 +1020,77 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const int k, 
         G.usx = cv_round_f(kp.x + win_offset);
         G.usy = cv_round_f(kp.y - win_offset);
     }
-    if (!is_area_fast && threadIdx.x >= 128 && threadIdx.x < 128 + dsz) span_s[threadIdx.x - 128] = area_span(threadIdx.x - 128, win, scale);
     __syncthreads();
     if (!upright) { G.sin_dir = trig_s[0]; G.cos_dir = trig_s[1]; }
     DT_MARK(0);
 
     // The rotated window is staged through LDS so that every bilinear sample is produced exactly once: the whole
-    // window when it fits (win <= 169), otherwise one band of source rows per row of output cells.  The INTER_AREA
-    // reduction then reads bytes from LDS in exactly the accumulation order of cv::resize's three area paths.
+    // window when it fits (win <= 128), otherwise as many rows of output cells as fit.  INTER_AREA then runs from LDS as two
+    // table-driven passes in cv::resize's accumulation order: buf[dx] of every staged source row (one (row, cell) per lane, uniform
+    // trip counts), then the output pixels from those row sums -- in chunks of whole output rows whose source rows fit `rowsum`.
+    // rows_lo .. rows_hi of WINBUF row index 0 hold window rows st_lo ..; reduce the output rows [dyA, dyB_end)
+    auto reduce_rows = [&](const int st_lo, int dyA, const int dy_stop) {
+        while (dyA < dy_stop) {
+            const int lo = REC[dyA].j0;
+            int dyB = dyA + 1;
+            while (dyB < dy_stop && REC[dyB].j0 + REC[dyB].n - lo <= 40) dyB++;
+            const int nr = REC[dyB - 1].j0 + REC[dyB - 1].n - lo;
+            for (int e = threadIdx.x; e < nr * 21; e += 256) {
+                const int r = (int)(((uint32_t)e * 3121u) >> 16), dx = e - 21 * r;      // e / 21, exact for e < 43690
+                rowsum[e] = area_row_tab(WINBUF + (lo - st_lo + r) * win, REC[dx], nmin, nmax);
+            }
+            __syncthreads();
+            for (int o = threadIdx.x; o < (dyB - dyA) * 21; o += 256) {
+                const int dyl = (int)(((uint32_t)o * 3121u) >> 16), dx = o - 21 * dyl;
+                const AreaRec ry = REC[dyA + dyl];
+                PATCH[dyA + dyl][dx] = area_col_tab(rowsum + (ry.j0 - lo) * 21 + dx, ry, mode, inv_area);
+            }
+            __syncthreads();
+            dyA = dyB;
+        }
+    };
     if (win * win <= DESC_WBUF) {
         stage_rows<4>(G, sx_row, sy_row, 0, win, WINBUF);
         __syncthreads();
         DT_MARK(1);
-        for (int o = threadIdx.x; o < dsz * dsz; o += 256) {
-            const int dy = o / dsz, dx = o % dsz;
-            uint8_t outv;
-            if (is_area_fast && iscale == 2) {
-                const uint8_t *S = WINBUF + (dy * 2) * win + dx * 2;
-                outv = (uint8_t)((S[0] + S[1] + S[win] + S[win + 1] + 2) >> 2);
-            } else if (is_area_fast) {
-                int sum = 0;
-                for (int sy = 0; sy < iscale; sy++)
-                    for (int sx = 0; sx < iscale; sx++) sum += WINBUF[(dy * iscale + sy) * win + dx * iscale + sx];
-                outv = sat_u8(sum * (1.f / (iscale * iscale)));
-            } else {
-                const AreaSpan Sy = span_s[dy], Sx = span_s[dx];
-                float sum = 0; bool first = true;
-                for (int pass = 0; pass < 3; pass++) {
-                    int r0 = pass == 0 ? Sy.s_left : pass == 1 ? Sy.sx1 : Sy.s_right;
-                    int r1 = pass == 1 ? Sy.sx2 : r0 + 1;
-                    float beta = pass == 0 ? Sy.a_left : pass == 1 ? Sy.a_full : Sy.a_right;
-                    if (pass != 1 && r0 < 0) continue;
-                    for (int sy = r0; sy < r1; sy++) {
-                        const float buf = area_row(WINBUF + sy * win, Sx);
-                        if (first) { sum = beta * buf; first = false; } else sum += beta * buf;
-                    }
-                }
-                outv = sat_u8(sum);
-            }
-            PATCH[dy][dx] = outv;
-        }
+        reduce_rows(0, 0, dsz);
         DT_MARK(2);
     } else {
-        int *irow = reinterpret_cast<int *>(&rowbuf[0][0]);
-        // source rows [rlo, rhi] of output row d (computeResizeAreaTab: left partial, full cells, right partial)
-        auto band_rows = [&](int d, int &lo, int &hi) {
-            if (is_area_fast) { lo = d * iscale; hi = lo + iscale - 1; }
-            else {
-                const volatile AreaSpan *vs = &span_s[d];
-                const int sl = vs->s_left, sr = vs->s_right;
-                lo = sl >= 0 ? sl : vs->sx1;
-                hi = sr >= 0 ? sr : vs->sx2 - 1;
-            }
-        };
         const int dy_end = band >= 0 ? band + 1 : dsz;
         const int crows = max(DESC_WBUF / win, 1);                 // window rows the LDS buffer holds (>= 22 for win <= 739)
-        int st_lo = 0, st_hi = -1;                                 // window rows currently staged (SUPER-BAND, see below)
-        for (int dy = band >= 0 ? band : 0; dy < dy_end; dy++) {
-            int rlo, rhi;
-            band_rows(dy, rlo, rhi);
-            const int nrows = rhi - rlo + 1;                       // <= scale + 2 <= 38
+        for (int dy = band >= 0 ? band : 0; dy < dy_end;) {
+            const int rlo = REC[dy].j0, nrows = REC[dy].n;         // <= scale + 2 <= 39
             if (nrows <= crows) {
                 // Super-band: the buffer is filled with the source rows of as many consecutive output rows as fit.  A band on
                 // its own is only scale + 2 (8-38) rows tall -- one or two 8-row strips, a third of their lanes idle, and every row
                 // shared by two bands sampled twice; a full buffer is sampled in whole strips and its shared rows once.
-                if (rlo < st_lo || rhi > st_hi) {
-                    int end = rhi;
-                    for (int d2 = dy + 1; d2 < dy_end; d2++) {
-                        int l2, h2;
-                        band_rows(d2, l2, h2);
-                        if (h2 - rlo + 1 > crows) break;
-                        end = h2;
-                    }
-                    __syncthreads();                               // (the previous band's sums have been consumed)
-                    stage_rows<4>(G, sx_row, sy_row, rlo, end - rlo + 1, WINBUF);
-                    st_lo = rlo; st_hi = end;
-                    __syncthreads();
-                    DT_MARK(3);
-                }
-                // t / nrows as a multiply-shift: exact for t < 21 * 127 and nrows <= 127 (t * (inv * nrows - 2^20) < 2^20)
-                const uint32_t inv_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((1u << 20) + (uint32_t)nrows - 1u) / (uint32_t)nrows));
-                for (int t = threadIdx.x; t < dsz * nrows; t += 256) { // horizontal sums, one (cell column, source row) per lane
-                    const int dx = (int)(((uint32_t)t * inv_n) >> 20), r = t - dx * nrows;
-                    const uint8_t *S = WINBUF + (rlo - st_lo + r) * win;
-                    if (is_area_fast) {
-                        int sum = 0;
-                        for (int sx = 0; sx < iscale; sx++) sum += S[dx * iscale + sx];
-                        irow[dx * 40 + r] = sum;
-                    } else {
-                        rowbuf[dx][r] = area_row(S, span_s[dx]);
-                    }
-                }
+                int d_stop = dy + 1;
+                while (d_stop < dy_end && REC[d_stop].j0 + REC[d_stop].n - rlo <= crows) d_stop++;
+                const int end = REC[d_stop - 1].j0 + REC[d_stop - 1].n - 1;
+                stage_rows<4>(G, sx_row, sy_row, rlo, end - rlo + 1, WINBUF);
                 __syncthreads();
+                DT_MARK(3);
+                reduce_rows(rlo, dy, d_stop);
+                DT_MARK(4);
+                dy = d_stop;
             } else {
-                st_hi = -1;                                        // (a band taller than the buffer: staged in chunks of its own)
+                // a band taller than the buffer (win > 409): staged in chunks of its own, row sums collected over the chunks
                 for (int c0 = 0; c0 < nrows; c0 += crows) {
                     const int cn = min(crows, nrows - c0);
                     stage_rows<4>(G, sx_row, sy_row, rlo + c0, cn, WINBUF);
                     __syncthreads();
                     DT_MARK(3);
-                    const uint32_t inv_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((1u << 20) + (uint32_t)cn - 1u) / (uint32_t)cn));
-                    for (int t = threadIdx.x; t < dsz * cn; t += 256) {
-                        const int dx = (int)(((uint32_t)t * inv_c) >> 20), r = t - dx * cn;
-                        const uint8_t *S = WINBUF + r * win;
-                        if (is_area_fast) {
-                            int sum = 0;
-                            for (int sx = 0; sx < iscale; sx++) sum += S[dx * iscale + sx];
-                            irow[dx * 40 + c0 + r] = sum;
-                        } else {
-                            rowbuf[dx][c0 + r] = area_row(S, span_s[dx]);
-                        }
+                    for (int e = threadIdx.x; e < cn * 21; e += 256) {
+                        const int r = (int)(((uint32_t)e * 3121u) >> 16), dx = e - 21 * r;
+                        rowsum[c0 * 21 + e] = area_row_tab(WINBUF + r * win, REC[dx], nmin, nmax);
                     }
                     __syncthreads();
                 }
+                if (threadIdx.x < dsz) PATCH[dy][threadIdx.x] = area_col_tab(rowsum + threadIdx.x, REC[dy], mode, inv_area);
+                __syncthreads();
+                DT_MARK(4);
+                dy++;
             }
-            if (threadIdx.x < dsz) {                                // vertical combine in source-row order
-                const int dx = threadIdx.x;
-                // the span is read again here (volatile: no value kept live across the staging loop above -- that cost four
-                // VGPR spills per band, ~1.1 GB of scratch traffic per launch at 5 workgroups per CU)
-                const volatile AreaSpan *vs = &span_s[dy];
-                AreaSpan Sy; Sy.s_left = vs->s_left; Sy.a_left = vs->a_left; Sy.sx2 = vs->sx2; Sy.a_full = vs->a_full;
-                Sy.s_right = vs->s_right; Sy.a_right = vs->a_right; Sy.sx1 = vs->sx1;
-                if (is_area_fast) {
-                    int sum = 0;
-                    for (int r = 0; r < nrows; r++) sum += irow[dx * 40 + r];
-                    PATCH[dy][dx] = sat_u8(sum * (1.f / (iscale * iscale)));
-                } else {
-                    float sum = 0; bool first = true;
-                    for (int r = 0; r < nrows; r++) {
-                        const int sy = rlo + r;
-                        const float beta = (sy == Sy.s_left) ? Sy.a_left : (sy == Sy.s_right && sy >= Sy.sx2) ? Sy.a_right : Sy.a_full;
-                        const float buf = rowbuf[dx][r];
-                        if (first) { sum = beta * buf; first = false; } else sum += beta * buf;
-                    }
-                    PATCH[dy][dx] = sat_u8(sum);
-                }
-            }
-            __syncthreads();
-            DT_MARK(4);
         }
     }
     __syncthreads();
@@ -1412,7 +1376,7 @@ __global__ __launch_bounds__(256) void k_pair_rows(const RoiDev *rois)
 #define DESC_WGS 5
 #endif
 __global__ __launch_bounds__(256, DESC_WGS) void k_describe(const RoiDev *rois, int nrois, int *counter, const SurfTables *T,
-                                                  int extended, int upright)
+                                                  const AreaRec *area_tab, int extended, int upright)
 {
     __shared__ TicketState S;
     ticket_init(rois, nrois, S);
@@ -1421,14 +1385,14 @@ __global__ __launch_bounds__(256, DESC_WGS) void k_describe(const RoiDev *rois, 
     unsigned long long tq = clock64();
     while (ticket_next(rois, counter, nrois, S, roi, k, band)) {
         if (threadIdx.x == 0) atomicAdd(&g_desc_cycles[6], clock64() - tq);
-        describe_one(rois[roi], T, k, extended, upright, band);
+        describe_one(rois[roi], T, area_tab, k, extended, upright, band);
         tq = clock64();
     }
 #else
     // (roi, k, band) come out of LDS, i.e. in VGPRs; they are the same for the whole workgroup: as SGPRs the ROI record and the
     // keypoint are fetched by scalar loads and everything derived from them stays off the VALU
     while (ticket_next(rois, counter, nrois, S, roi, k, band))
-        describe_one(rois[__builtin_amdgcn_readfirstlane(roi)], T, __builtin_amdgcn_readfirstlane(k), extended, upright,
+        describe_one(rois[__builtin_amdgcn_readfirstlane(roi)], T, area_tab, __builtin_amdgcn_readfirstlane(k), extended, upright,
                      __builtin_amdgcn_readfirstlane(band));
 #endif
 }
@@ -1653,11 +1617,61 @@ int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_roi
     return VFSMS_OK;
 }
 
+
+// ---- INTER_AREA tables (computeResizeAreaTab for every descriptor-window size, once per context) -----------------------------------
+int ctx_prepare_area_tab(vfsms_ctx *ctx)
+{
+    if (ctx->d_area_tab) return VFSMS_OK;
+    std::vector<AreaRec> tab((size_t)(VFSMS_MAX_WIN + 1) * AREA_RECS);
+    memset(tab.data(), 0, sizeof(AreaRec) * tab.size());
+    const int dsz = 21;
+    for (int win = dsz; win <= VFSMS_MAX_WIN; win++) {
+        AreaRec *rec = tab.data() + (size_t)win * AREA_RECS;
+        const double inv_scale = (double)dsz / win;
+        const double scale = 1. / inv_scale;
+        const int iscale = (int)rint(scale);
+        const bool fast = fabs(scale - iscale) < DBL_EPSILON;
+        int nmin = 1 << 30, nmax = 0;
+        for (int dx = 0; dx < dsz; dx++) {
+            AreaRec &c = rec[dx];
+            if (fast) { c.j0 = dx * iscale; c.n = iscale; c.a0 = c.af = c.al = 1.f; }
+            else {
+                // one destination index of computeResizeAreaTab: left partial, full cells [sx1, sx2), right partial
+                const double fsx1 = dx * scale;
+                const double fsx2 = fsx1 + scale;
+                const double cellWidth = fmin(scale, win - fsx1);
+                int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+                sx2 = std::min(sx2, win - 1);
+                sx1 = std::min(sx1, sx2);
+                const bool left = sx1 - fsx1 > 1e-3, right = fsx2 - sx2 > 1e-3;
+                const float a_left = (float)((sx1 - fsx1) / cellWidth), a_full = (float)(1.0 / cellWidth);
+                const float a_right = (float)(fmin(fmin(fsx2 - sx2, 1.), cellWidth) / cellWidth);
+                c.j0 = left ? sx1 - 1 : sx1;
+                c.n = (left ? 1 : 0) + (sx2 - sx1) + (right ? 1 : 0);
+                c.a0 = left ? a_left : (sx2 > sx1 ? a_full : a_right);
+                c.af = a_full;
+                c.al = right ? a_right : a_full;
+                if (c.n == 1 && left) c.al = a_left;
+            }
+            if (c.n < 1 || c.j0 < 0 || c.j0 + c.n > win) { vfsms_set_error("internal: INTER_AREA table of window %d", win); return VFSMS_ERR_UNSUPPORTED; }
+            nmin = std::min(nmin, c.n); nmax = std::max(nmax, c.n);
+        }
+        if (nmax > 40) { vfsms_set_error("internal: INTER_AREA run of window %d", win); return VFSMS_ERR_UNSUPPORTED; }
+        rec[21].j0 = nmin; rec[21].n = nmax; rec[21].a0 = fast ? 1.f / (iscale * iscale) : 1.f;
+        rec[21].mode = !fast ? 0 : iscale == 2 ? 2 : 1;
+    }
+    for (int win = 0; win < dsz; win++) memcpy(tab.data() + (size_t)win * AREA_RECS, tab.data() + (size_t)dsz * AREA_RECS, sizeof(AreaRec) * AREA_RECS);
+    HIP_TRY(hipMalloc((void **)&ctx->d_area_tab, sizeof(AreaRec) * tab.size()));
+    HIP_TRY(hipMemcpy(ctx->d_area_tab, tab.data(), sizeof(AreaRec) * tab.size(), hipMemcpyHostToDevice));
+    return VFSMS_OK;
+}
+
 int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_rois, int nrois,
                          const vfsms_surf_params *p)
 {
     if (nrois <= 0) return VFSMS_OK;
     if (nrois > VFSMS_MAX_ROIS) { vfsms_set_error("more than %d ROIs in one batch", VFSMS_MAX_ROIS); return VFSMS_ERR_CAPACITY; }
+    TRY(ctx_prepare_area_tab(ctx));
     int maxcap = 0;
     for (int r = 0; r < nrois; r++) maxcap = h_rois[r].cap > maxcap ? h_rois[r].cap : maxcap;
     {
@@ -1680,7 +1694,7 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
         hipLaunchKernelGGL(k_desc_order, dim3(nrois), dim3(1024), 0, ctx->stream, d_rois);
         if (!p->upright) hipLaunchKernelGGL(k_desc_trig, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
         hipLaunchKernelGGL(k_describe, dim3(256 * DESC_WGS), dim3(256), 0, ctx->stream, d_rois, nrois, tickets,
-                           ctx->d_tables, p->extended, p->upright);
+                           ctx->d_tables, (const AreaRec *)ctx->d_area_tab, p->extended, p->upright);
         hipLaunchKernelGGL(k_describe_small, dim3(256 * DESC_SMALL_WGS), dim3(256), 0, ctx->stream, d_rois, nrois,
                            tickets + DESC_HEADS * DESC_HEAD_STRIDE, p->upright);
         hipLaunchKernelGGL(k_desc_tail, dim3((maxcap + 15) / 16, nrois), dim3(256), 0, ctx->stream, d_rois, ctx->d_tables, p->extended);
