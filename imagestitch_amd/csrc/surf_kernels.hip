@@ -712,12 +712,18 @@ __device__ unsigned long long g_desc_cycles[8];
 #define DT_START unsigned long long _t0 = clock64()
 extern "C" int vfsms_debug_desc_cycles(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_desc_cycles), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -3; }
 __device__ unsigned long long g_desc_trips[4];      // [0] interior-strip trips, [1] border-strip trips that are all inside, [2] border trips (per-sample path), [3] keypoints
-#define DT_TRIP(n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_desc_trips[n], 1ull); } while (0)
+#define DT_TRIP(n) do {} while (0)
+__device__ unsigned long long g_desc_unit_cycles[4];  // wave-cycles inside [0] interior units, [1] border units, [2] stage_rows as a whole (per wave)
+#define DT_UNIT_BEGIN unsigned long long _u0 = clock64()
+#define DT_UNIT_END(n) do { _uacc[n] += clock64() - _u0; _ucnt[n]++; } while (0)
+extern "C" int vfsms_debug_desc_unit_cycles(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_desc_unit_cycles), sizeof(unsigned long long) * 4) == hipSuccess ? 0 : -3; }
 extern "C" int vfsms_debug_desc_trips(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_desc_trips), sizeof(unsigned long long) * 4) == hipSuccess ? 0 : -3; }
 #else
 #define DT_MARK(ph) do {} while (0)
 #define DT_START do {} while (0)
 #define DT_TRIP(n) do {} while (0)
+#define DT_UNIT_BEGIN do {} while (0)
+#define DT_UNIT_END(n) do {} while (0)
 #endif
 #ifndef VFSMS_EXP
 #define VFSMS_EXP 0
@@ -760,6 +766,20 @@ __device__ __forceinline__ int win_sample_upright(const WinGeom &G, int i, int j
 // tiles per trip: the 16 byte loads of a lane are issued back to back behind ONE wave-uniform interior test, so the
 // L2 latency is paid once per four samples.  (Measured: the kernel as a whole is bound by instruction issue at 5 workgroups/CU;
 // changes of tile shape, ILP depth or occupancy beyond that left its time unchanged -- DESIGN.md section 9.)
+typedef float float2v __attribute__((ext_vector_type(2)));
+// one bilinear sample from the dword of the row-pair image (bytes t00, t10, t01, t11), in the reference's operation order
+// t00 (1-a) (1-b) + t01 a (1-b) + t10 (1-a) b + t11 a b; the two products that share a factor go through one v_pk_mul_f32
+__device__ __forceinline__ float bilinear_pk(uint32_t top, float a, float b)
+{
+    const float na = 1.f - a, nb = 1.f - b;
+    const float2v w = {na, a};
+    const float2v r0 = {(float)(top & 0xff), (float)((top >> 16) & 0xff)};
+    const float2v r1 = {(float)((top >> 8) & 0xff), (float)(top >> 24)};
+    float2v p = r0 * w, q = r1 * w;
+    const float2v nb2 = {nb, nb}, b2 = {b, b};
+    p = p * nb2; q = q * b2;
+    return ((p.x + p.y) + q.x) + q.y;
+}
 #define STAGE_ILP 4
 #ifndef BORDER_ILP
 #define BORDER_ILP 2            // strips that cross the image border: shorter trips keep the register budget of the hot path
@@ -788,125 +808,124 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
     g_cu8 ubase = (g_cu8)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32)) << 32) |
                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)bp));
     const uint32_t pw = (uint32_t)(ncols1 + 1);                  // pitch of the pair image in elements
-    // Work unit = (strip of 8 rows, block of 32 columns); each wave takes a contiguous run of units.  (Strips alone left waves idle:
-    // a band of a large window is only 1-5 strips tall, so one to three of the four waves of the workgroup had nothing to sample.)
+    // Work unit = (strip of 8 rows, block of 32 columns), dealt to the waves ROUND-ROBIN: units that cross the image border cost
+    // several times an interior unit, and they come in runs (the last strips of a window that hangs over the edge) -- contiguous runs
+    // per wave left three waves of the workgroup waiting at the barrier for the one that had drawn the border strips.
     const int ncb = (win + 31) >> 5;
     const int total = strips * ncb;
-    const int chunk = (total + NW - 1) / NW;
-    const int u_end = min(total, (wv + 1) * chunk);
-    int cur_ty = -1; bool strip_in = false;
-    int ty = (wv * chunk) / ncb, cbi = wv * chunk - ty * ncb;    // (strip, column block) of the wave's first unit; stepped, not divided
-    for (int unit = wv * chunk; unit < u_end; unit++, cbi++) {
-        if (cbi == ncb) { cbi = 0; ty++; }
+    int ty = 0, cbi = wv;                                        // (strip, column block) of the wave's current unit; stepped, not divided
+    while (cbi >= ncb) { cbi -= ncb; ty++; }
+#ifdef VFSMS_DESC_TIMING
+    unsigned long long _s0 = clock64(), _uacc[2] = {0, 0}, _ucnt[2] = {0, 0};
+#endif
+    for (int unit = wv; unit < total; unit += NW) {
+        DT_UNIT_BEGIN;
         const int cb0 = cbi * 32;
         const int cb1 = min(win, cb0 + 32);
         const int r = ty * 8 + li;
-        const bool rok = r < nrows;
-        const int i = min(r0 + r, VFSMS_MAX_WIN - 1);
-        const double sxi = (double)sx_row[i], syi = (double)sy_row[i];
-        uint8_t *drow = dst + r * win;
+        // a lane past the strip's last row repeats that row: same position, same value, same LDS byte
+        const int rc = min(r, nrows - 1);
+        const int ic = min(r0 + rc, VFSMS_MAX_WIN - 1);
+        const double sxc = (double)sx_row[ic], syc = (double)sy_row[ic];
+        uint8_t *drc = dst + rc * win;
+        const int ty_cur = ty;
+        cbi += NW;
+        while (cbi >= ncb) { cbi -= ncb; ty++; }
         if (G.upright) {
-            for (int j = cb0 + lj; j < cb1; j += 8)
-                if (rok) drow[j] = (uint8_t)win_sample_upright(G, r0 + r, j);
+            for (int j = cb0 + lj; j < cb1; j += 8) drc[j] = (uint8_t)win_sample_upright(G, r0 + rc, j);
             continue;
         }
-        // Strip-level interior test: the samples of rows [r0 + 8 ty, +8) x [0, win) are linear in j and monotone in i, so
-        // their extremes sit at the four corners.  A strip that lies inside the image (with the 2 px of slack the dword
-        // taps need) runs without any per-sample bounds logic; other strips keep the per-trip test below.
-        if (ty != cur_ty) {
-            cur_ty = ty;
-            const int ia = min(r0 + ty * 8, VFSMS_MAX_WIN - 1), ib = min(min(r0 + ty * 8 + 7, r0 + nrows - 1), VFSMS_MAX_WIN - 1);
-            const double e = (double)(win - 1);
+        // Unit-level interior test: x = origin(row) + j * c is separable, rows are monotone, so the extremes of the unit's samples are
+        // (extreme row origin) + (extreme of j * c).  A unit inside the image (with the 2 px of slack the dword taps need) runs
+        // without any per-sample bounds logic.
+        bool unit_in;
+        {
+            const int ia = min(r0 + ty_cur * 8, VFSMS_MAX_WIN - 1), ib = min(min(r0 + ty_cur * 8 + 7, r0 + nrows - 1), VFSMS_MAX_WIN - 1);
             const double xa = (double)sx_row[ia], xb = (double)sx_row[ib], ya = (double)sy_row[ia], yb = (double)sy_row[ib];
-            const double xmin = fmin(fmin(xa, xa + e * c), fmin(xb, xb + e * c)), xmax = fmax(fmax(xa, xa + e * c), fmax(xb, xb + e * c));
-            const double ymin = fmin(fmin(ya, ya - e * sn), fmin(yb, yb - e * sn)), ymax = fmax(fmax(ya, ya - e * sn), fmax(yb, yb - e * sn));
-            strip_in = xmin >= 0.0 && ymin >= 0.0 && xmax < (double)(ncols1 - 2) && ymax < (double)nrows1;
+            const double ja = (double)cb0, jb = (double)(cb1 - 1);
+            const double jxa = ja * c, jxb = jb * c, jya = -(ja * sn), jyb = -(jb * sn);
+            const double xmin = fmin(xa, xb) + fmin(jxa, jxb), xmax = fmax(xa, xb) + fmax(jxa, jxb);
+            const double ymin = fmin(ya, yb) + fmin(jya, jyb), ymax = fmax(ya, yb) + fmax(jya, jyb);
+            unit_in = xmin >= 0.0 && ymin >= 0.0 && xmax < (double)(ncols1 - 2) && ymax < (double)nrows1;
         }
-        if (strip_in) {
-            const int jb = cb0;
+        if (unit_in) {
+            // No predicates here: a lane past the window's last column repeats that column, so every lane gathers from inside the
+            // tested unit, the loads keep the scalar-base form and there is no exec-mask bookkeeping around them.
             uint32_t top[STAGE_ILP];
             double px[STAGE_ILP], py[STAGE_ILP];
+            int jc[STAGE_ILP];
             DT_TRIP(0);
+            if (cb0 + 8 * STAGE_ILP <= win) {
+                // a full block: the lane's four columns are 8 apart; 8 c, 16 c, 24 c are exact doubles, so px0 + 8 u c rounds like
+                // start + j * step whenever that is exact (the same argument as for the fused form)
+                const double jd = (double)(cb0 + lj);
+                px[0] = __builtin_fma(jd, c, sxc); py[0] = __builtin_fma(jd, -sn, syc);
+#pragma unroll
+                for (int u = 1; u < STAGE_ILP; u++) { px[u] = px[0] + (double)(8 * u) * c; py[u] = py[0] - (double)(8 * u) * sn; }
+#pragma unroll
+                for (int u = 0; u < STAGE_ILP; u++) jc[u] = cb0 + u * 8 + lj;
+            } else {
+#pragma unroll
+                for (int u = 0; u < STAGE_ILP; u++) {
+                    jc[u] = min(cb0 + u * 8 + lj, win - 1);
+                    const double jd = (double)jc[u];
+                    px[u] = __builtin_fma(jd, c, sxc);             // start + j * step: the product is exact in double
+                    py[u] = __builtin_fma(jd, -sn, syc);
+                }
+            }
 #pragma unroll
             for (int u = 0; u < STAGE_ILP; u++) {
-                // start + j * step: the product is exact in double, so the fused form rounds exactly like mul-then-add
-                const double jd = (double)(jb + u * 8 + lj);
-                px[u] = __builtin_fma(jd, c, sxi);
-                py[u] = __builtin_fma(jd, -sn, syi);
-                const bool act = rok && jb + u * 8 + lj < win;
-                const uint32_t off = act ? ((uint32_t)__umul24((uint32_t)(int)py[u], pw) + (uint32_t)(int)px[u]) << 1 : 0u;
+                const uint32_t off = ((uint32_t)__umul24((uint32_t)(int)py[u], pw) + (uint32_t)(int)px[u]) << 1;
                 top[u] = *(GAS const uint32_t *)(ubase + off);      // 2-byte-aligned dword gather, uniform base + 32-bit offset
             }
 #pragma unroll
             for (int u = 0; u < STAGE_ILP; u++) {
                 const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
-                const uint8_t t00 = (uint8_t)(top[u] & 0xff), t10 = (uint8_t)((top[u] >> 8) & 0xff);
-                const uint8_t t01 = (uint8_t)((top[u] >> 16) & 0xff), t11 = (uint8_t)(top[u] >> 24);
-                const float v = t00 * (1.f - a) * (1.f - b) + t01 * a * (1.f - b) + t10 * (1.f - a) * b + t11 * a * b;
-                if (rok && jb + u * 8 + lj < win) drow[jb + u * 8 + lj] = (uint8_t)cv_round_f(v);
+                drc[jc[u]] = (uint8_t)cv_round_f(bilinear_pk(top[u], a, b));
             }
+            DT_UNIT_END(0);
             continue;
         }
+        // The unit crosses the image border.  No branch per sample: every lane gathers at clamped coordinates -- the bilinear taps
+        // when (ix, iy) is interior, the nearest pixel clamp(cvRound(px), cvRound(py)) otherwise -- and selects at the end.
+        DT_TRIP(2);
         for (int jb = cb0; jb < cb1; jb += 8 * BORDER_ILP) {
             double px[BORDER_ILP], py[BORDER_ILP];
-            bool act[BORDER_ILP], inb[BORDER_ILP];
-            bool all_in = true;
+            int jc[BORDER_ILP];
+            uint32_t q0[BORDER_ILP], q1[BORDER_ILP];          // pair elements (cy, cx) and (cy, cx1): two 16-bit gathers, not four bytes
+            bool inside[BORDER_ILP];
 #pragma unroll
             for (int u = 0; u < BORDER_ILP; u++) {
-                const int j = jb + u * 8 + lj;
-                act[u] = rok && j < win;
-                px[u] = sxi + (double)j * c;
-                py[u] = syi - (double)j * sn;
-                // interior with 2 px of slack on the right: the fast path reads 4 bytes at (ix, iy) and (ix, iy+1)
-                inb[u] = px[u] >= 0.0 && py[u] >= 0.0 && (int)px[u] < ncols1 - 2 && (int)py[u] < nrows1;
-                all_in = all_in && (inb[u] || !act[u]);
+                jc[u] = min(jb + u * 8 + lj, win - 1);
+                px[u] = sxc + (double)jc[u] * c;
+                py[u] = syc - (double)jc[u] * sn;
+                const int ix = (int)px[u], iy = (int)py[u];                       // trunc == floor wherever `inside` holds
+                inside[u] = px[u] >= 0.0 && py[u] >= 0.0 && ix < ncols1 && iy < nrows1;
+                const int rx = min(max(cv_round_d(px[u]), 0), ncols1), ry = min(max(cv_round_d(py[u]), 0), nrows1);
+                const int cx = inside[u] ? ix : rx, cy = inside[u] ? iy : ry;
+                const int cx1 = min(cx + 1, ncols1);
+                const uint32_t o0 = (uint32_t)__umul24((uint32_t)cy, pw);
+                q0[u] = *(GAS const uint16_t *)(ubase + ((o0 + (uint32_t)cx) << 1));
+                q1[u] = *(GAS const uint16_t *)(ubase + ((o0 + (uint32_t)cx1) << 1));
             }
-            if (__all(all_in)) DT_TRIP(1); else DT_TRIP(2);
-            if (__all(all_in)) {                                   // interior (the common case): branch-free gathers
-                // the gather path (one address per lane through the texture-address unit) is what bounds this kernel:
-                // the two horizontally adjacent taps of a row come from ONE unaligned dword load (2 loads / sample, not 4)
-                uint32_t top[BORDER_ILP];
 #pragma unroll
-                for (int u = 0; u < BORDER_ILP; u++) {
-                    const int ix = act[u] ? (int)px[u] : 0, iy = act[u] ? (int)py[u] : 0;
-                    top[u] = *(GAS const uint32_t *)(ubase + (((uint32_t)__umul24((uint32_t)iy, pw) + (uint32_t)ix) << 1));
-                }
-#pragma unroll
-                for (int u = 0; u < BORDER_ILP; u++) {
-                    const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
-                    const uint8_t t00 = (uint8_t)(top[u] & 0xff), t10 = (uint8_t)((top[u] >> 8) & 0xff);
-                    const uint8_t t01 = (uint8_t)((top[u] >> 16) & 0xff), t11 = (uint8_t)(top[u] >> 24);
-                    const float v = t00 * (1.f - a) * (1.f - b) + t01 * a * (1.f - b) + t10 * (1.f - a) * b + t11 * a * b;
-                    if (act[u]) drow[jb + u * 8 + lj] = (uint8_t)cv_round_f(v);
-                }
-            } else {
-                // The window crosses the image border here (a quarter of all sample slots on 409-row strips: not rare).  No branch
-                // per sample: every lane gathers four bytes at clamped coordinates -- the bilinear taps when (ix, iy) is interior,
-                // the nearest pixel clamp(cvRound(px), cvRound(py)) otherwise -- and selects at the end.
-                uint32_t q0[BORDER_ILP], q1[BORDER_ILP];          // pair elements (cy, cx) and (cy, cx1): two 16-bit gathers, not four bytes
-                bool inside[BORDER_ILP];
-#pragma unroll
-                for (int u = 0; u < BORDER_ILP; u++) {
-                    const int ix = (int)px[u], iy = (int)py[u];                       // trunc == floor wherever `inside` holds
-                    inside[u] = px[u] >= 0.0 && py[u] >= 0.0 && ix < ncols1 && iy < nrows1;
-                    const int rx = min(max(cv_round_d(px[u]), 0), ncols1), ry = min(max(cv_round_d(py[u]), 0), nrows1);
-                    const int cx = (inside[u] && act[u]) ? ix : (act[u] ? rx : 0), cy = (inside[u] && act[u]) ? iy : (act[u] ? ry : 0);
-                    const int cx1 = min(cx + 1, ncols1);
-                    const uint32_t o0 = (uint32_t)__umul24((uint32_t)cy, pw);
-                    q0[u] = *(GAS const uint16_t *)(ubase + ((o0 + (uint32_t)cx) << 1));
-                    q1[u] = *(GAS const uint16_t *)(ubase + ((o0 + (uint32_t)cx1) << 1));
-                }
-#pragma unroll
-                for (int u = 0; u < BORDER_ILP; u++) {
-                    const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
-                    // the high bytes are row min(cy + 1, h - 1): the clamped lower taps
-                    const float v = (uint8_t)(q0[u] & 0xff) * (1.f - a) * (1.f - b) + (uint8_t)(q1[u] & 0xff) * a * (1.f - b) +
-                                    (uint8_t)(q0[u] >> 8) * (1.f - a) * b + (uint8_t)(q1[u] >> 8) * a * b;
-                    if (act[u]) drow[jb + u * 8 + lj] = inside[u] ? (uint8_t)cv_round_f(v) : (uint8_t)(q0[u] & 0xff);
-                }
+            for (int u = 0; u < BORDER_ILP; u++) {
+                const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
+                // the high bytes are row min(cy + 1, h - 1): the clamped lower taps
+                const float v = (uint8_t)(q0[u] & 0xff) * (1.f - a) * (1.f - b) + (uint8_t)(q1[u] & 0xff) * a * (1.f - b) +
+                                (uint8_t)(q0[u] >> 8) * (1.f - a) * b + (uint8_t)(q1[u] >> 8) * a * b;
+                drc[jc[u]] = inside[u] ? (uint8_t)cv_round_f(v) : (uint8_t)(q0[u] & 0xff);
             }
         }
+        DT_UNIT_END(1);
     }
+#ifdef VFSMS_DESC_TIMING
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_desc_unit_cycles[2], clock64() - _s0);
+        atomicAdd(&g_desc_unit_cycles[0], _uacc[0]); atomicAdd(&g_desc_unit_cycles[1], _uacc[1]);
+        atomicAdd(&g_desc_trips[0], _ucnt[0]); atomicAdd(&g_desc_trips[2], _ucnt[1]);
+    }
+#endif
 }
 
 // one destination index of computeResizeAreaTab: up to (left partial, full cells [sx1,sx2), right partial)

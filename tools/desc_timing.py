@@ -25,3 +25,7 @@ for n, v in zip(names, d[:7]):
 
 tr = np.zeros(4, np.uint64); eng.lib.vfsms_debug_desc_trips(tr.ctypes.data_as(ctypes.c_void_p))
 print("wave trips (both runs): interior strips %d (x4 samples/lane), border strips all-in %d (x%d), border per-sample %d" % (tr[0], tr[1], 1, tr[2]))
+
+uc = np.zeros(4, np.uint64); eng.lib.vfsms_debug_desc_unit_cycles(uc.ctypes.data_as(ctypes.c_void_p))
+print("units (both runs): interior %d, border %d; wave-cycles per unit: interior %.0f, border %.0f; wave-cycles in stage_rows %.4g (in units %.4g)" % (
+    tr[0], tr[2], uc[0] / max(float(tr[0]), 1), uc[1] / max(float(tr[2]), 1), float(uc[2]), float(uc[0] + uc[1])))
