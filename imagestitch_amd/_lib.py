@@ -68,6 +68,8 @@ _SIGNATURES = {
     "vfsms_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "vfsms_tile_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "vfsms_tile_upload_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "vfsms_tile_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "vfsms_tile_fill": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
     "vfsms_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vfsms_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vfsms_tile_wrap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
@@ -227,6 +229,20 @@ class Engine:
         h = C.c_int64()
         self._check(self.lib.vfsms_tile_upload(self.ctx, _ptr(img), img.shape[0], img.shape[1], img.strides[0], C.byref(h)))
         return h.value
+
+    def tile_reserve(self, h, w):
+        """handle of a gray tile whose pixels a decoder thread delivers later (tile_fill); batch calls wait for exactly the tiles they name"""
+        hd = C.c_int64()
+        self._check(self.lib.vfsms_tile_reserve(self.ctx, int(h), int(w), C.byref(hd)))
+        return hd.value
+
+    def tile_fill(self, handle, img):
+        """deliver (img: u8 2-D array, C-contiguous rows) or give up on (img is None) a reserved tile; safe from any thread"""
+        if img is None:
+            self._check(self.lib.vfsms_tile_fill(self.ctx, C.c_int64(handle), None, 0))
+            return
+        assert img.dtype == np.uint8 and img.ndim == 2 and img.strides[1] == 1
+        self._check(self.lib.vfsms_tile_fill(self.ctx, C.c_int64(handle), _ptr(img), img.strides[0]))
 
     def tile_upload_async(self, img):
         """Upload without waiting: the copy overlaps the compute stream; `img` must stay alive and unchanged until sync() or

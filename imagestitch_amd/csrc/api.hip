@@ -234,7 +234,7 @@ extern "C" int vfsms_ctx_destroy(vfsms_ctx *ctx)
     for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
     hipStreamSynchronize(ctx->copy_stream);
     for (auto &kv : ctx->tiles) { if (kv.second.owned) hipFree(kv.second.ptr); if (kv.second.ready) hipEventDestroy(kv.second.ready); }
-    for (auto &pe : ctx->tile_pool) hipFree(pe.second);
+    for (auto &pe : ctx->tile_pool) { hipFree(pe.ptr); if (pe.idle) hipEventDestroy(pe.idle); }
     for (hipEvent_t ev : ctx->event_pool) hipEventDestroy(ev);
     hipStreamDestroy(ctx->copy_stream);
     for (auto &kv : ctx->canvases) { hipFree(kv.second.pix); hipFree(kv.second.mask); }
@@ -281,10 +281,23 @@ static int kp_capacity(vfsms_ctx *ctx, int h, int w)
     } while (0)
 
 // ---- tiles -------------------------------------------------------------------------------------------------
-static int tile_buffer(vfsms_ctx *ctx, size_t bytes, uint8_t **p)
+// A pooled buffer may still be read by work enqueued on the compute stream when its tile was freed (vfsms_canvas_paste_tile and
+// vfsms_canvas_fuse_tile_resident without an info readback only enqueue): the stream that writes the buffer next waits for the event
+// recorded at vfsms_tile_free.
+static int tile_buffer(vfsms_ctx *ctx, size_t bytes, uint8_t **p, hipStream_t writer)
 {
     for (size_t k = 0; k < ctx->tile_pool.size(); k++)
-        if (ctx->tile_pool[k].first == bytes) { *p = ctx->tile_pool[k].second; ctx->tile_pool.erase(ctx->tile_pool.begin() + k); return VFSMS_OK; }
+        if (ctx->tile_pool[k].bytes == bytes) {
+            PoolEnt e = ctx->tile_pool[k];
+            ctx->tile_pool.erase(ctx->tile_pool.begin() + k);
+            ctx->tile_pool_bytes -= e.bytes;
+            if (e.idle) {
+                if (writer != ctx->stream) HIP_TRY(hipStreamWaitEvent(writer, e.idle, 0));   // (same-stream reuse is ordered already)
+                ctx->event_pool.push_back(e.idle);
+            }
+            *p = e.ptr;
+            return VFSMS_OK;
+        }
     HIP_TRY(hipMalloc((void **)p, bytes));
     return VFSMS_OK;
 }
@@ -293,8 +306,8 @@ static int tile_upload_impl(vfsms_ctx *ctx, const uint8_t *img, int h, int w_px,
 {
     const int w = w_px * ch;                                 // bytes per row
     if (!img || !handle || h <= 0 || w_px <= 0 || ch < 1 || ch > 4 || stride < w) { vfsms_set_error("tile_upload: bad arguments"); return VFSMS_ERR_BAD_ARG; }
-    TileRec t; t.h = h; t.w = w_px; t.stride = w; t.owned = true; t.ready = nullptr; t.pending = false; t.ch = ch;
-    TRY(tile_buffer(ctx, (size_t)h * w, &t.ptr));
+    TileRec t; t.h = h; t.w = w_px; t.stride = w; t.owned = true; t.ready = nullptr; t.pending = false; t.ch = ch; t.bytes = (size_t)h * w;
+    TRY(tile_buffer(ctx, t.bytes, &t.ptr, async ? ctx->copy_stream : ctx->stream));
     if (async) {
         // the copy runs on the context's copy stream; the compute stream waits for it when a batch first names the tile
         if (!ctx->event_pool.empty()) { t.ready = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
@@ -306,6 +319,7 @@ static int tile_upload_impl(vfsms_ctx *ctx, const uint8_t *img, int h, int w_px,
         HIP_TRY(hipMemcpy2DAsync(t.ptr, w, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
+    std::lock_guard<std::mutex> lk(ctx->tiles_mu);           // (decoder threads look tiles up concurrently: vfsms_tile_fill)
     *handle = ctx->next_handle++;
     ctx->tiles[*handle] = t;
     return VFSMS_OK;
@@ -313,6 +327,11 @@ static int tile_upload_impl(vfsms_ctx *ctx, const uint8_t *img, int h, int w_px,
 // make the compute stream wait for a tile's asynchronous upload (once)
 static int tile_ready(vfsms_ctx *ctx, TileRec &t)
 {
+    if (t.fill) {                                            // reserved: block until its decoder thread has handed the pixels over
+        std::unique_lock<std::mutex> lk(ctx->tiles_mu);
+        ctx->tiles_cv.wait(lk, [&] { return t.fill != 1; });
+        if (t.fill == 2) { vfsms_set_error("a reserved tile was never filled (its decoder reported a failure)"); return VFSMS_ERR_BAD_ARG; }
+    }
     if (t.pending) { HIP_TRY(hipStreamWaitEvent(ctx->stream, t.ready, 0)); t.pending = false; }
     return VFSMS_OK;
 }
@@ -331,6 +350,49 @@ extern "C" int vfsms_tile_upload_ch(vfsms_ctx *ctx, const uint8_t *img, int h, i
     CTX_ENTER(ctx);
     return tile_upload_impl(ctx, img, h, w, stride_bytes, handle, async != 0, ch);
 }
+// ---- tiles whose pixels arrive later, from other threads: the ingest pipeline (Stitcher.py:68-69 decodes file after file BEFORE the
+// first pair is registered; here the registration of tiles 0, 1, ... starts while tile k is still being decoded) -------------------------
+extern "C" int vfsms_tile_reserve(vfsms_ctx *ctx, int h, int w, int64_t *handle)
+{
+    CTX_ENTER(ctx);
+    if (!handle || h <= 0 || w <= 0) { vfsms_set_error("tile_reserve: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    std::lock_guard<std::mutex> lk(ctx->tiles_mu);
+    TileRec t; t.h = h; t.w = w; t.stride = w; t.owned = true; t.ready = nullptr; t.pending = false; t.ch = 1; t.bytes = (size_t)h * w; t.fill = 1;
+    TRY(tile_buffer(ctx, t.bytes, &t.ptr, ctx->copy_stream));
+    if (!ctx->event_pool.empty()) { t.ready = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+    else HIP_TRY(hipEventCreateWithFlags(&t.ready, hipEventDisableTiming));
+    *handle = ctx->next_handle++;
+    ctx->tiles[*handle] = t;
+    return VFSMS_OK;
+}
+// May be called from ANY thread, concurrently with batch calls on the context's own thread: copies the pixels on the copy stream and returns
+// when the copy has completed, so `img` (a decoder thread's staging buffer) can be reused at once.  img == NULL reports a failed decode:
+// the batch call waiting for the tile returns an error instead of waiting forever.
+extern "C" int vfsms_tile_fill(vfsms_ctx *ctx, int64_t handle, const uint8_t *img, int stride)
+{
+    CTX_ENTER(ctx);
+    hipEvent_t ev; uint8_t *dst; int h, w;
+    {
+        std::lock_guard<std::mutex> lk(ctx->tiles_mu);
+        auto it = ctx->tiles.find(handle);
+        if (it == ctx->tiles.end() || it->second.fill != 1) { vfsms_set_error("tile_fill: not a reserved tile"); return VFSMS_ERR_BAD_ARG; }
+        if (!img) { it->second.fill = 2; ctx->tiles_cv.notify_all(); return VFSMS_OK; }
+        if (stride < it->second.w) { vfsms_set_error("tile_fill: stride smaller than the tile width"); return VFSMS_ERR_BAD_ARG; }
+        ev = it->second.ready; dst = it->second.ptr; h = it->second.h; w = it->second.w;
+    }
+    hipError_t e = hipMemcpy2DAsync(dst, w, img, stride, w, h, hipMemcpyHostToDevice, ctx->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(ev, ctx->copy_stream);
+    if (e == hipSuccess) e = hipEventSynchronize(ev);
+    {
+        std::lock_guard<std::mutex> lk(ctx->tiles_mu);
+        auto it = ctx->tiles.find(handle);
+        if (it != ctx->tiles.end()) { it->second.fill = e == hipSuccess ? 0 : 2; it->second.pending = false; }   // (the copy has landed: no stream wait needed)
+        ctx->tiles_cv.notify_all();
+    }
+    if (e != hipSuccess) { vfsms_set_error("tile_fill: %s", hipGetErrorString(e)); return VFSMS_ERR_HIP; }
+    return VFSMS_OK;
+}
+
 extern "C" int vfsms_host_alloc(vfsms_ctx *ctx, size_t bytes, void **ptr)
 {
     CTX_ENTER(ctx);
@@ -351,6 +413,7 @@ extern "C" int vfsms_tile_wrap(vfsms_ctx *ctx, const void *device_ptr, int h, in
     CTX_ENTER(ctx);
     if (!device_ptr || !handle || h <= 0 || w <= 0 || stride < w) { vfsms_set_error("tile_wrap: bad arguments"); return VFSMS_ERR_BAD_ARG; }
     TileRec t; t.ptr = (uint8_t *)device_ptr; t.h = h; t.w = w; t.stride = stride; t.owned = false; t.ready = nullptr; t.pending = false;
+    std::lock_guard<std::mutex> lk(ctx->tiles_mu);
     *handle = ctx->next_handle++;
     ctx->tiles[*handle] = t;
     return VFSMS_OK;
@@ -360,14 +423,22 @@ extern "C" int vfsms_tile_free(vfsms_ctx *ctx, int64_t handle)
     CTX_ENTER(ctx);
     auto it = ctx->tiles.find(handle);
     if (it == ctx->tiles.end()) { vfsms_set_error("tile_free: unknown handle"); return VFSMS_ERR_BAD_ARG; }
-    // every entry point is synchronous at return, so no compute work on this tile is in flight; an upload may still be
+    if (it->second.fill == 1) { vfsms_set_error("tile_free: the tile is reserved and its decoder has not filled it yet"); return VFSMS_ERR_BAD_ARG; }
+    // an upload may still be in flight; compute work on the tile may only be ENQUEUED (canvas paste / resident fuse return early)
     if (it->second.pending) HIP_TRY(hipEventSynchronize(it->second.ready));
     if (it->second.ready) ctx->event_pool.push_back(it->second.ready);
     if (it->second.owned) {
-        if (ctx->tile_pool.size() < 256) ctx->tile_pool.push_back(std::make_pair((size_t)it->second.h * it->second.w, it->second.ptr));
-        else { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(it->second.ptr)); }
+        // the pool is capped by bytes (colour tiles of a mosaic are three times a gray one) and by entries
+        if (ctx->tile_pool.size() < 256 && ctx->tile_pool_bytes + it->second.bytes <= ((size_t)8 << 30)) {
+            PoolEnt e; e.bytes = it->second.bytes; e.ptr = it->second.ptr; e.idle = nullptr;
+            if (!ctx->event_pool.empty()) { e.idle = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+            else HIP_TRY(hipEventCreateWithFlags(&e.idle, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(e.idle, ctx->stream));
+            ctx->tile_pool.push_back(e);
+            ctx->tile_pool_bytes += e.bytes;
+        } else { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(it->second.ptr)); }
     }
-    ctx->tiles.erase(it);
+    { std::lock_guard<std::mutex> lk(ctx->tiles_mu); ctx->tiles.erase(it); }
     return VFSMS_OK;
 }
 

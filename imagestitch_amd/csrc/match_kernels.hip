@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_bf_split16(const MatchDev *jobs, float 
 // products; a train is listed when its score is <= thr(q) -- a handful per query instead of the ~2 ln(n) records per list that a
 // running threshold admits, so the append branch is almost never taken (one min3 tree + one ballot per accumulator decides) and
 // the verifier has a few distances to evaluate instead of ~200.
-#define BFM_HI_ERR 9e-3f             // >= 2 * ((1 + 2^-9)^2 - 1) * |q||t| + the split filter's own 3e-5
+#define BFM_HI_ERR 1.6e-2f           // >= 2 * ((1 + 2^-8)^2 - 1) * |q||t| = 1.57e-2 (bf16 keeps 8 significand bits: RNE unit roundoff 2^-8) + the split filter's own 3e-5
 #define GASM __attribute__((address_space(1)))
 typedef GASM const s8v *g_cs8v;
 typedef float f2v __attribute__((ext_vector_type(2)));

@@ -199,17 +199,27 @@ int phase_destroy_plans(vfsms_ctx *ctx)
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// rocFFT plans are cached per (M, N, batch): the registrar's speculative batches come in every size from 1 to 32, and a plan costs tens
+// of milliseconds to create -- inside a timed call.  Batches are therefore rounded up to ten sizes; the surplus transforms run over
+// scratch planes nobody reads (the pad / cross-power / arg-max kernels only cover the real jobs).
+static inline int plan_batch(int c)
+{
+    static const int sizes[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+    for (int s : sizes) if (s >= c) return s;
+    return c;
+}
+
 // arena bytes for nb attempts of one ROI size; the rocFFT work buffer is whatever the (cached) plans of the chunks ask for
 int phase_bytes(vfsms_ctx *ctx, int h, int w, int nb, size_t *bytes)
 {
     const int M = optimal_dft_size(h), N = optimal_dft_size(w);
     const size_t real = sizeof(double) * (size_t)M * N, cp = sizeof(double) * 2 * (size_t)M * (N / 2 + 1);
-    const size_t chunk = (size_t)std::min(nb, PHASE_MAX_CHUNK);
+    const size_t chunk = (size_t)plan_batch(std::min(nb, PHASE_MAX_CHUNK));
     size_t wbytes = 0;
     for (int left = nb; left > 0;) {
         const int c = std::min(left, PHASE_MAX_CHUNK);
         FftPlan *P;
-        TRY(get_plan(ctx, M, N, c, &P));
+        TRY(get_plan(ctx, M, N, plan_batch(c), &P));
         wbytes = std::max(wbytes, std::max(P->fwd_work, P->inv_work));
         left -= c;
     }
@@ -226,7 +236,7 @@ int phase_correlate_batch_device(vfsms_ctx *ctx, const PhaseJobHost *jobs, int n
     const int M = optimal_dft_size(h), N = optimal_dft_size(w);
     const int Nc = N / 2 + 1;
     const size_t real = (size_t)M * N, cpl = (size_t)M * Nc;
-    const int cmax = std::min(nb, PHASE_MAX_CHUNK);
+    const int cmax = plan_batch(std::min(nb, PHASE_MAX_CHUNK));
     double *RE = (double *)ctx_arena_alloc(ctx, sizeof(double) * 2 * cmax * real);
     cplx *FQ = (cplx *)ctx_arena_alloc(ctx, sizeof(cplx) * 2 * cmax * cpl);
     cplx *CP = (cplx *)ctx_arena_alloc(ctx, sizeof(cplx) * cmax * cpl);
@@ -238,12 +248,13 @@ int phase_correlate_batch_device(vfsms_ctx *ctx, const PhaseJobHost *jobs, int n
     if (!RE || !FQ || !CP || !partial) { vfsms_set_error("arena exhausted in phase correlation"); return VFSMS_ERR_CAPACITY; }
     // chunks of at most PHASE_MAX_CHUNK attempts: plans first, so one work buffer serves every chunk
     std::vector<FftPlan *> chunks;
+    std::vector<int> chunk_jobs;
     size_t wbytes = 0;
     for (int left = nb; left > 0;) {
-        const int c = std::min(left, PHASE_MAX_CHUNK);             // one plan per exact batch size up to 32 (the registrar's batches)
+        const int c = std::min(left, PHASE_MAX_CHUNK);
         FftPlan *P;
-        TRY(get_plan(ctx, M, N, c, &P));
-        chunks.push_back(P);
+        TRY(get_plan(ctx, M, N, plan_batch(c), &P));
+        chunks.push_back(P); chunk_jobs.push_back(c);
         wbytes = std::max(wbytes, std::max(P->fwd_work, P->inv_work));
         left -= c;
     }
@@ -251,8 +262,9 @@ int phase_correlate_batch_device(vfsms_ctx *ctx, const PhaseJobHost *jobs, int n
     if (wbytes && !work) { vfsms_set_error("arena exhausted (rocFFT work buffer, %zu bytes)", wbytes); return VFSMS_ERR_CAPACITY; }
     ProfScope ps(ctx, "phase");
     int done = 0;
-    for (FftPlan *P : chunks) {
-        const int c = P->nb;
+    for (size_t ci = 0; ci < chunks.size(); ci++) {
+        FftPlan *P = chunks[ci];
+        const int c = chunk_jobs[ci];                                   // real jobs; the plan transforms P->nb >= c planes
         hipLaunchKernelGGL(k_pad_u8_f64, dim3((N + 255) / 256, M, c), dim3(256), 0, ctx->stream, dj + done, h, w, M, N, RE);
         void *in[1] = {RE}, *outb[1] = {FQ};
         if (wbytes) rocfft_execution_info_set_work_buffer((rocfft_execution_info)P->fwd_info, work, wbytes);

@@ -71,6 +71,13 @@ def _imread(path, color):
     return np.ascontiguousarray(np.asarray(im.convert("RGB"))[:, :, ::-1])
 
 
+def _imshape(path):
+    """(rows, cols) of an image file from its header (no decode)"""
+    from PIL import Image
+    with Image.open(path) as im:
+        return (im.size[1], im.size[0])
+
+
 def _imwrite(path, img):
     if img is None:                                          # streamed to Stitcher.mosaicSink instead
         return
@@ -181,6 +188,7 @@ class Stitcher(Utility.Method):
         return ((status, endfileIndex), stitchImage)
 
     batchRegistration = True     # let flowStitch register a whole file list in fused device batches when the stock search is used
+    decodeThreads = 0            # decoder threads of the ingest pipeline (0: one per host core, at most 64)
 
     def _registerBatched(self, fileList, caculateOffsetMethod):
         """The pair loop of flowStitch (Stitcher.py:64-79) through grid.GridRegistrar when `caculateOffsetMethod` is this
@@ -199,38 +207,9 @@ class Stitcher(Utility.Method):
         else:
             return None
         eng = self.engine
-        handles = []
-        if hasattr(eng, "tile_upload_async") and hasattr(eng, "pinned_empty"):
-            # decode once per tile (the reference decodes each tile three times: Stitcher.py:68-69,382-403) straight into a small
-            # ring of pinned staging buffers; every upload is an asynchronous DMA on the copy stream that overlaps the decode of
-            # the next files, and the first batch that names a tile waits for exactly that tile
-            first = _imread(fileList[0], False)
-            ring = self.__dict__.get("_stage")
-            if ring is None or ring[0].shape != first.shape:
-                ring = self._stage = [eng.pinned_empty(first.shape) for _ in range(4)]
-            images = []
-            ok = True
-            for n, f in enumerate(fileList):
-                im = first if n == 0 else _imread(f, False)
-                if im.shape != first.shape:
-                    ok = False
-                    break
-                if n >= len(ring) and n % len(ring) == 0:
-                    eng.sync_uploads()                       # the ring is about to wrap: its copies have long landed
-                buf = ring[n % len(ring)]
-                buf[...] = im
-                handles.append(eng.tile_upload_async(buf))
-                images.append(im)
-            eng.sync_uploads()
-            if not ok:
-                for h in handles:
-                    eng.tile_free(h)
-                return None
-        else:
-            images = [_imread(f, False) for f in fileList]
-            if any(im.shape != images[0].shape for im in images):
-                return None
-            handles = [eng.tile_upload(im) for im in images]
+        shapes = [_imshape(f) for f in fileList]             # from the file headers: nothing is decoded yet
+        if any(s != shapes[0] for s in shapes):
+            return None
         from .grid import GridRegistrar
         params = None if method == "phase" else (self._orbParams() if method == "orb" else self._surfParams())
         reg = GridRegistrar(eng, method=method, roiRatio=self.roiRatio, searchRatio=self.searchRatio, offsetEvaluate=self.offsetEvaluate,
@@ -239,18 +218,52 @@ class Stitcher(Utility.Method):
                             enhance=self._enhanceSpec() if method == "surf" else (0, 0.0, 0))
         reg.orbMaxDistance = self.orbMaxDistance if self.isGPUAvailable else -1
         keep = (not self.isColorMode) and self.fuseMethod in ("notFuse", "fadeInAndFadeOut") and hasattr(eng, "canvas_fuse_tile_resident")
+        handles, pool, futures, failed = [], None, [], False
         try:
-            table, _d = reg.register(handles, [im.shape for im in images], self.direction, stop_on_fail=True)
+            if hasattr(eng, "tile_reserve"):
+                # Ingest pipeline.  The reference decodes the whole file list before the first pair is looked at, and each tile three
+                # times (Stitcher.py:68-69, 382-403).  Here every tile gets its device handle up front (vfsms_tile_reserve) and a pool
+                # of decoder threads (Pillow releases the GIL while it decodes) fills them in path order; the native registrar starts
+                # at once and waits only for the tiles of the batch it is about to launch, so registration overlaps decoding and the
+                # decoded arrays never pile up on the host (a thread holds one tile at a time).
+                from concurrent.futures import ThreadPoolExecutor
+                handles = [eng.tile_reserve(s[0], s[1]) for s in shapes]
+                nthreads = max(1, min(int(self.decodeThreads or (os.cpu_count() or 4)), len(fileList), 64))
+
+                def ingest(k):
+                    try:
+                        im = _imread(fileList[k], False)
+                        if im.shape != shapes[k]:
+                            raise ValueError("decoded size %s of %s differs from its header %s" % (im.shape, fileList[k], shapes[k]))
+                        eng.tile_fill(handles[k], np.ascontiguousarray(im))
+                    except BaseException:
+                        eng.tile_fill(handles[k], None)          # the batch waiting for this tile fails instead of hanging
+                        raise
+                pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="vfsms-decode")
+                futures = [pool.submit(ingest, k) for k in range(len(fileList))]
+            else:
+                handles = [eng.tile_upload(_imread(f, False)) for f in fileList]
+            table, _d = reg.register(handles, shapes, self.direction, stop_on_fail=True)
         except BaseException:
-            keep = False
+            keep, failed = False, True
             raise
         finally:
-            if keep:
+            err = None
+            for fu in futures:                                # every decoder has finished with its handle before any is freed
+                try:
+                    fu.result()
+                except BaseException as e:                     # noqa: PERF203
+                    err = err or e
+            if pool is not None:
+                pool.shutdown(wait=True)
+            if keep and err is None:
                 # gray mosaics are assembled from these very tiles: getStitchByOffset takes them over (and frees them)
-                self._resident = dict(zip(fileList, zip(handles, [im.shape for im in images])))
+                self._resident = dict(zip(fileList, zip(handles, shapes)))
             else:
                 for h in handles:
                     eng.tile_free(h)
+            if err is not None and not failed:
+                raise err
         offsetList, endfileIndex, status, describtion = [], 0, True, ""
         for k, row in enumerate(table):
             self.printAndWrite("stitching " + str(fileList[k]) + " and " + str(fileList[k + 1]))

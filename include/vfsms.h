@@ -108,6 +108,13 @@ int vfsms_tile_upload_async(vfsms_ctx *ctx, const uint8_t *img, int h, int w, in
  * rows of w * ch bytes, stride_bytes between rows, synchronous or (async != 0) on the copy stream like vfsms_tile_upload_async.
  * Registration entry points reject tiles with ch != 1.                                                                          */
 int vfsms_tile_upload_ch(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int ch, int stride_bytes, int async, int64_t *handle);
+/* Ingest pipeline (replaces the decode loop of Stitcher.py:68-69, which reads every file before the first pair is registered):
+ * vfsms_tile_reserve hands out the handle of an h x w gray tile whose pixels arrive later; vfsms_tile_fill -- callable from ANY
+ * thread, concurrently with a batch call on the context's thread -- copies them (it returns when the copy has landed, so the
+ * decoder's staging buffer is free again; img == NULL reports a failed decode).  A batch / canvas call that names a reserved tile
+ * waits for exactly that tile, so vfsms_pairs_offsets works on tiles 0, 1, ... while tile k is still being decoded.               */
+int vfsms_tile_reserve(vfsms_ctx *ctx, int h, int w, int64_t *handle);
+int vfsms_tile_fill(vfsms_ctx *ctx, int64_t handle, const uint8_t *img, int stride);
 /* pinned host staging memory for tiles (decoders write into it; uploads from it are asynchronous DMA)                          */
 int vfsms_host_alloc(vfsms_ctx *ctx, size_t bytes, void **ptr);
 int vfsms_host_free(vfsms_ctx *ctx, void *ptr);

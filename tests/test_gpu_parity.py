@@ -746,3 +746,99 @@ def test_orb_at_config2_geometry(engine, oracle):
     st, off, votes = oracle.mode_offset(kxy, np.stack([kfb["x"], kfb["y"]], 1), pairs, 3)
     assert list(row[:7]) == [int(st), off[0], off[1], votes, len(da), len(db), len(pairs)], (row, st, off, votes)
     assert st and [off[0] + 2048 - int(0.2 * 2048), off[1]] == truth, (off, truth)
+
+
+@pytest.mark.gpu
+def test_config3_all_zirconcl_pairs_phase(engine, oracle, golden_dir):
+    """BASELINE configs[3] in full: the direction-4 ROI strips of all 24 zirconCL tiles (tests/golden/zirconcl_strips.npz), 23 pairs in
+    ONE batched launch: truncated offsets equal the oracle's (whose arithmetic tests/phase_numpy.py re-derives independently),
+    sub-pixel peak within 1e-6 px, response within 1e-9, and the accept decision (response > 0.15) is the same."""
+    import json
+    meta = json.load(open(os.path.join(golden_dir, "phase_independent.json")))
+    z = np.load(os.path.join(golden_dir, "zirconcl_strips.npz"))
+    rows = [r for r in meta["rows"] if r["dataset"] == "zirconCL"]
+    assert len(rows) == 23
+    H, W = meta["shape"]
+    ra, rb = meta["roi_first"], meta["roi_second"]
+    tiles = []
+    for k in range(24):                                         # frames rebuilt around the two strips of every tile
+        T = np.zeros((H, W), np.uint8)
+        T[ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]] = z["t%d_first" % k]
+        T[rb[0]:rb[0] + rb[2], rb[1]:rb[1] + rb[3]] = z["t%d_second" % k]
+        tiles.append(T)
+    hs = [engine.tile_upload(T) for T in tiles]
+    out = engine.attempt_phase_batch([(hs[k], hs[k + 1], ra[0], ra[1], rb[0], rb[1], ra[2], ra[3]) for k in range(23)])
+    for h in hs:
+        engine.tile_free(h)
+    for k, r in enumerate(rows):
+        (ox, oy), orr = oracle.phase_correlate(z["t%d_first" % k], z["t%d_second" % (k + 1)])
+        x, y, resp = out[k]
+        assert [int(y), int(x)] == [int(oy), int(ox)] == r["offset_int"], (k, x, y, ox, oy)
+        assert abs(x - ox) < 1e-6 and abs(y - oy) < 1e-6 and abs(resp - orr) < 1e-9 and (resp > 0.15) == r["accepted"], (k, x - ox, y - oy, resp - orr)
+
+
+@pytest.mark.gpu
+def test_real_dendritic_path_orb_through_grid_registrar(engine, golden_dir):
+    """The ORB leg on the reference's own ground truth: the 25 committed neighbourhood pairs (frames rebuilt around the stored strips)
+    through GridRegistrar(method="orb") with offsetEvaluate 3 as the reference has it -- every row equals the oracle's ORB row
+    (offset, direction, i, votes; tests/golden/real_path_strips.json `expected_orb`), false accepts included, and the 22 rows the
+    oracle puts within +-1 px of Stitcher.py:87 are within +-1 px here too."""
+    import json
+    from imagestitch_amd.grid import GridRegistrar
+    from test_oracle_golden import _rebuild_frames
+    meta = json.load(open(os.path.join(golden_dir, "real_path_strips.json")))["neighbourhoods"]
+    g = np.load(os.path.join(golden_dir, "real_path_strips.npz"))
+    n = 0
+    for nb in meta:
+        frames = _rebuild_frames(nb, g)
+        hs = [engine.tile_upload(f) for f in frames]
+        reg = GridRegistrar(engine, method="orb", roiRatio=0.2, offsetEvaluate=3, directIncre=1)
+        table, d_out = reg.register(hs, [f.shape for f in frames], nb["incoming_direction"])
+        for h in hs:
+            engine.tile_free(h)
+        for row, e in zip(table, nb["expected_orb"]):
+            assert row[0] == 1, (nb["turn"], e["a"], row)
+            assert [int(row[1]), int(row[2]), int(row[3]), int(row[4]), int(row[5])] == e["offset"] + [e["direction"], e["i"], e["votes"]], (nb["turn"], e, row)
+            if e["within_one"]:                                # (22 of the 25: see test_orb_real_path_strips_reproduced_by_oracle for the other three)
+                assert abs(int(row[1]) - e["gold"][0]) <= 1 and abs(int(row[2]) - e["gold"][1]) <= 1, (e, row)
+            n += 1
+    assert n == 25
+
+
+@pytest.mark.gpu
+def test_orb_grid_at_offset_evaluate_3_equals_oracle_chain(engine, oracle):
+    """configs[2] as it is written -- 2048^2 tiles, 10 % overlap, ORB + Hamming 1-NN + mode vote with offsetEvaluate = 3 -- on a 3 x 3
+    serpentine grid.  With every query voting (ImageUtility.py:297-302) a wrong candidate direction now and then collects three equal
+    votes and is ACCEPTED; whether cv2's ORB would do the same on these tiles cannot be known here, but the engine must take every
+    decision the oracle takes: the whole table (status, offset, direction, i, votes), false accepts included, pair by pair with the
+    direction threaded, through the fused native registrar AND through Stitcher.calculateOffsetForFeatureSearchIncre."""
+    from imagestitch_amd.grid import GridRegistrar
+    from test_oracle_golden import _chain_search, oracle_orb_attempt
+    g = SyntheticGrid(3, 3, 2048, overlap=0.10)
+    tiles = g.tiles(threads=4)
+    hs = [engine.tile_upload(t) for t in tiles]
+    reg = GridRegistrar(engine, method="orb", roiRatio=0.2, offsetEvaluate=3, directIncre=1)
+    table, d_out = reg.register(hs, [t.shape for t in tiles], 1)
+    for h in hs:
+        engine.tile_free(h)
+    direction, exp = 1, []
+    for k in range(len(tiles) - 1):
+        st, off, d, i, log = _chain_search(oracle_orb_attempt(oracle, tiles[k], tiles[k + 1]), tiles[k].shape, tiles[k + 1].shape, direction)
+        exp.append([int(st), off[0], off[1], d if st else direction, i, log[-1][5] if st else 0])
+        if st:
+            direction = d
+    got = [[int(v) for v in row[:6]] for row in table]
+    for k, (a, b) in enumerate(zip(got, exp)):
+        if b[0]:
+            assert a == b, (k, a, b, g.true_offsets()[k])
+        else:
+            assert a[0] == 0, (k, a, b)
+    # decisions that agree with the ground truth are exact (north_star: bit-exact for ORB); the others are the documented false accepts
+    truth = g.true_offsets()
+    n_true = sum(1 for k, r in enumerate(exp) if r[0] and [r[1], r[2]] == truth[k])
+    assert n_true >= len(exp) - 3, (exp, truth)
+    s = isa.Stitcher(); s._engine = engine; s.isPrintLog = False
+    s.roiRatio = 0.2; s.direction = 1; s.directIncre = 1; s.featureMethod = "orb"; s.offsetEvaluate = 3
+    for k in range(len(tiles) - 1):
+        status, off = s.calculateOffsetForFeatureSearchIncre([tiles[k], tiles[k + 1]])
+        assert (int(status), off if status else None) == (exp[k][0], [exp[k][1], exp[k][2]] if exp[k][0] else None), (k, off, exp[k])

@@ -378,9 +378,10 @@ def cap_real():
     print("real strips", len(meta), os.path.getsize(os.path.join(OUT, "real_strips.npz")) // 1024, "KiB")
 
 
-def _oracle_search(O, roi_rect, A, B, d0, roiRatio=0.2, directIncre=1, offsetEvaluate=3):
-    """Stitcher.calculateOffsetForFeatureSearchIncre (Stitcher.py:306-367) with the oracle's SURF + BF-L2 + mode vote as the
-    operators -> (status, [dx, dy], direction, i, attempts log)."""
+def _oracle_search(O, roi_rect, A, B, d0, roiRatio=0.2, directIncre=1, offsetEvaluate=3, method="surf"):
+    """Stitcher.calculateOffsetForFeatureSearchIncre (Stitcher.py:306-367) with the oracle's SURF + BF-L2 + ratio + mode vote
+    (method "surf") or ORB + BF-Hamming 1-NN + mode vote (method "orb": ImageUtility.py:260, 297-302 -- every query votes, no ratio
+    test, no distance threshold) as the operators -> (status, [dx, dy], direction, i, attempts log)."""
     def rot(d):
         d += directIncre
         return 1 if d == 5 else 4 if d == 0 else d
@@ -392,10 +393,13 @@ def _oracle_search(O, roi_rect, A, B, d0, roiRatio=0.2, directIncre=1, offsetEva
             ra = roi_rect(A.shape, d, "first", i * roiRatio); rb = roi_rect(B.shape, d, "second", i * roiRatio)
             a = np.ascontiguousarray(A[ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]])
             b = np.ascontiguousarray(B[rb[0]:rb[0] + rb[2], rb[1]:rb[1] + rb[3]])
-            ka, da = O.surf_detect_describe(a); kb, db = O.surf_detect_describe(b)
+            if method == "orb":
+                ka, da = O.orb_detect_describe(a); kb, db = O.orb_detect_describe(b)
+            else:
+                ka, da = O.surf_detect_describe(a); kb, db = O.surf_detect_describe(b)
             st, off, votes, nm = False, [0, 0], 0, 0
             if len(ka) and len(kb):
-                pairs = O.bf_l2_ratio_matches(da, db, 0.75)
+                pairs = O.bf_hamming_matches(da, db)[0] if method == "orb" else O.bf_l2_ratio_matches(da, db, 0.75)
                 nm = len(pairs)
                 st, off, votes = O.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, offsetEvaluate)
             log.append([d, i, int(st), int(off[0]), int(off[1]), int(votes), len(ka), len(kb), nm])
@@ -505,6 +509,80 @@ def cap_real_path():
     print("real path strips", os.path.getsize(os.path.join(OUT, "real_path_strips.npz")) // 1024, "KiB")
 
 
+def cap_real_path_orb():
+    """The ORB leg against the only vector the reference holds.  Stitcher.py:87 lists TRUE offsets of the dendriticCrystal path (it is
+    not a list of SURF outputs), so ORB + BF-Hamming + mode vote behind the same incremental search must land on it too wherever it
+    accepts the right direction:
+
+    1. dendritic_path_oracle_orb.json -- the oracle's ORB (cv2.ORB_create(5000, 1.2, 8, 31, 0, 2, 0, 31, 20), ImageUtility.py:31-39,260)
+       + Hamming 1-NN (no ratio, no threshold: :297-302) + mode vote (offsetEvaluate 3) over tiles 003..090 on the real 1936 x 2584
+       tiles, direction threaded as Stitcher.py:361 does.  Nothing is asserted while capturing: every pair's outcome is recorded,
+       with `within_one` and, for the others, what happened (a falsely accepted direction is the reference's own fragility: three
+       equal votes out of ~5000 unconditional matches).
+    2. real_path_strips.json gains `expected_orb` per neighbourhood: the oracle's ORB rows on the rebuilt frames of the 25 committed
+       pairs (tests compare the HIP path with them row for row, and with Stitcher.py:87 within +-1 px)."""
+    from PIL import Image
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    from imagestitch_amd.utility import roi_rect
+    O.build()
+    src = open(os.path.join(refshim.REF, "Stitcher.py"), encoding="utf-8-sig").read().splitlines()[86]
+    gold = ast.literal_eval(src[src.index("["):])
+    d = os.path.join(refshim.REF, "demoImages", "dendriticCrystal", "1")
+
+    def load(t):
+        im = Image.open(os.path.join(d, "1-%03d.jpg" % t)); im.draft("L", im.size)
+        return np.asarray(im.convert("L"))
+
+    surf_rows = {r["a"]: r for r in json.load(open(os.path.join(OUT, "dendritic_path_oracle.json")))["rows"]}
+    rows, direction = [], 1
+    prev = None
+    for a in range(3, 90):
+        A = prev if prev is not None else load(a)
+        B = load(a + 1)
+        st, off, dn, i, log = _oracle_search(O, roi_rect, A, B, direction, method="orb")
+        g = gold[a - 1]
+        ok = bool(st and abs(off[0] - g[0]) <= 1 and abs(off[1] - g[1]) <= 1)
+        true_dir = surf_rows[a]["direction"]
+        note = "" if ok else ("not registered" if not st else
+                              ("accepted direction %d (i = %d) with %d votes; the true direction is %d" % (dn, i, log[-1][5], true_dir)
+                               if dn != true_dir else "true direction, offset off by more than 1 px"))
+        rows.append(dict(a=a, b=a + 1, gold=g, oracle=off, status=bool(st), direction=dn, i=i, votes=log[-1][5], incoming_direction=direction,
+                         within_one=ok, note=note, attempts=log))
+        print("orb path", a, a + 1, g, off, st, dn, i, log[-1][5], "OK" if ok else note, flush=True)
+        if st:
+            direction = dn
+        prev = B
+    json.dump(dict(source="oracle ORB (oracle/vfsms_oracle_orb.c) + BF-Hamming 1-NN + mode vote (offsetEvaluate 3) on the reference's "
+                          "demoImages/dendriticCrystal/1 tiles 003..090 (Pillow draft-L decode); gold = Stitcher.py:87; attempts = "
+                          "[direction, i, status, raw dx, raw dy, votes, nA, nB, matches]",
+                   pairs=len(rows), within_one=sum(r["within_one"] for r in rows), exact=sum(r["gold"] == r["oracle"] for r in rows),
+                   rows=rows), open(os.path.join(OUT, "dendritic_path_oracle_orb.json"), "w"))
+    print("orb real path: %d pairs, %d within 1 px, %d exact" % (len(rows), sum(r["within_one"] for r in rows), sum(r["gold"] == r["oracle"] for r in rows)))
+
+    # ---- the 25 committed neighbourhood pairs, rebuilt frames
+    meta = json.load(open(os.path.join(OUT, "real_path_strips.json")))
+    z = np.load(os.path.join(OUT, "real_path_strips.npz"))
+    for nb in meta["neighbourhoods"]:
+        H, W = nb["shape"]
+        frames = {t: np.zeros((H, W), np.uint8) for t in nb["tiles"]}
+        for s_ in nb["strips"]:
+            arr = z[s_["key"]]
+            frames[s_["tile"]][s_["y0"]:s_["y0"] + arr.shape[0], s_["x0"]:s_["x0"] + arr.shape[1]] = arr
+        direction = nb["incoming_direction"]
+        exp = []
+        for a in nb["tiles"][:-1]:
+            st, off, dn, i, log = _oracle_search(O, roi_rect, frames[a], frames[a + 1], direction, method="orb")
+            g = gold[a - 1]
+            exp.append(dict(a=a, gold=g, status=bool(st), offset=off, direction=dn, i=i, votes=log[-1][5], nA=log[-1][6], nB=log[-1][7], matches=log[-1][8],
+                            within_one=bool(st and abs(off[0] - g[0]) <= 1 and abs(off[1] - g[1]) <= 1)))
+            print("orb nbhd", nb["turn"], a, g, off, st, dn, i, log[-1][5:], flush=True)
+            if st:
+                direction = dn
+        nb["expected_orb"] = exp
+    json.dump(meta, open(os.path.join(OUT, "real_path_strips.json"), "w"))
+
+
 def cap_demo_strips():
     """BASELINE configs[0] / configs[3]: ROI strips of the iron pair (direction 1) and of the first zirconCL pairs (direction 4)
     at roiRatio 0.2.  cv2 is not installable here, so the expected offsets are produced by the oracle (oracle/): these
@@ -543,10 +621,55 @@ def cap_demo_strips():
     print("demo strips", os.path.getsize(os.path.join(OUT, "demo_strips.npz")) // 1024, "KiB")
 
 
+def cap_phase_independent():
+    """BASELINE configs[3] in full, and an independent check of the phase-correlation oracle: the direction-4 ROI strips (roiRatio 0.2)
+    of ALL 24 zirconCL tiles (23 pairs; demo_strips holds 3) + for each pair and for the iron strip pair the result of tests/phase_numpy.py
+    -- a second float64 restatement of cv2.phaseCorrelate (numpy rfft2 / irfft2) that shares no code with the C oracle -- next to the
+    oracle's.  Both are restatements (cv2 is not installable here); what this pins is that the oracle's per-bin rules were not
+    mis-transcribed in a way a second transcription would not repeat."""
+    from PIL import Image
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as O
+    import phase_numpy as PN
+    from imagestitch_amd.utility import roi_rect
+    O.build()
+
+    def load(path):
+        im = Image.open(path); im.draft("L", im.size)
+        return np.asarray(im.convert("L"))
+    zdir = os.path.join(refshim.REF, "demoImages", "zirconCL", "1")
+    z = sorted(os.listdir(zdir))
+    store, rows = {}, []
+    tiles = [load(os.path.join(zdir, f)) for f in z]
+    H, W = tiles[0].shape
+    ra = roi_rect((H, W), 4, "first", 0.2); rb = roi_rect((H, W), 4, "second", 0.2)
+    for k, T in enumerate(tiles):
+        store["t%d_first" % k] = np.ascontiguousarray(T[ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]])
+        store["t%d_second" % k] = np.ascontiguousarray(T[rb[0]:rb[0] + rb[2], rb[1]:rb[1] + rb[3]])
+    cases = [("zirconCL", z[k], z[k + 1], store["t%d_first" % k], store["t%d_second" % (k + 1)]) for k in range(len(z) - 1)]
+    iron = np.load(os.path.join(OUT, "demo_strips.npz"))
+    cases.append(("iron", "1.jpg", "2.jpg", iron["d0_roiA"], iron["d0_roiB"]))
+    for ds, fa, fb, a, b in cases:
+        (ox, oy), orr = O.phase_correlate(a, b)
+        (nx, ny), nr, pk = PN.phase_correlate(a, b)
+        assert int(ox) == int(nx) and int(oy) == int(ny) and abs(ox - nx) < 1e-9 and abs(oy - ny) < 1e-9 and abs(orr - nr) < 1e-12, (ds, fa, ox, nx, oy, ny, orr, nr)
+        rows.append(dict(dataset=ds, a=fa, b=fb, roi=list(a.shape), numpy_xy=[float(nx), float(ny)], numpy_response=float(nr), peak=list(pk),
+                         oracle_xy=[ox, oy], oracle_response=orr, offset_int=[int(oy), int(ox)], accepted=bool(orr > 0.15)))
+        print(ds, fa, fb, a.shape, (nx, ny, nr), "|d|", abs(ox - nx), abs(oy - ny), abs(orr - nr))
+    np.savez_compressed(os.path.join(OUT, "zirconcl_strips.npz"), **store)
+    json.dump(dict(source="direction-4 ROI strips (roiRatio 0.2) of the reference's demoImages/zirconCL/1 tiles (Pillow draft-L decode), sorted by name; "
+                          "numpy_* = tests/phase_numpy.py, oracle_* = oracle/vfsms_oracle.c at capture time; offset_int = [int(y), int(x)] as "
+                          "Stitcher.py:231-232 truncates; accepted = response > phaseResponseThreshold 0.15 (Stitcher.py:30, 235)",
+                   roi_first=list(ra), roi_second=list(rb), shape=[H, W], tiles=z, rows=rows),
+              open(os.path.join(OUT, "phase_independent.json"), "w"), indent=1)
+    print("zirconCL strips", os.path.getsize(os.path.join(OUT, "zirconcl_strips.npz")) // 1024, "KiB; pairs", len(rows))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["roi", "mode", "sm", "cache", "fuse", "stitch", "flow", "real", "realpath", "demo"]
     fns = dict(roi=cap_roi, mode=cap_mode, sm=cap_state_machine, cache=cap_feature_search_cache,
-               fuse=cap_fuse, stitch=cap_stitch, flow=cap_flow, real=cap_real, realpath=cap_real_path, demo=cap_demo_strips)
+               fuse=cap_fuse, stitch=cap_stitch, flow=cap_flow, real=cap_real, realpath=cap_real_path, realpath_orb=cap_real_path_orb,
+               demo=cap_demo_strips, phase2=cap_phase_independent)
     for w in which:
         fns[w]()
