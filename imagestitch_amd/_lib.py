@@ -121,6 +121,11 @@ _SIGNATURES = {
                                                   C.c_int, C.c_int, C.c_void_p]),
     "vfsms_canvas_fuse_tile": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vfsms_canvas_fuse_tile_resident_m": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                    C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vfsms_canvas_fuse_tile_m": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vfsms_fuse_trig_i64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vfsms_canvas_download": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "vfsms_canvas_download_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "vfsms_tile_upload_ch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
@@ -411,6 +416,18 @@ class Engine:
         self._check(self.lib.vfsms_fuse_fade_i64(self.ctx, _ptr(A), _ptr(B), r, c, ch, int(dx), int(dy), _ptr(out), _ptr(info)))
         return (out, info) if return_info else out
 
+    def fuse_trig_i64(self, A, B, dx, dy, return_info=False):
+        """ImageFusion.fuseByTrigonometric on int64 regions (-1 = empty) -> uint8"""
+        A = np.ascontiguousarray(A, np.int64); B = np.ascontiguousarray(B, np.int64)
+        if A.shape != B.shape:
+            raise ValueError("fuse: shapes differ")
+        r, c = A.shape[:2]
+        ch = 1 if A.ndim == 2 else A.shape[2]
+        out = np.empty(A.shape, np.uint8)
+        info = np.zeros(4, np.int32)
+        self._check(self.lib.vfsms_fuse_trig_i64(self.ctx, _ptr(A), _ptr(B), r, c, ch, int(dx), int(dy), _ptr(out), _ptr(info)))
+        return (out, info) if return_info else out
+
     def fuse_ramps_i64(self, A, dx, dy, force_corner=False):
         """-> ((wA_r, wB_r, wA_c, wB_c), info): the separable float32 ramps of the fade blend / getWeightsMatrix."""
         A = np.ascontiguousarray(A, np.int64)
@@ -537,12 +554,13 @@ class Engine:
         tile = np.ascontiguousarray(tile, np.uint8)
         self._check(self.lib.vfsms_canvas_paste(self.ctx, C.c_int64(handle), _ptr(tile), tile.shape[0], tile.shape[1], int(y0), int(x0)))
 
-    def canvas_fuse_tile(self, handle, tile, y0, x0, roi, dx, dy):
+    def canvas_fuse_tile(self, handle, tile, y0, x0, roi, dx, dy, method=0):
+        """method 0: fadeInAndFadeOut, 1: trigonometric"""
         tile = np.ascontiguousarray(tile, np.uint8)
         info = np.zeros(4, np.int32)
         ry0, rx0, ry1, rx1 = [int(v) for v in roi]
-        self._check(self.lib.vfsms_canvas_fuse_tile(self.ctx, C.c_int64(handle), _ptr(tile), tile.shape[0], tile.shape[1],
-                                                    int(y0), int(x0), ry0, rx0, ry1, rx1, int(dx), int(dy), _ptr(info)))
+        self._check(self.lib.vfsms_canvas_fuse_tile_m(self.ctx, C.c_int64(handle), _ptr(tile), tile.shape[0], tile.shape[1],
+                                                      int(y0), int(x0), ry0, rx0, ry1, rx1, int(dx), int(dy), int(method), _ptr(info)))
         return info
 
     def canvas_blend_tile(self, handle, tile, y0, x0, roi, mode):
@@ -556,12 +574,12 @@ class Engine:
         """paste of a single-channel tile that is already resident in HBM (tile_upload handle)."""
         self._check(self.lib.vfsms_canvas_paste_tile(self.ctx, C.c_int64(handle), C.c_int64(tile_handle), int(y0), int(x0)))
 
-    def canvas_fuse_tile_resident(self, handle, tile_handle, y0, x0, roi, dx, dy, want_info=False):
-        """want_info=False: the call only enqueues work; geometry errors surface in canvas_download."""
+    def canvas_fuse_tile_resident(self, handle, tile_handle, y0, x0, roi, dx, dy, want_info=False, method=0):
+        """want_info=False: the call only enqueues work; geometry errors surface in canvas_download.  method 0: fadeInAndFadeOut, 1: trigonometric"""
         info = np.zeros(4, np.int32) if want_info else None
         ry0, rx0, ry1, rx1 = [int(v) for v in roi]
-        self._check(self.lib.vfsms_canvas_fuse_tile_resident(self.ctx, C.c_int64(handle), C.c_int64(tile_handle), int(y0), int(x0),
-                                                             ry0, rx0, ry1, rx1, int(dx), int(dy), _ptr(info) if want_info else None))
+        self._check(self.lib.vfsms_canvas_fuse_tile_resident_m(self.ctx, C.c_int64(handle), C.c_int64(tile_handle), int(y0), int(x0),
+                                                               ry0, rx0, ry1, rx1, int(dx), int(dy), int(method), _ptr(info) if want_info else None))
         return info
 
     def canvas_download(self, handle, rows, cols, ch):

@@ -7,7 +7,7 @@
 #include <algorithm>
 
 int fuse_i64_device(vfsms_ctx *ctx, const long long *dA, const long long *dB, int r, int c, int ch, int dx, int dy,
-                    uint8_t *d_out, int32_t *info);
+                    uint8_t *d_out, int32_t *info, int method = 0);
 
 // ---- errors -------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -1051,6 +1051,24 @@ extern "C" int vfsms_fuse_fade_i64(vfsms_ctx *ctx, const int64_t *A, const int64
     return VFSMS_OK;
 }
 
+// ImageFusion.fuseByTrigonometric (ImageFusion.py:246-293) on the reference's own array representation
+extern "C" int vfsms_fuse_trig_i64(vfsms_ctx *ctx, const int64_t *A, const int64_t *B, int r, int c, int ch,
+                                   int dx, int dy, uint8_t *out, int32_t *info)
+{
+    CTX_ENTER(ctx);
+    if (!A || !B || !out || r <= 0 || c <= 0 || ch < 1 || ch > 4) { vfsms_set_error("fuse_trig_i64: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    const size_t nel = (size_t)r * c * ch;
+    TRY(ctx_arena_reserve(ctx, nel * 17 + sizeof(float) * 4 * ((size_t)r + c) + sizeof(int) * 4 * ((size_t)r + c) + 65536));
+    long long *dA, *dB;
+    TRY(upload_array(ctx, (const long long *)A, nel, &dA));
+    TRY(upload_array(ctx, (const long long *)B, nel, &dB));
+    uint8_t *d_out = (uint8_t *)ctx_arena_alloc(ctx, nel);
+    TRY(fuse_i64_device(ctx, dA, dB, r, c, ch, dx, dy, d_out, info, 1));
+    HIP_TRY(hipMemcpyAsync(out, d_out, nel, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VFSMS_OK;
+}
+
 int fuse_i64_ramps(vfsms_ctx *ctx, const long long *dA, int r, int c, int ch, int dx, int dy, int force_corner,
                    float *h_ramps, int32_t *info);
 
@@ -1115,10 +1133,11 @@ extern "C" int vfsms_canvas_paste(vfsms_ctx *ctx, int64_t canvas, const uint8_t 
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return VFSMS_OK;
 }
-extern "C" int vfsms_canvas_fuse_tile(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w,
-                                      int y0, int x0, int ry0, int rx0, int ry1, int rx1, int dx, int dy, int32_t *info)
+extern "C" int vfsms_canvas_fuse_tile_m(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w,
+                                        int y0, int x0, int ry0, int rx0, int ry1, int rx1, int dx, int dy, int method, int32_t *info)
 {
     CTX_ENTER(ctx);
+    if (method < 0 || method > 1) { vfsms_set_error("canvas_fuse_tile: method must be 0 (fadeInAndFadeOut) or 1 (trigonometric)"); return VFSMS_ERR_BAD_ARG; }
     CanvasRec *cv;
     TRY(canvas_tile_args(ctx, canvas, tile, h, w, y0, x0, &cv));
     if (ry1 > ry0 && rx1 > rx0 && (ry0 < y0 || rx0 < x0 || ry1 > y0 + h || rx1 > x0 + w)) {
@@ -1129,9 +1148,14 @@ extern "C" int vfsms_canvas_fuse_tile(vfsms_ctx *ctx, int64_t canvas, const uint
     TRY(ctx_arena_reserve(ctx, nb + sizeof(float) * 8 * ((size_t)r + c) + 65536));
     uint8_t *d_tile;
     TRY(upload_array(ctx, tile, nb, &d_tile));
-    TRY(canvas_fuse_device(ctx, cv, d_tile, h, w, y0, x0, ry0, rx0, ry1, rx1, dx, dy, info));
+    TRY(canvas_fuse_device(ctx, cv, d_tile, h, w, y0, x0, ry0, rx0, ry1, rx1, dx, dy, info, method));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return VFSMS_OK;
+}
+extern "C" int vfsms_canvas_fuse_tile(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w,
+                                      int y0, int x0, int ry0, int rx0, int ry1, int rx1, int dx, int dy, int32_t *info)
+{
+    return vfsms_canvas_fuse_tile_m(ctx, canvas, tile, h, w, y0, x0, ry0, rx0, ry1, rx1, dx, dy, 0, info);
 }
 extern "C" int vfsms_canvas_blend_tile(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w,
                                        int y0, int x0, int ry0, int rx0, int ry1, int rx1, int mode)
@@ -1174,10 +1198,11 @@ extern "C" int vfsms_canvas_paste_tile(vfsms_ctx *ctx, int64_t canvas, int64_t t
     TRY(canvas_paste_device(ctx, cv, tr->ptr, tr->h, tr->w, y0, x0));
     return VFSMS_OK;                                       // enqueued only: resident tiles need no host synchronisation
 }
-extern "C" int vfsms_canvas_fuse_tile_resident(vfsms_ctx *ctx, int64_t canvas, int64_t tile,
-                                               int y0, int x0, int ry0, int rx0, int ry1, int rx1, int dx, int dy, int32_t *info)
+extern "C" int vfsms_canvas_fuse_tile_resident_m(vfsms_ctx *ctx, int64_t canvas, int64_t tile,
+                                                 int y0, int x0, int ry0, int rx0, int ry1, int rx1, int dx, int dy, int method, int32_t *info)
 {
     CTX_ENTER(ctx);
+    if (method < 0 || method > 1) { vfsms_set_error("canvas_fuse_tile: method must be 0 (fadeInAndFadeOut) or 1 (trigonometric)"); return VFSMS_ERR_BAD_ARG; }
     CanvasRec *cv; TileRec *tr;
     TRY(canvas_resident_args(ctx, canvas, tile, y0, x0, &cv, &tr));
     const int h = tr->h, w = tr->w;
@@ -1186,9 +1211,14 @@ extern "C" int vfsms_canvas_fuse_tile_resident(vfsms_ctx *ctx, int64_t canvas, i
     }
     const int r = std::max(ry1 - ry0, 0), c = std::max(rx1 - rx0, 0);
     TRY(ctx_arena_reserve(ctx, sizeof(float) * 8 * ((size_t)r + c) + 65536));
-    TRY(canvas_fuse_device(ctx, cv, tr->ptr, h, w, y0, x0, ry0, rx0, ry1, rx1, dx, dy, info));
+    TRY(canvas_fuse_device(ctx, cv, tr->ptr, h, w, y0, x0, ry0, rx0, ry1, rx1, dx, dy, info, method));
     if (info) HIP_TRY(hipStreamSynchronize(ctx->stream));   // without a readback the call only enqueues (stream order keeps the canvas consistent)
     return VFSMS_OK;
+}
+extern "C" int vfsms_canvas_fuse_tile_resident(vfsms_ctx *ctx, int64_t canvas, int64_t tile,
+                                               int y0, int x0, int ry0, int rx0, int ry1, int rx1, int dx, int dy, int32_t *info)
+{
+    return vfsms_canvas_fuse_tile_resident_m(ctx, canvas, tile, y0, x0, ry0, rx0, ry1, rx1, dx, dy, 0, info);
 }
 extern "C" int vfsms_canvas_download(vfsms_ctx *ctx, int64_t canvas, uint8_t *out)
 {

@@ -235,7 +235,7 @@ int enhance_carve(vfsms_ctx *ctx, EnhJob *J, const uint8_t *src, int stride, int
 int launch_enhance(vfsms_ctx *ctx, const EnhJob *d_jobs, const EnhJob *h_jobs, int n, int mode, double clip_limit, int tiles);
 // fuse_kernels.hip
 int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0,
-                       int ry0, int rx0, int ry1, int rx1, int dx, int dy, int32_t *info);
+                       int ry0, int rx0, int ry1, int rx1, int dx, int dy, int32_t *info, int method = 0);   // method 0 fadeInAndFadeOut, 1 trigonometric
 int canvas_blend_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0,
                         int ry0, int rx0, int ry1, int rx1, int mode);
 int canvas_paste_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0);

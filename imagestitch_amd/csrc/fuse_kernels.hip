@@ -10,6 +10,7 @@
 // reduction kernel; the ramp construction itself (a few hundred scalar ops with the reference's index
 // quirks) runs on the host.
 #include "common.h"
+#include "detmath.h"
 #include <vector>
 #include <string.h>
 
@@ -145,10 +146,38 @@ __device__ __forceinline__ uint8_t fade_px(float wA, float wB, bool av, int a0, 
     res = res > 255 ? 255 : res;
     return (uint8_t)res;                                               // np.uint8(): truncation
 }
+// ImageFusion.fuseByTrigonometric (ImageFusion.py:246-293): the same regions and geometry decisions as the fade, other weights:
+// wA = sin(w pi / 2)^2, wB = 1 - wA with w the float64 ramp i / n or (n - i) / n of the strip modes, or getWeightsMatrix's float32
+// 1 - wB1 wB2 in corner mode (numpy keeps float32 through `* math.pi / 2`, np.sin, np.power(., 2) and `1 -`).  sin is the explicit
+// double-precision algorithm of detmath.h (numpy's own SIMD sin may differ from it in the last ulp: tests allow one grey level on
+// < 0.1 % of the bytes).
+struct TrigGeom { int on, r, c, dx, dy; };
+__device__ __forceinline__ uint8_t trig_px(const TrigGeom &G, bool corner, int i, int j, float wbr, float wbc, bool av, int a0, int b)
+{
+    double wA, wB;
+    if (corner) {
+        const float wBf = wbr * wbc, wAf = 1.f - wBf;
+        const float x = (wAf * 3.14159274101257324f) / 2;
+        double sd, cd;
+        det_sincos((double)x, &sd, &cd);
+        const float s = (float)sd, wa = s * s, wb = 1.f - wa;
+        wA = (double)wa; wB = (double)wb;
+    } else {
+        const double t = G.c <= G.r ? (double)(G.dy >= 0 ? j : G.c - j) / (double)G.c : (double)(G.dx <= 0 ? i : G.r - i) / (double)G.r;
+        double sd, cd;
+        det_sincos((t * 3.141592653589793) / 2, &sd, &cd);
+        wA = sd * sd; wB = 1 - wA;
+    }
+    const int a = av ? a0 : b;                                         // imageA[imageA < 0] = imageB[imageA < 0]
+    double res = wA * (double)a + wB * (double)b;
+    res = res < 0 ? 0 : res;
+    res = res > 255 ? 255 : res;
+    return (uint8_t)res;
+}
 __global__ __launch_bounds__(256) void k_fuse_apply(uint8_t *pix, uint8_t *mask, int ccols, int ch,
                                                     const uint8_t *tile, int th, int tw, int y0, int x0,
                                                     int ry0, int rx0, int r, int c, const int *mode,
-                                                    const float *wAr, const float *wAc, const float *wBr, const float *wBc)
+                                                    const float *wAr, const float *wAc, const float *wBr, const float *wBc, TrigGeom TG)
 {
     const int y = blockIdx.y;
     const int cy = y0 + y;
@@ -175,10 +204,13 @@ __global__ __launch_bounds__(256) void k_fuse_apply(uint8_t *pix, uint8_t *mask,
                 const int b = (tb >> (8 * k)) & 0xff;
                 uint32_t o = (uint32_t)b;
                 if (k < nk && j >= 0 && j < c) {
-                    float wA, wB;
-                    if (corner) { wB = wbr * wBc[j]; wA = 1 - wB; }
-                    else { wA = war * wAc[j]; wB = wbr * wBc[j]; }
-                    o = fade_px(wA, wB, ((mb >> (8 * k)) & 0xff) != 0, (pb >> (8 * k)) & 0xff, b);
+                    if (TG.on) o = trig_px(TG, corner, i, j, wbr, wBc[j], ((mb >> (8 * k)) & 0xff) != 0, (pb >> (8 * k)) & 0xff, b);
+                    else {
+                        float wA, wB;
+                        if (corner) { wB = wbr * wBc[j]; wA = 1 - wB; }
+                        else { wA = war * wAc[j]; wB = wbr * wBc[j]; }
+                        o = fade_px(wA, wB, ((mb >> (8 * k)) & 0xff) != 0, (pb >> (8 * k)) & 0xff, b);
+                    }
                 }
                 ob |= o << (8 * k);
             }
@@ -199,7 +231,8 @@ __global__ __launch_bounds__(256) void k_fuse_apply(uint8_t *pix, uint8_t *mask,
         else { wA = wAr[i] * wAc[j]; wB = wBr[i] * wBc[j]; }
         const bool av = mask[co] != 0;
         for (int k = 0; k < ch; k++)
-            pix[co * ch + k] = fade_px(wA, wB, av, (int)pix[co * ch + k], tile[((size_t)y * tw + x) * ch + k]);
+            pix[co * ch + k] = TG.on ? trig_px(TG, corner, i, j, wBr[i], wBc[j], av, (int)pix[co * ch + k], tile[((size_t)y * tw + x) * ch + k])
+                                     : fade_px(wA, wB, av, (int)pix[co * ch + k], tile[((size_t)y * tw + x) * ch + k]);
     } else {
         for (int k = 0; k < ch; k++) pix[co * ch + k] = tile[((size_t)y * tw + x) * ch + k];
     }
@@ -262,7 +295,7 @@ __global__ __launch_bounds__(256) void k_i64_stats_cols(I64View V, int r, int c,
     colFirst[j] = first; colLast[j] = last;
 }
 __global__ __launch_bounds__(256) void k_i64_apply(I64View V, int r, int c, const int *mode, const float *wAr, const float *wAc,
-                                                   const float *wBr, const float *wBc, uint8_t *out)
+                                                   const float *wBr, const float *wBc, uint8_t *out, TrigGeom TG)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int i = blockIdx.y;
@@ -272,6 +305,10 @@ __global__ __launch_bounds__(256) void k_i64_apply(I64View V, int r, int c, cons
     else { wA = wAr[i] * wAc[j]; wB = wBr[i] * wBc[j]; }
     for (int k = 0; k < V.ch; k++) {
         long long a = V.a_raw(i, j, k), b = V.b_val(i, j, k);
+        if (TG.on) {                                   // (u8-valued inputs: the reference's regions hold -1 or grey levels)
+            out[((size_t)i * c + j) * V.ch + k] = trig_px(TG, mode[0] != 0, i, j, wBr[i], wBc[j], a >= 0, (int)a, (int)b);
+            continue;
+        }
         if (a < 0) a = b;
         double res = (double)wA * (double)a + (double)wB * (double)b;
         res = res < 0 ? 0 : res;
@@ -479,7 +516,7 @@ int canvas_paste_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, in
 }
 
 int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0,
-                       int ry0, int rx0, int ry1, int rx1, int dx, int dy, int32_t *info)
+                       int ry0, int rx0, int ry1, int rx1, int dx, int dy, int32_t *info, int method)
 {
     const int r = ry1 - ry0, c = rx1 - rx0;
     if (r <= 0 || c <= 0) return canvas_paste_device(ctx, cv, d_tile, h, w, y0, x0);
@@ -503,7 +540,7 @@ int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int
     hipLaunchKernelGGL(k_fuse_stats_cols, dim3((c + 1023) / 1024, (r + FUSE_CBAND - 1) / FUSE_CBAND), dim3(256), 0, ctx->stream, V, r, c, S.colFirst, S.colLast);
     TRY(launch_weights(ctx, S, r, c, cv->ch, dx, dy, 0, cv->d_err, 1, true));
     hipLaunchKernelGGL(k_fuse_apply, dim3(cv->ch == 1 ? (w + 1023) / 1024 : (w + 255) / 256, h), dim3(256), 0, ctx->stream, cv->pix, cv->mask, cv->cols, cv->ch,
-                       d_tile, h, w, y0, x0, ry0, rx0, r, c, S.out, S.wAr, S.wAc, S.wBr, S.wBc);
+                       d_tile, h, w, y0, x0, ry0, rx0, r, c, S.out, S.wAr, S.wAc, S.wBr, S.wBc, TrigGeom{method == 1, r, c, dx, dy});
     HIP_TRY(hipGetLastError());
     if (!info) return VFSMS_OK;          // no readback wanted: a degenerate geometry is latched in the canvas and reported by the download
     return finish_weights(ctx, S, r, c, info);
@@ -511,7 +548,7 @@ int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int
 
 // A, B: device int64 [r][c][ch]; out: device u8
 int fuse_i64_device(vfsms_ctx *ctx, const long long *dA, const long long *dB, int r, int c, int ch, int dx, int dy,
-                    uint8_t *d_out, int32_t *info)
+                    uint8_t *d_out, int32_t *info, int method)
 {
     FuseScratch S;
     TRY(fuse_scratch(ctx, r, c, &S));
@@ -521,7 +558,7 @@ int fuse_i64_device(vfsms_ctx *ctx, const long long *dA, const long long *dB, in
     hipLaunchKernelGGL(k_i64_stats_cols, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, V, r, c, S.colFirst, S.colLast);
     TRY(launch_weights(ctx, S, r, c, ch, dx, dy));
     hipLaunchKernelGGL(k_i64_apply, dim3((c + 255) / 256, r), dim3(256), 0, ctx->stream, V, r, c, S.out,
-                       S.wAr, S.wAc, S.wBr, S.wBc, d_out);
+                       S.wAr, S.wAc, S.wBr, S.wBc, d_out, TrigGeom{method == 1, r, c, dx, dy});
     HIP_TRY(hipGetLastError());
     return finish_weights(ctx, S, r, c, info);
 }

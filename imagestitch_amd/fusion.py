@@ -2,13 +2,10 @@
 (/root/reference/ImageFusion.py).  Regions are int64 arrays with -1 = empty, exactly what
 Stitcher.getStitchByOffset hands to fuseImage (Stitcher.py:434-436,475-483).
 
-On the hot path (north_star): fuseByFadeInAndFadeOut + getWeightsMatrix -> HIP (csrc/fuse_kernels.hip).
-fuseByAverage / Maximum / Minimum / Trigonometric are listed OUT OF SCOPE for kernels in SURVEY section 2
-(rows 7-8); as array operators they are kept as numpy one-liners so the `fuseMethod` switch keeps working.  (Inside
-Stitcher.getStitchByOffset the first three run on the device canvas: vfsms_canvas_blend_tile.)
+On the hot path (north_star): fuseByFadeInAndFadeOut + getWeightsMatrix -> HIP (csrc/fuse_kernels.hip); fuseByTrigonometric
+shares their kernels (scope row f-4).  fuseByAverage / Maximum / Minimum are numpy one-liners as array operators (inside
+Stitcher.getStitchByOffset they run on the device canvas: vfsms_canvas_blend_tile).
 """
-import math
-
 import numpy as np
 
 from . import utility as Utility
@@ -56,31 +53,17 @@ class ImageFusion(Utility.Method):
         weightMatB = weightMatB.astype(np.float32)
         return (np.float32(1) - weightMatB, weightMatB)
 
-    # ---- trigonometric re-weighting (ImageFusion.py:246-293; "next" row f-4 of the scope table) --------
+    # ---- trigonometric re-weighting (ImageFusion.py:246-293) --------------------------------------------
     def fuseByTrigonometric(self, images, dx, dy):
+        """wA = sin(w pi / 2)^2 of the fade's ramps (float64 i / n in the strip modes, getWeightsMatrix's float32 matrix in corner
+        mode), wB = 1 - wA, on the device (vfsms_fuse_trig_i64).  sin is the library's explicit double-precision routine; the
+        reference's bytes hang on numpy's own sin in the last ulp, so single grey levels may differ on < 0.1 % of the pixels.
+        Like the reference, empty pixels of imageA are filled from imageB IN PLACE."""
         (imageA, imageB) = images
-        row, col = imageA.shape[:2]
-        tail = (1,) * (imageA.ndim - 2)
-        if np.count_nonzero(imageA > -1) / imageA.size > 0.65:
-            weightMatA = np.ones(imageA.shape, dtype=np.float64)
-            if col <= row:
-                k = np.arange(col, dtype=np.float64)
-                ramp = (k if dy >= 0 else (col - k)) * 1.0 / col
-                weightMatA = weightMatA * ramp.reshape((1, col) + tail)
-            else:
-                k = np.arange(row, dtype=np.float64)
-                ramp = (k if dx <= 0 else (row - k)) * 1.0 / row
-                weightMatA = weightMatA * ramp.reshape((row, 1) + tail)
-        else:
-            weightMatA, _ = self.getWeightsMatrix(images)
-        weightMatA = np.power(np.sin(weightMatA * math.pi / 2), 2)
-        weightMatB = 1 - weightMatA
+        out = self.engine.fuse_trig_i64(imageA, imageB, dx, dy)
         hole = imageA < 0
         imageA[hole] = imageB[hole]
-        result = weightMatA * imageA.astype(np.int64) + weightMatB * imageB.astype(np.int64)
-        result[result < 0] = 0
-        result[result > 255] = 255
-        return np.uint8(result)
+        return out
 
     def fuseByMultiBandBlending(self, images):
         raise NotImplementedError("multi-band blending (ImageFusion.py:296-367) is outside the VFSMS hot path")

@@ -217,7 +217,7 @@ class Stitcher(Utility.Method):
                             phaseResponseThreshold=self.phaseResponseThreshold, window=24,
                             enhance=self._enhanceSpec() if method == "surf" else (0, 0.0, 0))
         reg.orbMaxDistance = self.orbMaxDistance if self.isGPUAvailable else -1
-        keep = (not self.isColorMode) and self.fuseMethod in ("notFuse", "fadeInAndFadeOut") and hasattr(eng, "canvas_fuse_tile_resident")
+        keep = (not self.isColorMode) and self.fuseMethod in ("notFuse", "fadeInAndFadeOut", "trigonometric") and hasattr(eng, "canvas_fuse_tile_resident")
         handles, pool, futures, failed = [], None, [], False
         try:
             if hasattr(eng, "tile_reserve"):
@@ -634,7 +634,8 @@ class Stitcher(Utility.Method):
         eng = self.engine
         # tiles the batched registration left in HBM (gray mosaics only): fused from where they are, no second decode / upload
         resident = self.__dict__.pop("_resident", None) or {}
-        device_fuse = self.fuseMethod in ("notFuse", "fadeInAndFadeOut")
+        device_fuse = self.fuseMethod in ("notFuse", "fadeInAndFadeOut", "trigonometric")
+        fmethod = 1 if self.fuseMethod == "trigonometric" else 0
         handles = None
         use_res = (not color) and device_fuse and all(fileList[i] in resident for i in range(n))
         try:
@@ -664,7 +665,7 @@ class Stitcher(Utility.Method):
             simple = {"average": 0, "maximum": 1, "minimum": 2}.get(self.fuseMethod)
             if simple is not None and not hasattr(eng, "canvas_blend_tile"):
                 simple = None
-            if self.fuseMethod not in ("notFuse", "fadeInAndFadeOut") and simple is None:
+            if not device_fuse and simple is None:
                 return self._stitchWithHostFuse(fileList, imageList, originOffsetList, offsetList, rangeX, rangeY, resultRow, resultCol)
             ch = 3 if color else 1
             canvas = eng.canvas_create(resultRow, resultCol, ch)
@@ -684,9 +685,9 @@ class Stitcher(Utility.Method):
                     if simple is not None:
                         eng.canvas_blend_tile(canvas, imageList[i], oy, ox, roi, simple)
                     elif use_res:
-                        eng.canvas_fuse_tile_resident(canvas, handles[i], oy, ox, roi, originOffsetList[i][0], originOffsetList[i][1])
+                        eng.canvas_fuse_tile_resident(canvas, handles[i], oy, ox, roi, originOffsetList[i][0], originOffsetList[i][1], method=fmethod)
                     else:
-                        eng.canvas_fuse_tile(canvas, imageList[i], oy, ox, roi, originOffsetList[i][0], originOffsetList[i][1])
+                        eng.canvas_fuse_tile(canvas, imageList[i], oy, ox, roi, originOffsetList[i][0], originOffsetList[i][1], method=fmethod)
                 sink = getattr(self, "mosaicSink", None)
                 if sink is not None and hasattr(eng, "canvas_download_bands"):
                     # streamed write-out: the mosaic leaves the device band by band and is never whole in host memory
@@ -703,8 +704,8 @@ class Stitcher(Utility.Method):
                 eng.tile_free(h)
 
     def _stitchWithHostFuse(self, fileList, imageList, originOffsetList, offsetList, rangeX, rangeY, resultRow, resultCol):
-        """average / maximum / minimum / trigonometric: outside the accelerated scope (SURVEY section 2 rows 7-8);
-        same int64 / -1 canvas walk as Stitcher.py:434-486, blend through self.fuseImage."""
+        """Fallback for engines without the canvas blend entry points (the CPU test doubles): same int64 / -1 canvas walk as
+        Stitcher.py:434-486, blend through self.fuseImage."""
         color = self.isColorMode
         shape = (resultRow, resultCol, 3) if color else (resultRow, resultCol)
         stitchResult = np.zeros(shape, np.int64) - 1

@@ -173,6 +173,11 @@ int vfsms_phase_correlate_u8(vfsms_ctx *ctx, const uint8_t *a, const uint8_t *b,
  * info (optional, 4 ints) = {mode 0 strip / 1 corner, corner index, rowIndex, colIndex}.           */
 int vfsms_fuse_fade_i64(vfsms_ctx *ctx, const int64_t *A, const int64_t *B, int r, int c, int ch,
                         int dx, int dy, uint8_t *out, int32_t *info);
+/* ImageFusion.fuseByTrigonometric([A,B],dx,dy) (ImageFusion.py:246-293), same representation and geometry decisions, weights
+ * sin(w pi / 2)^2 of the float64 strip ramps / of getWeightsMatrix's float32 matrix.  The bytes hang on numpy's own sin in the
+ * last ulp (where A == B the truncated result sits on an integer): equal to the reference on > 99.9 % of the bytes, |diff| <= 1.  */
+int vfsms_fuse_trig_i64(vfsms_ctx *ctx, const int64_t *A, const int64_t *B, int r, int c, int ch,
+                        int dx, int dy, uint8_t *out, int32_t *info);
 
 /* The separable float32 ramps behind that blend, without blending: ramps = [wA_r(r) | wB_r(r) | wA_c(c) | wB_c(c)].
  * force_corner != 0 -> ImageFusion.getWeightsMatrix (ImageFusion.py:43-190): weightMatB = wB_r x wB_c,
@@ -262,6 +267,10 @@ int vfsms_canvas_paste(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int 
 int vfsms_canvas_fuse_tile(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w,
                            int y0, int x0, int ry0, int rx0, int ry1, int rx1,
                            int dx, int dy, int32_t *info);
+/* the same with the blend chosen by `method`: 0 fadeInAndFadeOut, 1 trigonometric (Stitcher.fuseImage, Stitcher.py:488-525)  */
+int vfsms_canvas_fuse_tile_m(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w,
+                             int y0, int x0, int ry0, int rx0, int ry1, int rx1,
+                             int dx, int dy, int method, int32_t *info);
 /* paste + element-wise blend of the ROI for fuseMethod "average" / "maximum" / "minimum" (mode 0 / 1 / 2): ImageFusion.py:12-41
  * behind the zero / empty filling of Stitcher.fuseImage (Stitcher.py:498-504).                                              */
 int vfsms_canvas_blend_tile(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w,
@@ -275,6 +284,9 @@ int vfsms_canvas_paste_tile(vfsms_ctx *ctx, int64_t canvas, int64_t tile, int y0
 int vfsms_canvas_fuse_tile_resident(vfsms_ctx *ctx, int64_t canvas, int64_t tile,
                                     int y0, int x0, int ry0, int rx0, int ry1, int rx1,
                                     int dx, int dy, int32_t *info);
+int vfsms_canvas_fuse_tile_resident_m(vfsms_ctx *ctx, int64_t canvas, int64_t tile,
+                                      int y0, int x0, int ry0, int rx0, int ry1, int rx1,
+                                      int dx, int dy, int method, int32_t *info);
 /* final image: empty -> 0 (Stitcher.py:485-486).  out: u8 [rows][cols][ch]                           */
 int vfsms_canvas_download(vfsms_ctx *ctx, int64_t canvas, uint8_t *out);
 /* rows [row0, row0 + nrows) of the same image: a multi-GB mosaic leaves the device band by band and can be handed to an

@@ -66,7 +66,34 @@ class OracleEngine:
     def canvas_paste(self, h, tile, y0, x0):
         self._canvases[h][y0:y0 + tile.shape[0], x0:x0 + tile.shape[1]] = tile
 
-    def canvas_fuse_tile(self, h, tile, y0, x0, roi, dx, dy):
+    def fuse_trig_i64(self, A, B, dx, dy, return_info=False):
+        """ImageFusion.fuseByTrigonometric (ImageFusion.py:246-293) in numpy, as the reference evaluates it (CPU test double)."""
+        import math
+        imageA = np.array(A, np.int64); imageB = np.asarray(B, np.int64)
+        row, col = imageA.shape[:2]
+        tail = (1,) * (imageA.ndim - 2)
+        if np.count_nonzero(imageA > -1) / imageA.size > 0.65:
+            weightMatA = np.ones(imageA.shape, dtype=np.float64)
+            if col <= row:
+                k = np.arange(col, dtype=np.float64)
+                weightMatA = weightMatA * ((k if dy >= 0 else (col - k)) * 1.0 / col).reshape((1, col) + tail)
+            else:
+                k = np.arange(row, dtype=np.float64)
+                weightMatA = weightMatA * ((k if dx <= 0 else (row - k)) * 1.0 / row).reshape((row, 1) + tail)
+        else:
+            wr, wc, _info = self.O.corner_ramps(imageA)
+            wB = (wr.reshape((row, 1) + tail) * wc.reshape((1, col) + tail)).astype(np.float32) * np.ones(imageA.shape, np.float32)
+            weightMatA = np.float32(1) - wB
+        weightMatA = np.power(np.sin(weightMatA * math.pi / 2), 2)
+        weightMatB = 1 - weightMatA
+        hole = imageA < 0
+        imageA[hole] = imageB[hole]
+        result = weightMatA * imageA + weightMatB * imageB
+        result[result < 0] = 0
+        result[result > 255] = 255
+        return np.uint8(result)
+
+    def canvas_fuse_tile(self, h, tile, y0, x0, roi, dx, dy, method=0):
         cv = self._canvases[h]
         ry0, rx0, ry1, rx1 = roi
         A = cv[ry0:ry1, rx0:rx1].copy()
@@ -74,7 +101,7 @@ class OracleEngine:
         B = cv[ry0:ry1, rx0:rx1].copy()
         self.fuse_calls.append((A.shape, dx, dy))
         if A.size:
-            cv[ry0:ry1, rx0:rx1] = self.O.fuse_fade(A, B, dx, dy)
+            cv[ry0:ry1, rx0:rx1] = self.fuse_trig_i64(A, B, dx, dy) if method == 1 else self.O.fuse_fade(A, B, dx, dy)
 
     def canvas_download(self, h, rows, cols, ch):
         cv = self._canvases[h].copy()
