@@ -19,6 +19,8 @@ tables closes the step ("strong" scaling: total work is fixed).  Prints ONE JSON
 
 --method orb | phase | fuse time the other paths of the scope table on the same grid (each with its own roofline object);
 the default, surf, is the BASELINE metric.
+--workload dendritic25 (N = 1): the 25 committed pairs of the reference's dendriticCrystal set (tests/golden/real_path_strips.*), a second
+SURF line on real texture.  --from-files (N = 1): the same grid as JPEG files through Stitcher's ingest pipeline, decode inclusive.
 """
 import argparse
 import json
@@ -42,6 +44,11 @@ VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # 2 v_fma_f64, 2 v_cvt_i32_f64, 2 address, 2 v_fract_f64, 2 v_cvt_f32_f64, 2 v_sub, 4 v_cvt_f32_ubyte, 4 v_pk_mul (+2 moves), 3 v_add,
 # v_rndne, v_cvt, LDS address) -- the ALGORITHMIC work of one sample as this kernel formulates it
 DESC_VALU_PER_SAMPLE = 30
+# An op count that does not depend on how the kernel is written: the arithmetic the REFERENCE's expression needs per window sample
+# (SURFInvoker: pixel_x += cos, pixel_y -= sin (2), two floors (2), two (float)(p - i) (2), four u8 -> float (4), 1 - a, 1 - b (2),
+# eight products (8), three sums (3), cvRound (1)) = 24, + resize(INTER_AREA)'s multiply-add per window pixel (2) = 26 lane-ops.
+# valu_insts_issued / (samples x 26 / 64) says how far the kernels are from that floor.
+DESC_OPS_LOWER_BOUND = 26
 MIN_WARM_S = float(os.environ.get("VFSMS_BENCH_MIN_WARM", "1.5"))     # 0 under rocprofv3 --pmc (serialised kernels make every step slow)
 
 
@@ -167,6 +174,168 @@ def bench_fuse(args, eng, grid, tiles, handles, torch):
     eng.close()
 
 
+def _jsonline(d):
+    print(json.dumps(d))
+
+
+def bench_dendritic25(args, eng, torch):
+    """Second SURF line: the 25 committed pairs of the reference's dendriticCrystal set (five 6-tile neighbourhoods around the serpentine
+    turns, tests/golden/real_path_strips.*: 1936 x 2584 frames rebuilt around the 640-px crops of the ROI strips the accepted attempts
+    read).  Real dendrite texture carries ~1.6x the SURF keypoints per pixel of the synthetic grid, so BF work per attempt is what
+    configs[1] really costs.  One step = all five neighbourhoods through GridRegistrar (direction threaded inside each)."""
+    import imagestitch_amd as isa
+    from imagestitch_amd.grid import GridRegistrar
+    if args.gpus != 1 or args.method != "surf":
+        raise SystemExit("--workload dendritic25 is a single-GPU SURF measurement")
+    gd = os.path.join(ROOT, "tests", "golden")
+    meta = json.load(open(os.path.join(gd, "real_path_strips.json")))["neighbourhoods"]
+    z = np.load(os.path.join(gd, "real_path_strips.npz"))
+    nbs = []
+    for nb in meta:
+        H, W = nb["shape"]
+        frames = {t: np.zeros((H, W), np.uint8) for t in nb["tiles"]}
+        for s_ in nb["strips"]:
+            a = z[s_["key"]]
+            frames[s_["tile"]][s_["y0"]:s_["y0"] + a.shape[0], s_["x0"]:s_["x0"] + a.shape[1]] = a
+        fr = [frames[t] for t in nb["tiles"]]
+        nbs.append(dict(nb=nb, hs=[eng.tile_upload(f) for f in fr], shapes=[f.shape for f in fr]))
+    reg = GridRegistrar(eng, method="surf", roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3, directIncre=1, surfParams=eng.surf_params(), window=args.window)
+
+    def step():
+        return [reg.register(n["hs"], n["shapes"], n["nb"]["incoming_direction"])[0] for n in nbs]
+    tables = step()
+    worst = 0
+    for n, tb in zip(nbs, tables):
+        for row, e in zip(tb, n["nb"]["expected"]):
+            assert row[0] == 1 and [int(row[1]), int(row[2])] == e["offset"], (e, row)
+            worst = max(worst, abs(int(row[1]) - e["gold"][0]), abs(int(row[2]) - e["gold"][1]))
+    t_w = time.perf_counter()
+    warm_extra = 0
+    for _ in range(args.warmup):
+        step()
+    while time.perf_counter() - t_w < MIN_WARM_S and warm_extra < 400:
+        step(); warm_extra += 1
+    for k in reg.stats:
+        reg.stats[k] = 0
+    eng.profile_enable(True); eng.profile_read(reset=True)
+    torch.cuda.synchronize(); eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(); eng.sync()
+    dt = (time.perf_counter() - t0) / args.steps
+    prof = eng.profile_read(reset=True); eng.profile_enable(False)
+    st = dict(reg.stats)
+    stages = {k: dict(ms=round(v[0], 3), launches=v[1], ms_per_launch=round(v[0] / max(v[1], 1), 4)) for k, v in prof.items()}
+    P = 25
+    bf_ms, bf_n = prof.get("bf_mfma", (0.0, 0))
+    de_ms, de_n = prof.get("describe", (0.0, 0))
+    roof = None
+    if bf_n:
+        dur = bf_ms / bf_n * 1e-3
+        flops = 2.0 * 64 * st["sum_nq_nt"] / bf_n
+        roof = dict(kernel="k_bf_split16+k_bf_mfma16_d64", bound="mfma", achieved=round(flops / dur / 1e12, 3), peak=BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(flops / dur / 1e12 / BF16_PEAK_TFLOPS, 4), traffic=None, avg_launch_ms=round(dur * 1e3, 4), flops_per_launch=flops, launches=bf_n,
+                    note="the BF filter at the real keypoint density (the describe stage is reported under stages; its roofline is the grid workload's)")
+    _jsonline({"metric": "image-pairs/sec (dendriticCrystal neighbourhoods, SURF+BF)", "value": round(P / dt, 3), "unit": "image-pairs/s", "n_gpus": 1,
+               "steps": args.steps, "warmup": args.warmup, "warmup_extra_steps_until_1p5s": warm_extra, "ms_per_step": round(dt * 1e3, 3),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "real (committed crops of the reference's demo tiles)",
+               "config": {"workload": "the 25 committed pairs of demoImages/dendriticCrystal (5 neighbourhoods x 6 tiles of 1936x2584, 640-px crops of the "
+                                      "accepted ROI strips in zero frames); SURF(100,4,3,64-d)+BF-L2 knn2 ratio 0.75 + mode vote; roiRatio 0.2, offsetEvaluate 3, directIncre 1",
+                          "pairs": P, "parallelism": "pairs1"},
+               "max_abs_offset_error_px_vs_stitcher_py_87": worst, "rows_equal_oracle": True,
+               "attempts_per_step": st["attempts"] / max(args.steps, 1), "batches_per_step": st["batches"] / max(args.steps, 1),
+               "keypoints_per_roi": round(st["sum_nq_plus_nt"] / max(2 * st["attempts"], 1), 1),
+               "keypoints_per_kpx_of_textured_roi": round(st["sum_nq_plus_nt"] / max(2 * st["attempts"], 1) / (640 * 387 / 1000.0), 2),
+               "roofline": roof, "cpu_baseline": None, "stages": stages})
+    eng.close()
+
+
+def bench_from_files(args, eng, grid, torch):
+    """Decode-inclusive registration (scope row f-1): the grid's tiles as JPEG files on disk, registered through the Stitcher's own
+    entry (Stitcher._registerBatched: device handles reserved up front, a pool of decoder threads fills them while the native registrar
+    already works on the first pairs).  Reported beside the decode-only rate of the same pool and the resident-tiles registration rate:
+    the pipeline is good when end-to-end is close to the slower of the two."""
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    import imagestitch_amd as isa
+    from imagestitch_amd import stitcher as ST
+    if args.gpus != 1 or args.method != "surf":
+        raise SystemExit("--from-files is a single-GPU SURF measurement")
+    nthreads = max(1, min(args.decode_threads or min(os.cpu_count() or 4, 16), grid.n_tiles, 64))
+    with tempfile.TemporaryDirectory(prefix="vfsms_bench_") as d:
+        files = []
+        for k, t in enumerate(grid.tiles(range(grid.n_tiles), threads=min(8, os.cpu_count() or 1))):
+            f = os.path.join(d, "tile_%03d.jpg" % k)
+            Image.fromarray(t).save(f, quality=90)
+            files.append(f)
+        mb = sum(os.path.getsize(f) for f in files) / 1e6
+        s = isa.Stitcher(); s._engine = eng; s.isPrintLog = False
+        old = (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate,
+               isa.Stitcher.isColorMode, isa.Stitcher.fuseMethod)
+        isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate = 1, 0.2, "surf", args.offset_evaluate
+        isa.Stitcher.isColorMode, isa.Stitcher.fuseMethod = True, "notFuse"      # (colour mosaics: the registration tiles are not kept for the canvas)
+        s.decodeThreads = nthreads
+        truth = grid.true_offsets()
+
+        def e2e():
+            s.direction = 1
+            return s._registerBatched(files, s.calculateOffsetForFeatureSearchIncre)
+        try:
+            status, end, offs, _desc = e2e()
+            assert status and end == grid.n_pairs, (status, end)
+            worst = max(max(abs(o[0] - t_[0]), abs(o[1] - t_[1])) for o, t_ in zip(offs, truth))
+            for _ in range(max(args.warmup, 1)):
+                e2e()
+            torch.cuda.synchronize(); eng.sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                e2e()
+            torch.cuda.synchronize(); eng.sync()
+            dt = (time.perf_counter() - t0) / args.steps
+            # decode only, same pool size
+            with ThreadPoolExecutor(max_workers=nthreads) as ex:
+                t0 = time.perf_counter()
+                list(ex.map(lambda f: ST._imread_gray_pointer(f)[2], files))
+                dt_dec = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            ST._imread(files[0], False)
+            dt_one = time.perf_counter() - t0
+            # registration only (tiles resident)
+            from imagestitch_amd.grid import GridRegistrar
+            hs = [eng.tile_upload(ST._imread(f, False)) for f in files]
+            reg = GridRegistrar(eng, method="surf", roiRatio=0.2, searchRatio=0.75, offsetEvaluate=args.offset_evaluate, directIncre=1,
+                                surfParams=eng.surf_params(), window=24)
+            shapes = [(grid.th, grid.tw)] * grid.n_tiles
+            reg.register(hs, shapes, 1)
+            eng.sync(); t0 = time.perf_counter()
+            for _ in range(args.steps):
+                reg.register(hs, shapes, 1)
+            eng.sync()
+            dt_reg = (time.perf_counter() - t0) / args.steps
+            for h in hs:
+                eng.tile_free(h)
+        finally:
+            (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate,
+             isa.Stitcher.isColorMode, isa.Stitcher.fuseMethod) = old
+    P = grid.n_pairs
+    slower = max(dt_dec, dt_reg)
+    _jsonline({"metric": "image-pairs/sec, decode inclusive (2048x2048 grayscale JPEG files, SURF+BF)", "value": round(P / dt, 3), "unit": "image-pairs/s",
+               "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic (JPEG quality 90 on local disk, %.0f MB for %d tiles)" % (mb, grid.n_tiles),
+               "config": {"workload": "synthetic %dx%d grid of %dx%d tiles as JPEG files -> Stitcher ingest pipeline (vfsms_tile_reserve / vfsms_tile_fill, "
+                                      "%d decoder threads) -> native registrar; SURF+BF-L2+mode as the default workload" % (args.rows, args.cols, args.tile, args.tile, nthreads),
+                          "pairs": P, "decode_threads": nthreads, "host_cores": os.cpu_count()},
+               "max_abs_offset_error_px": int(worst),
+               "decode_only_ms_per_step": round(dt_dec * 1e3, 2), "decode_only_tiles_per_s": round(grid.n_tiles / dt_dec, 1),
+               "decode_one_tile_one_thread_ms": round(dt_one * 1e3, 2),
+               "registration_only_ms_per_step": round(dt_reg * 1e3, 2), "registration_only_pairs_per_s": round(P / dt_reg, 1),
+               "end_to_end_over_slower_stage": round(dt / slower, 3),
+               "roofline": None, "cpu_baseline": None})
+    eng.close()
+
+
 def cpu_baseline_surf(args, grid, tiles, isa):
     """The oracle (a port: cv2 is not installable) on a bounded sample of the same grid, built -O3 -march=native ON this box
     (oracle/Makefile `native`): single-thread row and all-host-threads row.  One ROI attempt per pair at the true
@@ -191,12 +360,20 @@ def cpu_baseline_surf(args, grid, tiles, isa):
             pr = O.bf_l2_ratio_matches(da, db, 0.75, nthreads=nthreads)
             O.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pr, 3)
         return time.perf_counter() - t1
-    dt_all = run(range(S), cores)
+    # all-cores row: ONE PAIR PER THREAD (the pairs are independent -- what a multi-process CPU deployment of the reference would do);
+    # OpenMP inside a pair barely scales (1.9x on 256 threads), so that is not the fair all-cores number
+    from concurrent.futures import ThreadPoolExecutor
+    n_par = min(grid.n_pairs, max(cores, 1))
+    pair_ids = [k % len(tiles) for k in range(n_par)] if not isinstance(tiles, dict) else [k for k in sorted(tiles) if k + 1 in tiles][:n_par]
+    t1 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=min(cores, len(pair_ids))) as ex:
+        list(ex.map(lambda k: run([k], 1), pair_ids))
+    dt_all = time.perf_counter() - t1
     S1 = max(1, min(S, 6))
-    dt_one = run(range(S1), 1)
-    return dict(value=round(S / dt_all, 4), unit="image-pairs/s", cores=cores, kind="port",
-                sample="first %d pairs of the same grid, one ROI attempt each at the true direction (oracle SURF+BF-L2+mode built -O3 "
-                       "-march=native here, OpenMP over %d threads), %.1f s" % (S, cores, dt_all),
+    dt_one = run(pair_ids[:S1], 1)
+    return dict(value=round(len(pair_ids) / dt_all, 4), unit="image-pairs/s", cores=min(cores, len(pair_ids)), kind="port",
+                sample="%d pairs of the same grid, one pair per host thread (%d threads of %d), one ROI attempt each at the true direction (oracle "
+                       "SURF+BF-L2+mode built -O3 -march=native here), %.1f s" % (len(pair_ids), min(cores, len(pair_ids)), cores, dt_all),
                 single_thread=dict(value=round(S1 / dt_one, 4), cores=1, sample="first %d pair(s), %.1f s" % (S1, dt_one)),
                 build=O.build_kind())
 
@@ -217,6 +394,10 @@ def main():
     ap.add_argument("--offset-evaluate", type=int, default=3, help="Method.offsetEvaluate (Main.py:12: 3)")
     ap.add_argument("--cpu-sample", type=int, default=12, help="pairs timed on the host cores for cpu_baseline (0 = skip)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-resident-tiles measurement")
+    ap.add_argument("--workload", default="grid", choices=["grid", "dendritic25"],
+                    help="grid = the synthetic serpentine grid (BASELINE metric); dendritic25 = the 25 committed real pairs (N = 1, surf)")
+    ap.add_argument("--from-files", action="store_true", help="N = 1: JPEG tiles on disk through Stitcher's ingest pipeline (decode inclusive)")
+    ap.add_argument("--decode-threads", type=int, default=0, help="decoder threads of --from-files (0 = one per host core, at most 64)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -245,7 +426,11 @@ def main():
     from imagestitch_amd.synthetic import SyntheticGrid
 
     eng = isa.Engine(local_rank)
+    if args.workload == "dendritic25":
+        return bench_dendritic25(args, eng, torch)
     grid = SyntheticGrid(args.rows, args.cols, args.tile, overlap=args.overlap)
+    if args.from_files:
+        return bench_from_files(args, eng, grid, torch)
     P = grid.n_pairs
     truth = np.array(grid.true_offsets(), np.int64)
     bounds = GridRegistrar.chunk_bounds(P, world)
@@ -386,7 +571,11 @@ def main():
                              "instructions k_describe issues (PMC SQ_INSTS_VALU, profiles/) keep its SIMDs busy for valu_busy_frac_pmc of the "
                              "launch (lane padding of 8 x 32-sample units, INTER_AREA reduction, row-origin chains, tickets)"
                              % (100.0 * de_ms / max(sum(v[0] for v in prof.values()), 1e-9)),
-                        valu_insts_per_launch_pmc=valu_insts, valu_busy_frac_pmc=valu_busy)
+                        valu_insts_per_launch_pmc=valu_insts, valu_busy_frac_pmc=valu_busy,
+                        ops_per_sample_lower_bound=DESC_OPS_LOWER_BOUND,
+                        valu_insts_lower_bound_per_launch=round(kps * spk * DESC_OPS_LOWER_BOUND / 64.0),
+                        valu_issued_over_lower_bound=(round((valu_insts + (pmc_value("k_describe_small", "INSTS_VALU")[0] or 0.0)) /
+                                                            (kps * spk * DESC_OPS_LOWER_BOUND / 64.0), 3) if valu_insts and kps * spk > 0 else None))
     bf_ms, bf_n = prof.get("bf_mfma", (0.0, 0))
     if bf_n:
         dur = bf_ms / bf_n * 1e-3
@@ -473,7 +662,19 @@ def main():
             "cpu_baseline": cpu,
             "stages": stages,
             "per_rank": per_rank,
+            "collective": (dict(backend=dist.get_backend(), world_size=dist.get_world_size(), device=str(coll_device),
+                                op="one all_gather of the int32 offset tables per step") if dist is not None else None),
         }
+        if args.method == "orb" and max_err > 1:
+            out["note"] = ("max_abs_offset_error_px is the reference's own ORB search at offsetEvaluate = %d: every query votes (no ratio test, no "
+                           "distance threshold, ImageUtility.py:297-302), so a wrong candidate direction now and then collects %d equal votes and "
+                           "is ACCEPTED (on the reference's real tiles too: tests/golden/dendritic_path_oracle_orb.json, 15 of 87 pairs); the engine "
+                           "takes the oracle's decisions one for one (tests: test_orb_grid_at_offset_evaluate_3_equals_oracle_chain); with "
+                           "--offset-evaluate 10 every offset equals the ground truth" % (args.offset_evaluate, args.offset_evaluate))
+        if args.method == "phase" and max_err > 1:
+            out["note"] = ("max_abs_offset_error_px is the reference as written: cv2.phaseCorrelate returns the shift of B's content relative to A's "
+                           "and Stitcher.py:244-251 adds it with the sign of the feature path (SURVEY 8a-G; configs[0] gives [1400, 0] where the "
+                           "true offset is ~[1699, -1]); parity target = the reference's arithmetic, phaseSignFix is the opt-in correction")
         out.update(extra)
         print(json.dumps(out))
     if dist is not None:

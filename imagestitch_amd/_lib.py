@@ -249,6 +249,10 @@ class Engine:
         assert img.dtype == np.uint8 and img.ndim == 2 and img.strides[1] == 1
         self._check(self.lib.vfsms_tile_fill(self.ctx, C.c_int64(handle), _ptr(img), img.strides[0]))
 
+    def tile_fill_ptr(self, handle, address, stride):
+        """tile_fill from a raw host address (rows `stride` bytes apart); the caller keeps the memory alive until this returns"""
+        self._check(self.lib.vfsms_tile_fill(self.ctx, C.c_int64(handle), C.c_void_p(address), int(stride)))
+
     def tile_upload_async(self, img):
         """Upload without waiting: the copy overlaps the compute stream; `img` must stay alive and unchanged until sync() or
         the first synchronous call that used the tile (arrays from pinned_empty() make the copy a true asynchronous DMA)."""
