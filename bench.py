@@ -251,6 +251,64 @@ def bench_dendritic25(args, eng, torch):
     eng.close()
 
 
+def bench_line_scan(args, eng, torch):
+    """The path 4 of the reference's 6 demo datasets take (Main.py:29-51): calculateOffsetForFeatureSearch over a line scan of 24 tiles of
+    1024 x 1280 (zirconCL's geometry; synthetic texture with a burned-in data bar): whole-tile SURF, B -> A feature reuse.  Two numbers:
+    the pair-by-pair loop through the reference's call surface (one launch sequence + two host synchronisations per tile) and the
+    batched form flowStitch uses (16 tiles per fused launch sequence, all matches in one batch)."""
+    import imagestitch_amd as isa
+    from imagestitch_amd.synthetic import line_scan
+    if args.gpus != 1:
+        raise SystemExit("--method surf_full is a single-GPU measurement")
+    tiles, truth = line_scan(n=24)
+    P = len(tiles) - 1
+    old = (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate, isa.Stitcher.isEnhance)
+    isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate, isa.Stitcher.isEnhance = 4, 0, "surf", 3, False
+    try:
+        s = isa.Stitcher(); s._engine = eng; s.isPrintLog = False
+        hs = [eng.tile_upload(t) for t in tiles]
+
+        def loop():
+            s.tempImageFeature.isBreak = True
+            out = [s.calculateOffsetForFeatureSearch([tiles[k], tiles[k + 1]]) for k in range(P)]
+            s.releaseTiles()
+            return out
+
+        def batched():
+            return s._fullImageTable(hs)
+        want = loop(); got = batched()
+        assert all(w[0] for w in want) and [[r[1], r[2]] for r in got] == [w[1] for w in want]
+        worst = max(max(abs(r[1] - t_[0]), abs(r[2] - t_[1])) for r, t_ in zip(got, truth))
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < MIN_WARM_S:
+            batched()
+        eng.profile_enable(True); eng.profile_read(reset=True)
+        torch.cuda.synchronize(); eng.sync(); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            batched()
+        torch.cuda.synchronize(); eng.sync()
+        dt = (time.perf_counter() - t0) / args.steps
+        prof = eng.profile_read(reset=True); eng.profile_enable(False)
+        loop(); eng.sync(); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loop()
+        eng.sync()
+        dt_loop = (time.perf_counter() - t0) / args.steps
+    finally:
+        isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate, isa.Stitcher.isEnhance = old
+    stages = {k: dict(ms=round(v[0], 3), launches=v[1], ms_per_launch=round(v[0] / max(v[1], 1), 4)) for k, v in prof.items()}
+    _jsonline({"metric": "image-pairs/sec (1024x1280 line scan, whole-tile SURF+BF, feature reuse)", "value": round(P / dt, 3), "unit": "image-pairs/s", "n_gpus": 1,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "24-tile line scan of 1024x1280 u8 tiles (20 % overlap, burned-in data bar), calculateOffsetForFeatureSearch: whole-tile "
+                                      "SURF(100,4,3,64-d), every tile described once, BF-L2 knn2 ratio 0.75 + mode vote; batched: 16 tiles per launch sequence, 23 matches in one batch",
+                          "pairs": P, "parallelism": "pairs1"},
+               "max_abs_offset_error_px": int(worst),
+               "pair_by_pair_loop_pairs_per_s": round(P / dt_loop, 3), "pair_by_pair_loop_ms_per_step": round(dt_loop * 1e3, 3),
+               "batched_over_loop": round(dt_loop / dt, 2), "roofline": None, "cpu_baseline": None, "stages": stages})
+    eng.close()
+
+
 def bench_from_files(args, eng, grid, torch):
     """Decode-inclusive registration (scope row f-1): the grid's tiles as JPEG files on disk, registered through the Stitcher's own
     entry (Stitcher._registerBatched: device handles reserved up front, a pool of decoder threads fills them while the native registrar
@@ -387,7 +445,7 @@ def main():
     ap.add_argument("--cols", type=int, default=9)
     ap.add_argument("--tile", type=int, default=2048)
     ap.add_argument("--window", type=int, default=24)
-    ap.add_argument("--method", default="surf", choices=["surf", "orb", "phase", "fuse"],
+    ap.add_argument("--method", default="surf", choices=["surf", "orb", "phase", "fuse", "surf_full"],
                     help="surf = the BASELINE metric; orb / phase time the other registration paths on the same grid; fuse = the"
                          " secondary metric of SURVEY 8d (mosaic assembly with fadeInAndFadeOut blending, N = 1 only)")
     ap.add_argument("--overlap", type=float, default=0.10, help="nominal tile overlap of the synthetic grid (SURVEY 8d: 10 %%)")
@@ -428,6 +486,8 @@ def main():
     eng = isa.Engine(local_rank)
     if args.workload == "dendritic25":
         return bench_dendritic25(args, eng, torch)
+    if args.method == "surf_full":
+        return bench_line_scan(args, eng, torch)
     grid = SyntheticGrid(args.rows, args.cols, args.tile, overlap=args.overlap)
     if args.from_files:
         return bench_from_files(args, eng, grid, torch)

@@ -126,6 +126,8 @@ _SIGNATURES = {
     "vfsms_canvas_fuse_tile_m": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vfsms_fuse_trig_i64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vfsms_features_surf_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+    "vfsms_features_match_offset_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]),
     "vfsms_canvas_download": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "vfsms_canvas_download_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "vfsms_tile_upload_ch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
@@ -512,6 +514,24 @@ class Engine:
         self._check(self.lib.vfsms_features_surf(self.ctx, C.c_int64(tile_handle), y0, x0, h, w, C.byref(params), int(enhance[0]),
                                                  float(enhance[1]), int(enhance[2]), C.byref(f), C.byref(n)))
         return f.value, n.value
+
+    def features_surf_batch(self, tile_handles, params=None, enhance=(0, 0.0, 0)):
+        """whole-tile SURF of many resident tiles in fused launches -> (feature handles, keypoint counts)"""
+        params = params or self.surf_params()
+        n = len(tile_handles)
+        th = np.ascontiguousarray(tile_handles, np.int64)
+        feats = np.zeros(max(n, 1), np.int64); counts = np.zeros(max(n, 1), np.int32)
+        self._check(self.lib.vfsms_features_surf_batch(self.ctx, _ptr(th), n, C.byref(params), int(enhance[0]), float(enhance[1]), int(enhance[2]),
+                                                       _ptr(feats), _ptr(counts)))
+        return [int(f) for f in feats[:n]], [int(c) for c in counts[:n]]
+
+    def features_match_offset_batch(self, feats_a, feats_b, ratio=0.75, offset_evaluate=3):
+        """matchDescriptors + getOffsetByMode of n (A, B) jobs in one batch -> int32[n][8]"""
+        n = len(feats_a)
+        fa = np.ascontiguousarray(feats_a, np.int64); fb = np.ascontiguousarray(feats_b, np.int64)
+        out = np.zeros((max(n, 1), ATTEMPT_INTS), np.int32)
+        self._check(self.lib.vfsms_features_match_offset_batch(self.ctx, _ptr(fa), _ptr(fb), n, float(ratio), int(offset_evaluate), _ptr(out)))
+        return out[:n]
 
     def features_match_offset(self, feat_a, feat_b, ratio=0.75, offset_evaluate=3):
         """matchDescriptors + getOffsetByMode on two resident sets -> int32[8] = status, dx, dy, votes, nA, nB, nMatches, 0."""

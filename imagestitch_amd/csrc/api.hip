@@ -238,7 +238,8 @@ extern "C" int vfsms_ctx_destroy(vfsms_ctx *ctx)
     for (hipEvent_t ev : ctx->event_pool) hipEventDestroy(ev);
     hipStreamDestroy(ctx->copy_stream);
     for (auto &kv : ctx->canvases) { hipFree(kv.second.pix); hipFree(kv.second.mask); }
-    for (auto &kv : ctx->feats) { if (kv.second.kps_xy) hipFree(kv.second.kps_xy); if (kv.second.desc) hipFree(kv.second.desc); }
+    for (auto &kv : ctx->feats) if (!kv.second.block) { if (kv.second.kps_xy) hipFree(kv.second.kps_xy); if (kv.second.desc) hipFree(kv.second.desc); }
+    for (auto &kv : ctx->feat_blocks) hipFree(kv.second.base);
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->d_layers) hipFree(ctx->d_layers);
@@ -971,14 +972,171 @@ extern "C" int vfsms_features_surf(vfsms_ctx *ctx, int64_t tile, int y0, int x0,
     return VFSMS_OK;
 }
 
+// Whole-tile feature sets of MANY tiles in fused launches: the line scans of Main.py:29-51 (4 of the 6 demo datasets) call
+// calculateOffsetForFeatureSearch pair after pair (Stitcher.py:260-304); with all tiles of a scan in HBM every tile is described once, up to
+// 16 per launch sequence, and the N - 1 matches + mode votes run as one batch (vfsms_features_match_offset_batch) -- one host synchronisation
+// per 16 tiles instead of two per tile.
+extern "C" int vfsms_features_surf_batch(vfsms_ctx *ctx, const int64_t *tiles, int n, const vfsms_surf_params *params,
+                                         int enhance_mode, double clip_limit, int tile_grid, int64_t *feats, int *counts)
+{
+    CTX_ENTER(ctx);
+    if (n < 0 || (n && (!tiles || !feats || !counts)) || !params) { vfsms_set_error("features_surf_batch: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    if (enhance_mode < 0 || enhance_mode > 2) { vfsms_set_error("features_surf_batch: enhance_mode must be 0, 1 or 2"); return VFSMS_ERR_BAD_ARG; }
+    TRY(ctx_prepare_surf(ctx, params));
+    const int dim = params->extended ? 128 : 64;
+    for (int k = 0; k < n; k++) feats[k] = 0;
+    for (int c0 = 0; c0 < n;) {
+        // a chunk: at most 16 tiles and ~6 GB of scratch
+        int c1 = c0; size_t need = 0;
+        std::vector<TileRec *> T; std::vector<int> caps;
+        while (c1 < n && c1 - c0 < 16) {
+            auto it = ctx->tiles.find(tiles[c1]);
+            if (it == ctx->tiles.end()) { vfsms_set_error("features_surf_batch: unknown tile handle"); return VFSMS_ERR_BAD_ARG; }
+            TileRec &t = it->second;
+            if (t.ch != 1) { vfsms_set_error("features_surf_batch: registration takes single-channel tiles"); return VFSMS_ERR_BAD_ARG; }
+            const int cap = kp_capacity(ctx, t.h, t.w);
+            const size_t b = surf_roi_bytes(t.h, t.w, cap, ctx->n_layers, params->n_octaves, dim) +
+                             (enhance_mode ? enhance_scratch_bytes(t.h, t.w, enhance_mode, tile_grid) + sizeof(EnhJob) + 512 : 0);
+            if (c1 > c0 && need + b > ((size_t)6 << 30)) break;
+            need += b; T.push_back(&t); caps.push_back(cap); c1++;
+        }
+        const int m = c1 - c0;
+        TRY(ctx_arena_reserve(ctx, need + (sizeof(RoiDev) + 64) * m + 65536));
+        ctx->pinned_off = 0;
+        std::vector<RoiDev> R(m);
+        std::vector<EnhJob> E(enhance_mode ? m : 0);
+        int *cblock = (int *)ctx_arena_alloc(ctx, sizeof(int) * 16 * m);
+        for (int k = 0; k < m; k++) {
+            TRY(tile_ready(ctx, *T[k]));
+            const uint8_t *src = T[k]->ptr; int sstride = T[k]->stride;
+            if (enhance_mode) {
+                TRY(enhance_carve(ctx, &E[k], src, sstride, T[k]->h, T[k]->w, enhance_mode, tile_grid));
+                src = E[k].dst; sstride = T[k]->w;
+            }
+            TRY(surf_roi_carve(ctx, &R[k], src, sstride, T[k]->h, T[k]->w, caps[k], params));
+            R[k].counters = cblock + 16 * k;
+        }
+        RoiDev *dR;
+        TRY(upload_pinned(ctx, R.data(), sizeof(RoiDev) * m, (void **)&dR));
+        if (enhance_mode) {
+            EnhJob *dE;
+            TRY(upload_pinned(ctx, E.data(), sizeof(EnhJob) * m, (void **)&dE));
+            TRY(launch_enhance(ctx, dE, E.data(), m, enhance_mode, clip_limit, tile_grid));
+        }
+        HIP_TRY(hipMemsetAsync(cblock, 0, sizeof(int) * 16 * m, ctx->stream));
+        TRY(launch_surf_detect(ctx, dR, R.data(), m, params));
+        TRY(launch_surf_describe(ctx, dR, R.data(), m, params));
+        std::vector<int> counters((size_t)16 * m);
+        HIP_TRY(hipMemcpyAsync(counters.data(), cblock, sizeof(int) * 16 * m, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < m; k++)
+            if (counters[(size_t)16 * k + 2] || counters[(size_t)16 * k] > R[k].cap) {
+                vfsms_set_error("features_surf_batch: tile %d exceeded %d keypoint candidates (vfsms_ctx_set_keypoint_capacity)", c0 + k, R[k].cap);
+                return VFSMS_ERR_CAPACITY;
+            }
+        // ONE allocation for the sets of the chunk (a hipMalloc / hipFree pair per set costs more than describing it)
+        size_t total = 0;
+        for (int k = 0; k < m; k++) total += (((size_t)counters[(size_t)16 * k + 1] * (2 + dim) * sizeof(float)) + 255) & ~(size_t)255;
+        char *base = nullptr; int64_t blk = 0;
+        if (total) {
+            HIP_TRY(hipMalloc((void **)&base, total));
+            blk = ctx->next_handle++;
+            ctx->feat_blocks[blk] = FeatBlock{base, 0};
+        }
+        size_t off = 0;
+        for (int k = 0; k < m; k++) {
+            FeatRec F; F.n = counters[(size_t)16 * k + 1]; F.dim = dim; F.is_orb = 0; F.kps_xy = nullptr; F.desc = nullptr;
+            if (F.n > 0) {
+                F.block = blk; ctx->feat_blocks[blk].refs++;
+                F.kps_xy = (float *)(base + off); F.desc = base + off + sizeof(float) * 2 * F.n;
+                off += (((size_t)F.n * (2 + dim) * sizeof(float)) + 255) & ~(size_t)255;
+                HIP_TRY(hipMemcpyAsync(F.kps_xy, R[k].kps_xy, sizeof(float) * 2 * F.n, hipMemcpyDeviceToDevice, ctx->stream));
+                HIP_TRY(hipMemcpyAsync(F.desc, R[k].desc, sizeof(float) * (size_t)F.n * dim, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            feats[c0 + k] = ctx->next_handle++;
+            ctx->feats[feats[c0 + k]] = F;
+            counts[c0 + k] = F.n;
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));          // the copies out of the arena have landed before the next chunk reuses it
+        c0 = c1;
+    }
+    return VFSMS_OK;
+}
+
+// matchDescriptors + getOffsetByMode of n (query set A_k, train set B_k) jobs as ONE batch: out[8 * k ..] as vfsms_features_match_offset
+extern "C" int vfsms_features_match_offset_batch(vfsms_ctx *ctx, const int64_t *feat_a, const int64_t *feat_b, int n, double ratio,
+                                                 int offset_evaluate, int32_t *out)
+{
+    CTX_ENTER(ctx);
+    if (n < 0 || (n && (!feat_a || !feat_b || !out))) { vfsms_set_error("features_match_batch: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    std::vector<const FeatRec *> A(n), B(n);
+    std::vector<int> live;
+    int maxq = 0, maxt = 0, dim = 0;
+    for (int k = 0; k < n; k++) {
+        auto ia = ctx->feats.find(feat_a[k]), ib = ctx->feats.find(feat_b[k]);
+        if (ia == ctx->feats.end() || ib == ctx->feats.end()) { vfsms_set_error("features_match_batch: unknown handle"); return VFSMS_ERR_BAD_ARG; }
+        A[k] = &ia->second; B[k] = &ib->second;
+        if (A[k]->dim != B[k]->dim || A[k]->is_orb || B[k]->is_orb || (dim && A[k]->dim != dim)) { vfsms_set_error("features_match_batch: descriptor kinds differ"); return VFSMS_ERR_BAD_ARG; }
+        dim = A[k]->dim;
+        for (int c = 0; c < VFSMS_ATTEMPT_INTS; c++) out[VFSMS_ATTEMPT_INTS * k + c] = 0;
+        out[VFSMS_ATTEMPT_INTS * k + 4] = A[k]->n; out[VFSMS_ATTEMPT_INTS * k + 5] = B[k]->n;
+        if (A[k]->n > 0 && B[k]->n > 0) { live.push_back(k); maxq = std::max(maxq, A[k]->n); maxt = std::max(maxt, B[k]->n); }
+    }
+    const int m = (int)live.size();
+    if (m == 0) return VFSMS_OK;
+    const bool filtered = dim == 64 && !bf_force_exact();
+    const int cns = pick_filter_nsplit(maxq, m);
+    const int ns = filtered ? 1 : pick_nsplit(maxq, maxt, m, dim);
+    size_t need = 0;
+    for (int j = 0; j < m; j++)
+        need += match_bytes(A[live[j]]->n, ns) + (filtered ? match_filter_bytes(A[live[j]]->n, B[live[j]]->n, cns) : 0);
+    TRY(ctx_arena_reserve(ctx, need + (sizeof(MatchDev) + 64 + sizeof(int32_t) * VFSMS_ATTEMPT_INTS) * m + 65536));
+    ctx->pinned_off = 0;
+    std::vector<MatchDev> M(m);
+    std::vector<int> cnt(2 * m);
+    for (int j = 0; j < m; j++) { cnt[2 * j] = A[live[j]]->n; cnt[2 * j + 1] = B[live[j]]->n; }
+    int32_t *rblock = (int32_t *)ctx_arena_alloc(ctx, sizeof(int32_t) * VFSMS_ATTEMPT_INTS * m);
+    int *dcnt;
+    TRY(upload_pinned(ctx, cnt.data(), sizeof(int) * 2 * m, (void **)&dcnt));
+    for (int j = 0; j < m; j++) {
+        const FeatRec &a = *A[live[j]], &b = *B[live[j]];
+        memset(&M[j], 0, sizeof(MatchDev));
+        TRY(match_carve(ctx, &M[j], a.n, dim, ns));
+        if (filtered) TRY(match_filter_carve(ctx, &M[j], a.n, b.n, cns));
+        M[j].result = rblock + VFSMS_ATTEMPT_INTS * j;
+        M[j].q = (const float *)a.desc; M[j].t = (const float *)b.desc; M[j].kq = a.kps_xy; M[j].kt = b.kps_xy;
+        M[j].nq_ptr = dcnt + 2 * j; M[j].nt_ptr = dcnt + 2 * j + 1;
+    }
+    MatchDev *dM;
+    TRY(upload_pinned(ctx, M.data(), sizeof(MatchDev) * m, (void **)&dM));
+    if (filtered) { TRY(launch_bf_l2_filtered(ctx, dM, m, maxq, maxt, cns)); }
+    else { TRY(launch_bf_l2(ctx, dM, m, maxq, ns, dim)); }
+    TRY(launch_ratio_mode(ctx, dM, m, maxq, ratio, offset_evaluate));
+    std::vector<int32_t> res((size_t)VFSMS_ATTEMPT_INTS * m);
+    HIP_TRY(hipMemcpyAsync(res.data(), rblock, sizeof(int32_t) * VFSMS_ATTEMPT_INTS * m, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < m; j++)
+        for (int c = 0; c < VFSMS_ATTEMPT_INTS; c++) out[VFSMS_ATTEMPT_INTS * live[j] + c] = res[(size_t)VFSMS_ATTEMPT_INTS * j + c];
+    return VFSMS_OK;
+}
+
 extern "C" int vfsms_features_free(vfsms_ctx *ctx, int64_t feat)
 {
     CTX_ENTER(ctx);
     auto it = ctx->feats.find(feat);
     if (it == ctx->feats.end()) { vfsms_set_error("features_free: unknown handle"); return VFSMS_ERR_BAD_ARG; }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (it->second.kps_xy) HIP_TRY(hipFree(it->second.kps_xy));
-    if (it->second.desc) HIP_TRY(hipFree(it->second.desc));
+    if (it->second.block) {
+        auto bt = ctx->feat_blocks.find(it->second.block);
+        if (bt != ctx->feat_blocks.end() && --bt->second.refs == 0) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipFree(bt->second.base));
+            ctx->feat_blocks.erase(bt);
+        }
+    } else {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (it->second.kps_xy) HIP_TRY(hipFree(it->second.kps_xy));
+        if (it->second.desc) HIP_TRY(hipFree(it->second.desc));
+    }
     ctx->feats.erase(it);
     return VFSMS_OK;
 }

@@ -110,7 +110,8 @@ struct OrbTables { int nfeat[VFSMS_ORB_MAX_LEVELS]; int umax[34]; int half_patch
 struct EnhJob { const uint8_t *src; int stride, h, w, eh, ew; uint8_t *dst; int *hist; uint8_t *lut; };   // eh, ew: size extended to the CLAHE grid
 
 // ---- device-resident feature set (keypoints + descriptors of one image; Stitcher.tempImageFeature's payload) ---------------
-struct FeatRec { float *kps_xy; void *desc; int n, dim, is_orb; };
+struct FeatRec { float *kps_xy; void *desc; int n, dim, is_orb; int64_t block = 0; };   // block != 0: kps_xy / desc point into a shared allocation (feat_blocks)
+struct FeatBlock { void *base; int refs; };
 
 // ---- one (query ROI, train ROI) matching job --------------------------------------------------------
 struct MatchDev {
@@ -167,6 +168,7 @@ struct vfsms_ctx {
     std::vector<hipEvent_t> event_pool;
     std::unordered_map<int64_t, CanvasRec> canvases;
     std::unordered_map<int64_t, FeatRec> feats;
+    std::unordered_map<int64_t, FeatBlock> feat_blocks;      // one allocation for the sets of a batch (vfsms_features_surf_batch), freed with its last set
     int64_t next_handle;
     std::list<FftPlan> plans;            // list: get_plan hands out stable pointers
     // optional per-stage timing with HIP events on this context's stream (vfsms_profile_*)

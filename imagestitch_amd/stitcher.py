@@ -226,6 +226,9 @@ class Stitcher(Utility.Method):
             method = self.featureMethod
         elif fn is Stitcher.calculateOffsetForPhaseCorrleateIncre and not self.phaseSignFix:
             method = "phase"
+        elif (fn is Stitcher.calculateOffsetForFeatureSearch and self._usesStockOperators() and self.featureMethod == "surf"
+              and self.offsetCaculate == "mode" and hasattr(self.engine, "features_surf_batch")):
+            method = "surf_full"                              # the line scans of Main.py:29-51: whole-tile features, no ROI search
         else:
             return None
         eng = self.engine
@@ -234,10 +237,10 @@ class Stitcher(Utility.Method):
             return None
         from .grid import GridRegistrar
         params = None if method == "phase" else (self._orbParams() if method == "orb" else self._surfParams())
-        reg = GridRegistrar(eng, method=method, roiRatio=self.roiRatio, searchRatio=self.searchRatio, offsetEvaluate=self.offsetEvaluate,
+        reg = GridRegistrar(eng, method="surf" if method == "surf_full" else method, roiRatio=self.roiRatio, searchRatio=self.searchRatio, offsetEvaluate=self.offsetEvaluate,
                             directIncre=self.directIncre, surfParams=params,
                             phaseResponseThreshold=self.phaseResponseThreshold, window=24,
-                            enhance=self._enhanceSpec() if method == "surf" else (0, 0.0, 0))
+                            enhance=self._enhanceSpec() if method in ("surf", "surf_full") else (0, 0.0, 0))
         reg.orbMaxDistance = self.orbMaxDistance if self.isGPUAvailable else -1
         keep = (not self.isColorMode) and self.fuseMethod in ("notFuse", "fadeInAndFadeOut", "trigonometric") and hasattr(eng, "canvas_fuse_tile_resident")
         handles, pool, futures, failed = [], None, [], False
@@ -266,7 +269,10 @@ class Stitcher(Utility.Method):
                 futures = [pool.submit(ingest, k) for k in range(len(fileList))]
             else:
                 handles = [eng.tile_upload(_imread(f, False)) for f in fileList]
-            table, _d = reg.register(handles, shapes, self.direction, stop_on_fail=True)
+            if method == "surf_full":
+                table = self._fullImageTable(handles)
+            else:
+                table, _d = reg.register(handles, shapes, self.direction, stop_on_fail=True)
         except BaseException:
             keep, failed = False, True
             raise
@@ -294,11 +300,33 @@ class Stitcher(Utility.Method):
                 status = False
                 describtion = "  " + str(fileList[k]) + " and " + str(fileList[k + 1]) + " can not be stitched"
                 break
-            self.direction = int(row[3])
+            if method != "surf_full":
+                self.direction = int(row[3])
             self.printAndWrite("  The offset of stitching: dx is " + str(int(row[1])) + " dy is " + str(int(row[2])))
             offsetList.append([int(row[1]), int(row[2])])
             endfileIndex = k + 1
         return (status, endfileIndex, offsetList, describtion)
+
+    def _fullImageTable(self, handles):
+        """calculateOffsetForFeatureSearch (Stitcher.py:260-304) over consecutive resident tiles, batched: every tile is described once
+        (vfsms_features_surf_batch: 16 tiles per fused launch sequence -- the reference's B -> A feature reuse, Stitcher.py:278-290, taken
+        to its end), the N - 1 matches + mode votes are ONE batch.  Rows as the incremental registrar's: (status, dx, dy, 0, 0, votes);
+        like the pair loop, nothing behind the first pair that cannot be matched is reported (flowStitch breaks there)."""
+        eng = self.engine
+        feats, counts = eng.features_surf_batch(handles, self._surfParams(), self._enhanceSpec())
+        try:
+            rows = eng.features_match_offset_batch(feats[:-1], feats[1:], self.searchRatio, self.offsetEvaluate)
+        finally:
+            for f in feats:
+                if f:
+                    eng.features_free(f)
+        table = []
+        for r in rows:
+            table.append([int(r[0]), int(r[1]), int(r[2]), 0, 0, int(r[3])])
+            if not r[0]:
+                break
+        self.tempImageFeature.isBreak = True                  # the scan owns no cached set afterwards
+        return table
 
     def flowStitchWithMutiple(self, fileList, caculateOffsetMethod):
         """Stitcher.py:96-127: restart after every registration break; a trailing lone tile is its own result."""

@@ -174,3 +174,23 @@ class SyntheticGrid:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(threads) as ex:
             return list(ex.map(self.tile, ks))
+
+
+def line_scan(n=4, h=1024, w=1280, bar=48):
+    """A zircon-like line scan (Main.py:29-51): n tiles of h x w, tile k+1 to the LEFT of tile k (direction 4, full-image search), with a
+    static data bar burned into the bottom rows of every tile (pixel-identical between tiles, like zirconCL's) -> (tiles, true offsets)."""
+    rng = np.random.default_rng(77)
+    step = w - int(0.2 * w)
+    bar_px = rng.integers(0, 256, (bar, w), dtype=np.uint8)
+    bar_px[:, ::7] = 255
+    tiles, offs = [], []
+    x = 5000 + max(0, n - 4) * step
+    for k in range(n):
+        jy, jx = int(rng.integers(-6, 7)), int(rng.integers(-6, 7))
+        y0, x0 = 300 + jy, x - k * step + jx
+        t = texture_window(y0, x0, h, w)
+        img = np.clip(np.rint(128.0 + 45.0 * t + rng.normal(0, 2.0, t.shape)), 0, 255).astype(np.uint8)
+        img[h - bar:, :] = bar_px
+        tiles.append(img); offs.append((y0, x0))
+    truth = [[offs[k + 1][0] - offs[k][0], offs[k + 1][1] - offs[k][1]] for k in range(n - 1)]
+    return tiles, truth

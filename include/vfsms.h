@@ -148,7 +148,7 @@ int vfsms_orb_detect_describe(vfsms_ctx *ctx, const uint8_t *img, int h, int w, 
  * pairs: int32[cap][2] = (trainIdx, queryIdx) in query order.
  * Results are those of the reference's float arithmetic (4-wide accumulation of (a-b)^2, sqrt-domain compares, ties to the
  * lower train index) for every input.  64-d inputs whose rows all have norm <= 1 (SURF descriptors are L2-normalised; checked
- * on the device) are searched with the f32-MFMA candidate filter + exact verification, anything else with the exhaustive
+ * on the device) are searched with the split-bf16 MFMA candidate filter + exact verification, anything else with the exhaustive
  * kernel; VFSMS_BF_EXACT=1 in the environment forces the exhaustive kernel.                                                  */
 int vfsms_bf_l2_knn2_ratio(vfsms_ctx *ctx, const float *q, int nq, const float *t, int nt, int dim,
                            double ratio, int32_t *pairs, int cap, int *m_out);
@@ -250,6 +250,14 @@ int vfsms_features_surf(vfsms_ctx *ctx, int64_t tile, int y0, int x0, int h, int
                         int enhance_mode, double clip_limit, int tile_grid, int64_t *feat, int *n_out);
 int vfsms_features_match_offset(vfsms_ctx *ctx, int64_t feat_a, int64_t feat_b, double ratio, int offset_evaluate, int32_t *out);
 int vfsms_features_download(vfsms_ctx *ctx, int64_t feat, float *kps_xy, float *desc, int cap, int *n_out, int *dim_out);
+/* The same for MANY tiles at once (the line scans of Main.py:29-51: 4 of the 6 demo datasets run calculateOffsetForFeatureSearch over
+ * consecutive files, Stitcher.py:260-304): whole tiles, up to 16 per fused launch sequence, one host synchronisation per chunk;
+ * feats[k] / counts[k] receive the set of tiles[k].  vfsms_features_match_offset_batch matches n (query set, train set) jobs --
+ * the N - 1 consecutive pairs of a scan -- and votes in ONE batch: out[8 k ..] as vfsms_features_match_offset.                 */
+int vfsms_features_surf_batch(vfsms_ctx *ctx, const int64_t *tiles, int n, const vfsms_surf_params *params,
+                              int enhance_mode, double clip_limit, int tile_grid, int64_t *feats, int *counts);
+int vfsms_features_match_offset_batch(vfsms_ctx *ctx, const int64_t *feat_a, const int64_t *feat_b, int n, double ratio,
+                                      int offset_evaluate, int32_t *out);
 int vfsms_features_free(vfsms_ctx *ctx, int64_t feat);
 /* cv2.equalizeHist(img) (mode 1) / cv2.createCLAHE(clip_limit, (tile_grid, tile_grid)).apply(img) (mode 2), Stitcher.py:269-276;
  * out: uint8 [h][w] contiguous                                                                                                     */

@@ -598,25 +598,7 @@ def test_enhancement_bit_exact(engine, oracle, strips):
             assert np.array_equal(engine.enhance(img, 2, clip, ts), oracle.clahe(img, clip, ts)), ("clahe", img.shape, clip, ts)
 
 
-def _line_scan(n=4, h=1024, w=1280, bar=48):
-    """a zircon-like line scan (Main.py:29-51): n tiles of h x w, tile k+1 to the LEFT of tile k (direction 4, full-image search),
-    with a static data bar burned into the bottom rows of every tile (pixel-identical between tiles, like zirconCL's)."""
-    from imagestitch_amd.synthetic import texture_window
-    rng = np.random.default_rng(77)
-    step = w - int(0.2 * w)
-    bar_px = rng.integers(0, 256, (bar, w), dtype=np.uint8)
-    bar_px[:, ::7] = 255
-    tiles, offs = [], []
-    x = 5000
-    for k in range(n):
-        jy, jx = int(rng.integers(-6, 7)), int(rng.integers(-6, 7))
-        y0, x0 = 300 + jy, x - k * step + jx
-        t = texture_window(y0, x0, h, w)
-        img = np.clip(np.rint(128.0 + 45.0 * t + rng.normal(0, 2.0, t.shape)), 0, 255).astype(np.uint8)
-        img[h - bar:, :] = bar_px
-        tiles.append(img); offs.append((y0, x0))
-    truth = [[offs[k + 1][0] - offs[k][0], offs[k + 1][1] - offs[k][1]] for k in range(n - 1)]
-    return tiles, truth
+from imagestitch_amd.synthetic import line_scan as _line_scan  # noqa: E402
 
 
 def test_full_image_feature_search_resident_cache(engine, oracle):
@@ -883,3 +865,52 @@ def test_fuse_trigonometric_operator_vs_reference_formula(engine, oracle, golden
             assert d.max() <= 1, (r, c, hole, int(d.max()))
             nbytes += d.size; ndiff += np.count_nonzero(d)
     assert ndiff <= 1e-3 * nbytes, (ndiff, nbytes)
+
+
+@pytest.mark.gpu
+def test_line_scan_batched_full_image_path(engine, tmp_path):
+    """flowStitch over a line scan with caculateOffsetMethod = calculateOffsetForFeatureSearch (Main.py:29-51): the batched path (files ->
+    ingest pipeline -> vfsms_features_surf_batch -> vfsms_features_match_offset_batch) must report exactly what the pair-by-pair mirror
+    of Stitcher.py:260-304 reports (status, offsets, log lines), with and without CLAHE, and stop behind a pair that cannot be matched."""
+    from PIL import Image
+    tiles, truth = _line_scan()
+    files = []
+    for k, t in enumerate(tiles):
+        f = os.path.join(str(tmp_path), "scan_%02d.png" % k)
+        Image.fromarray(t).save(f); files.append(f)
+    old = (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate, isa.Stitcher.isEnhance,
+           isa.Stitcher.isClahe, isa.Stitcher.isColorMode, isa.Stitcher.fuseMethod)
+    try:
+        isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate = 4, 0, "surf", 3
+        isa.Stitcher.isColorMode, isa.Stitcher.fuseMethod = False, "notFuse"
+        for enh, clahe in ((False, False), (True, True)):
+            isa.Stitcher.isEnhance, isa.Stitcher.isClahe = enh, clahe
+            seq = isa.Stitcher(); seq._engine = engine; seq.isPrintLog = False
+            seq.tempImageFeature.isBreak = True
+            want = [seq.calculateOffsetForFeatureSearch([tiles[k], tiles[k + 1]]) for k in range(len(tiles) - 1)]
+            seq.releaseTiles()
+            st = isa.Stitcher(); st._engine = engine
+            msgs = []
+            st.printAndWrite = lambda c, msgs=msgs: msgs.append(c)
+            got = st._registerBatched(files, st.calculateOffsetForFeatureSearch)
+            assert got is not None, "the batched full-image path did not engage"
+            status, end, offs, _desc = got
+            for h, _s in (st.__dict__.pop("_resident", None) or {}).values():
+                engine.tile_free(h)
+            assert status and end == len(tiles) - 1 and offs == [w[1] for w in want], (enh, offs, want)
+            assert all(w[0] for w in want)
+            for k, o in enumerate(offs):
+                assert abs(o[0] - truth[k][0]) <= 1 and abs(o[1] - truth[k][1]) <= 1
+                assert "  The offset of stitching: dx is %d dy is %d" % (o[0], o[1]) in msgs
+        # a tile that cannot be matched (blank) breaks the scan where the pair loop breaks it
+        isa.Stitcher.isEnhance = False
+        Image.fromarray(np.zeros_like(tiles[0])).save(files[3])
+        st = isa.Stitcher(); st._engine = engine; st.isPrintLog = False
+        status, end, offs, desc = st._registerBatched(files, st.calculateOffsetForFeatureSearch)
+        for h, _s in (st.__dict__.pop("_resident", None) or {}).values():
+            engine.tile_free(h)
+        assert status is False and end == 2 and len(offs) == 2 and "can not be stitched" in desc
+    finally:
+        (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate, isa.Stitcher.isEnhance,
+         isa.Stitcher.isClahe, isa.Stitcher.isColorMode, isa.Stitcher.fuseMethod) = old
+        isa.Stitcher.tempImageFeature.isBreak = True
