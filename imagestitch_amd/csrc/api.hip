@@ -237,7 +237,7 @@ extern "C" int vfsms_ctx_destroy(vfsms_ctx *ctx)
     for (auto &pe : ctx->tile_pool) { hipFree(pe.ptr); if (pe.idle) hipEventDestroy(pe.idle); }
     for (hipEvent_t ev : ctx->event_pool) hipEventDestroy(ev);
     hipStreamDestroy(ctx->copy_stream);
-    for (auto &kv : ctx->canvases) { hipFree(kv.second.pix); hipFree(kv.second.mask); }
+    for (auto &kv : ctx->canvases) { hipFree(kv.second.pix); hipFree(kv.second.mask); hipFree(kv.second.d_err); hipFree(kv.second.scratch); }
     for (auto &kv : ctx->feats) if (!kv.second.block) { if (kv.second.kps_xy) hipFree(kv.second.kps_xy); if (kv.second.desc) hipFree(kv.second.desc); }
     for (auto &kv : ctx->feat_blocks) hipFree(kv.second.base);
     if (ctx->arena) hipFree(ctx->arena);
@@ -1251,6 +1251,8 @@ extern "C" int vfsms_canvas_create(vfsms_ctx *ctx, int rows, int cols, int ch, i
     HIP_TRY(hipMalloc((void **)&cv.pix, (size_t)rows * cols * ch));
     HIP_TRY(hipMalloc((void **)&cv.mask, (size_t)rows * cols));
     HIP_TRY(hipMalloc((void **)&cv.d_err, sizeof(int)));
+    HIP_TRY(hipMalloc(&cv.scratch, canvas_scratch_bytes(rows, cols)));
+    TRY(canvas_scratch_init(ctx, &cv));
     HIP_TRY(hipMemsetAsync(cv.d_err, 0, sizeof(int), ctx->stream));
     HIP_TRY(hipMemsetAsync(cv.pix, 0, (size_t)rows * cols * ch, ctx->stream));
     HIP_TRY(hipMemsetAsync(cv.mask, 0, (size_t)rows * cols, ctx->stream));
@@ -1264,7 +1266,7 @@ extern "C" int vfsms_canvas_free(vfsms_ctx *ctx, int64_t handle)
     auto it = ctx->canvases.find(handle);
     if (it == ctx->canvases.end()) { vfsms_set_error("canvas_free: unknown handle"); return VFSMS_ERR_BAD_ARG; }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(it->second.pix)); HIP_TRY(hipFree(it->second.mask)); HIP_TRY(hipFree(it->second.d_err));
+    HIP_TRY(hipFree(it->second.pix)); HIP_TRY(hipFree(it->second.mask)); HIP_TRY(hipFree(it->second.d_err)); HIP_TRY(hipFree(it->second.scratch));
     ctx->canvases.erase(it);
     return VFSMS_OK;
 }

@@ -141,7 +141,7 @@ struct MatchDev {
 // fill: 0 filled (or being copied: `ready` is recorded), 1 reserved -- a decoder thread still owes the pixels (vfsms_tile_fill), 2 the decoder gave up
 struct TileRec { uint8_t *ptr; int h, w, stride; bool owned; hipEvent_t ready; bool pending; int ch = 1; size_t bytes = 0; int fill = 0; };
 struct PoolEnt { size_t bytes; uint8_t *ptr; hipEvent_t idle; };   // a freed tile buffer; idle: recorded on the compute stream when the tile was freed
-struct CanvasRec { uint8_t *pix; uint8_t *mask; int rows, cols, ch; int *d_err; };   // d_err: sticky "degenerate fuse geometry" flag for calls made without an info readback
+struct CanvasRec { uint8_t *pix; uint8_t *mask; int rows, cols, ch; int *d_err; void *scratch; };   // d_err: sticky "degenerate fuse geometry" flag for calls made without an info readback; scratch: the fuse's statistics records + ramps
 struct FftPlan { int M, N, nb; void *fwd, *inv, *fwd_info, *inv_info; size_t fwd_work, inv_work; };   // rocfft_plan / rocfft_execution_info
 struct PhaseJobHost { const uint8_t *a, *b; int sa, sb; };
 struct ProfRec { int id; hipEvent_t a, b; };
@@ -241,6 +241,8 @@ int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int
 int canvas_blend_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0,
                         int ry0, int rx0, int ry1, int rx1, int mode);
 int canvas_paste_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0);
+size_t canvas_scratch_bytes(int rows, int cols);
+int canvas_scratch_init(vfsms_ctx *ctx, CanvasRec *cv);
 
 #ifdef __HIPCC__
 // Speed only (placement is not a contract): workgroups are observed to land on XCD (linear block id % 8), each XCD with a private

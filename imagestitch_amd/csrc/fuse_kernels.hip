@@ -39,103 +39,7 @@ struct I64View {
     __device__ long long b_val(int i, int j, int k) const { return B[((size_t)i * c + j) * ch + k]; }
 };
 
-// occupancy + quadrant counts + first/last valid column of every ROI row.  A workgroup owns FUSE_RBAND rows (one wave-sized
-// reduction per row for first / last; the counts stay in registers across the band) and issues ONE set of global atomics -- a set
-// per row put 3 x r same-address 64-bit atomics behind each other: 70 us of an 2048-row ROI's 73 us.
-#define FUSE_RBAND 8
 typedef uint32_t u32u1 __attribute__((aligned(1)));
-__global__ __launch_bounds__(256) void k_fuse_stats_rows(CanvasView V, int r, int c, FuseStats *st, int *rowFirst, int *rowLast)
-{
-    __shared__ int sf[256], sl[256];
-    __shared__ unsigned sv[256], s0[256], s1[256], s2[256], s3[256];
-    const int c2 = c / 2, r2 = r / 2;
-    unsigned valid = 0, q_tl = 0, q_bl = 0, q_br = 0, q_tr = 0;
-    const int i0 = blockIdx.x * FUSE_RBAND, i1 = min(i0 + FUSE_RBAND, r);
-    for (int i = i0; i < i1; i++) {
-        int first = 0x7fffffff, last = -1;
-        unsigned qlo = 0, qhi = 0;
-        if (V.ch == 1) {
-            // four pixels per lane and trip: the validity bytes and the grey values as (unaligned) dwords
-            const uint8_t *mrow = V.mask + (size_t)(V.ry0 + i) * V.ccols + V.rx0, *prow = V.pix + (size_t)(V.ry0 + i) * V.ccols + V.rx0;
-            for (int j = threadIdx.x * 4; j < c; j += 1024) {
-                uint32_t m, p;
-                if (j + 3 < c) { m = *(const u32u1 *)(mrow + j); p = *(const u32u1 *)(prow + j); }
-                else { m = 0; p = 0; for (int k = 0; j + k < c; k++) { m |= (uint32_t)mrow[j + k] << (8 * k); p |= (uint32_t)prow[j + k] << (8 * k); } }
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if ((m >> (8 * k)) & 0xff) {
-                        first = min(first, j + k); last = max(last, j + k);
-                        valid += 1;
-                        const unsigned pos = ((p >> (8 * k)) & 0xff) != 0;
-                        if (j + k < c2) qlo += pos; else qhi += pos;
-                    }
-            }
-        } else {
-            for (int j = threadIdx.x; j < c; j += 256)
-                if (V.a_valid(i, j)) {
-                    first = min(first, j); last = max(last, j);
-                    valid += V.ch;
-                    int pos = 0;
-                    for (int k = 0; k < V.ch; k++) pos += V.a_val(i, j, k) > 0;
-                    if (j < c2) qlo += pos; else qhi += pos;
-                }
-        }
-        if (i < r2) { q_tl += qlo; q_tr += qhi; } else { q_bl += qlo; q_br += qhi; }
-        sf[threadIdx.x] = first; sl[threadIdx.x] = last;
-        __syncthreads();
-        for (int d = 128; d > 0; d >>= 1) {
-            if ((int)threadIdx.x < d) {
-                sf[threadIdx.x] = min(sf[threadIdx.x], sf[threadIdx.x + d]);
-                sl[threadIdx.x] = max(sl[threadIdx.x], sl[threadIdx.x + d]);
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) { rowFirst[i] = sf[0] == 0x7fffffff ? -1 : sf[0]; rowLast[i] = sl[0]; }
-        __syncthreads();
-    }
-    sv[threadIdx.x] = valid; s0[threadIdx.x] = q_tl; s1[threadIdx.x] = q_bl; s2[threadIdx.x] = q_br; s3[threadIdx.x] = q_tr;
-    __syncthreads();
-    for (int d = 128; d > 0; d >>= 1) {
-        if ((int)threadIdx.x < d) {
-            sv[threadIdx.x] += sv[threadIdx.x + d]; s0[threadIdx.x] += s0[threadIdx.x + d]; s1[threadIdx.x] += s1[threadIdx.x + d];
-            s2[threadIdx.x] += s2[threadIdx.x + d]; s3[threadIdx.x] += s3[threadIdx.x + d];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        if (sv[0]) atomicAdd(&st->valid, (unsigned long long)sv[0]);
-        if (s0[0]) atomicAdd(&st->quad[0], (unsigned long long)s0[0]);   // TL
-        if (s1[0]) atomicAdd(&st->quad[1], (unsigned long long)s1[0]);   // BL
-        if (s2[0]) atomicAdd(&st->quad[2], (unsigned long long)s2[0]);   // BR
-        if (s3[0]) atomicAdd(&st->quad[3], (unsigned long long)s3[0]);   // TR
-    }
-}
-
-// first / last valid row of every ROI column.  A workgroup owns 256 columns x FUSE_CBAND rows (one lane per column walks the band:
-// row-major reads, coalesced across lanes) and folds its band into the column records with one atomicMax each.  Encoding:
-// colLast[j] = last valid row (or -1); colFirstEnc[j] = r - 1 - first valid row (or -1), so both start at -1 (one memset) and
-// both are maxima.  (The single-lane-per-column loop this replaces walked all r rows sequentially: 0.3 ms per 2048-row ROI.)
-#define FUSE_CBAND 64
-__global__ __launch_bounds__(256) void k_fuse_stats_cols(CanvasView V, int r, int c, int *colFirstEnc, int *colLast)
-{
-    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;                 // four adjacent columns per lane: validity bytes as one dword
-    if (j >= c) return;
-    const int i0 = blockIdx.y * FUSE_CBAND, i1 = min(i0 + FUSE_CBAND, r);
-    int first[4] = {-1, -1, -1, -1}, last[4] = {-1, -1, -1, -1};
-    const uint8_t *mcol = V.mask + (size_t)V.ry0 * V.ccols + V.rx0 + j;
-    const int nk = min(4, c - j);
-    for (int i = i0; i < i1; i++) {
-        const uint8_t *mp = mcol + (size_t)i * V.ccols;
-        uint32_t m;
-        if (nk == 4) m = *(const u32u1 *)mp;
-        else { m = 0; for (int k = 0; k < nk; k++) m |= (uint32_t)mp[k] << (8 * k); }
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if ((m >> (8 * k)) & 0xff) { if (first[k] < 0) first[k] = i; last[k] = i; }
-    }
-    for (int k = 0; k < nk; k++)
-        if (last[k] >= 0) { atomicMax(&colLast[j + k], last[k]); atomicMax(&colFirstEnc[j + k], r - 1 - first[k]); }
-}
 
 // the blend: writes the whole tile rectangle (outside the ROI: plain paste) and marks it valid
 __device__ __forceinline__ uint8_t fade_px(float wA, float wB, bool av, int a0, int b)
@@ -329,13 +233,15 @@ __global__ __launch_bounds__(256) void k_i64_apply(I64View V, int r, int c, cons
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int pywrap(int i, int n) { return i < 0 ? i + n : i; }
 
-__global__ __launch_bounds__(256) void k_fuse_weights(int r, int c, int ch, int dx, int dy, int force_corner, const FuseStats *st,
-                                                      const int *rowFirst, const int *rowLast, const int *colFirstRaw, const int *colLast,
-                                                      float *wAr, float *wAc, float *wBr, float *wBc, int *out, int *sticky_err, int first_encoded)
+// (first_encoded: the canvas path stores "first valid" positions as n - 1 - first so that every record starts at -1 and is a maximum;
+//  bit 0: columns' first valid row, bit 1: rows' first valid column)
+__device__ __forceinline__ void fuse_weights_body(int r, int c, int ch, int dx, int dy, int force_corner, const FuseStats *st,
+                                                  const int *rowFirstRaw, const int *rowLast, const int *colFirstRaw, const int *colLast,
+                                                  float *wAr, float *wAc, float *wBr, float *wBc, int *out, int *sticky_err, int first_encoded)
 {
-    // colFirst: first valid row of a column, or -1 (the canvas path stores it as r - 1 - first so that one memset initialises it)
-    struct ColFirst { const int *p; int r, enc; __device__ int operator[](int j) const { const int v = p[j]; return (enc && v >= 0) ? r - 1 - v : v; } };
-    const ColFirst colFirst = {colFirstRaw, r, first_encoded};
+    struct First { const int *p; int n, enc; __device__ int operator[](int j) const { const int v = p[j]; return (enc && v >= 0) ? n - 1 - v : v; } };
+    const First colFirst = {colFirstRaw, r, first_encoded & 1};
+    const First rowFirst = {rowFirstRaw, c, (first_encoded >> 1) & 1};
     const int t = threadIdx.x;
     __shared__ int s_first, s_geom[4];          // first scan position with a non-zero candidate; index,rowIndex,colIndex,err
     for (int i = t; i < r; i += 256) { wAr[i] = 1.f; wBr[i] = 1.f; }
@@ -424,6 +330,109 @@ __global__ __launch_bounds__(256) void k_fuse_weights(int r, int c, int ch, int 
     }
     if (err) { atomicOr(&out[5], 1); if (sticky_err) atomicOr(sticky_err, 1); }
     if (t == 0) { out[0] = 1; out[1] = 1; out[2] = s_geom[0]; out[3] = rowIndex; out[4] = colIndex; }
+}
+
+__global__ __launch_bounds__(256) void k_fuse_weights(int r, int c, int ch, int dx, int dy, int force_corner, const FuseStats *st,
+                                                      const int *rowFirst, const int *rowLast, const int *colFirstRaw, const int *colLast,
+                                                      float *wAr, float *wAc, float *wBr, float *wBc, int *out, int *sticky_err, int first_encoded)
+{
+    fuse_weights_body(r, c, ch, dx, dy, force_corner, st, rowFirst, rowLast, colFirstRaw, colLast, wAr, wAc, wBr, wBc, out, sticky_err, first_encoded);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ONE statistics launch per fused tile (canvas path).  A workgroup owns FUSE_SB rows x 1024 columns of the ROI: a lane walks its four
+// columns down the band (first / last valid row per column in registers, one atomicMax each at the end), every row's first / last valid
+// column inside the block comes from two wave ballots (one atomicMax per wave and row), the occupancy and quadrant counts from one
+// block reduction.  The workgroup that finishes LAST (a ticket counter) builds the ramps right there -- no separate launch -- and then
+// puts every record back to its initial value, so the scratch (allocated with the canvas, sized by its rows + cols) needs no memset per
+// tile either: a fused tile is this launch + the blend.  (Before: two memsets + rows, columns, ramps, blend = six dependent launches;
+// the statistics themselves stay latency-bound at ~55 us per tile -- 26 workgroups, atomics per row and column -- see DESIGN.md.)
+// ---------------------------------------------------------------------------------------------------
+#define FUSE_SB 32
+struct FuseCanvasScratch { FuseStats *st; int *out; unsigned *done; int *rowFirstEnc, *rowLast, *colFirstEnc, *colLast; float *wAr, *wBr, *wAc, *wBc; };
+
+__global__ __launch_bounds__(256) void k_fuse_stats_weights(CanvasView V, int r, int c, FuseCanvasScratch S, int dx, int dy, int *sticky_err)
+{
+    __shared__ unsigned s_cnt[5][4];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;                 // four adjacent columns per lane: validity bytes as one dword
+    const int i0 = blockIdx.y * FUSE_SB, i1 = min(i0 + FUSE_SB, r);
+    const int c2 = c / 2, r2 = r / 2;
+    const int nk = max(0, min(4, c - j));
+    int first[4] = {-1, -1, -1, -1}, last[4] = {-1, -1, -1, -1};
+    unsigned valid = 0, q_tl = 0, q_bl = 0, q_br = 0, q_tr = 0;
+    for (int i = i0; i < i1; i++) {
+        uint32_t m = 0, pz = 0;
+        unsigned pos_lo = 0, pos_hi = 0;
+        if (nk > 0) {
+            const size_t o = (size_t)(V.ry0 + i) * V.ccols + V.rx0 + j;
+            if (nk == 4) m = *(const u32u1 *)(V.mask + o);
+            else for (int k = 0; k < nk; k++) m |= (uint32_t)V.mask[o + k] << (8 * k);
+            if (m) {
+                if (V.ch == 1) {
+                    if (nk == 4) pz = *(const u32u1 *)(V.pix + o);
+                    else for (int k = 0; k < nk; k++) pz |= (uint32_t)V.pix[o + k] << (8 * k);
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if ((m >> (8 * k)) & 0xff) {
+                            valid += 1;
+                            const unsigned pos = ((pz >> (8 * k)) & 0xff) != 0;
+                            if (j + k < c2) pos_lo += pos; else pos_hi += pos;
+                        }
+                } else {
+                    for (int k = 0; k < nk; k++)
+                        if ((m >> (8 * k)) & 0xff) {
+                            valid += V.ch;
+                            unsigned pos = 0;
+                            for (int q = 0; q < V.ch; q++) pos += V.pix[(o + k) * V.ch + q] > 0;
+                            if (j + k < c2) pos_lo += pos; else pos_hi += pos;
+                        }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if ((m >> (8 * k)) & 0xff) { if (first[k] < 0) first[k] = i; last[k] = i; }
+            }
+        }
+        if (i < r2) { q_tl += pos_lo; q_tr += pos_hi; } else { q_bl += pos_lo; q_br += pos_hi; }
+        // first / last valid column of row i inside this wave's 256 columns
+        const unsigned long long any = __ballot(m != 0);
+        if (any) {
+            const int lo_lane = __ffsll((long long)any) - 1, hi_lane = 63 - __clzll((long long)any);
+            if (lane == lo_lane) atomicMax(&S.rowFirstEnc[i], c - 1 - (j + (__ffs((int)m) - 1) / 8));
+            if (lane == hi_lane) atomicMax(&S.rowLast[i], j + (31 - __clz((int)m)) / 8);
+        }
+    }
+    for (int k = 0; k < nk; k++)
+        if (last[k] >= 0) { atomicMax(&S.colLast[j + k], last[k]); atomicMax(&S.colFirstEnc[j + k], r - 1 - first[k]); }
+    // block reduction of the five counts: wave shuffles, then one set of atomics per workgroup
+    unsigned v5[5] = {valid, q_tl, q_bl, q_br, q_tr};
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        unsigned x = v5[q];
+        for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+        if (lane == 0) s_cnt[q][wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const unsigned x = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
+        if (x) atomicAdd(threadIdx.x == 0 ? &S.st->valid : &S.st->quad[threadIdx.x - 1], (unsigned long long)x);
+    }
+    // the last workgroup to arrive builds the ramps
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(S.done, 1u) == gridDim.x * gridDim.y - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x < 8) S.out[threadIdx.x] = 0;
+    __syncthreads();
+    fuse_weights_body(r, c, V.ch, dx, dy, 0, S.st, S.rowFirstEnc, S.rowLast, S.colFirstEnc, S.colLast, S.wAr, S.wAc, S.wBr, S.wBc, S.out, sticky_err, 3);
+    __syncthreads();
+    // records back to their initial values for the next tile
+    for (int i = threadIdx.x; i < r; i += 256) { S.rowFirstEnc[i] = -1; S.rowLast[i] = -1; }
+    for (int jj = threadIdx.x; jj < c; jj += 256) { S.colFirstEnc[jj] = -1; S.colLast[jj] = -1; }
+    if (threadIdx.x == 0) { S.st->valid = 0; S.st->quad[0] = 0; S.st->quad[1] = 0; S.st->quad[2] = 0; S.st->quad[3] = 0; *S.done = 0; }
 }
 
 struct FuseScratch { FuseStats *st; int *rowFirst, *rowLast, *colFirst, *colLast; float *wAr, *wAc, *wBr, *wBc; int *out; };
@@ -521,29 +530,39 @@ int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int
     const int r = ry1 - ry0, c = rx1 - rx0;
     if (r <= 0 || c <= 0) return canvas_paste_device(ctx, cv, d_tile, h, w, y0, x0);
     ProfScope ps(ctx, "fuse");
-    // scratch: [stats | status out] cleared to 0 and [colFirstEnc | colLast] preset to -1 -- two memsets for the whole tile
-    FuseScratch S;
-    char *zero = (char *)ctx_arena_alloc(ctx, 256);
-    S.st = (FuseStats *)zero; S.out = (int *)(zero + 128);
-    int *cols = (int *)ctx_arena_alloc(ctx, sizeof(int) * 2 * (size_t)c);
-    S.colFirst = cols; S.colLast = cols + c;
-    S.rowFirst = (int *)ctx_arena_alloc(ctx, sizeof(int) * r); S.rowLast = (int *)ctx_arena_alloc(ctx, sizeof(int) * r);
-    S.wAr = (float *)ctx_arena_alloc(ctx, sizeof(float) * r); S.wBr = (float *)ctx_arena_alloc(ctx, sizeof(float) * r);
-    S.wAc = (float *)ctx_arena_alloc(ctx, sizeof(float) * c); S.wBc = (float *)ctx_arena_alloc(ctx, sizeof(float) * c);
-    if (!zero || !cols || !S.wBc) { vfsms_set_error("arena exhausted in fuse"); return VFSMS_ERR_CAPACITY; }
-    HIP_TRY(hipMemsetAsync(zero, 0, 256, ctx->stream));
-    HIP_TRY(hipMemsetAsync(cols, 0xff, sizeof(int) * 2 * (size_t)c, ctx->stream));
+    // the canvas's own scratch (allocated and initialised once: canvas_scratch_bytes / canvas_scratch_init): st | out | done | rows | cols | ramps
+    FuseCanvasScratch S;
+    char *base = (char *)cv->scratch;
+    S.st = (FuseStats *)base; S.out = (int *)(base + 64); S.done = (unsigned *)(base + 128);
+    int *ib = (int *)(base + 256);
+    S.rowFirstEnc = ib; S.rowLast = ib + cv->rows; S.colFirstEnc = ib + 2 * (size_t)cv->rows; S.colLast = S.colFirstEnc + cv->cols;
+    float *fb = (float *)(S.colLast + cv->cols);
+    S.wAr = fb; S.wBr = fb + cv->rows; S.wAc = fb + 2 * (size_t)cv->rows; S.wBc = S.wAc + cv->cols;
     CanvasView V;
     V.pix = cv->pix; V.mask = cv->mask; V.ccols = cv->cols; V.ch = cv->ch; V.ry0 = ry0; V.rx0 = rx0;
     V.tile = d_tile; V.tw = w; V.ty0 = ry0 - y0; V.tx0 = rx0 - x0;
-    hipLaunchKernelGGL(k_fuse_stats_rows, dim3((r + FUSE_RBAND - 1) / FUSE_RBAND), dim3(256), 0, ctx->stream, V, r, c, S.st, S.rowFirst, S.rowLast);
-    hipLaunchKernelGGL(k_fuse_stats_cols, dim3((c + 1023) / 1024, (r + FUSE_CBAND - 1) / FUSE_CBAND), dim3(256), 0, ctx->stream, V, r, c, S.colFirst, S.colLast);
-    TRY(launch_weights(ctx, S, r, c, cv->ch, dx, dy, 0, cv->d_err, 1, true));
+    hipLaunchKernelGGL(k_fuse_stats_weights, dim3((c + 1023) / 1024, (r + FUSE_SB - 1) / FUSE_SB), dim3(256), 0, ctx->stream, V, r, c, S, dx, dy, cv->d_err);
     hipLaunchKernelGGL(k_fuse_apply, dim3(cv->ch == 1 ? (w + 1023) / 1024 : (w + 255) / 256, h), dim3(256), 0, ctx->stream, cv->pix, cv->mask, cv->cols, cv->ch,
                        d_tile, h, w, y0, x0, ry0, rx0, r, c, S.out, S.wAr, S.wAc, S.wBr, S.wBc, TrigGeom{method == 1, r, c, dx, dy});
     HIP_TRY(hipGetLastError());
     if (!info) return VFSMS_OK;          // no readback wanted: a degenerate geometry is latched in the canvas and reported by the download
-    return finish_weights(ctx, S, r, c, info);
+    int out[8];
+    HIP_TRY(hipMemcpyAsync(out, S.out, sizeof(out), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 4; k++) info[k] = out[1 + k];
+    if (out[5]) {
+        vfsms_set_error("fuse: degenerate corner geometry (the reference's getWeightsMatrix raises here)");
+        return VFSMS_ERR_BAD_ARG;
+    }
+    return VFSMS_OK;
+}
+
+size_t canvas_scratch_bytes(int rows, int cols) { return 256 + (sizeof(int) * 2 + sizeof(float) * 2) * ((size_t)rows + cols) + 256; }
+int canvas_scratch_init(vfsms_ctx *ctx, CanvasRec *cv)
+{
+    HIP_TRY(hipMemsetAsync(cv->scratch, 0, 256, ctx->stream));
+    HIP_TRY(hipMemsetAsync((char *)cv->scratch + 256, 0xff, sizeof(int) * 2 * ((size_t)cv->rows + cv->cols), ctx->stream));
+    return VFSMS_OK;
 }
 
 // A, B: device int64 [r][c][ch]; out: device u8

@@ -728,7 +728,9 @@ extern "C" int vfsms_debug_desc_trips(unsigned long long *out) { return hipMemcp
 #ifndef VFSMS_EXP
 #define VFSMS_EXP 0
 #endif
-#define DESC_WBUF 16384           // LDS bytes for the staged descriptor window (win <= 128) / band chunk
+#ifndef DESC_WBUF
+#define DESC_WBUF 16384
+#endif                            // LDS bytes for the staged descriptor window (win <= 128) / band chunk
 struct WinGeom {
     int win; float sin_dir, cos_dir;
     int h, w, stride; g_cu8 img;
@@ -780,7 +782,10 @@ __device__ __forceinline__ float bilinear_pk(uint32_t top, float a, float b)
     p = p * nb2; q = q * b2;
     return ((p.x + p.y) + q.x) + q.y;
 }
+#ifndef STAGE_ILP
 #define STAGE_ILP 4
+#endif
+#define UNIT_W (8 * STAGE_ILP)    // columns of a work unit
 #ifndef BORDER_ILP
 #define BORDER_ILP 2            // strips that cross the image border: shorter trips keep the register budget of the hot path
 #endif
@@ -811,7 +816,7 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
     // Work unit = (strip of 8 rows, block of 32 columns), dealt to the waves ROUND-ROBIN: units that cross the image border cost
     // several times an interior unit, and they come in runs (the last strips of a window that hangs over the edge) -- contiguous runs
     // per wave left three waves of the workgroup waiting at the barrier for the one that had drawn the border strips.
-    const int ncb = (win + 31) >> 5;
+    const int ncb = (win + UNIT_W - 1) / UNIT_W;
     const int total = strips * ncb;
     int ty = 0, cbi = wv;                                        // (strip, column block) of the wave's current unit; stepped, not divided
     while (cbi >= ncb) { cbi -= ncb; ty++; }
@@ -820,8 +825,8 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
 #endif
     for (int unit = wv; unit < total; unit += NW) {
         DT_UNIT_BEGIN;
-        const int cb0 = cbi * 32;
-        const int cb1 = min(win, cb0 + 32);
+        const int cb0 = cbi * UNIT_W;
+        const int cb1 = min(win, cb0 + UNIT_W);
         const int r = ty * 8 + li;
         // a lane past the strip's last row repeats that row: same position, same value, same LDS byte
         const int rc = min(r, nrows - 1);
