@@ -108,6 +108,8 @@ _SIGNATURES = {
     "vfsms_enhance_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]),
     "vfsms_pairs_offsets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(GridParams), C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "vfsms_pairs_offsets_blind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vfsms_pairs_offsets_blind_eval": (C.c_int, [ATTEMPT_EVAL, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vfsms_pairs_offsets_eval": (C.c_int, [ATTEMPT_EVAL, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.POINTER(GridParams), C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "vfsms_attempt_phase_batch": (C.c_int, [C.c_void_p, C.POINTER(RoiPair), C.c_int, C.c_void_p]),
@@ -505,6 +507,18 @@ class Engine:
                                                  int(bool(stop_on_fail)), C.byref(params), _ptr(out), C.byref(d_out), _ptr(stats)))
         return out, d_out.value, tuple(int(v) for v in stats)
 
+    def pairs_offsets_blind(self, handles, shapes, params, first, last, per):
+        """vfsms_pairs_offsets_blind: the chunk [first, last) for every possible incoming direction -> (int32[4, per, 6], int32[4] directions out, stats)."""
+        n = len(shapes)
+        hs = np.array([h if h is not None else 0 for h in handles], np.int64)
+        sh = np.ascontiguousarray(np.array([[s[0], s[1]] for s in shapes], np.int32))
+        out = np.zeros((4, max(per, 1), 6), np.int32)
+        d_out = np.zeros(4, np.int32)
+        stats = np.zeros(8, np.int64)
+        self._check(self.lib.vfsms_pairs_offsets_blind(self.ctx, _ptr(hs), _ptr(sh), n, int(first), int(last), int(max(per, 1)), C.byref(params),
+                                                       _ptr(out), _ptr(d_out), _ptr(stats)))
+        return out[:, :per], d_out, tuple(int(v) for v in stats)
+
     # -- resident feature sets (Stitcher.tempImageFeature's payload kept in HBM) -----------------------------------------------
     def features_surf(self, tile_handle, rect, params=None, enhance=(0, 0.0, 0)):
         """SURF of rect = (y0, x0, h, w) of a resident tile -> (feature handle, n keypoints); nothing returns to the host."""
@@ -641,6 +655,37 @@ def default_engine():
             raise VfsmsError("no HIP device visible: imagestitch_amd needs an MI355X (there is no CPU fallback)")
         _default_engine = Engine(dev % n)
     return _default_engine
+
+
+def pairs_offsets_blind_eval(attempts, shapes, params, first, last, per):
+    """vfsms_pairs_offsets_blind_eval over a Python evaluator (needs no GPU) -> (int32[4, per, 6], int32[4], stats)."""
+    lib = load_library()
+    n = len(shapes)
+    err = []
+
+    def cb(_user, items, count, rows):
+        try:
+            res = attempts([(items[k].pair, items[k].direction, items[k].i) for k in range(count)])
+            for k, r in enumerate(res):
+                for c in range(min(len(r), ATTEMPT_INTS)):
+                    rows[k * ATTEMPT_INTS + c] = int(r[c])
+            return 0
+        except Exception as e:            # never let an exception cross the C frame
+            err.append(e)
+            return -1
+    sh = np.ascontiguousarray(np.array([[s[0], s[1]] for s in shapes], np.int32))
+    out = np.zeros((4, max(per, 1), 6), np.int32)
+    d_out = np.zeros(4, np.int32)
+    stats = np.zeros(8, np.int64)
+    rc = lib.vfsms_pairs_offsets_blind_eval(ATTEMPT_EVAL(cb), None, _ptr(sh), n, int(first), int(last), int(max(per, 1)), C.byref(params),
+                                            _ptr(out), _ptr(d_out), _ptr(stats))
+    if err:
+        raise err[0]
+    if rc != VFSMS_OK:
+        buf = C.create_string_buffer(512)
+        lib.vfsms_last_error(buf, 512)
+        raise VfsmsError("libvfsms error %d: %s" % (rc, buf.value.decode(errors="replace")))
+    return out[:, :per], d_out, tuple(int(v) for v in stats)
 
 
 def pairs_offsets_eval(attempts, shapes, params, first=0, last=None, direction=1, midpath=False, stop_on_fail=False):

@@ -41,6 +41,7 @@ struct Chain {
     const int32_t *shapes; int n_tiles;
     const vfsms_grid_params *P;
     std::map<Key, Attempt> cache;
+    std::map<std::pair<int, int>, std::pair<Row, int>> memo;   // (pair, incoming direction) -> (row, next direction): chains that start blind share it
     long long n_attempts = 0, n_batches = 0;
 
     int maxI() const { return (int)(floor(0.5 / P->roi_ratio) + 1) + 1; }
@@ -98,6 +99,10 @@ struct Chain {
         std::map<int, int> ring_hint;                        // direction -> ring position that resolved the last turn from it
         std::map<std::pair<int, int>, int> trans2;           // (direction before, direction) -> direction the next turn led to
         for (int k = first; k < last; k++) {
+          Row row; int d_next;
+          const auto mem = memo.find(std::make_pair(k, d));
+          if (mem != memo.end()) { row = mem->second.first; d_next = mem->second.second; }    // another chain has been here: same state, same future
+          else {
             // ---- predicted continuation of the path as one batch (up to `window` attempts)
             if (!cache.count(Key(k, d, 1))) {
                 std::vector<Key> items;
@@ -132,7 +137,8 @@ struct Chain {
                     kk += 1;
                 }
                 if (items.empty())                            // no history yet: slow start
-                    for (int kk2 = k; kk2 < std::min(k + slow, last); kk2++) items.push_back(Key(kk2, d, 1));
+                    for (int kk2 = k; kk2 < std::min(k + slow, last); kk2++)
+                        if (!memo.count(std::make_pair(kk2, d))) items.push_back(Key(kk2, d, 1));
                 TRY(evaluate(items, last));
                 if (!cache.count(Key(k, d, 1))) { std::vector<Key> one(1, Key(k, d, 1)); TRY(evaluate(one, last)); }
             }
@@ -160,7 +166,6 @@ struct Chain {
                     }
                 }
             }
-            Row row; int d_next;
             if (found) {
                 int dx = fa, dy = fb;
                 correct(dx, dy, fd, fi, k);
@@ -170,6 +175,8 @@ struct Chain {
                 row.v[0] = 0; row.v[1] = 0; row.v[2] = 0; row.v[3] = d; row.v[4] = 0; row.v[5] = 0;
                 d_next = d;                                    // a failed pair leaves self.direction untouched
             }
+            memo[std::make_pair(k, d)] = std::make_pair(row, d_next);
+          }
             // ---- predictor bookkeeping
             if (row.v[0] && d_next == d) {
                 run_len += 1;
@@ -286,6 +293,42 @@ extern "C" int vfsms_pairs_offsets_eval(vfsms_attempt_eval eval, void *user, con
     Chain C; C.eval = eval; C.user = user; C.shapes = shapes_hw; C.n_tiles = n_tiles; C.P = p;
     const int rc = C.run(first_pair, last_pair, direction_in, midpath, stop_on_fail, out, direction_out);
     if (stats) { for (int k = 0; k < 8; k++) stats[k] = 0; stats[0] = C.n_attempts; stats[1] = C.n_batches; }
+    return rc;
+}
+
+// A chunk in the MIDDLE of a path (rank > 0 of the pair-sharded form): the direction it is entered with is the result of the
+// pairs before it, which another GPU is still working on.  The chunk is therefore registered for every possible incoming direction:
+// the four first candidates of its first pair go out as ONE batch, the four chains share one attempt cache and one (pair, direction)
+// memo, and they merge as soon as they agree on a direction -- after the first pair, in practice.  out: [4][per][6] rows, chain d at
+// out + (d - 1) * per * 6; direction_out[4].
+extern "C" int vfsms_pairs_offsets_blind_eval(vfsms_attempt_eval eval, void *user, const int32_t *shapes_hw, int n_tiles, int first_pair, int last_pair,
+                                              int per, const vfsms_grid_params *p, int32_t *out, int32_t *direction_out, int64_t *stats)
+{
+    if (!eval) { vfsms_set_error("pairs_offsets: null evaluator"); return VFSMS_ERR_BAD_ARG; }
+    TRY(check_args(shapes_hw, n_tiles, first_pair, last_pair, 1, p, out, direction_out));
+    if (per < last_pair - first_pair) { vfsms_set_error("pairs_offsets_blind: per < chunk length"); return VFSMS_ERR_BAD_ARG; }
+    memset(out, 0, sizeof(int32_t) * 6 * 4 * (size_t)per);
+    Chain C; C.eval = eval; C.user = user; C.shapes = shapes_hw; C.n_tiles = n_tiles; C.P = p;
+    if (last_pair > first_pair) {
+        std::vector<Key> heads;
+        for (int d = 1; d <= 4; d++) heads.push_back(Key(first_pair, d, 1));
+        TRY(C.evaluate(heads, last_pair));
+    }
+    for (int d = 1; d <= 4; d++) {
+        direction_out[d - 1] = d;
+        if (last_pair > first_pair) TRY(C.run(first_pair, last_pair, d, 1, 0, out + (size_t)(d - 1) * per * 6, &direction_out[d - 1]));
+    }
+    if (stats) { for (int k = 0; k < 8; k++) stats[k] = 0; stats[0] = C.n_attempts; stats[1] = C.n_batches; }
+    return VFSMS_OK;
+}
+
+extern "C" int vfsms_pairs_offsets_blind(vfsms_ctx *ctx, const int64_t *tiles, const int32_t *shapes_hw, int n_tiles, int first_pair, int last_pair,
+                                         int per, const vfsms_grid_params *p, int32_t *out, int32_t *direction_out, int64_t *stats)
+{
+    if (!ctx || !tiles) { vfsms_set_error("pairs_offsets: null context / tiles"); return VFSMS_ERR_BAD_ARG; }
+    DeviceEval E; E.ctx = ctx; E.tiles = tiles; E.shapes = shapes_hw; E.P = p;
+    const int rc = vfsms_pairs_offsets_blind_eval(device_eval, &E, shapes_hw, n_tiles, first_pair, last_pair, per, p, out, direction_out, stats);
+    if (stats) { stats[2] = E.cap_retries; stats[3] = E.sum_nq_nt; stats[4] = E.sum_nq_plus_nt; stats[5] = E.roi_px; }
     return rc;
 }
 

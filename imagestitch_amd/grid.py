@@ -299,6 +299,11 @@ class GridRegistrar:
         table = np.zeros((4, per, RESULT_INTS), np.int32)
         d_out = np.zeros(4, np.int32)
         memo, cache = {}, {}
+        if len(dirs) > 1 and hi > lo and self.native and hasattr(self.eng, "pairs_offsets_blind"):
+            # the four blind chains inside the library (csrc/grid.hip: the same machine, shared cache and memo)
+            res, dn, st = self.eng.pairs_offsets_blind(handles, shapes, self._grid_params(), lo, hi, per)
+            self._native_stats(st)
+            return np.concatenate([np.asarray(res, np.int32).reshape(-1), np.asarray(dn, np.int32)])
         if len(dirs) > 1 and hi > lo:
             # the incoming direction is unknown here: every chain needs its own first candidate of the first pair, so all four
             # are evaluated as one batch instead of being discovered one chain after the other

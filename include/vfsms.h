@@ -240,6 +240,15 @@ typedef int (*vfsms_attempt_eval)(void *user, const vfsms_attempt_key *items, in
 int vfsms_pairs_offsets_eval(vfsms_attempt_eval eval, void *user, const int32_t *shapes_hw, int n_tiles, int first_pair, int last_pair,
                              int direction_in, int midpath, int stop_on_fail, const vfsms_grid_params *p, int32_t *out,
                              int32_t *direction_out, int64_t *stats);
+/* A chunk in the MIDDLE of a path (a rank > 0 of the pair-sharded multi-GPU form): its incoming `self.direction` (Stitcher.py:252,361)
+ * is the result of pairs another GPU is still registering, so the chunk [first_pair, last_pair) is registered for each of the four
+ * possible incoming directions -- first candidates of the first pair in ONE batch, shared attempt cache, chains merged as soon as
+ * they agree (after one pair, in practice).  out: int32[4][per][6], chain of incoming direction d at (d - 1) * per * 6 (per >= chunk
+ * length: the padded row count of the all-gather payload); direction_out[4] = the direction each chain ends in.              */
+int vfsms_pairs_offsets_blind(vfsms_ctx *ctx, const int64_t *tiles, const int32_t *shapes_hw, int n_tiles, int first_pair, int last_pair,
+                              int per, const vfsms_grid_params *p, int32_t *out, int32_t *direction_out, int64_t *stats);
+int vfsms_pairs_offsets_blind_eval(vfsms_attempt_eval eval, void *user, const int32_t *shapes_hw, int n_tiles, int first_pair, int last_pair,
+                                   int per, const vfsms_grid_params *p, int32_t *out, int32_t *direction_out, int64_t *stats);
 
 /* ---- whole-tile feature search with the reference's feature cache (Stitcher.calculateOffsetForFeatureSearch, Stitcher.py:260-304) --
  * Stitcher.tempImageFeature (Stitcher.py:14-18,278-290) keeps tile B's keypoints + descriptors so that they become tile A's of the

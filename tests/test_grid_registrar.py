@@ -155,3 +155,47 @@ def test_native_pairs_offsets_state_machine_equals_python_and_sequential():
     res, d, _st = pairs_offsets_eval(lambda items: [[int((dd, i) in accept[k])] + ([3, 3, 5] if (dd, i) in accept[k] else [0, 0, 0]) + [9, 9, 4, 0] for (k, dd, i) in items],
                                      [SHAPE] * 4, Engine.grid_params(roiRatio=0.2, directIncre=1, window=8), 0, 3, 1, False, True)
     assert res[:, 0].tolist() == [1, 0, 0]
+
+
+def test_native_blind_chains_equal_python_twin():
+    """vfsms_pairs_offsets_blind_eval (csrc/grid.hip) -- the chunk of a rank > 0, registered for all four possible incoming directions with a
+    shared attempt cache and (pair, direction) memo -- against GridRegistrar.shard_payload's Python twin on random truth tables: the same
+    payload (4 x per x 6 rows + 4 end directions), the same attempts in the same order, the same batch count; and the chain of the TRUE
+    incoming direction equals the sequential search of that chunk."""
+    from imagestitch_amd._lib import pairs_offsets_blind_eval, Engine
+    for seed in range(30):
+        rng = np.random.default_rng(7000 + seed)
+        roiRatio = float(rng.choice([0.1, 0.2]))
+        incre = int(rng.choice([-1, 1]))
+        P = int(rng.integers(4, 60))
+        world = int(rng.integers(2, 5))
+        rank = int(rng.integers(1, world))
+        window = int(rng.choice([3, 8, 24]))
+        accept = random_truth(rng, P, roiRatio)
+        eng = ScriptedAttemptEngine(SHAPE, roiRatio, accept)
+        reg = GridRegistrar(eng, roiRatio=roiRatio, directIncre=incre, window=window)
+        reg.native = False
+        shapes = [SHAPE] * (P + 1)
+        pay_py = reg.shard_payload(list(range(P + 1)), shapes, 1, rank, world)
+        bounds = GridRegistrar.chunk_bounds(P, world)
+        lo, hi = bounds[rank]
+        per = max(b - a for a, b in bounds)
+        log = []
+
+        def attempts(items, accept=accept, log=log):
+            rows = []
+            for (k, d, i) in items:
+                log.append((k, d, i))
+                acc = accept[k]
+                ok = (d, i) in acc
+                raw = acc[(d, i)] if ok else (7, -3)
+                rows.append([int(ok), raw[0], raw[1], 5 if ok else 1, 100, 100, 10, 0])
+            return rows
+        params = Engine.grid_params(method="surf", roiRatio=roiRatio, directIncre=incre, window=window)
+        res, dn, st = pairs_offsets_blind_eval(attempts, shapes, params, lo, hi, per)
+        pay_c = np.concatenate([np.asarray(res, np.int32).reshape(-1), np.asarray(dn, np.int32)])
+        assert np.array_equal(pay_c, pay_py), (seed, lo, hi)
+        assert log == eng.log and st[0] == len(log) == reg.stats["attempts"] and st[1] == reg.stats["batches"], (seed, len(log), len(eng.log))
+        for d_in in (1, 2, 3, 4):                              # every chain is the sequential search of the chunk entered with d_in
+            seq, d_end, _ = sequential(accept[lo:hi], roiRatio, incre, d_in)
+            assert [list(r[:4]) for r in res[d_in - 1][:hi - lo].tolist()] == seq and int(dn[d_in - 1]) == d_end, (seed, d_in)
