@@ -551,6 +551,80 @@ __global__ __launch_bounds__(256) void k_rank_sort(const RoiDev *rois)
     }
 }
 
+// The same order by BUCKETS instead of all-pairs counting (k_rank_sort above: n^2 key compares, 190 us per 16-ROI launch): one 1024-thread
+// workgroup per ROI histograms the candidates over 1024 buckets of the response's float bits (exponent + 5 mantissa bits; responses
+// are > hessianThreshold), scans the histogram from the top (descending order), scatters (key, index) records bucket by bucket into
+// scratch (the patch buffer, unused until the descriptor stage) and ranks every candidate against its own bucket only -- a few dozen
+// full KeypointGreater compares instead of n (k_bucket_rank, on the whole chip).  The result is the identical permutation: rank = (candidates in higher buckets) +
+// (candidates of the same bucket that sort before it), and bucket order is response order.
+#define SORT_BUCKETS 1024
+struct SortRec { unsigned long long k1, k2, k3; int idx, pad; };
+__device__ __forceinline__ int sort_bucket(unsigned long long k1)
+{
+    const int b = (int)((uint32_t)(k1 >> 32) >> 18) - (133 << 5);     // float bits >> 18: exponent and 5 mantissa bits; 2^6 <= response
+    return min(max(b, 0), SORT_BUCKETS - 1);
+}
+__global__ __launch_bounds__(1024) void k_bucket_sort(const RoiDev *rois)
+{
+    const RoiDev &R = rois[blockIdx.x];
+    const int n = min(R.counters[0], R.cap);
+    if (n <= 0) return;
+    __shared__ int hist[SORT_BUCKETS], base[SORT_BUCKETS], cursor[SORT_BUCKETS], wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    hist[tid] = 0; cursor[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[sort_bucket(make_key(R.cand[i]).k1)], 1);
+    __syncthreads();
+    {   // base[b] = candidates in buckets above b: inclusive scan over the reversed histogram minus the own count
+        const int rb = SORT_BUCKETS - 1 - tid;
+        const int v = hist[rb];
+        int incl = wave_incl_scan(v);
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        int off = 0;
+        for (int k = 0; k < wid; k++) off += wsum[k];
+        base[rb] = off + incl - v;
+    }
+    __syncthreads();
+    SortRec *S = reinterpret_cast<SortRec *>(R.patch);                // cap * 464 B >= cap * 32 B
+    for (int i = tid; i < n; i += 1024) {
+        const SortKey k = make_key(R.cand[i]);
+        const int b = sort_bucket(k.k1);
+        const int pos = base[b] + atomicAdd(&cursor[b], 1);
+        SortRec r; r.k1 = k.k1; r.k2 = k.k2; r.k3 = k.k3; r.idx = i; r.pad = 0;
+        S[pos] = r;
+    }
+    // bucket bounds for the ranking kernel (keep_pos / order are free until the descriptor stage; the launcher checks cap >= SORT_BUCKETS)
+    R.keep_pos[tid] = base[tid]; R.order[tid] = hist[tid];
+}
+
+// rank of every candidate inside its bucket (a few dozen to a few hundred full KeypointGreater compares), 256 candidates per workgroup
+__global__ __launch_bounds__(256) void k_bucket_rank(const RoiDev *rois)
+{
+    const RoiDev &R = rois[blockIdx.y];
+    const int n = min(R.counters[0], R.cap);
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const SortRec *S = reinterpret_cast<const SortRec *>(R.patch);
+    const SortRec me = S[p];
+    const int b = sort_bucket(me.k1);
+    const int lo = R.keep_pos[b], hi = lo + R.order[b];
+    int rank = lo;
+    for (int q = lo; q < hi; q++) {
+        const unsigned long long a1 = S[q].k1;
+        if (a1 > me.k1) rank++;
+        else if (a1 == me.k1) {
+            const unsigned long long a2 = S[q].k2, a3 = S[q].k3;
+            rank += (a2 < me.k2 || (a2 == me.k2 && a3 < me.k3)) ? 1 : 0;
+        }
+    }
+    const Cand c = R.cand[me.idx];
+    vfsms_keypoint kp;
+    kp.x = c.x; kp.y = c.y; kp.size = c.size; kp.angle = -1.f; kp.response = c.response;
+    kp.octave = c.octave; kp.class_id = c.class_id;
+    R.kps[rank] = kp;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K4 orientation (SURFInvoker, upright == 0): 128 threads per keypoint
 // ---------------------------------------------------------------------------------------------------
@@ -1635,7 +1709,14 @@ int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_roi
     }
     {
         ProfScope ps(ctx, "sort");
-        hipLaunchKernelGGL(k_rank_sort, dim3((maxcap + 63) / 64, nrois), dim3(256), 0, ctx->stream, d_rois);
+        static const bool n2sort = getenv("VFSMS_SORT_N2") && atoi(getenv("VFSMS_SORT_N2")) != 0;
+        int mincap = maxcap;
+        for (int r = 0; r < nrois; r++) mincap = h_rois[r].cap < mincap ? h_rois[r].cap : mincap;
+        if (n2sort || mincap < SORT_BUCKETS) hipLaunchKernelGGL(k_rank_sort, dim3((maxcap + 63) / 64, nrois), dim3(256), 0, ctx->stream, d_rois);
+        else {
+            hipLaunchKernelGGL(k_bucket_sort, dim3(nrois), dim3(1024), 0, ctx->stream, d_rois);
+            hipLaunchKernelGGL(k_bucket_rank, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
+        }
     }
     HIP_TRY(hipGetLastError());
     return VFSMS_OK;
