@@ -1007,38 +1007,10 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
 #endif
 }
 
-// one destination index of computeResizeAreaTab: up to (left partial, full cells [sx1,sx2), right partial)
-struct AreaSpan { int s_left; float a_left; int sx1, sx2; float a_full; int s_right; float a_right; };
-
-__device__ __forceinline__ AreaSpan area_span(int dx, int ssize, double scale)
-{
-    AreaSpan S;
-    double fsx1 = dx * scale;
-    double fsx2 = fsx1 + scale;
-    double cellWidth = fmin(scale, ssize - fsx1);
-    int sx1 = cv_ceil_d(fsx1), sx2 = cv_floor_d(fsx2);
-    sx2 = min(sx2, ssize - 1);
-    sx1 = min(sx1, sx2);
-    S.s_left = -1; S.s_right = -1; S.a_left = 0; S.a_right = 0;
-    if (sx1 - fsx1 > 1e-3) { S.s_left = sx1 - 1; S.a_left = (float)((sx1 - fsx1) / cellWidth); }
-    S.sx1 = sx1; S.sx2 = sx2; S.a_full = (float)(1.0 / cellWidth);
-    if (fsx2 - sx2 > 1e-3) { S.s_right = sx2; S.a_right = (float)(fmin(fmin(fsx2 - sx2, 1.), cellWidth) / cellWidth); }
-    return S;
-}
-
 __device__ __forceinline__ uint8_t sat_u8(float v)
 {
     int iv = cv_round_f(v);
     return (uint8_t)(iv < 0 ? 0 : iv > 255 ? 255 : iv);
-}
-
-__device__ __forceinline__ float area_row(const uint8_t *S, const AreaSpan &Sx)   // one source row of one cell (buf[dx])
-{
-    float buf = 0;
-    if (Sx.s_left >= 0) buf += (float)S[Sx.s_left] * Sx.a_left;
-    for (int sxx = Sx.sx1; sxx < Sx.sx2; sxx++) buf += (float)S[sxx] * Sx.a_full;
-    if (Sx.s_right >= 0) buf += (float)S[Sx.s_right] * Sx.a_right;
-    return buf;
 }
 
 // computeResizeAreaTab per window size, built ONCE per context on the host (ctx_prepare_area_tab): record dx < 21 of window `win` = the run of
@@ -1341,7 +1313,7 @@ __global__ __launch_bounds__(1024, 8) void k_orientation(const RoiDev *rois, con
 // the sampling and INTER_AREA arithmetic of describe_one (stage_rows<1>, the same cell code).
 // ---------------------------------------------------------------------------------------------------
 #define DESC_SMALL_WIN 64
-struct SmallLds { uint8_t win[DESC_SMALL_WIN * DESC_SMALL_WIN]; float sx[DESC_SMALL_WIN + 8], sy[DESC_SMALL_WIN + 8]; AreaSpan span[21]; };
+struct SmallLds { uint8_t win[DESC_SMALL_WIN * DESC_SMALL_WIN + 64]; float sx[DESC_SMALL_WIN + 8], sy[DESC_SMALL_WIN + 8]; AreaRec rec[AREA_RECS]; int rec_win; };
 
 __device__ __forceinline__ void wave_sync_lds()
 {
@@ -1349,7 +1321,7 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ void describe_small(const RoiDev &R, const int k, int upright, SmallLds &L)
+__device__ void describe_small(const RoiDev &R, const AreaRec *area_tab, const int k, int upright, SmallLds &L)
 {
     const int lane = threadIdx.x & 63;
     const vfsms_keypoint kp = R.kps[k];
@@ -1361,10 +1333,13 @@ __device__ void describe_small(const RoiDev &R, const int k, int upright, SmallL
     G.upright = upright; G.usx = 0; G.usy = 0; G.sin_dir = 0.f; G.cos_dir = 0.f;
     const int win = G.win;
     const int dsz = 21;
-    const double inv_scale = (double)dsz / win;
-    const double scale = 1. / inv_scale;
-    const int iscale = cv_round_d(scale);
-    const bool is_area_fast = fabs(scale - iscale) < DBL_EPSILON;
+    // computeResizeAreaTab of this window size from the host-built table (kept while the wave's next keypoint has the same window)
+    if (L.rec_win != win) {
+        wave_sync_lds();
+        const int *src = (const int *)(area_tab + (size_t)max(win, dsz) * AREA_RECS);
+        for (int e = lane; e < AREA_RECS * 8; e += 64) ((int *)L.rec)[e] = src[e];
+        if (lane == 0) L.rec_win = win;
+    }
     if (!upright) {
         const float sin_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[0];
         const float cos_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[1];
@@ -1384,47 +1359,39 @@ __device__ void describe_small(const RoiDev &R, const int k, int upright, SmallL
         G.usx = cv_round_f(kp.x + win_offset);
         G.usy = cv_round_f(kp.y - win_offset);
     }
-    if (!is_area_fast && lane >= 32 && lane < 32 + dsz) L.span[lane - 32] = area_span(lane - 32, win, scale);
     wave_sync_lds();
     stage_rows<1>(G, L.sx, L.sy, 0, win, L.win);
     wave_sync_lds();
+    const int nmin = __builtin_amdgcn_readfirstlane(L.rec[21].j0), nmax = __builtin_amdgcn_readfirstlane(L.rec[21].n);
+    const int mode = __builtin_amdgcn_readfirstlane(L.rec[21].mode);
+    const float inv_area = L.rec[21].a0;
     uint8_t *prow = R.patch + (size_t)k * VFSMS_PATCH_ROW;
+    // one output pixel per lane: sum over its source rows of beta * (row sum of its cell), uniform trip counts (surplus rows / pixels
+    // weigh 0; they read at most nmax bytes past the window, inside L.win's padding or the row origins behind it)
     for (int o = lane; o < dsz * dsz; o += 64) {
-        const int dy = o / dsz, dx = o % dsz;
-        uint8_t outv;
-        if (is_area_fast && iscale == 2) {
-            const uint8_t *S = L.win + (dy * 2) * win + dx * 2;
-            outv = (uint8_t)((S[0] + S[1] + S[win] + S[win + 1] + 2) >> 2);
-        } else if (is_area_fast) {
-            int sum = 0;
-            for (int sy = 0; sy < iscale; sy++)
-                for (int sx = 0; sx < iscale; sx++) sum += L.win[(dy * iscale + sy) * win + dx * iscale + sx];
-            outv = sat_u8(sum * (1.f / (iscale * iscale)));
-        } else {
-            const AreaSpan Sy = L.span[dy], Sx = L.span[dx];
-            float sum = 0; bool first = true;
-            for (int pass = 0; pass < 3; pass++) {
-                int r0 = pass == 0 ? Sy.s_left : pass == 1 ? Sy.sx1 : Sy.s_right;
-                int r1 = pass == 1 ? Sy.sx2 : r0 + 1;
-                float beta = pass == 0 ? Sy.a_left : pass == 1 ? Sy.a_full : Sy.a_right;
-                if (pass != 1 && r0 < 0) continue;
-                for (int sy = r0; sy < r1; sy++) {
-                    const float buf = area_row(L.win + sy * win, Sx);
-                    if (first) { sum = beta * buf; first = false; } else sum += beta * buf;
-                }
-            }
-            outv = sat_u8(sum);
+        const int dy = (int)(((uint32_t)o * 3121u) >> 16), dx = o - dsz * dy;
+        const AreaRec ry = L.rec[dy], rx = L.rec[dx];
+        const uint8_t *S = L.win + ry.j0 * win;
+        float sum = ry.a0 * area_row_tab(S, rx, nmin, nmax);
+        for (int ty = 1; ty < nmax; ty++) {
+            const float beta = ty < ry.n - 1 ? ry.af : (ty == ry.n - 1 ? ry.al : 0.f);
+            sum += beta * area_row_tab(S + ty * win, rx, nmin, nmax);
         }
+        uint8_t outv;
+        if (mode == 2) outv = (uint8_t)(((int)sum + 2) >> 2);
+        else if (mode == 1) outv = sat_u8(sum * inv_area);
+        else outv = sat_u8(sum);
         prow[o] = outv;                                    // the 21 x 21 patch for k_desc_tail
     }
     wave_sync_lds();                                       // the next keypoint of this wave overwrites L
 }
 
 #define DESC_SMALL_WGS 6
-__global__ __launch_bounds__(256, DESC_SMALL_WGS) void k_describe_small(const RoiDev *rois, int nrois, int *counter, int upright)
+__global__ __launch_bounds__(256, DESC_SMALL_WGS) void k_describe_small(const RoiDev *rois, int nrois, int *counter, const AreaRec *area_tab, int upright)
 {
     __shared__ int prefix[VFSMS_MAX_ROIS + 1];            // class-3 keypoints of the ROIs before each ROI
     __shared__ SmallLds L[4];
+    if (threadIdx.x < 4) L[threadIdx.x].rec_win = -1;
     for (int e = threadIdx.x; e < nrois; e += 256) prefix[e + 1] = rois[e].counters[12 + 3];
     __syncthreads();
     if (threadIdx.x == 0) { prefix[0] = 0; for (int e = 0; e < nrois; e++) prefix[e + 1] += prefix[e]; }
@@ -1448,7 +1415,7 @@ __global__ __launch_bounds__(256, DESC_SMALL_WGS) void k_describe_small(const Ro
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= t) lo = mid; else hi = mid; }
         const RoiDev &R = rois[lo];
         const int within = t - prefix[lo] + R.counters[12] + R.counters[13] + R.counters[14];   // the ROI's list is class-major
-        describe_small(R, __builtin_amdgcn_readfirstlane(R.order[within]), upright, L[wave]);
+        describe_small(R, area_tab, __builtin_amdgcn_readfirstlane(R.order[within]), upright, L[wave]);
     }
 }
 
@@ -1801,7 +1768,7 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
         hipLaunchKernelGGL(k_describe, dim3(256 * DESC_WGS), dim3(256), 0, ctx->stream, d_rois, nrois, tickets,
                            ctx->d_tables, (const AreaRec *)ctx->d_area_tab, p->extended, p->upright);
         hipLaunchKernelGGL(k_describe_small, dim3(256 * DESC_SMALL_WGS), dim3(256), 0, ctx->stream, d_rois, nrois,
-                           tickets + DESC_HEADS * DESC_HEAD_STRIDE, p->upright);
+                           tickets + DESC_HEADS * DESC_HEAD_STRIDE, (const AreaRec *)ctx->d_area_tab, p->upright);
         hipLaunchKernelGGL(k_desc_tail, dim3((maxcap + 15) / 16, nrois), dim3(256), 0, ctx->stream, d_rois, ctx->d_tables, p->extended);
     }
     HIP_TRY(hipGetLastError());
