@@ -444,7 +444,7 @@ def main():
     ap.add_argument("--rows", type=int, default=10)
     ap.add_argument("--cols", type=int, default=9)
     ap.add_argument("--tile", type=int, default=2048)
-    ap.add_argument("--window", type=int, default=24)
+    ap.add_argument("--window", type=int, default=48)
     ap.add_argument("--method", default="surf", choices=["surf", "orb", "phase", "fuse", "surf_full"],
                     help="surf = the BASELINE metric; orb / phase time the other registration paths on the same grid; fuse = the"
                          " secondary metric of SURVEY 8d (mosaic assembly with fadeInAndFadeOut blending, N = 1 only)")

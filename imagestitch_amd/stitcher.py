@@ -239,7 +239,7 @@ class Stitcher(Utility.Method):
         params = None if method == "phase" else (self._orbParams() if method == "orb" else self._surfParams())
         reg = GridRegistrar(eng, method="surf" if method == "surf_full" else method, roiRatio=self.roiRatio, searchRatio=self.searchRatio, offsetEvaluate=self.offsetEvaluate,
                             directIncre=self.directIncre, surfParams=params,
-                            phaseResponseThreshold=self.phaseResponseThreshold, window=24,
+                            phaseResponseThreshold=self.phaseResponseThreshold, window=48,
                             enhance=self._enhanceSpec() if method in ("surf", "surf_full") else (0, 0.0, 0))
         reg.orbMaxDistance = self.orbMaxDistance if self.isGPUAvailable else -1
         keep = (not self.isColorMode) and self.fuseMethod in ("notFuse", "fadeInAndFadeOut", "trigonometric") and hasattr(eng, "canvas_fuse_tile_resident")
