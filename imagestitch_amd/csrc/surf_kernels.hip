@@ -865,7 +865,7 @@ __device__ __forceinline__ float bilinear_pk(uint32_t top, float a, float b)
 #endif
 template <int NW>                                              // NW waves share the strips (4: the workgroup; 1: one wave on its own)
 __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row, const float *sy_row,
-                                           int r0, int nrows, uint8_t *dst)
+                                           int r0, int nrows, uint8_t *dst, uint8_t *strip_in)
 {
     // everything that is the same for the whole wave is pinned to SGPRs (the compiler cannot know that a keypoint read through a
     // ticket index, or threadIdx.x >> 6, is wave-uniform): the unit bookkeeping below then runs on the scalar unit, not on the VALU
@@ -892,11 +892,35 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
     // per wave left three waves of the workgroup waiting at the barrier for the one that had drawn the border strips.
     const int ncb = (win + UNIT_W - 1) / UNIT_W;
     const int total = strips * ncb;
+    // Which strips lie inside the image as a whole (all `win` columns)?  One lane per strip answers once for everybody (the same
+    // separable extremes as the unit test below, over the full width); units of such strips skip their own test -- it was a sixth of
+    // the instructions of an interior unit.
+    if (!G.upright) {
+        const int tid = NW == 1 ? lane : (int)threadIdx.x;
+        if (tid < strips) {
+            const int ia = min(r0 + tid * 8, VFSMS_MAX_WIN - 1), ib = min(min(r0 + tid * 8 + 7, r0 + nrows - 1), VFSMS_MAX_WIN - 1);
+            const double xa = (double)sx_row[ia], xb = (double)sx_row[ib], ya = (double)sy_row[ia], yb = (double)sy_row[ib];
+            const double jb = (double)(win - 1);
+            const double jxb = jb * c, jyb = -(jb * sn);
+            const double xmin = fmin(xa, xb) + fmin(0.0, jxb), xmax = fmax(xa, xb) + fmax(0.0, jxb);
+            const double ymin = fmin(ya, yb) + fmin(0.0, jyb), ymax = fmax(ya, yb) + fmax(0.0, jyb);
+            strip_in[tid] = xmin >= 0.0 && ymin >= 0.0 && xmax < (double)(ncols1 - 2) && ymax < (double)nrows1;
+        }
+        if (NW == 1) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    }
     int ty = 0, cbi = wv;                                        // (strip, column block) of the wave's current unit; stepped, not divided
     while (cbi >= ncb) { cbi -= ncb; ty++; }
 #ifdef VFSMS_DESC_TIMING
     unsigned long long _s0 = clock64(), _uacc[2] = {0, 0}, _ucnt[2] = {0, 0};
 #endif
+    // The row origins and the strip flag of a unit sit at the head of its dependency chain (LDS read -> f64 position -> address ->
+    // gather): they are fetched ONE UNIT AHEAD, so the chain of a unit starts with values that are already in registers.
+    float nsx = 0.f, nsy = 0.f; int nflag = 0;
+    if (wv < total) {
+        const int ic0 = min(r0 + min(ty * 8 + li, nrows - 1), VFSMS_MAX_WIN - 1);
+        nsx = sx_row[ic0]; nsy = sy_row[ic0]; nflag = strip_in[ty];
+    }
     for (int unit = wv; unit < total; unit += NW) {
         DT_UNIT_BEGIN;
         const int cb0 = cbi * UNIT_W;
@@ -904,12 +928,16 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
         const int r = ty * 8 + li;
         // a lane past the strip's last row repeats that row: same position, same value, same LDS byte
         const int rc = min(r, nrows - 1);
-        const int ic = min(r0 + rc, VFSMS_MAX_WIN - 1);
-        const double sxc = (double)sx_row[ic], syc = (double)sy_row[ic];
+        const double sxc = (double)nsx, syc = (double)nsy;
+        const int flag_cur = nflag;
         uint8_t *drc = dst + rc * win;
         const int ty_cur = ty;
         cbi += NW;
         while (cbi >= ncb) { cbi -= ncb; ty++; }
+        if (unit + NW < total) {
+            const int icn = min(r0 + min(ty * 8 + li, nrows - 1), VFSMS_MAX_WIN - 1);
+            nsx = sx_row[icn]; nsy = sy_row[icn]; nflag = strip_in[ty];
+        }
         if (G.upright) {
             for (int j = cb0 + lj; j < cb1; j += 8) drc[j] = (uint8_t)win_sample_upright(G, r0 + rc, j);
             continue;
@@ -917,8 +945,8 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
         // Unit-level interior test: x = origin(row) + j * c is separable, rows are monotone, so the extremes of the unit's samples are
         // (extreme row origin) + (extreme of j * c).  A unit inside the image (with the 2 px of slack the dword taps need) runs
         // without any per-sample bounds logic.
-        bool unit_in;
-        {
+        bool unit_in = __builtin_amdgcn_readfirstlane(flag_cur) != 0;
+        if (!unit_in) {
             const int ia = min(r0 + ty_cur * 8, VFSMS_MAX_WIN - 1), ib = min(min(r0 + ty_cur * 8 + 7, r0 + nrows - 1), VFSMS_MAX_WIN - 1);
             const double xa = (double)sx_row[ia], xb = (double)sx_row[ib], ya = (double)sy_row[ia], yb = (double)sy_row[ib];
             const double ja = (double)cb0, jb = (double)(cb1 - 1);
@@ -1053,6 +1081,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
     __shared__ AreaRec REC[AREA_RECS];                     // computeResizeAreaTab of this window size: same records for x and y
     __shared__ uint8_t WINBUF[DESC_WBUF];
     __shared__ float rowsum[40 * 21];                      // buf[dx] of up to 40 source rows
+    __shared__ uint8_t STRIP_IN[VFSMS_MAX_WIN / 8 + 8];    // per 8-row strip of a staging call: inside the image as a whole?
     const float s = kp.size * 1.2f / 9.0f;
     WinGeom G;
     G.win = __builtin_amdgcn_readfirstlane(max(21, min((int)((20 + 1) * s), VFSMS_MAX_WIN)));     // wave-uniform: keep it (and what derives from it) scalar
@@ -1120,7 +1149,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
         }
     };
     if (win * win <= DESC_WBUF) {
-        stage_rows<4>(G, sx_row, sy_row, 0, win, WINBUF);
+        stage_rows<4>(G, sx_row, sy_row, 0, win, WINBUF, STRIP_IN);
         __syncthreads();
         DT_MARK(1);
         reduce_rows(0, 0, dsz);
@@ -1137,7 +1166,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
                 int d_stop = dy + 1;
                 while (d_stop < dy_end && REC[d_stop].j0 + REC[d_stop].n - rlo <= crows) d_stop++;
                 const int end = REC[d_stop - 1].j0 + REC[d_stop - 1].n - 1;
-                stage_rows<4>(G, sx_row, sy_row, rlo, end - rlo + 1, WINBUF);
+                stage_rows<4>(G, sx_row, sy_row, rlo, end - rlo + 1, WINBUF, STRIP_IN);
                 __syncthreads();
                 DT_MARK(3);
                 reduce_rows(rlo, dy, d_stop);
@@ -1147,7 +1176,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
                 // a band taller than the buffer (win > 409): staged in chunks of its own, row sums collected over the chunks
                 for (int c0 = 0; c0 < nrows; c0 += crows) {
                     const int cn = min(crows, nrows - c0);
-                    stage_rows<4>(G, sx_row, sy_row, rlo + c0, cn, WINBUF);
+                    stage_rows<4>(G, sx_row, sy_row, rlo + c0, cn, WINBUF, STRIP_IN);
                     __syncthreads();
                     DT_MARK(3);
                     for (int e = threadIdx.x; e < cn * 21; e += 256) {
@@ -1313,7 +1342,7 @@ __global__ __launch_bounds__(1024, 8) void k_orientation(const RoiDev *rois, con
 // the sampling and INTER_AREA arithmetic of describe_one (stage_rows<1>, the same cell code).
 // ---------------------------------------------------------------------------------------------------
 #define DESC_SMALL_WIN 64
-struct SmallLds { uint8_t win[DESC_SMALL_WIN * DESC_SMALL_WIN + 64]; float sx[DESC_SMALL_WIN + 8], sy[DESC_SMALL_WIN + 8]; AreaRec rec[AREA_RECS]; int rec_win; };
+struct SmallLds { uint8_t win[DESC_SMALL_WIN * DESC_SMALL_WIN + 64]; float sx[DESC_SMALL_WIN + 8], sy[DESC_SMALL_WIN + 8]; AreaRec rec[AREA_RECS]; int rec_win; uint8_t strip_in[DESC_SMALL_WIN / 8 + 8]; };
 
 __device__ __forceinline__ void wave_sync_lds()
 {
@@ -1360,7 +1389,7 @@ __device__ void describe_small(const RoiDev &R, const AreaRec *area_tab, const i
         G.usy = cv_round_f(kp.y - win_offset);
     }
     wave_sync_lds();
-    stage_rows<1>(G, L.sx, L.sy, 0, win, L.win);
+    stage_rows<1>(G, L.sx, L.sy, 0, win, L.win, L.strip_in);
     wave_sync_lds();
     const int nmin = __builtin_amdgcn_readfirstlane(L.rec[21].j0), nmax = __builtin_amdgcn_readfirstlane(L.rec[21].n);
     const int mode = __builtin_amdgcn_readfirstlane(L.rec[21].mode);
