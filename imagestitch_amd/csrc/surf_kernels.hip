@@ -228,6 +228,19 @@ __device__ __forceinline__ float haar_box(g_ci32 sp, int sw, const LayerPat &P, 
     return (float)d;
 }
 
+// KeyPoint::class_id = sign(trace) of the candidate's own sample, trace = dx + dy of calcLayerDetAndTrace recomputed from the integral image
+// for the few thousand candidates of an ROI (one dense thread each, in the ordering kernels) -- the trace LAYERS are not materialised:
+// round 2 wrote 4 B per sample and layer (277 MB per launch) for the sign of a fraction of a per cent of the cells.
+__device__ __forceinline__ int cand_class_id(const RoiDev &R, const LayerPat *pats, const Cand &c)
+{
+    const LayerPat &P = pats[c.layer];
+    const int ss = P.step, size = P.size;
+    const int sum_i = ss * (c.i - (size / 2) / ss), sum_j = ss * (c.j - (size / 2) / ss);
+    g_ci32 sp = (g_ci32)R.sum + (size_t)sum_i * (R.w + 1) + sum_j;
+    const float tr = haar_box(sp, R.w + 1, P, 0, 3) + haar_box(sp, R.w + 1, P, 3, 3);
+    return (tr > 0) - (tr < 0);
+}
+
 // Gather variant (coarse octaves; every octave when n_octave_layers != 3): ONE launch for all its octaves -- first[q] counts the
 // 64 x 4-sample tiles of the octaves before o0 + q -- so the small octaves share a launch and fill each other's tails.
 struct HessPlan { int o0, noct; int first[VFSMS_MAX_OCTAVES + 1]; int tiles_x[VFSMS_MAX_OCTAVES]; };
@@ -258,8 +271,7 @@ __global__ __launch_bounds__(256) void k_hessian(const RoiDev *rois, const Layer
     float dy = haar_box(sp, sw, P, 3, 3);
     float dxy = haar_box(sp, sw, P, 6, 4);
     size_t o = (size_t)(i + P.margin) * lcols + (j + P.margin);
-    ((g_f32)R.det[li])[o] = dx * dy - 0.81f * dxy * dxy;
-    ((g_f32)R.trace[li])[o] = dx + dy;
+    ((g_f32)R.det[li])[o] = dx * dy - 0.81f * dxy * dxy;     // (the trace is recomputed for the few NMS survivors: see k_nms)
 }
 
 // LDS-tiled variant for the fine octaves (0 and 1 hold 94 % of the samples): the five layers of an octave read the
@@ -296,7 +308,7 @@ __global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const L
         const int size = (9 + 6 * l) << OCT;                      // == P.size (checked by ctx_prepare_surf)
         if (size > R.h || size > R.w) continue;
         const int samples_i = 1 + (R.h - size) / STEP, samples_j = 1 + (R.w - size) / STEP;
-        g_f32 det = (g_f32)R.det[li], trace = (g_f32)R.trace[li];
+        g_f32 det = (g_f32)R.det[li];
         const int margin = (size / 2) / STEP;
         float w[10];
 #pragma unroll
@@ -322,7 +334,6 @@ __global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const L
             }
             const size_t o = (size_t)(i + margin) * lcols + (j + margin);
             det[o] = d3[0] * d3[1] - 0.81f * d3[2] * d3[2];
-            trace[o] = d3[0] + d3[1];
         }
     }
 }
@@ -456,8 +467,7 @@ __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat 
         cd.size = (float)size;
         cd.response = val0;
         cd.octave = octave;
-        const float tr = ((g_cf32)R.trace[li])[(size_t)i * lcols + jj];
-        cd.class_id = (tr > 0) - (tr < 0);
+        cd.class_id = 0;                                   // sign of the trace: filled in by the ordering kernels (cand_class_id)
         cd.layer = li; cd.i = i; cd.j = jj;
         const int ds = size - pats[li - 1].size;
         if (!interpolate_keypoint(N9, ss, ss, ds, cd)) continue;
@@ -507,7 +517,7 @@ __device__ __forceinline__ SortKey make_key(const Cand &c)
     return k;
 }
 
-__global__ __launch_bounds__(256) void k_rank_sort(const RoiDev *rois)
+__global__ __launch_bounds__(256) void k_rank_sort(const RoiDev *rois, const LayerPat *pats)
 {
     // one workgroup ranks 64 candidates; its 4 waves each scan a quarter of every 256-key LDS tile
     const RoiDev &R = rois[blockIdx.y];
@@ -546,7 +556,7 @@ __global__ __launch_bounds__(256) void k_rank_sort(const RoiDev *rois)
         rank = partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane];
         vfsms_keypoint kp;
         kp.x = me.x; kp.y = me.y; kp.size = me.size; kp.angle = -1.f; kp.response = me.response;
-        kp.octave = me.octave; kp.class_id = me.class_id;
+        kp.octave = me.octave; kp.class_id = cand_class_id(R, pats, me);
         R.kps[rank] = kp;
     }
 }
@@ -599,7 +609,7 @@ __global__ __launch_bounds__(1024) void k_bucket_sort(const RoiDev *rois)
 }
 
 // rank of every candidate inside its bucket (a few dozen to a few hundred full KeypointGreater compares), 256 candidates per workgroup
-__global__ __launch_bounds__(256) void k_bucket_rank(const RoiDev *rois)
+__global__ __launch_bounds__(256) void k_bucket_rank(const RoiDev *rois, const LayerPat *pats)
 {
     const RoiDev &R = rois[blockIdx.y];
     const int n = min(R.counters[0], R.cap);
@@ -621,7 +631,7 @@ __global__ __launch_bounds__(256) void k_bucket_rank(const RoiDev *rois)
     const Cand c = R.cand[me.idx];
     vfsms_keypoint kp;
     kp.x = c.x; kp.y = c.y; kp.size = c.size; kp.angle = -1.f; kp.response = c.response;
-    kp.octave = c.octave; kp.class_id = c.class_id;
+    kp.octave = c.octave; kp.class_id = cand_class_id(R, pats, c);
     R.kps[rank] = kp;
 }
 
@@ -1607,7 +1617,7 @@ size_t surf_roi_bytes(int h, int w, int cap, int nlayers_total, int noctaves, in
     int lpo = nlayers_total / noctaves;
     for (int o = 0; o < noctaves; o++) {
         size_t n = (size_t)(h >> o) * (w >> o);
-        b += 2 * lpo * al(sizeof(float) * (n ? n : 1));
+        b += lpo * al(sizeof(float) * (n ? n : 1));
     }
     b += al(16 * sizeof(int)) + al(sizeof(Cand) * cap) + al(sizeof(vfsms_keypoint) * cap) + al((size_t)cap * VFSMS_PATCH_ROW);
     b += 2 * al(sizeof(int) * cap) + al(sizeof(float) * 2 * cap) + al(sizeof(float) * (size_t)cap * dim) + al(sizeof(vfsms_keypoint) * cap);
@@ -1629,7 +1639,6 @@ int surf_roi_carve(vfsms_ctx *ctx, RoiDev *r, const uint8_t *img, int stride, in
         size_t n = (size_t)(h / step) * (w / step);
         for (int l = 0; l < lpo; l++) {
             r->det[o * lpo + l] = (float *)ctx_arena_alloc(ctx, sizeof(float) * (n ? n : 1));
-            r->trace[o * lpo + l] = (float *)ctx_arena_alloc(ctx, sizeof(float) * (n ? n : 1));
         }
         step *= 2;
     }
@@ -1708,10 +1717,10 @@ int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_roi
         static const bool n2sort = getenv("VFSMS_SORT_N2") && atoi(getenv("VFSMS_SORT_N2")) != 0;
         int mincap = maxcap;
         for (int r = 0; r < nrois; r++) mincap = h_rois[r].cap < mincap ? h_rois[r].cap : mincap;
-        if (n2sort || mincap < SORT_BUCKETS) hipLaunchKernelGGL(k_rank_sort, dim3((maxcap + 63) / 64, nrois), dim3(256), 0, ctx->stream, d_rois);
+        if (n2sort || mincap < SORT_BUCKETS) hipLaunchKernelGGL(k_rank_sort, dim3((maxcap + 63) / 64, nrois), dim3(256), 0, ctx->stream, d_rois, ctx->d_layers);
         else {
             hipLaunchKernelGGL(k_bucket_sort, dim3(nrois), dim3(1024), 0, ctx->stream, d_rois);
-            hipLaunchKernelGGL(k_bucket_rank, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
+            hipLaunchKernelGGL(k_bucket_rank, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois, ctx->d_layers);
         }
     }
     HIP_TRY(hipGetLastError());
