@@ -120,7 +120,11 @@ def bench_fuse(args, eng, grid, tiles, handles, torch):
     def assemble(download, resident=True):
         canvas = eng.canvas_create(rows, cols, 1)
         try:
-            for i in range(n):
+            if resident:                                   # what Stitcher.getStitchByOffset calls for resident tiles: the whole walk, one call
+                geom = [(offsetList[0][0], offsetList[0][1], 0, 0, 0, 0, 0, 0, -1)]
+                geom += [(offsetList[i][0], offsetList[i][1]) + tuple(rois[i - 1]) + (offs[i][0], offs[i][1], 0) for i in range(1, n)]
+                eng.canvas_assemble_resident(canvas, handles, geom)
+            for i in range(0 if not resident else n, n):
                 oy, ox = offsetList[i]
                 if i == 0:
                     eng.canvas_paste_tile(canvas, handles[i], oy, ox) if resident else eng.canvas_paste(canvas, tiles[i], oy, ox)

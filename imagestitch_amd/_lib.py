@@ -123,6 +123,7 @@ _SIGNATURES = {
                                                   C.c_int, C.c_int, C.c_void_p]),
     "vfsms_canvas_fuse_tile": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vfsms_canvas_assemble_resident": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "vfsms_canvas_fuse_tile_resident_m": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vfsms_canvas_fuse_tile_m": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -619,6 +620,15 @@ class Engine:
         self._check(self.lib.vfsms_canvas_fuse_tile_resident_m(self.ctx, C.c_int64(handle), C.c_int64(tile_handle), int(y0), int(x0),
                                                                ry0, rx0, ry1, rx1, int(dx), int(dy), int(method), _ptr(info) if want_info else None))
         return info
+
+    def canvas_assemble_resident(self, handle, tile_handles, geom):
+        """The mosaic walk over resident tiles as one call.  geom: int32 [n][9] = y0, x0, ry0, rx0, ry1, rx1, dx, dy, mode
+        (mode -1 paste, 0 fadeInAndFadeOut, 1 trigonometric); enqueue only, geometry errors surface in canvas_download."""
+        th = np.ascontiguousarray(tile_handles, np.int64)
+        g = np.ascontiguousarray(geom, np.int32).reshape(-1, 9)
+        if len(th) != len(g):
+            raise ValueError("canvas_assemble_resident: one geometry row per tile")
+        self._check(self.lib.vfsms_canvas_assemble_resident(self.ctx, C.c_int64(handle), len(th), _ptr(th), _ptr(g)))
 
     def canvas_download(self, handle, rows, cols, ch):
         out = np.empty((rows, cols, ch) if ch > 1 else (rows, cols), np.uint8)

@@ -1380,6 +1380,30 @@ extern "C" int vfsms_canvas_fuse_tile_resident(vfsms_ctx *ctx, int64_t canvas, i
 {
     return vfsms_canvas_fuse_tile_resident_m(ctx, canvas, tile, y0, x0, ry0, rx0, ry1, rx1, dx, dy, 0, info);
 }
+// The whole mosaic walk of Stitcher.getStitchByOffset (Stitcher.py:434-483) over resident tiles as ONE call: per tile nine ints
+// [y0, x0, ry0, rx0, ry1, rx1, dx, dy, mode] with mode -1 = paste (the first tile, notFuse), 0 = fadeInAndFadeOut, 1 = trigonometric.
+// Enqueue only (one library call per mosaic instead of one per tile; the device chain stays two launches per tile); geometry errors are latched
+// in the canvas and reported by the download, as with vfsms_canvas_fuse_tile_resident(info = NULL).
+extern "C" int vfsms_canvas_assemble_resident(vfsms_ctx *ctx, int64_t canvas, int n, const int64_t *tiles, const int32_t *geom)
+{
+    CTX_ENTER(ctx);
+    if (n < 0 || (n > 0 && (!tiles || !geom))) { vfsms_set_error("canvas_assemble_resident: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    for (int i = 0; i < n; i++) {                       // everything is checked before anything is enqueued
+        const int32_t *g = geom + 9 * (size_t)i;
+        if (g[8] < -1 || g[8] > 1) { vfsms_set_error("canvas_assemble_resident: mode must be -1 (paste), 0 (fadeInAndFadeOut) or 1 (trigonometric)"); return VFSMS_ERR_BAD_ARG; }
+        CanvasRec *cv; TileRec *tr;
+        TRY(canvas_resident_args(ctx, canvas, tiles[i], g[0], g[1], &cv, &tr));
+        if (g[8] >= 0 && g[4] > g[2] && g[5] > g[3] && (g[2] < g[0] || g[3] < g[1] || g[4] > g[0] + tr->h || g[5] > g[1] + tr->w)) {
+            vfsms_set_error("canvas_assemble_resident: fuse ROI must lie inside the tile rectangle"); return VFSMS_ERR_BAD_ARG;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        const int32_t *g = geom + 9 * (size_t)i;
+        if (g[8] < 0) TRY(vfsms_canvas_paste_tile(ctx, canvas, tiles[i], g[0], g[1]));
+        else TRY(vfsms_canvas_fuse_tile_resident_m(ctx, canvas, tiles[i], g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], nullptr));
+    }
+    return VFSMS_OK;
+}
 extern "C" int vfsms_canvas_download(vfsms_ctx *ctx, int64_t canvas, uint8_t *out)
 {
     CTX_ENTER(ctx);

@@ -78,19 +78,21 @@ __device__ __forceinline__ uint8_t trig_px(const TrigGeom &G, bool corner, int i
     res = res > 255 ? 255 : res;
     return (uint8_t)res;
 }
-__global__ __launch_bounds__(256) void k_fuse_apply(uint8_t *pix, uint8_t *mask, int ccols, int ch,
-                                                    const uint8_t *tile, int th, int tw, int y0, int x0,
-                                                    int ry0, int rx0, int r, int c, const int *mode,
-                                                    const float *wAr, const float *wAc, const float *wBr, const float *wBc, TrigGeom TG)
+// (bx, by): the block of the tile this workgroup blends -- blockIdx for the per-tile launch, a drawn index inside k_mosaic_walk
+__device__ __forceinline__ void fuse_apply_block(uint8_t *pix, uint8_t *mask, int ccols, int ch,
+                                                 const uint8_t *tile, int th, int tw, int y0, int x0,
+                                                 int ry0, int rx0, int r, int c, const int *mode,
+                                                 const float *wAr, const float *wAc, const float *wBr, const float *wBc, const TrigGeom &TG,
+                                                 unsigned bx, unsigned by)
 {
-    const int y = blockIdx.y;
+    const int y = (int)by;
     const int cy = y0 + y;
     const int i = cy - ry0;
     const bool row_in = i >= 0 && i < r;
     const int corner = mode[0];
     if (ch == 1) {
         // four pixels per lane: tile, canvas and validity bytes move as (unaligned) dwords
-        const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+        const int x = (int)(bx * 256 + threadIdx.x) * 4;
         if (x >= tw) return;
         const size_t co = (size_t)cy * ccols + x0 + x;
         const uint8_t *tp = tile + (size_t)y * tw + x;
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void k_fuse_apply(uint8_t *pix, uint8_t *mask,
         else for (int k = 0; k < nk; k++) { pix[co + k] = (uint8_t)(ob >> (8 * k)); mask[co + k] = 1; }
         return;
     }
-    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int x = (int)(bx * 256 + threadIdx.x);
     if (x >= tw) return;
     const int cx = x0 + x;
     const size_t co = (size_t)cy * ccols + cx;
@@ -143,15 +145,28 @@ __global__ __launch_bounds__(256) void k_fuse_apply(uint8_t *pix, uint8_t *mask,
     mask[co] = 1;
 }
 
-__global__ __launch_bounds__(256) void k_paste(uint8_t *pix, uint8_t *mask, int ccols, int ch,
-                                               const uint8_t *tile, int th, int tw, int y0, int x0)
+__global__ __launch_bounds__(256) void k_fuse_apply(uint8_t *pix, uint8_t *mask, int ccols, int ch,
+                                                    const uint8_t *tile, int th, int tw, int y0, int x0,
+                                                    int ry0, int rx0, int r, int c, const int *mode,
+                                                    const float *wAr, const float *wAc, const float *wBr, const float *wBc, TrigGeom TG)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
+    fuse_apply_block(pix, mask, ccols, ch, tile, th, tw, y0, x0, ry0, rx0, r, c, mode, wAr, wAc, wBr, wBc, TG, blockIdx.x, blockIdx.y);
+}
+
+__device__ __forceinline__ void paste_block(uint8_t *pix, uint8_t *mask, int ccols, int ch,
+                                            const uint8_t *tile, int th, int tw, int y0, int x0, unsigned bx, unsigned by)
+{
+    const int x = (int)(bx * 256 + threadIdx.x);
+    const int y = (int)by;
     if (x >= tw) return;
     const size_t co = (size_t)(y0 + y) * ccols + (x0 + x);
     for (int k = 0; k < ch; k++) pix[co * ch + k] = tile[((size_t)y * tw + x) * ch + k];
     mask[co] = 1;
+}
+__global__ __launch_bounds__(256) void k_paste(uint8_t *pix, uint8_t *mask, int ccols, int ch,
+                                               const uint8_t *tile, int th, int tw, int y0, int x0)
+{
+    paste_block(pix, mask, ccols, ch, tile, th, tw, y0, x0, blockIdx.x, blockIdx.y);
 }
 
 // ---- int64 compatibility path (the reference's own array representation) -----------------------------
@@ -340,39 +355,58 @@ __global__ __launch_bounds__(256) void k_fuse_weights(int r, int c, int ch, int 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// ONE statistics launch per fused tile (canvas path).  A workgroup owns FUSE_SB rows x 1024 columns of the ROI: a lane walks its four
-// columns down the band (first / last valid row per column in registers, one atomicMax each at the end), every row's first / last valid
-// column inside the block comes from two wave ballots (one atomicMax per wave and row), the occupancy and quadrant counts from one
-// block reduction.  The workgroup that finishes LAST (a ticket counter) builds the ramps right there -- no separate launch -- and then
+// ONE statistics launch per fused tile (canvas path).  A wave owns FUSE_SB rows x 256 columns of the ROI, the four waves of a workgroup
+// sit 4 x 1, 2 x 2 or 1 x 4 (tall overlap strips) over it: a lane walks its four columns down the band with the dwords of all FUSE_SB
+// rows in flight (first / last valid row per column in registers, combined over the workgroup's sub-bands in LDS, one atomicMax each),
+// every row's first / last valid column comes from two wave ballots (one atomicMax per wave and row), the occupancy and quadrant counts
+// from one block reduction into the workgroup's own slot.  The workgroup that finishes LAST (a ticket counter) builds the ramps right there -- no separate launch -- and then
 // puts every record back to its initial value, so the scratch (allocated with the canvas, sized by its rows + cols) needs no memset per
 // tile either: a fused tile is this launch + the blend.  (Before: two memsets + rows, columns, ramps, blend = six dependent launches;
-// the statistics themselves stay latency-bound at ~55 us per tile -- 26 workgroups, atomics per row and column -- see DESIGN.md.)
+// the chain of a tile is still latency-bound at ~50 us -- see DESIGN.md for what was tried.)
 // ---------------------------------------------------------------------------------------------------
-#define FUSE_SB 32
-struct FuseCanvasScratch { FuseStats *st; int *out; unsigned *done; int *rowFirstEnc, *rowLast, *colFirstEnc, *colLast; float *wAr, *wBr, *wAc, *wBc; };
+#define FUSE_SB 16
+#define FUSE_NW 4                    // waves of a statistics workgroup (16-wave workgroups, i.e. a quarter of the tickets: 8 % slower)
+struct FuseCanvasScratch { unsigned *slots; int *out; unsigned *done; int *rowFirstEnc, *rowLast, *colFirstEnc, *colLast; float *wAr, *wBr, *wAc, *wBc; };
 
-__global__ __launch_bounds__(256) void k_fuse_stats_weights(CanvasView V, int r, int c, FuseCanvasScratch S, int dx, int dy, int *sticky_err)
+template <int FUSE_SBT, int FUSE_UR>
+__device__ __forceinline__ void fuse_stats_block(const CanvasView &V, int r, int c, const FuseCanvasScratch &S, int wx_n, unsigned bx, unsigned by, unsigned nbx)
 {
-    __shared__ unsigned s_cnt[5][4];
-    __shared__ int s_last;
+    __shared__ unsigned s_cnt[5][FUSE_NW];
+    __shared__ int s_col[2][FUSE_NW * 256];                                   // [first | last][wave row][column of the workgroup]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;                 // four adjacent columns per lane: validity bytes as one dword
-    const int i0 = blockIdx.y * FUSE_SB, i1 = min(i0 + FUSE_SB, r);
+    // The four waves are laid out wx_n wide x 4 / wx_n high (1 x 4 for ROIs of up to 256 columns -- the tall overlap strips of a mosaic row --
+    // so that no wave idles beside the ROI and a column receives one atomic per 4 sub-bands).
+    const int wx = wave % wx_n, wy = wave / wx_n, wy_n = FUSE_NW / wx_n, wcols = wx_n * 256;
+    const int jl = (wx * 64 + lane) * 4;                                // column inside the workgroup
+    const int j = (int)bx * wx_n * 256 + jl;                         // four adjacent columns per lane: validity bytes as one dword
+    const int i0 = min(((int)by * wy_n + wy) * FUSE_SBT, r), i1 = min(i0 + FUSE_SBT, r);
     const int c2 = c / 2, r2 = r / 2;
     const int nk = max(0, min(4, c - j));
     int first[4] = {-1, -1, -1, -1}, last[4] = {-1, -1, -1, -1};
     unsigned valid = 0, q_tl = 0, q_bl = 0, q_br = 0, q_tr = 0;
-    for (int i = i0; i < i1; i++) {
-        uint32_t m = 0, pz = 0;
-        unsigned pos_lo = 0, pos_hi = 0;
-        if (nk > 0) {
-            const size_t o = (size_t)(V.ry0 + i) * V.ccols + V.rx0 + j;
-            if (nk == 4) m = *(const u32u1 *)(V.mask + o);
-            else for (int k = 0; k < nk; k++) m |= (uint32_t)V.mask[o + k] << (8 * k);
+    // The rows of a band are independent, but the atomics keep the compiler from hoisting the loads of row i + 1 above the work of row i,
+    // which left 32 dependent memory round trips per lane.  Validity (and, for gray canvases, pixel) dwords of FUSE_UR rows are fetched
+    // up front, then consumed.
+    for (int ib = i0; ib < i1; ib += FUSE_UR) {
+        uint32_t mm[FUSE_UR], pp[FUSE_UR];
+#pragma unroll
+        for (int u = 0; u < FUSE_UR; u++) {
+            mm[u] = 0; pp[u] = 0;
+            const int i = ib + u;
+            if (i < i1 && nk > 0) {
+                const size_t o = (size_t)(V.ry0 + i) * V.ccols + V.rx0 + j;
+                if (nk == 4) { mm[u] = *(const u32u1 *)(V.mask + o); if (V.ch == 1) pp[u] = *(const u32u1 *)(V.pix + o); }
+                else for (int k = 0; k < nk; k++) { mm[u] |= (uint32_t)V.mask[o + k] << (8 * k); if (V.ch == 1) pp[u] |= (uint32_t)V.pix[o + k] << (8 * k); }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FUSE_UR; u++) {
+            const int i = ib + u;
+            if (i >= i1) continue;
+            const uint32_t m = mm[u], pz = pp[u];
+            unsigned pos_lo = 0, pos_hi = 0;
             if (m) {
                 if (V.ch == 1) {
-                    if (nk == 4) pz = *(const u32u1 *)(V.pix + o);
-                    else for (int k = 0; k < nk; k++) pz |= (uint32_t)V.pix[o + k] << (8 * k);
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                         if ((m >> (8 * k)) & 0xff) {
@@ -381,6 +415,7 @@ __global__ __launch_bounds__(256) void k_fuse_stats_weights(CanvasView V, int r,
                             if (j + k < c2) pos_lo += pos; else pos_hi += pos;
                         }
                 } else {
+                    const size_t o = (size_t)(V.ry0 + i) * V.ccols + V.rx0 + j;
                     for (int k = 0; k < nk; k++)
                         if ((m >> (8 * k)) & 0xff) {
                             valid += V.ch;
@@ -393,18 +428,36 @@ __global__ __launch_bounds__(256) void k_fuse_stats_weights(CanvasView V, int r,
                 for (int k = 0; k < 4; k++)
                     if ((m >> (8 * k)) & 0xff) { if (first[k] < 0) first[k] = i; last[k] = i; }
             }
-        }
-        if (i < r2) { q_tl += pos_lo; q_tr += pos_hi; } else { q_bl += pos_lo; q_br += pos_hi; }
-        // first / last valid column of row i inside this wave's 256 columns
-        const unsigned long long any = __ballot(m != 0);
-        if (any) {
-            const int lo_lane = __ffsll((long long)any) - 1, hi_lane = 63 - __clzll((long long)any);
-            if (lane == lo_lane) atomicMax(&S.rowFirstEnc[i], c - 1 - (j + (__ffs((int)m) - 1) / 8));
-            if (lane == hi_lane) atomicMax(&S.rowLast[i], j + (31 - __clz((int)m)) / 8);
+            if (i < r2) { q_tl += pos_lo; q_tr += pos_hi; } else { q_bl += pos_lo; q_br += pos_hi; }
+            // first / last valid column of row i inside this wave's 256 columns
+            const unsigned long long any = __ballot(m != 0);
+            if (any) {
+                const int lo_lane = __ffsll((long long)any) - 1, hi_lane = 63 - __clzll((long long)any);
+                if (lane == lo_lane) atomicMax(&S.rowFirstEnc[i], c - 1 - (j + (__ffs((int)m) - 1) / 8));
+                if (lane == hi_lane) atomicMax(&S.rowLast[i], j + (31 - __clz((int)m)) / 8);
+            }
         }
     }
-    for (int k = 0; k < nk; k++)
-        if (last[k] >= 0) { atomicMax(&S.colLast[j + k], last[k]); atomicMax(&S.colFirstEnc[j + k], r - 1 - first[k]); }
+    if (wy_n == 1) {
+        for (int k = 0; k < nk; k++)
+            if (last[k] >= 0) { atomicMax(&S.colLast[j + k], last[k]); atomicMax(&S.colFirstEnc[j + k], r - 1 - first[k]); }
+    } else {
+        // sub-bands are in row order: the first valid row of a column is that of the lowest wy with one, the last valid row that of the highest
+#pragma unroll
+        for (int k = 0; k < 4; k++) { s_col[0][wy * wcols + jl + k] = first[k]; s_col[1][wy * wcols + jl + k] = last[k]; }
+        __syncthreads();
+        if (wy == 0) {
+            for (int k = 0; k < nk; k++) {
+                int f = -1, l = -1;
+                for (int y = 0; y < wy_n; y++) {
+                    const int fy = s_col[0][y * wcols + jl + k], ly = s_col[1][y * wcols + jl + k];
+                    if (f < 0) f = fy;
+                    if (ly >= 0) l = ly;
+                }
+                if (l >= 0) { atomicMax(&S.colLast[j + k], l); atomicMax(&S.colFirstEnc[j + k], r - 1 - f); }
+            }
+        }
+    }
     // block reduction of the five counts: wave shuffles, then one set of atomics per workgroup
     unsigned v5[5] = {valid, q_tl, q_bl, q_br, q_tr};
 #pragma unroll
@@ -414,25 +467,58 @@ __global__ __launch_bounds__(256) void k_fuse_stats_weights(CanvasView V, int r,
         if (lane == 0) s_cnt[q][wave] = x;
     }
     __syncthreads();
-    if (threadIdx.x < 5) {
-        const unsigned x = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
-        if (x) atomicAdd(threadIdx.x == 0 ? &S.st->valid : &S.st->quad[threadIdx.x - 1], (unsigned long long)x);
+    // the five counts go to the workgroup's own slot (plain stores: five atomics per workgroup on ONE cache line were what the launch waited for)
+    const unsigned wg = by * nbx + bx;
+    if (threadIdx.x < 5)
+    {
+        unsigned x = 0;
+        for (int w = 0; w < FUSE_NW; w++) x += s_cnt[threadIdx.x][w];
+        S.slots[(size_t)wg * 8 + threadIdx.x] = x;
     }
+}
+
+// one workgroup, after every statistics block of the tile is visible: sums the slots, builds the ramps, puts the records back to -1
+__device__ __forceinline__ void fuse_ramps_tail(int r, int c, int ch, int dx, int dy, const FuseCanvasScratch &S, unsigned nwg, int *sticky_err)
+{
+    __shared__ FuseStats s_st;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 8) S.out[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_st.valid = 0; s_st.quad[0] = 0; s_st.quad[1] = 0; s_st.quad[2] = 0; s_st.quad[3] = 0; }
+    __syncthreads();
+    {
+        unsigned long long sum5[5] = {0, 0, 0, 0, 0};
+        for (unsigned w = threadIdx.x; w < nwg; w += 256)
+#pragma unroll
+            for (int q = 0; q < 5; q++) sum5[q] += __builtin_nontemporal_load(&S.slots[(size_t)w * 8 + q]);
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            unsigned long long x = sum5[q];
+            for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+            if (lane == 0 && x) atomicAdd(q == 0 ? &s_st.valid : &s_st.quad[q - 1], x);
+        }
+    }
+    __syncthreads();
+    fuse_weights_body(r, c, ch, dx, dy, 0, &s_st, S.rowFirstEnc, S.rowLast, S.colFirstEnc, S.colLast, S.wAr, S.wAc, S.wBr, S.wBc, S.out, sticky_err, 3);
+    __syncthreads();
+    // records back to their initial values for the next tile
+    for (int i = threadIdx.x; i < r; i += 256) { S.rowFirstEnc[i] = -1; S.rowLast[i] = -1; }
+    for (int jj = threadIdx.x; jj < c; jj += 256) { S.colFirstEnc[jj] = -1; S.colLast[jj] = -1; }
+    if (threadIdx.x == 0) *S.done = 0;
+}
+
+template <int FUSE_SBT, int FUSE_UR>
+__global__ __launch_bounds__(FUSE_NW * 64) void k_fuse_stats_weights(CanvasView V, int r, int c, FuseCanvasScratch S, int dx, int dy, int *sticky_err, int wx_n)
+{
+    __shared__ int s_last;
+    fuse_stats_block<FUSE_SBT, FUSE_UR>(V, r, c, S, wx_n, blockIdx.x, blockIdx.y, gridDim.x);
     // the last workgroup to arrive builds the ramps
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(S.done, 1u) == gridDim.x * gridDim.y - 1;
     __syncthreads();
-    if (!s_last) return;
+    if (!s_last || threadIdx.x >= 256) return;          // the ramps are a 256-thread job (finished waves do not count at the barriers)
     __threadfence();
-    if (threadIdx.x < 8) S.out[threadIdx.x] = 0;
-    __syncthreads();
-    fuse_weights_body(r, c, V.ch, dx, dy, 0, S.st, S.rowFirstEnc, S.rowLast, S.colFirstEnc, S.colLast, S.wAr, S.wAc, S.wBr, S.wBc, S.out, sticky_err, 3);
-    __syncthreads();
-    // records back to their initial values for the next tile
-    for (int i = threadIdx.x; i < r; i += 256) { S.rowFirstEnc[i] = -1; S.rowLast[i] = -1; }
-    for (int jj = threadIdx.x; jj < c; jj += 256) { S.colFirstEnc[jj] = -1; S.colLast[jj] = -1; }
-    if (threadIdx.x == 0) { S.st->valid = 0; S.st->quad[0] = 0; S.st->quad[1] = 0; S.st->quad[2] = 0; S.st->quad[3] = 0; *S.done = 0; }
+    fuse_ramps_tail(r, c, V.ch, dx, dy, S, gridDim.x * gridDim.y, sticky_err);
 }
 
 struct FuseScratch { FuseStats *st; int *rowFirst, *rowLast, *colFirst, *colLast; float *wAr, *wAc, *wBr, *wBc; int *out; };
@@ -533,15 +619,18 @@ int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int
     // the canvas's own scratch (allocated and initialised once: canvas_scratch_bytes / canvas_scratch_init): st | out | done | rows | cols | ramps
     FuseCanvasScratch S;
     char *base = (char *)cv->scratch;
-    S.st = (FuseStats *)base; S.out = (int *)(base + 64); S.done = (unsigned *)(base + 128);
+    S.out = (int *)(base + 64); S.done = (unsigned *)(base + 128);
     int *ib = (int *)(base + 256);
     S.rowFirstEnc = ib; S.rowLast = ib + cv->rows; S.colFirstEnc = ib + 2 * (size_t)cv->rows; S.colLast = S.colFirstEnc + cv->cols;
     float *fb = (float *)(S.colLast + cv->cols);
     S.wAr = fb; S.wBr = fb + cv->rows; S.wAc = fb + 2 * (size_t)cv->rows; S.wBc = S.wAc + cv->cols;
+    S.slots = (unsigned *)(S.wBc + cv->cols);          // 8 dwords per statistics workgroup (canvas_scratch_bytes bounds their number)
     CanvasView V;
     V.pix = cv->pix; V.mask = cv->mask; V.ccols = cv->cols; V.ch = cv->ch; V.ry0 = ry0; V.rx0 = rx0;
     V.tile = d_tile; V.tw = w; V.ty0 = ry0 - y0; V.tx0 = rx0 - x0;
-    hipLaunchKernelGGL(k_fuse_stats_weights, dim3((c + 1023) / 1024, (r + FUSE_SB - 1) / FUSE_SB), dim3(256), 0, ctx->stream, V, r, c, S, dx, dy, cv->d_err);
+    const int wx_n = c <= 256 ? 1 : c <= 512 ? 2 : 4, wy_n = FUSE_NW / wx_n;
+    hipLaunchKernelGGL((k_fuse_stats_weights<FUSE_SB, FUSE_SB>), dim3((c + 256 * wx_n - 1) / (256 * wx_n), (r + FUSE_SB * wy_n - 1) / (FUSE_SB * wy_n)),
+                       dim3(FUSE_NW * 64), 0, ctx->stream, V, r, c, S, dx, dy, cv->d_err, wx_n);
     hipLaunchKernelGGL(k_fuse_apply, dim3(cv->ch == 1 ? (w + 1023) / 1024 : (w + 255) / 256, h), dim3(256), 0, ctx->stream, cv->pix, cv->mask, cv->cols, cv->ch,
                        d_tile, h, w, y0, x0, ry0, rx0, r, c, S.out, S.wAr, S.wAc, S.wBr, S.wBc, TrigGeom{method == 1, r, c, dx, dy});
     HIP_TRY(hipGetLastError());
@@ -557,7 +646,11 @@ int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int
     return VFSMS_OK;
 }
 
-size_t canvas_scratch_bytes(int rows, int cols) { return 256 + (sizeof(int) * 2 + sizeof(float) * 2) * ((size_t)rows + cols) + 256; }
+size_t canvas_scratch_bytes(int rows, int cols)
+{
+    const size_t slots = ((size_t)rows / FUSE_SB + 2) * ((size_t)cols / 1024 + 2);       // >= workgroups of any ROI inside the canvas, every wave layout
+    return 256 + (sizeof(int) * 2 + sizeof(float) * 2) * ((size_t)rows + cols) + 32 * slots + 256;
+}
 int canvas_scratch_init(vfsms_ctx *ctx, CanvasRec *cv)
 {
     HIP_TRY(hipMemsetAsync(cv->scratch, 0, 256, ctx->stream));

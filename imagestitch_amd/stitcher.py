@@ -721,7 +721,22 @@ class Stitcher(Utility.Method):
             ch = 3 if color else 1
             canvas = eng.canvas_create(resultRow, resultCol, ch)
             try:
-                for i in range(0, n):
+                one_call = use_res and simple is None and hasattr(eng, "canvas_assemble_resident")
+                if one_call:
+                    # every tile is resident: the walk below as ONE library call (the per-tile calls cost the host more than
+                    # their two launches cost the device)
+                    geom = np.zeros((n, 9), np.int32)
+                    for i in range(0, n):
+                        self.printAndWrite("  stitching " + str(fileList[i]))
+                        th, tw = shapes[i][0], shapes[i][1]
+                        oy, ox = offsetList[i][0], offsetList[i][1]
+                        if i == 0 or self.fuseMethod == "notFuse":
+                            geom[i] = (oy, ox, 0, 0, 0, 0, 0, 0, -1)
+                        else:
+                            geom[i] = (oy, ox, max(oy, rangeX[i - 1][0]), max(ox, rangeY[i - 1][0]), min(oy + th, rangeX[i - 1][1]),
+                                       min(ox + tw, rangeY[i - 1][1]), originOffsetList[i][0], originOffsetList[i][1], fmethod)
+                    eng.canvas_assemble_resident(canvas, handles, geom)
+                for i in range(n if one_call else 0, n):
                     self.printAndWrite("  stitching " + str(fileList[i]))
                     th, tw = shapes[i][0], shapes[i][1]
                     oy, ox = offsetList[i][0], offsetList[i][1]

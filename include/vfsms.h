@@ -304,6 +304,10 @@ int vfsms_canvas_fuse_tile_resident(vfsms_ctx *ctx, int64_t canvas, int64_t tile
 int vfsms_canvas_fuse_tile_resident_m(vfsms_ctx *ctx, int64_t canvas, int64_t tile,
                                       int y0, int x0, int ry0, int rx0, int ry1, int rx1,
                                       int dx, int dy, int method, int32_t *info);
+/* The canvas walk of Stitcher.getStitchByOffset (Stitcher.py:434-483) over n resident tiles in one call.
+ * geom: n x 9 ints [y0, x0, ry0, rx0, ry1, rx1, dx, dy, mode], mode -1 = paste (first tile / notFuse),
+ * 0 = fadeInAndFadeOut, 1 = trigonometric.  Enqueue only: errors of a tile's geometry surface in the download. */
+int vfsms_canvas_assemble_resident(vfsms_ctx *ctx, int64_t canvas, int n, const int64_t *tiles, const int32_t *geom);
 /* final image: empty -> 0 (Stitcher.py:485-486).  out: u8 [rows][cols][ch]                           */
 int vfsms_canvas_download(vfsms_ctx *ctx, int64_t canvas, uint8_t *out);
 /* rows [row0, row0 + nrows) of the same image: a multi-GB mosaic leaves the device band by band and can be handed to an

@@ -701,6 +701,47 @@ def _fuse_production(engine, oracle, tmp_path, tile):
         isa.Stitcher.isColorMode = old
 
 
+def test_canvas_assemble_resident_equals_per_tile_calls(engine):
+    """vfsms_canvas_assemble_resident (the mosaic walk as one call) == paste + one vfsms_canvas_fuse_tile_resident per tile, byte for
+    byte, for both separable blends; a bad mode is refused before anything is enqueued."""
+    g = SyntheticGrid(2, 3, 512, overlap=0.12)
+    tiles = g.tiles(threads=2)
+    offs = [[0, 0]] + [list(map(int, o)) for o in g.true_offsets()]
+    shapes = [t.shape for t in tiles]
+    offsetList, rangeX, rangeY, rows, cols = isa.Stitcher._layout(shapes, offs)
+    handles = [engine.tile_upload(t) for t in tiles]
+    try:
+        for method in (0, 1):
+            geom = [(offsetList[0][0], offsetList[0][1], 0, 0, 0, 0, 0, 0, -1)]
+            for i in range(1, len(tiles)):
+                oy, ox = offsetList[i]
+                geom.append((oy, ox, max(oy, rangeX[i - 1][0]), max(ox, rangeY[i - 1][0]), min(oy + 512, rangeX[i - 1][1]),
+                             min(ox + 512, rangeY[i - 1][1]), offs[i][0], offs[i][1], method))
+            outs = []
+            for one_call in (True, False):
+                cv = engine.canvas_create(rows, cols, 1)
+                try:
+                    if one_call:
+                        engine.canvas_assemble_resident(cv, handles, geom)
+                    else:
+                        engine.canvas_paste_tile(cv, handles[0], geom[0][0], geom[0][1])
+                        for i in range(1, len(tiles)):
+                            engine.canvas_fuse_tile_resident(cv, handles[i], geom[i][0], geom[i][1], geom[i][2:6], geom[i][6], geom[i][7], method=method)
+                    outs.append(engine.canvas_download(cv, rows, cols, 1))
+                finally:
+                    engine.canvas_free(cv)
+            assert np.array_equal(outs[0], outs[1]) and outs[0].any(), method
+        cv = engine.canvas_create(rows, cols, 1)
+        try:
+            with pytest.raises(Exception):
+                engine.canvas_assemble_resident(cv, handles[:1], [(0, 0, 0, 0, 0, 0, 0, 0, 2)])
+        finally:
+            engine.canvas_free(cv)
+    finally:
+        for h in handles:
+            engine.tile_free(h)
+
+
 def test_orb_at_config2_geometry(engine, oracle):
     """BASELINE configs[2] geometry: 2048 x 2048 tiles, 10 % overlap, ROI strips 409 x 2048, ORB(5000, 1.2, 8, 31, 0, 2, HARRIS, 31, 20)
     with upstream's learned sampling table.  Keypoints + descriptor bytes of a full-size strip equal the oracle's; size-independent
