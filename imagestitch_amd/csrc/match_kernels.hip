@@ -452,11 +452,18 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, 
             }
         }
         if (PASS == 0) {
+            // A lane's 16 scores of an accumulator belong to ONE query.  Only their minimum enters the running (best, second best): the
+            // second smallest of a SUBSET of the scores (one per tile and lane) is >= the true second smallest, so thr(q) stays an upper
+            // bound -- exact unless a query's two nearest trains share a tile and a lane half (15 / nt of the queries; pass 1 then lists a
+            // few more candidates for them) -- and the sweep costs 11 VALU operations per accumulator instead of 48 (it was VALU-bound).
+            float ta = fminf(fminf(acc0[0], acc0[1]), fminf(acc0[2], acc0[3])), tb = fminf(fminf(acc1[0], acc1[1]), fminf(acc1[2], acc1[3]));
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                m2a = fminf(m2a, fmaxf(m1a, acc0[i])); m1a = fminf(m1a, acc0[i]);
-                m2b = fminf(m2b, fmaxf(m1b, acc1[i])); m1b = fminf(m1b, acc1[i]);
+            for (int i = 4; i < 16; i += 3) {
+                ta = fminf(ta, fminf(acc0[i], fminf(acc0[i + 1], acc0[i + 2])));
+                tb = fminf(tb, fminf(acc1[i], fminf(acc1[i + 1], acc1[i + 2])));
             }
+            m2a = fminf(m2a, fmaxf(m1a, ta)); m1a = fminf(m1a, ta);
+            m2b = fminf(m2b, fmaxf(m1b, tb)); m1b = fminf(m1b, tb);
         } else {
             const int row0 = tl * 32 + 4 * half;
 #pragma unroll
