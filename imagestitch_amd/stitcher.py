@@ -183,20 +183,24 @@ class Stitcher(Utility.Method):
         batched = self._registerBatched(fileList, caculateOffsetMethod)
         if batched is not None:
             (status, endfileIndex, offsetList, describtion) = batched
-        for fileIndex in (range(0, fileNum - 1) if batched is None else ()):
-            self.printAndWrite("stitching " + str(fileList[fileIndex]) + " and " + str(fileList[fileIndex + 1]))
-            imageA = imageB if imageB is not None else _imread(fileList[fileIndex], False)   # decoded once per tile
-            imageB = _imread(fileList[fileIndex + 1], False)
-            if caculateOffsetMethod == self.calculateOffsetForPhaseCorrleate:
-                (status, offset) = self.calculateOffsetForPhaseCorrleate([fileList[fileIndex], fileList[fileIndex + 1]])
-            else:
-                (status, offset) = caculateOffsetMethod([imageA, imageB])
-            if status == False:
-                describtion = "  " + str(fileList[fileIndex]) + " and " + str(fileList[fileIndex + 1]) + " can not be stitched"
-                break
-            else:
-                offsetList.append(offset)
-                endfileIndex = fileIndex + 1
+        try:
+            for fileIndex in (range(0, fileNum - 1) if batched is None else ()):
+                self.printAndWrite("stitching " + str(fileList[fileIndex]) + " and " + str(fileList[fileIndex + 1]))
+                imageA = imageB if imageB is not None else _imread(fileList[fileIndex], False)   # decoded once per tile
+                imageB = _imread(fileList[fileIndex + 1], False)
+                if caculateOffsetMethod == self.calculateOffsetForPhaseCorrleate:
+                    (status, offset) = self.calculateOffsetForPhaseCorrleate([fileList[fileIndex], fileList[fileIndex + 1]])
+                else:
+                    (status, offset) = caculateOffsetMethod([imageA, imageB])
+                if status == False:
+                    describtion = "  " + str(fileList[fileIndex]) + " and " + str(fileList[fileIndex + 1]) + " can not be stitched"
+                    break
+                else:
+                    offsetList.append(offset)
+                    endfileIndex = fileIndex + 1
+        except Exception:
+            self.releaseTiles()                     # an operator that raises must not leave the pair's tiles in HBM
+            raise
         self.releaseTiles()
         endTime = time.time()
         self.printAndWrite("The time of registering is " + str(endTime - startTime) + "s")
@@ -587,7 +591,12 @@ class Stitcher(Utility.Method):
             featA = describe(imageA)
         else:
             featA = prev
-        featB = describe(imageB)
+        try:
+            featB = describe(imageB)
+        except Exception:
+            featA.release()                                     # nothing cached may point at a set that is gone
+            tf.isBreak, tf.kps, tf.feature = True, None, None
+            raise
         tf.isBreak = False
         tf.kps = featB if featB.n else np.float32([])
         tf.feature = featB if featB.n else None            # cv2 returns (kps, None) for an image without keypoints

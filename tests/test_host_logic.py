@@ -337,3 +337,35 @@ def test_npy_band_writer_reassembles_the_mosaic(tmp_path):
         for r0 in range(0, shape[0], 7):
             sink(r0, img[r0:r0 + 7], shape)
         assert np.array_equal(np.load(path), img)
+
+
+def test_flow_stitch_releases_tiles_when_an_operator_raises(tmp_path):
+    """A pair method that raises in the middle of a path must not leave the tiles the earlier pairs cached in HBM
+    (flowStitch frees them on the way out, as it does at its normal end)."""
+    import imagestitch_amd as isa
+
+    class Eng:
+        def __init__(self):
+            self.live, self.next, self.calls = set(), 1, 0
+        def tile_upload(self, img):
+            h = self.next; self.next += 1; self.live.add(h)
+            return h
+        def tile_free(self, h):
+            assert h in self.live, "freed twice"
+            self.live.remove(h)
+        @staticmethod
+        def surf_params(*a, **k):
+            return None
+        def attempt_surf_batch(self, jobs, params, ratio, ev):
+            self.calls += 1
+            if self.calls == 2:
+                raise RuntimeError("device error in the second pair")
+            return np.array([[1, 5, -3, 9, 10, 10, 9, 0]] * len(jobs), np.int32)
+    files = _write_tiles(tmp_path, [np.full((64, 80), 40 * k, np.uint8) for k in range(1, 4)], "raise")
+    eng = Eng()
+    st = isa.Stitcher(); st._engine = eng; st.isPrintLog = False
+    st.batchRegistration = False                                 # the pair-by-pair loop is the one under test
+    st.direction = 1
+    with pytest.raises(RuntimeError):
+        st.flowStitch(files, st.calculateOffsetForFeatureSearchIncre)
+    assert eng.calls == 2 and not eng.live
