@@ -338,6 +338,9 @@ __global__ __launch_bounds__(256) void k_bf_split16(const MatchDev *jobs, float 
 // running threshold admits, so the append branch is almost never taken (one min3 tree + one ballot per accumulator decides) and
 // the verifier has a few distances to evaluate instead of ~200.
 #define BFM_HI_ERR 1.6e-2f           // >= 2 * ((1 + 2^-8)^2 - 1) * |q||t| = 1.57e-2 (bf16 keeps 8 significand bits: RNE unit roundoff 2^-8) + the split filter's own 3e-5
+#ifndef BFM_UNIT
+#define BFM_UNIT 2                 // train tiles per workgroup barrier of the filter sweeps
+#endif
 #define GASM __attribute__((address_space(1)))
 typedef GASM const s8v *g_cs8v;
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -401,94 +404,113 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, 
     uint2 *lista = J.c_ent + (size_t)lst * BFM_CAPL * pitch + (q0 + col), *listb = lista + 32;
     // Train tiles go through LDS: the four waves of a workgroup sweep the SAME tiles (for different queries), so one cooperative
     // copy per tile (2.25 x 16 B per thread, straight in fragment order) replaces four sets of per-wave loads, and the operands
-    // arrive by ds_read_b128 instead of waiting on L2.  Three buffers, one barrier per tile: tile t + 2 is fetched into registers
-    // before the MFMAs of tile t and stored after them into the buffer that tile t - 1 vacated.
+    // arrive by ds_read_b128 instead of waiting on L2.  The waves meet once per UNIT of BFM_UNIT tiles (they sit on four SIMDs, each
+    // shared with other workgroups: every meeting waits for the slowest): two buffers of one unit each; unit u + 1 is put into the
+    // buffer that unit u - 1 vacated right after the barrier (it was fetched into registers an iteration ago), unit u + 2 is fetched
+    // before the MFMAs of unit u.
     constexpr int NFR = PASS == 0 ? 5 : BF16_FRAGS;      // fragments staged: hi x 4 (+ lo x 4) + norm
-    __shared__ s8v stage[3][NFR * 64];
+    __shared__ s8v stage[2][BFM_UNIT][NFR * 64];
     g_cs8v T = (g_cs8v)J.t16;                            // fragment order: tile * 9 fragments * 64 lanes (k_bf_split16)
     const int tid = threadIdx.x;
-    s8v g0 = zero, g1 = zero, g2 = zero;
-    auto fetch = [&](int tl) {
-        g_cs8v pn = T + (size_t)tl * (BF16_FRAGS * 64);
-        g0 = pn[tid];
-        if (PASS == 1) { g1 = pn[256 + tid]; if (tid < 64) g2 = pn[512 + tid]; }
-        else if (tid < 64) g1 = pn[512 + tid];
+    s8v g0[BFM_UNIT], g1[BFM_UNIT], g2[BFM_UNIT];
+#pragma unroll
+    for (int u = 0; u < BFM_UNIT; u++) { g0[u] = zero; g1[u] = zero; g2[u] = zero; }
+    const int nunits = (tile1 - tile0 + BFM_UNIT - 1) / BFM_UNIT;
+    auto fetch = [&](int unit) {
+#pragma unroll
+        for (int u = 0; u < BFM_UNIT; u++) {
+            const int tl = tile0 + unit * BFM_UNIT + u;
+            if (tl < tile1) {
+                g_cs8v pn = T + (size_t)tl * (BF16_FRAGS * 64);
+                g0[u] = pn[tid];
+                if (PASS == 1) { g1[u] = pn[256 + tid]; if (tid < 64) g2[u] = pn[512 + tid]; }
+                else if (tid < 64) g1[u] = pn[512 + tid];
+            }
+        }
     };
     auto put = [&](int b) {
-        stage[b][tid] = g0;
-        if (PASS == 1) { stage[b][256 + tid] = g1; if (tid < 64) stage[b][512 + tid] = g2; }
-        else if (tid < 64) stage[b][256 + tid] = g1;
+#pragma unroll
+        for (int u = 0; u < BFM_UNIT; u++) {
+            stage[b][u][tid] = g0[u];
+            if (PASS == 1) { stage[b][u][256 + tid] = g1[u]; if (tid < 64) stage[b][u][512 + tid] = g2[u]; }
+            else if (tid < 64) stage[b][u][256 + tid] = g1[u];
+        }
     };
-    if (tile0 < tile1) { fetch(tile0); put(0); }
-    if (tile0 + 1 < tile1) { fetch(tile0 + 1); put(1); }
-    for (int tl = tile0; tl < tile1; tl++) {
-        const int b = (tl - tile0) % 3;
+    if (nunits > 0) { fetch(0); put(0); }
+    if (nunits > 1) fetch(1);
+    for (int unit = 0; unit < nunits; unit++) {
+        const int b = unit & 1;
         __syncthreads();
-        const bool more = tl + 2 < tile1;
-        if (more) fetch(tl + 2);
-        if (!live) { if (more) put((b + 2) % 3); continue; }
-        f16v acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+        if (unit + 1 < nunits) put(b ^ 1);
+        if (unit + 2 < nunits) fetch(unit + 2);
+        if (!live) continue;
 #pragma unroll
-        for (int s = 0; s < 4; s++) {            // fragment s = hi, 4 + s = lo of the lane's dims 8s .. 8s + 7
-            const s8v ah = stage[b][s * 64 + lane];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1[s], acc1, 0, 0, 0);
-            if (PASS == 1) {
-                const s8v al = stage[b][(4 + s) * 64 + lane];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1[s], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1[s], acc1, 0, 0, 0);
+        for (int u = 0; u < BFM_UNIT; u++) {
+            const int tl = tile0 + unit * BFM_UNIT + u;
+            if (tl >= tile1) break;
+            const s8v *st = stage[b][u];
+            f16v acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {            // fragment s = hi, 4 + s = lo of the lane's dims 8s .. 8s + 7
+                const s8v ah = st[s * 64 + lane];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1[s], acc1, 0, 0, 0);
+                if (PASS == 1) {
+                    const s8v al = st[(4 + s) * 64 + lane];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1[s], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1[s], acc1, 0, 0, 0);
+                }
             }
-        }
-        const s8v na = stage[b][(NFR - 1) * 64 + lane];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na, bn0, acc0, 0, 0, 0);      // + |t|^2 (hi + lo in both passes)
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na, bn1, acc1, 0, 0, 0);
-        if (tl * 32 + 31 >= nt) {                // train rows beyond nt never qualify
+            const s8v na = st[(NFR - 1) * 64 + lane];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na, bn0, acc0, 0, 0, 0);      // + |t|^2 (hi + lo in both passes)
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na, bn1, acc1, 0, 0, 0);
+            if (tl * 32 + 31 >= nt) {                // train rows beyond nt never qualify
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const bool past = tl * 32 + 4 * half + (i & 3) + 8 * (i >> 2) >= nt;
-                acc0[i] = past ? BFM_FAR : acc0[i]; acc1[i] = past ? BFM_FAR : acc1[i];
+                for (int i = 0; i < 16; i++) {
+                    const bool past = tl * 32 + 4 * half + (i & 3) + 8 * (i >> 2) >= nt;
+                    acc0[i] = past ? BFM_FAR : acc0[i]; acc1[i] = past ? BFM_FAR : acc1[i];
+                }
             }
-        }
-        if (PASS == 0) {
-            // A lane's 16 scores of an accumulator belong to ONE query.  Only their minimum enters the running (best, second best): the
-            // second smallest of a SUBSET of the scores (one per tile and lane) is >= the true second smallest, so thr(q) stays an upper
-            // bound -- exact unless a query's two nearest trains share a tile and a lane half (15 / nt of the queries; pass 1 then lists a
-            // few more candidates for them) -- and the sweep costs 11 VALU operations per accumulator instead of 48 (it was VALU-bound).
-            float ta = fminf(fminf(acc0[0], acc0[1]), fminf(acc0[2], acc0[3])), tb = fminf(fminf(acc1[0], acc1[1]), fminf(acc1[2], acc1[3]));
+            if (PASS == 0) {
+                // A lane's 16 scores of an accumulator belong to ONE query.  Only their minimum enters the running (best, second best): the
+                // second smallest of a SUBSET of the scores (one per tile and lane) is >= the true second smallest, so thr(q) stays an upper
+                // bound -- exact unless a query's two nearest trains share a tile and a lane half (15 / nt of the queries; pass 1 then lists a
+                // few more candidates for them) -- and the sweep costs 11 VALU operations per accumulator instead of 48 (it was VALU-bound).
+                float ta = fminf(fminf(acc0[0], acc0[1]), fminf(acc0[2], acc0[3])), tb = fminf(fminf(acc1[0], acc1[1]), fminf(acc1[2], acc1[3]));
 #pragma unroll
-            for (int i = 4; i < 16; i += 3) {
-                ta = fminf(ta, fminf(acc0[i], fminf(acc0[i + 1], acc0[i + 2])));
-                tb = fminf(tb, fminf(acc1[i], fminf(acc1[i + 1], acc1[i + 2])));
-            }
-            m2a = fminf(m2a, fmaxf(m1a, ta)); m1a = fminf(m1a, ta);
-            m2b = fminf(m2b, fmaxf(m1b, tb)); m1b = fminf(m1b, tb);
-        } else {
-            const int row0 = tl * 32 + 4 * half;
+                for (int i = 4; i < 16; i += 3) {
+                    ta = fminf(ta, fminf(acc0[i], fminf(acc0[i + 1], acc0[i + 2])));
+                    tb = fminf(tb, fminf(acc1[i], fminf(acc1[i + 1], acc1[i + 2])));
+                }
+                m2a = fminf(m2a, fmaxf(m1a, ta)); m1a = fminf(m1a, ta);
+                m2b = fminf(m2b, fmaxf(m1b, tb)); m1b = fminf(m1b, tb);
+            } else {
+                const int row0 = tl * 32 + 4 * half;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const f16v &acc = h == 0 ? acc0 : acc1;
-                const float thr = h == 0 ? thra : thrb;
-                float mn = fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3]));
+                for (int h = 0; h < 2; h++) {
+                    const f16v &acc = h == 0 ? acc0 : acc1;
+                    const float thr = h == 0 ? thra : thrb;
+                    float mn = fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3]));
 #pragma unroll
-                for (int i = 4; i < 16; i += 3) mn = fminf(mn, fminf(acc[i], fminf(acc[i + 1], acc[i + 2])));
-                if (__any(mn <= thr)) {
-                    uint2 *list = h == 0 ? lista : listb;
-                    int cnt = h == 0 ? cnta : cntb;
+                    for (int i = 4; i < 16; i += 3) mn = fminf(mn, fminf(acc[i], fminf(acc[i + 1], acc[i + 2])));
+                    if (__any(mn <= thr)) {
+                        uint2 *list = h == 0 ? lista : listb;
+                        int cnt = h == 0 ? cnta : cntb;
 #pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const float v = acc[i];
-                        if (v <= thr && v < 1e29f) {
-                            if (cnt < BFM_CAPL) list[cnt * pitch] = make_uint2(__float_as_uint(v), (unsigned)(row0 + (i & 3) + 8 * (i >> 2)));
-                            cnt++;
+                        for (int i = 0; i < 16; i++) {
+                            const float v = acc[i];
+                            if (v <= thr && v < 1e29f) {
+                                if (cnt < BFM_CAPL) list[cnt * pitch] = make_uint2(__float_as_uint(v), (unsigned)(row0 + (i & 3) + 8 * (i >> 2)));
+                                cnt++;
+                            }
                         }
+                        if (h == 0) cnta = cnt; else cntb = cnt;
                     }
-                    if (h == 0) cnta = cnt; else cntb = cnt;
                 }
             }
         }
-        if (more) put((b + 2) % 3);
     }
     if (PASS == 0) {
         GASM f2v *B = (GASM f2v *)J.c_m12;

@@ -1561,6 +1561,8 @@ __global__ __launch_bounds__(256) void k_desc_tail(const RoiDev *rois, const Sur
     __shared__ uint32_t P32[16][VFSMS_PATCH_ROW / 4];
     __shared__ float vec[16][128];
     __shared__ float scl[16];
+    __shared__ float DWs[400];                               // the 20 x 20 Gaussian weights: 25 taps per thread come from LDS, not through the TA
+    for (int i = threadIdx.x; i < 400; i += 256) DWs[i] = T->DW[i];
     {
         const uint32_t __attribute__((address_space(1))) *src =
             (const uint32_t __attribute__((address_space(1))) *)(R.patch + (size_t)k0 * VFSMS_PATCH_ROW);
@@ -1574,10 +1576,17 @@ __global__ __launch_bounds__(256) void k_desc_tail(const RoiDev *rois, const Sur
         const uint8_t *P = (const uint8_t *)&P32[kk][0];
         const int ci = c >> 2, cj = c & 3;
         float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int y = ci * 5; y < ci * 5 + 5; y++)
-            for (int x = cj * 5; x < cj * 5 + 5; x++) {
-                const float dw = T->DW[y * 20 + x];
-                const int p00 = P[y * 21 + x], p01 = P[y * 21 + x + 1], p10 = P[(y + 1) * 21 + x], p11 = P[(y + 1) * 21 + x + 1];
+        int pb[6][6];                                       // the cell's 6 x 6 pixels, read once (each is a tap of up to four gradients)
+#pragma unroll
+        for (int yy = 0; yy < 6; yy++)
+#pragma unroll
+            for (int xx = 0; xx < 6; xx++) pb[yy][xx] = P[(ci * 5 + yy) * 21 + cj * 5 + xx];
+#pragma unroll
+        for (int yy = 0; yy < 5; yy++)
+#pragma unroll
+            for (int xx = 0; xx < 5; xx++) {
+                const float dw = DWs[(ci * 5 + yy) * 20 + cj * 5 + xx];
+                const int p00 = pb[yy][xx], p01 = pb[yy][xx + 1], p10 = pb[yy + 1][xx], p11 = pb[yy + 1][xx + 1];
                 const float tx = (float)(p01 - p00 + p11 - p10) * dw;
                 const float ty = (float)(p10 - p00 + p11 - p01) * dw;
                 if (extended) {
