@@ -345,6 +345,19 @@ __global__ __launch_bounds__(256) void k_bf_split16(const MatchDev *jobs, float 
 typedef GASM const s8v *g_cs8v;
 typedef float f2v __attribute__((ext_vector_type(2)));
 
+#ifdef VFSMS_DESC_TIMING
+// debug build: per-wave cycles of the filter sweeps, [pass][0 prologue, 1 barrier wait, 2 put + fetch issue, 3 LDS reads + MFMAs + minimum tree, 4 append, 5 whole kernel, 6 waves]
+__device__ unsigned long long g_bf_cycles[2][8];
+extern "C" int vfsms_debug_bf_cycles(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bf_cycles), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -3; }
+#define BT_DECL unsigned long long _bt[5] = {0, 0, 0, 0, 0}, _bt0 = clock64(), _btl = _bt0
+#define BT_MARK(ph) do { const unsigned long long _n = clock64(); _bt[ph] += _n - _btl; _btl = _n; } while (0)
+#define BT_FLUSH(pass) do { if ((threadIdx.x & 63) == 0) { for (int _q = 0; _q < 5; _q++) atomicAdd(&g_bf_cycles[pass][_q], _bt[_q]); \
+        atomicAdd(&g_bf_cycles[pass][5], clock64() - _bt0); atomicAdd(&g_bf_cycles[pass][6], 1ull); } } while (0)
+#else
+#define BT_DECL do {} while (0)
+#define BT_MARK(ph) do {} while (0)
+#define BT_FLUSH(pass) do {} while (0)
+#endif
 template <int PASS>
 __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, int qblocks, int nsplit, int njobs)
 {
@@ -356,6 +369,7 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, 
     const int nq = __builtin_amdgcn_readfirstlane(*J.nq_ptr), nt = __builtin_amdgcn_readfirstlane(*J.nt_ptr);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if ((int)qb * 256 >= nq) return;                    // (whole workgroup)
+    BT_DECL;
     const int q0 = ((int)qb * 4 + wave) * 64;
     const bool live = q0 < nq;                           // a wave beyond nq still stages train tiles and keeps the barriers
     const int ntiles = (nt + 31) >> 5;
@@ -393,10 +407,19 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, 
     if (PASS == 1) {
         GASM const f2v *B = (GASM const f2v *)J.c_m12;
         float a1 = INFINITY, a2 = INFINITY, b1 = INFINITY, b2 = INFINITY;
-        for (int L = 0; L < nl; L++) {
-            const f2v ua = B[(size_t)L * pitch + min(q0 + col, nq - 1)], ub = B[(size_t)L * pitch + min(q0 + 32 + col, nq - 1)];
-            a2 = fminf(fminf(a2, ua.y), fmaxf(a1, ua.x)); a1 = fminf(a1, ua.x);
-            b2 = fminf(fminf(b2, ub.y), fmaxf(b1, ub.x)); b1 = fminf(b1, ub.x);
+        for (int L0 = 0; L0 < nl; L0 += 4) {                  // four lists per round trip (the loop was one dependent load per list)
+            f2v ua[4], ub[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const size_t row = (size_t)min(L0 + k, nl - 1) * pitch;
+                ua[k] = B[row + min(q0 + col, nq - 1)]; ub[k] = B[row + min(q0 + 32 + col, nq - 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (L0 + k >= nl) break;
+                a2 = fminf(fminf(a2, ua[k].y), fmaxf(a1, ua[k].x)); a1 = fminf(a1, ua[k].x);
+                b2 = fminf(fminf(b2, ub[k].y), fmaxf(b1, ub[k].x)); b1 = fminf(b1, ub[k].x);
+            }
         }
         if (va) thra = a2 + (BFM_HI_ERR + BFM_MARGIN);
         if (vb) thrb = b2 + (BFM_HI_ERR + BFM_MARGIN);
@@ -412,37 +435,52 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, 
     __shared__ s8v stage[2][BFM_UNIT][NFR * 64];
     g_cs8v T = (g_cs8v)J.t16;                            // fragment order: tile * 9 fragments * 64 lanes (k_bf_split16)
     const int tid = threadIdx.x;
-    s8v g0[BFM_UNIT], g1[BFM_UNIT], g2[BFM_UNIT];
+    // Units are fetched BFM_SETS + 1 ahead of their MFMAs into BFM_SETS register sets (pass 0 has the registers for two: its iteration --
+    // ten MFMAs per tile -- is shorter than a trip to memory, and half of its wave cycles were the wait in front of the put).
+    constexpr int NSET = PASS == 0 ? 2 : 1;
+    s8v g0[NSET][BFM_UNIT], g1[NSET][BFM_UNIT], g2[NSET][BFM_UNIT];
 #pragma unroll
-    for (int u = 0; u < BFM_UNIT; u++) { g0[u] = zero; g1[u] = zero; g2[u] = zero; }
+    for (int e = 0; e < NSET; e++)
+#pragma unroll
+        for (int u = 0; u < BFM_UNIT; u++) { g0[e][u] = zero; g1[e][u] = zero; g2[e][u] = zero; }
     const int nunits = (tile1 - tile0 + BFM_UNIT - 1) / BFM_UNIT;
-    auto fetch = [&](int unit) {
+    // (no branch around a load: beyond the chunk the last tile is fetched again and never used, every thread fetches a norm fragment lane --
+    //  with a fixed number of loads per fetch the compiler waits for exactly the set it is about to put, not for everything outstanding)
+    auto fetch = [&](int unit, int e) {
 #pragma unroll
         for (int u = 0; u < BFM_UNIT; u++) {
-            const int tl = tile0 + unit * BFM_UNIT + u;
-            if (tl < tile1) {
-                g_cs8v pn = T + (size_t)tl * (BF16_FRAGS * 64);
-                g0[u] = pn[tid];
-                if (PASS == 1) { g1[u] = pn[256 + tid]; if (tid < 64) g2[u] = pn[512 + tid]; }
-                else if (tid < 64) g1[u] = pn[512 + tid];
-            }
+            const int tl = min(tile0 + unit * BFM_UNIT + u, tile1 - 1);
+            g_cs8v pn = T + (size_t)tl * (BF16_FRAGS * 64);
+            g0[e][u] = pn[tid];
+            if (PASS == 1) { g1[e][u] = pn[256 + tid]; g2[e][u] = pn[512 + (tid & 63)]; }
+            else g1[e][u] = pn[512 + (tid & 63)];
         }
     };
-    auto put = [&](int b) {
+    auto put = [&](int b, int e) {
 #pragma unroll
         for (int u = 0; u < BFM_UNIT; u++) {
-            stage[b][u][tid] = g0[u];
-            if (PASS == 1) { stage[b][u][256 + tid] = g1[u]; if (tid < 64) stage[b][u][512 + tid] = g2[u]; }
-            else if (tid < 64) stage[b][u][256 + tid] = g1[u];
+            stage[b][u][tid] = g0[e][u];
+            if (PASS == 1) { stage[b][u][256 + tid] = g1[e][u]; if (tid < 64) stage[b][u][512 + tid] = g2[e][u]; }
+            else if (tid < 64) stage[b][u][256 + tid] = g1[e][u];
         }
     };
-    if (nunits > 0) { fetch(0); put(0); }
-    if (nunits > 1) fetch(1);
-    for (int unit = 0; unit < nunits; unit++) {
+    if (nunits > 0) {
+        fetch(0, 0); put(0, 0);
+#pragma unroll
+        for (int k = 1; k <= NSET; k++) fetch(min(k, nunits - 1), k % NSET);
+    }
+    BT_MARK(0);
+    for (int unit0 = 0; unit0 < nunits; unit0 += NSET) {
+#pragma unroll
+      for (int v = 0; v < NSET; v++) {                 // unrolled: the register set of unit + 1 is (v + 1) % NSET, a constant
+        const int unit = unit0 + v;
+        if (unit >= nunits) break;
         const int b = unit & 1;
         __syncthreads();
-        if (unit + 1 < nunits) put(b ^ 1);
-        if (unit + 2 < nunits) fetch(unit + 2);
+        BT_MARK(1);
+        if (unit + 1 < nunits) put(b ^ 1, (v + 1) % NSET);
+        fetch(min(unit + 1 + NSET, nunits - 1), (v + 1) % NSET);
+        BT_MARK(2);
         if (!live) continue;
 #pragma unroll
         for (int u = 0; u < BFM_UNIT; u++) {
@@ -492,26 +530,40 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, 
                 for (int h = 0; h < 2; h++) {
                     const f16v &acc = h == 0 ? acc0 : acc1;
                     const float thr = h == 0 ? thra : thrb;
-                    float mn = fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3]));
+                    // minima of the value groups {0..3}, {4..6}, {7..9}, {10..12}, {13..15}: the append walks only the groups that hold a hit
+                    // (one or two values of the 16, as a rule), in ascending order -- the lists are the ones a full walk writes
+                    float gm[5];
+                    gm[0] = fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3]));
 #pragma unroll
-                    for (int i = 4; i < 16; i += 3) mn = fminf(mn, fminf(acc[i], fminf(acc[i + 1], acc[i + 2])));
-                    if (__any(mn <= thr)) {
+                    for (int g = 1; g < 5; g++) gm[g] = fminf(acc[3 * g + 1], fminf(acc[3 * g + 2], acc[3 * g + 3]));
+                    const float mn = fminf(fminf(gm[0], fminf(gm[1], gm[2])), fminf(gm[3], gm[4]));
+                    const bool some = __any(mn <= thr);
+                    BT_MARK(3);
+                    if (some) {
                         uint2 *list = h == 0 ? lista : listb;
                         int cnt = h == 0 ? cnta : cntb;
 #pragma unroll
-                        for (int i = 0; i < 16; i++) {
-                            const float v = acc[i];
-                            if (v <= thr && v < 1e29f) {
-                                if (cnt < BFM_CAPL) list[cnt * pitch] = make_uint2(__float_as_uint(v), (unsigned)(row0 + (i & 3) + 8 * (i >> 2)));
-                                cnt++;
+                        for (int g = 0; g < 5; g++) {
+                            if (!__any(gm[g] <= thr)) continue;
+#pragma unroll
+                            for (int i = (g == 0 ? 0 : 3 * g + 1); i < (g == 0 ? 4 : 3 * g + 4); i++) {
+                                const float v = acc[i];
+                                if (v <= thr && v < 1e29f) {
+                                    if (cnt < BFM_CAPL) list[cnt * pitch] = make_uint2(__float_as_uint(v), (unsigned)(row0 + (i & 3) + 8 * (i >> 2)));
+                                    cnt++;
+                                }
                             }
                         }
                         if (h == 0) cnta = cnt; else cntb = cnt;
+                        BT_MARK(4);
                     }
                 }
             }
+            if (PASS == 0) BT_MARK(3);
         }
+      }
     }
+    BT_FLUSH(PASS);
     if (PASS == 0) {
         GASM f2v *B = (GASM f2v *)J.c_m12;
         if (va) B[(size_t)lst * pitch + q0 + col] = f2v{m1a, m2a};

@@ -29,3 +29,12 @@ print("wave trips (both runs): interior strips %d (x4 samples/lane), border stri
 uc = np.zeros(4, np.uint64); eng.lib.vfsms_debug_desc_unit_cycles(uc.ctypes.data_as(ctypes.c_void_p))
 print("units (both runs): interior %d, border %d; wave-cycles per unit: interior %.0f, border %.0f; wave-cycles in stage_rows %.4g (in units %.4g)" % (
     tr[0], tr[2], uc[0] / max(float(tr[0]), 1), uc[1] / max(float(tr[2]), 1), float(uc[2]), float(uc[0] + uc[1])))
+
+# BF filter sweeps: per-wave cycles by phase (both runs)
+bf = np.zeros(16, np.uint64)
+if hasattr(eng.lib, "vfsms_debug_bf_cycles") and eng.lib.vfsms_debug_bf_cycles(bf.ctypes.data_as(ctypes.c_void_p)) == 0:
+    bf = bf.reshape(2, 8).astype(np.float64)
+    for p in (0, 1):
+        tot, waves = bf[p, 5], max(bf[p, 6], 1)
+        print("bf pass %d: %d waves, %.0f cycles per wave; prologue %.1f %%, barrier wait %.1f %%, put+fetch %.1f %%, lds+mfma+min %.1f %%, append %.1f %%, rest %.1f %%" % (
+            p, waves, tot / waves, *[100 * bf[p, q] / tot for q in range(5)], 100 * (tot - bf[p, :5].sum()) / tot))
