@@ -338,9 +338,6 @@ __global__ __launch_bounds__(256) void k_bf_split16(const MatchDev *jobs, float 
 // running threshold admits, so the append branch is almost never taken (one min3 tree + one ballot per accumulator decides) and
 // the verifier has a few distances to evaluate instead of ~200.
 #define BFM_HI_ERR 1.6e-2f           // >= 2 * ((1 + 2^-8)^2 - 1) * |q||t| = 1.57e-2 (bf16 keeps 8 significand bits: RNE unit roundoff 2^-8) + the split filter's own 3e-5
-#ifndef BFM_UNIT
-#define BFM_UNIT 2                 // train tiles per workgroup barrier of the filter sweeps
-#endif
 #define GASM __attribute__((address_space(1)))
 typedef GASM const s8v *g_cs8v;
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -390,6 +387,47 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, 
         bn0 = half == 0 ? *(g_cs8v)(J.q16 + (size_t)min(q0 + col, nq - 1) * BF16_ROW + 128) : zero;
         bn1 = half == 0 ? *(g_cs8v)(J.q16 + (size_t)min(q0 + 32 + col, nq - 1) * BF16_ROW + 128) : zero;
     }
+    // Train tiles go through LDS: the four waves of a workgroup sweep the SAME tiles (for different queries), so one cooperative
+    // copy per tile (2.25 x 16 B per thread, straight in fragment order) replaces four sets of per-wave loads, and the operands
+    // arrive by ds_read_b128 instead of waiting on L2.  The waves meet once per UNIT of BFM_UNIT tiles (they sit on four SIMDs, each
+    // shared with other workgroups: every meeting waits for the slowest): two buffers of one unit each; unit u + 1 is put into the
+    // buffer that unit u - 1 vacated right after the barrier (it was fetched into registers an iteration ago), unit u + 2 is fetched
+    // before the MFMAs of unit u.
+    constexpr int NFR = PASS == 0 ? 5 : BF16_FRAGS;      // fragments staged: hi x 4 (+ lo x 4) + norm
+    constexpr int BFM_UNIT = 2;                          // train tiles per meeting (four in pass 0 -- twice the bytes in flight -- changed nothing)
+    __shared__ s8v stage[2][BFM_UNIT][NFR * 64];
+    g_cs8v T = (g_cs8v)J.t16;                            // fragment order: tile * 9 fragments * 64 lanes (k_bf_split16)
+    const int tid = threadIdx.x;
+    // Units are fetched BFM_SETS + 1 ahead of their MFMAs into BFM_SETS register sets (pass 0 has the registers for two: its iteration --
+    // ten MFMAs per tile -- is shorter than a trip to memory, and half of its wave cycles were the wait in front of the put).
+    constexpr int NSET = PASS == 0 ? 2 : 1;
+    s8v g0[NSET][BFM_UNIT], g1[NSET][BFM_UNIT], g2[NSET][BFM_UNIT];
+#pragma unroll
+    for (int e = 0; e < NSET; e++)
+#pragma unroll
+        for (int u = 0; u < BFM_UNIT; u++) { g0[e][u] = zero; g1[e][u] = zero; g2[e][u] = zero; }
+    const int nunits = (tile1 - tile0 + BFM_UNIT - 1) / BFM_UNIT;
+    // (no branch around a load: beyond the chunk the last tile is fetched again and never used, every thread fetches a norm fragment lane --
+    //  with a fixed number of loads per fetch the compiler waits for exactly the set it is about to put, not for everything outstanding)
+    auto fetch = [&](int unit, int e) {
+#pragma unroll
+        for (int u = 0; u < BFM_UNIT; u++) {
+            const int tl = min(tile0 + unit * BFM_UNIT + u, tile1 - 1);
+            g_cs8v pn = T + (size_t)tl * (BF16_FRAGS * 64);
+            g0[e][u] = pn[tid];
+            if (PASS == 1) { g1[e][u] = pn[256 + tid]; g2[e][u] = pn[512 + (tid & 63)]; }
+            else g1[e][u] = pn[512 + (tid & 63)];
+        }
+    };
+    auto put = [&](int b, int e) {
+#pragma unroll
+        for (int u = 0; u < BFM_UNIT; u++) {
+            stage[b][u][tid] = g0[e][u];
+            if (PASS == 1) { stage[b][u][256 + tid] = g1[e][u]; if (tid < 64) stage[b][u][512 + tid] = g2[e][u]; }
+            else if (tid < 64) stage[b][u][256 + tid] = g1[e][u];
+        }
+    };
+    if (nunits > 0) fetch(0, 0);                     // under way while the query operands and the thresholds arrive
     // Pin the query operands as "defined here": the compiler otherwise carries their load waits into the tile loop as in-order
     // vmcnt counts, which also drain the train prefetch issued at the top of every iteration (a full L2 round trip per tile).
 #pragma unroll
@@ -425,47 +463,8 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, 
         if (vb) thrb = b2 + (BFM_HI_ERR + BFM_MARGIN);
     }
     uint2 *lista = J.c_ent + (size_t)lst * BFM_CAPL * pitch + (q0 + col), *listb = lista + 32;
-    // Train tiles go through LDS: the four waves of a workgroup sweep the SAME tiles (for different queries), so one cooperative
-    // copy per tile (2.25 x 16 B per thread, straight in fragment order) replaces four sets of per-wave loads, and the operands
-    // arrive by ds_read_b128 instead of waiting on L2.  The waves meet once per UNIT of BFM_UNIT tiles (they sit on four SIMDs, each
-    // shared with other workgroups: every meeting waits for the slowest): two buffers of one unit each; unit u + 1 is put into the
-    // buffer that unit u - 1 vacated right after the barrier (it was fetched into registers an iteration ago), unit u + 2 is fetched
-    // before the MFMAs of unit u.
-    constexpr int NFR = PASS == 0 ? 5 : BF16_FRAGS;      // fragments staged: hi x 4 (+ lo x 4) + norm
-    __shared__ s8v stage[2][BFM_UNIT][NFR * 64];
-    g_cs8v T = (g_cs8v)J.t16;                            // fragment order: tile * 9 fragments * 64 lanes (k_bf_split16)
-    const int tid = threadIdx.x;
-    // Units are fetched BFM_SETS + 1 ahead of their MFMAs into BFM_SETS register sets (pass 0 has the registers for two: its iteration --
-    // ten MFMAs per tile -- is shorter than a trip to memory, and half of its wave cycles were the wait in front of the put).
-    constexpr int NSET = PASS == 0 ? 2 : 1;
-    s8v g0[NSET][BFM_UNIT], g1[NSET][BFM_UNIT], g2[NSET][BFM_UNIT];
-#pragma unroll
-    for (int e = 0; e < NSET; e++)
-#pragma unroll
-        for (int u = 0; u < BFM_UNIT; u++) { g0[e][u] = zero; g1[e][u] = zero; g2[e][u] = zero; }
-    const int nunits = (tile1 - tile0 + BFM_UNIT - 1) / BFM_UNIT;
-    // (no branch around a load: beyond the chunk the last tile is fetched again and never used, every thread fetches a norm fragment lane --
-    //  with a fixed number of loads per fetch the compiler waits for exactly the set it is about to put, not for everything outstanding)
-    auto fetch = [&](int unit, int e) {
-#pragma unroll
-        for (int u = 0; u < BFM_UNIT; u++) {
-            const int tl = min(tile0 + unit * BFM_UNIT + u, tile1 - 1);
-            g_cs8v pn = T + (size_t)tl * (BF16_FRAGS * 64);
-            g0[e][u] = pn[tid];
-            if (PASS == 1) { g1[e][u] = pn[256 + tid]; g2[e][u] = pn[512 + (tid & 63)]; }
-            else g1[e][u] = pn[512 + (tid & 63)];
-        }
-    };
-    auto put = [&](int b, int e) {
-#pragma unroll
-        for (int u = 0; u < BFM_UNIT; u++) {
-            stage[b][u][tid] = g0[e][u];
-            if (PASS == 1) { stage[b][u][256 + tid] = g1[e][u]; if (tid < 64) stage[b][u][512 + tid] = g2[e][u]; }
-            else if (tid < 64) stage[b][u][256 + tid] = g1[e][u];
-        }
-    };
     if (nunits > 0) {
-        fetch(0, 0); put(0, 0);
+        put(0, 0);
 #pragma unroll
         for (int k = 1; k <= NSET; k++) fetch(min(k, nunits - 1), k % NSET);
     }
