@@ -653,10 +653,11 @@ def main():
                                    traffic=(pmc_traffic("k_bf_mfma_d64")[0] if f32_filter else
                                             sum_or_none([pmc_traffic("void k_bf_mfma16_d64<%d>" % q)[0] for q in (0, 1)])),
                                    avg_launch_ms=round(dur * 1e3, 4), flops_per_launch=flops, launches=bf_n,
-                                   issued_mfma_flops_per_launch=flops if f32_filter else flops * 3.25,
+                                   issued_mfma_flops_per_launch=flops if f32_filter else flops * 4.5,
                                    note=("v_mfma_f32_32x32x2_f32 candidate filter (peak = dense f32 MFMA)" if f32_filter else
-                                         "split-bf16 candidate filter: q.t = hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 (3.25x the algorithmic "
-                                         "flops are issued; peak = dense bf16 MFMA); achieved counts one 64-d dot product per pair") +
+                                         "split-bf16 candidate filter in two sweeps: bounds from hi.hi (5 MFMA k-steps per tile), then q.t = hi.hi + hi.lo + lo.hi "
+                                         "(13) on v_mfma_f32_32x32x16_bf16 -- 18 issued k-steps per 4 algorithmic ones = 4.5x the flops; peak = dense "
+                                         "bf16 MFMA; achieved counts one 64-d dot product per pair") +
                                         "; the exact distances are evaluated by k_bf_verify_d64 for the few surviving candidates")
         extra["bf_l2_hbm"] = dict(bound="hbm", achieved=round(bytes_ / dur / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                                   frac=round(bytes_ / dur / 1e9 / HBM_PEAK_GBS, 5), bytes_per_launch=bytes_)
