@@ -336,6 +336,14 @@ static int tile_ready(vfsms_ctx *ctx, TileRec &t)
     if (t.pending) { HIP_TRY(hipStreamWaitEvent(ctx->stream, t.ready, 0)); t.pending = false; }
     return VFSMS_OK;
 }
+// non-blocking: has the tile's image been handed over (or was it never a reserved tile)?  An unknown handle counts as ready: the
+// evaluator reports it.  (csrc/grid.hip sizes speculative batches by this while decoder threads are still filling tiles.)
+int tile_is_filled(vfsms_ctx *ctx, int64_t handle)
+{
+    std::lock_guard<std::mutex> lk(ctx->tiles_mu);
+    auto it = ctx->tiles.find(handle);
+    return it == ctx->tiles.end() || it->second.fill != 1;
+}
 extern "C" int vfsms_tile_upload(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int64_t *handle)
 {
     CTX_ENTER(ctx);

@@ -38,6 +38,7 @@ inline int rotate_dir(int d, int incre)
 
 struct Chain {
     vfsms_attempt_eval eval; void *user;
+    int (*ready)(void *user, int tile) = nullptr;         // optional: is this tile's image on the device yet? (tiles filled by decoder threads)
     const int32_t *shapes; int n_tiles;
     const vfsms_grid_params *P;
     std::map<Key, Attempt> cache;
@@ -66,6 +67,15 @@ struct Chain {
             todo.push_back(k);
         }
         if (todo.empty()) return VFSMS_OK;
+        if (ready) {
+            // Ingest pipeline: a batch takes the attempts of its first pair (the one the chain is waiting for -- the evaluator blocks until
+            // those two tiles are there) and, of the speculative rest, only what is decoded already: the batches grow with the decoder
+            // pool's progress instead of making the first one wait for a whole window of tiles.  What is left out is simply not cached.
+            size_t keep = 0;
+            for (size_t n = 0; n < todo.size(); n++)
+                if (todo[n].pair == todo[0].pair || (ready(user, todo[n].pair) && ready(user, todo[n].pair + 1))) todo[keep++] = todo[n];
+            todo.resize(keep);
+        }
         std::vector<int32_t> rows((size_t)todo.size() * VFSMS_ATTEMPT_INTS, 0);
         const int rc = eval(user, todo.data(), (int)todo.size(), rows.data());
         if (rc != VFSMS_OK) return rc;
@@ -283,14 +293,26 @@ int check_args(const int32_t *shapes, int n_tiles, int first, int last, int dire
 
 }  // namespace
 
+// the library's own evaluator hands its readiness query to the chain it is about to start (the public *_eval entry points keep their signature)
+static thread_local int (*g_ready_for_next_chain)(void *user, int tile) = nullptr;
+int tile_is_filled(vfsms_ctx *ctx, int64_t handle);          // api.hip
+static int device_ready(void *user, int tile)
+{
+    DeviceEval *E = (DeviceEval *)user;
+    return tile_is_filled(E->ctx, E->tiles[tile]);
+}
+
 extern "C" int vfsms_pairs_offsets_eval(vfsms_attempt_eval eval, void *user, const int32_t *shapes_hw, int n_tiles, int first_pair, int last_pair,
                                         int direction_in, int midpath, int stop_on_fail, const vfsms_grid_params *p, int32_t *out,
                                         int32_t *direction_out, int64_t *stats)
 {
+    int (*const ready)(void *, int) = g_ready_for_next_chain;
+    g_ready_for_next_chain = nullptr;                        // consumed whatever happens below
     if (!eval) { vfsms_set_error("pairs_offsets: null evaluator"); return VFSMS_ERR_BAD_ARG; }
     TRY(check_args(shapes_hw, n_tiles, first_pair, last_pair, direction_in, p, out, direction_out));
     memset(out, 0, sizeof(int32_t) * 6 * (size_t)(last_pair - first_pair));
     Chain C; C.eval = eval; C.user = user; C.shapes = shapes_hw; C.n_tiles = n_tiles; C.P = p;
+    C.ready = ready;
     const int rc = C.run(first_pair, last_pair, direction_in, midpath, stop_on_fail, out, direction_out);
     if (stats) { for (int k = 0; k < 8; k++) stats[k] = 0; stats[0] = C.n_attempts; stats[1] = C.n_batches; }
     return rc;
@@ -304,11 +326,14 @@ extern "C" int vfsms_pairs_offsets_eval(vfsms_attempt_eval eval, void *user, con
 extern "C" int vfsms_pairs_offsets_blind_eval(vfsms_attempt_eval eval, void *user, const int32_t *shapes_hw, int n_tiles, int first_pair, int last_pair,
                                               int per, const vfsms_grid_params *p, int32_t *out, int32_t *direction_out, int64_t *stats)
 {
+    int (*const ready)(void *, int) = g_ready_for_next_chain;
+    g_ready_for_next_chain = nullptr;
     if (!eval) { vfsms_set_error("pairs_offsets: null evaluator"); return VFSMS_ERR_BAD_ARG; }
     TRY(check_args(shapes_hw, n_tiles, first_pair, last_pair, 1, p, out, direction_out));
     if (per < last_pair - first_pair) { vfsms_set_error("pairs_offsets_blind: per < chunk length"); return VFSMS_ERR_BAD_ARG; }
     memset(out, 0, sizeof(int32_t) * 6 * 4 * (size_t)per);
     Chain C; C.eval = eval; C.user = user; C.shapes = shapes_hw; C.n_tiles = n_tiles; C.P = p;
+    C.ready = ready;
     if (last_pair > first_pair) {
         std::vector<Key> heads;
         for (int d = 1; d <= 4; d++) heads.push_back(Key(first_pair, d, 1));
@@ -327,6 +352,7 @@ extern "C" int vfsms_pairs_offsets_blind(vfsms_ctx *ctx, const int64_t *tiles, c
 {
     if (!ctx || !tiles) { vfsms_set_error("pairs_offsets: null context / tiles"); return VFSMS_ERR_BAD_ARG; }
     DeviceEval E; E.ctx = ctx; E.tiles = tiles; E.shapes = shapes_hw; E.P = p;
+    g_ready_for_next_chain = device_ready;
     const int rc = vfsms_pairs_offsets_blind_eval(device_eval, &E, shapes_hw, n_tiles, first_pair, last_pair, per, p, out, direction_out, stats);
     if (stats) { stats[2] = E.cap_retries; stats[3] = E.sum_nq_nt; stats[4] = E.sum_nq_plus_nt; stats[5] = E.roi_px; }
     return rc;
@@ -338,6 +364,7 @@ extern "C" int vfsms_pairs_offsets(vfsms_ctx *ctx, const int64_t *tiles, const i
 {
     if (!ctx || !tiles) { vfsms_set_error("pairs_offsets: null context / tiles"); return VFSMS_ERR_BAD_ARG; }
     DeviceEval E; E.ctx = ctx; E.tiles = tiles; E.shapes = shapes_hw; E.P = p;
+    g_ready_for_next_chain = device_ready;
     const int rc = vfsms_pairs_offsets_eval(device_eval, &E, shapes_hw, n_tiles, first_pair, last_pair, direction_in, midpath, stop_on_fail, p, out,
                                             direction_out, stats);
     if (stats) { stats[2] = E.cap_retries; stats[3] = E.sum_nq_nt; stats[4] = E.sum_nq_plus_nt; stats[5] = E.roi_px; }

@@ -701,6 +701,47 @@ def _fuse_production(engine, oracle, tmp_path, tile):
         isa.Stitcher.isColorMode = old
 
 
+def test_ingest_pipeline_reserved_tiles_filled_by_a_slow_decoder(engine):
+    """The ingest pipeline (vfsms_tile_reserve / vfsms_tile_fill): the native registrar starts while a slow 'decoder' thread is still
+    handing tiles over in path order.  Its speculative batches take only what has arrived (more, smaller batches than with resident
+    tiles), the offset table is the same, and a tile whose decoder gives up fails the call instead of hanging it."""
+    import threading, time
+    g = SyntheticGrid(2, 5, 1024, overlap=0.12)
+    tiles = g.tiles(threads=4)
+    shapes = [t.shape for t in tiles]
+    params = engine.grid_params(method="surf", roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3, directIncre=1, window=48, surf=engine.surf_params())
+    res_handles = [engine.tile_upload(t) for t in tiles]
+    ref, d_ref, st_ref = engine.pairs_offsets(res_handles, shapes, params)
+    for h in res_handles:
+        engine.tile_free(h)
+    assert ref[:, 0].all()
+
+    handles = [engine.tile_reserve(*s) for s in shapes]
+    def decoder(fail_at=None):
+        for k, (h, t) in enumerate(zip(handles, tiles)):
+            time.sleep(0.02)
+            engine.tile_fill(h, None if k == fail_at else t)
+    th = threading.Thread(target=decoder); th.start()
+    try:
+        out, d_out, st = engine.pairs_offsets(handles, shapes, params)
+    finally:
+        th.join()
+        for h in handles:
+            engine.tile_free(h)
+    assert np.array_equal(out, ref) and d_out == d_ref
+    assert st[1] > st_ref[1], (st, st_ref)                      # batches followed the decoder instead of waiting for a window of tiles
+
+    handles = [engine.tile_reserve(*s) for s in shapes]
+    th = threading.Thread(target=decoder, kwargs=dict(fail_at=3)); th.start()
+    try:
+        with pytest.raises(Exception):
+            engine.pairs_offsets(handles, shapes, params)
+    finally:
+        th.join()
+        for h in handles:
+            engine.tile_free(h)
+
+
 def test_canvas_assemble_resident_equals_per_tile_calls(engine):
     """vfsms_canvas_assemble_resident (the mosaic walk as one call) == paste + one vfsms_canvas_fuse_tile_resident per tile, byte for
     byte, for both separable blends; a bad mode is refused before anything is enqueued."""
