@@ -75,7 +75,6 @@ struct RoiDev {
     uint16_t *pair;                   // h x w: pixel (y, x) in the low byte, pixel (min(y+1, h-1), x) in the high byte (k_pair_rows)
     int32_t *icarry; int ipitch;      // integral-image band carries: ceil(h/16) x ipitch column sums (ipitch = w rounded up to 4)
     float *det[VFSMS_MAX_LAYERS];
-    float *trace[VFSMS_MAX_LAYERS];
     int cap;
     int *counters;                    // [0] n candidates, [1] n kept after deletion, [2] overflow flag
     Cand *cand;

@@ -213,7 +213,7 @@ int launch_integral(vfsms_ctx *ctx, const RoiDev *d_rois, int nrois, int maxh, i
 size_t integral_carry_bytes(int h, int w) { return sizeof(int32_t) * (size_t)((h + INT_TH - 1) / INT_TH) * (size_t)((w + 3) & ~3); }
 
 // ---------------------------------------------------------------------------------------------------
-// K2 fast-Hessian det/trace, one launch per octave, blockIdx.z = roi * (nLayers+2) + layer
+// K2 fast-Hessian determinant, one launch per octave, blockIdx.z = roi * (nLayers+2) + layer
 //   calcLayerDetAndTrace: box sums are int, each multiplied by its float weight as float, accumulated
 //   in double, cast to float; det = dx*dy - 0.81f*dxy*dxy.
 // ---------------------------------------------------------------------------------------------------
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_hessian(const RoiDev *rois, const Layer
     float dy = haar_box(sp, sw, P, 3, 3);
     float dxy = haar_box(sp, sw, P, 6, 4);
     size_t o = (size_t)(i + P.margin) * lcols + (j + P.margin);
-    ((g_f32)R.det[li])[o] = dx * dy - 0.81f * dxy * dxy;     // (the trace is recomputed for the few NMS survivors: see k_nms)
+    ((g_f32)R.det[li])[o] = dx * dy - 0.81f * dxy * dxy;     // (the trace is recomputed for the candidates: cand_class_id)
 }
 
 // LDS-tiled variant for the fine octaves (0 and 1 hold 94 % of the samples): the five layers of an octave read the
@@ -815,6 +815,19 @@ extern "C" int vfsms_debug_desc_trips(unsigned long long *out) { return hipMemcp
 #ifndef DESC_WBUF
 #define DESC_WBUF 16384
 #endif                            // LDS bytes for the staged descriptor window (win <= 128) / band chunk
+// start, start + d, (start + d) + d, ... : the reference's running float sum (one rounding per step, so the chain cannot be split), four
+// links per trip -- the trip overhead (counter, compare, branch, address) was four fifths of the instructions of this single-lane loop
+__device__ __forceinline__ void origin_chain(float *row, float s, const float d, const int n)
+{
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const float a = s, b = a + d, c = b + d, e = c + d;
+        s = e + d;
+        row[i] = a; row[i + 1] = b; row[i + 2] = c; row[i + 3] = e;
+    }
+    for (; i < n; i++, s += d) row[i] = s;
+}
+
 struct WinGeom {
     int win; float sin_dir, cos_dir;
     int h, w, stride; g_cu8 img;
@@ -1117,11 +1130,9 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
             const int need = band >= 0 ? min(win, REC[band].j0 + REC[band].n) : win;
             if (threadIdx.x == 0) {
                 trig_s[0] = sin_dir; trig_s[1] = cos_dir;
-                float start_x = kp.x + win_offset * cos_dir + win_offset * sin_dir;
-                for (int i = 0; i < need; i++, start_x += sin_dir) sx_row[i] = start_x;
+                origin_chain(sx_row, kp.x + win_offset * cos_dir + win_offset * sin_dir, sin_dir, need);
             } else {
-                float start_y = kp.y - win_offset * sin_dir + win_offset * cos_dir;
-                for (int i = 0; i < need; i++, start_y += cos_dir) sy_row[i] = start_y;
+                origin_chain(sy_row, kp.y - win_offset * sin_dir + win_offset * cos_dir, cos_dir, need);
             }
         }
     } else {
@@ -1383,15 +1394,10 @@ __device__ void describe_small(const RoiDev &R, const AreaRec *area_tab, const i
         const float sin_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[0];
         const float cos_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[1];
         G.sin_dir = sin_dir; G.cos_dir = cos_dir;
-        if (lane < 2) {                                    // running float sums of the reference: lane 0 walks x, lane 1 walks y
+        if (lane < 2) {                                    // running float sums of the reference: lane 0 walks x, lane 1 walks y, in ONE loop
             const float win_offset = -(float)(win - 1) / 2;
-            if (lane == 0) {
-                float start_x = kp.x + win_offset * cos_dir + win_offset * sin_dir;
-                for (int i = 0; i < win; i++, start_x += sin_dir) L.sx[i] = start_x;
-            } else {
-                float start_y = kp.y - win_offset * sin_dir + win_offset * cos_dir;
-                for (int i = 0; i < win; i++, start_y += cos_dir) L.sy[i] = start_y;
-            }
+            const float sx0 = kp.x + win_offset * cos_dir + win_offset * sin_dir, sy0 = kp.y - win_offset * sin_dir + win_offset * cos_dir;
+            origin_chain(lane == 0 ? L.sx : L.sy, lane == 0 ? sx0 : sy0, lane == 0 ? sin_dir : cos_dir, win);
         }
     } else {
         const float win_offset = -(float)(win - 1) / 2;
@@ -1596,8 +1602,13 @@ __global__ __launch_bounds__(256) void k_desc_tail(const RoiDev *rois, const Sur
                     v[0] += tx; v[1] += ty; v[2] += fabsf(tx); v[3] += fabsf(ty);
                 }
             }
-        const int per = extended ? 8 : 4;
-        for (int q = 0; q < per; q++) vec[kk][c * per + q] = v[q];
+        if (extended) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) vec[kk][c * 8 + q] = v[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) vec[kk][c * 4 + q] = v[q];
+        }
     }
     __syncthreads();
     if (pos >= 0 && c == 0) {
@@ -1670,7 +1681,7 @@ int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_roi
     if (nrois <= 0) return VFSMS_OK;
     const int lpo = p->n_octave_layers + 2;
     int maxh = 0, maxw = 0, maxcap = 0;
-    // (the caller zeroes the ROI counters; det/trace layers need no clearing: the non-maximum search only ever reads cells
+    // (the caller zeroes the ROI counters; det layers need no clearing: the non-maximum search only ever reads cells
     //  that k_hessian wrote -- its margins are those of the layer above -- so the 53 B/px layer memset is gone)
     for (int r = 0; r < nrois; r++) {
         maxh = h_rois[r].h > maxh ? h_rois[r].h : maxh;
