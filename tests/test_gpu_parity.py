@@ -701,6 +701,27 @@ def _fuse_production(engine, oracle, tmp_path, tile):
         isa.Stitcher.isColorMode = old
 
 
+def test_zirconcl_surf_attempts_equal_the_oracle(engine, oracle, golden_dir):
+    """The fused SURF attempts on the 23 real zirconCL strip pairs (1024 x 256, BASELINE configs[3]'s tiles): every row -- status,
+    offset, votes, keypoint and match counts -- equals the oracle chain, whose offsets tests/test_oracle_golden.py pins against phase
+    correlation and NCC."""
+    from test_oracle_golden import zirconcl_surf_rows
+    want = zirconcl_surf_rows(oracle, golden_dir)
+    hs = []
+    try:
+        jobs = []
+        for A, B, _r in want:
+            ha, hb = engine.tile_upload(A), engine.tile_upload(B)
+            hs += [ha, hb]
+            jobs.append((ha, hb, 0, 0, 0, 0, A.shape[0], A.shape[1]))
+        rows = engine.attempt_surf_batch(jobs, None, 0.75, 3)
+        for k, (_A, _B, r) in enumerate(want):
+            assert list(rows[k][:7]) == r, (k, list(rows[k][:7]), r)
+    finally:
+        for h in hs:
+            engine.tile_free(h)
+
+
 def test_ingest_pipeline_reserved_tiles_filled_by_a_slow_decoder(engine):
     """The ingest pipeline (vfsms_tile_reserve / vfsms_tile_fill): the native registrar starts while a slow 'decoder' thread is still
     handing tiles over in path order.  Its speculative batches take only what has arrived (more, smaller batches than with resident

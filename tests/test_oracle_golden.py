@@ -394,3 +394,52 @@ def test_orb_real_path_strips_reproduced_by_oracle(oracle, golden_dir):
         st, off, d, i, log = _chain_search(oracle_orb_attempt(oracle, frames[k], frames[k + 1]), frames[k].shape, frames[k + 1].shape, direction)
         assert [st, off, d, i, log[-1][5]] == [True, e["offset"], e["direction"], e["i"], e["votes"]], (k, off, e)
         direction = d
+
+
+def _ncc(a, b):
+    a = a.astype(np.float64) - a.mean(); b = b.astype(np.float64) - b.mean()
+    d = np.sqrt((a * a).sum() * (b * b).sum())
+    return float((a * b).sum() / d) if d > 0 else 0.0
+
+
+def _overlap_ncc(A, B, dx, dy):
+    """normalised cross-correlation of the pixels two equal-size strips share when B's (y, x) lies on A's (y + dx, x + dy)
+    (the vote is ptA - ptB, ImageUtility.py:150-152)"""
+    h, w = A.shape
+    y0, y1, x0, x1 = max(0, dx), min(h, h + dx), max(0, dy), min(w, w + dy)
+    if y1 - y0 < 8 or x1 - x0 < 8:
+        return -2.0
+    return _ncc(A[y0:y1, x0:x1], B[y0 - dx:y1 - dx, x0 - dy:x1 - dy])
+
+
+def zirconcl_surf_rows(oracle, golden_dir):
+    """oracle SURF + BF-L2 + ratio + mode vote on the direction-4 ROI strips of the 23 zirconCL pairs (tests/golden/zirconcl_strips.npz)"""
+    z = np.load(os.path.join(golden_dir, "zirconcl_strips.npz"))
+    out = []
+    for k in range(23):
+        A, B = z["t%d_first" % k], z["t%d_second" % (k + 1)]
+        ka, da = oracle.surf_detect_describe(A); kb, db = oracle.surf_detect_describe(B)
+        pairs = oracle.bf_l2_ratio_matches(da, db, 0.75)
+        st, off, votes = oracle.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, 3)
+        out.append((A, B, [int(st), int(off[0]), int(off[1]), int(votes), len(ka), len(kb), len(pairs)]))
+    return out
+
+
+def test_surf_oracle_against_phase_and_ncc_on_zirconcl(oracle, golden_dir):
+    """A pin of the SURF leg that owes nothing to the SURF code: on the 23 real zirconCL pairs (BASELINE configs[3]'s tiles) the oracle's
+    SURF + BF + mode offset must (a) agree within 1.5 px with the sub-pixel phase-correlation peak of the same strips -- an unrelated algorithm,
+    itself pinned by the independent numpy restatement (phase_independent.json) -- up to the two things that are properties of the phase
+    path: the reference-as-written sign (mirrored) and the period of the 256-column strip; and (b) be, within 1 px, the
+    maximum of the normalised cross-correlation of the overlapping pixels, with a correlation above 0.93 there."""
+    rows = json.load(open(os.path.join(golden_dir, "phase_independent.json")))["rows"]
+    got = zirconcl_surf_rows(oracle, golden_dir)
+    for k, (A, B, r) in enumerate(got):
+        assert r[0] == 1 and r[3] >= 12, (k, r)
+        dx, dy = r[1], r[2]
+        py, px = rows[k]["numpy_xy"]                              # sub-pixel peak (x = columns, y = rows); Stitcher.py:244-251 truncates it
+        assert abs(dx + px) <= 1.5, (k, dx, px)
+        wrapped = (dy + py + 128) % 256 - 128                     # dy + py == 0 modulo the strip width
+        assert abs(wrapped) <= 1.5, (k, dy, py)
+        c = {(u, v): _overlap_ncc(A, B, dx + u, dy + v) for u in (-2, -1, 0, 1, 2) for v in (-2, -1, 0, 1, 2)}
+        best = max(c, key=c.get)
+        assert c[(0, 0)] > 0.93 and max(abs(best[0]), abs(best[1])) <= 1, (k, c[(0, 0)], best)
