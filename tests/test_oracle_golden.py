@@ -443,3 +443,28 @@ def test_surf_oracle_against_phase_and_ncc_on_zirconcl(oracle, golden_dir):
         c = {(u, v): _overlap_ncc(A, B, dx + u, dy + v) for u in (-2, -1, 0, 1, 2) for v in (-2, -1, 0, 1, 2)}
         best = max(c, key=c.get)
         assert c[(0, 0)] > 0.93 and max(abs(best[0]), abs(best[1])) <= 1, (k, c[(0, 0)], best)
+
+
+def test_orb_oracle_against_surf_and_ncc_on_zirconcl(oracle, golden_dir):
+    """The ORB leg on the same 23 real pairs: every decision carried by MORE than three votes lies within 2 px of the SURF offset (a
+    different detector, descriptor and matcher) and of the NCC maximum, at a correlation above 0.93; the two decisions that rest on
+    exactly three votes (pairs 8 and 20) are the reference's own false accepts at offsetEvaluate = 3 (no overlap at all: NCC ~ 0) --
+    the same behaviour as on Stitcher.py:87's path (test_orb_whole_path_against_reference_vector)."""
+    z = np.load(os.path.join(golden_dir, "zirconcl_strips.npz"))
+    surf = zirconcl_surf_rows(oracle, golden_dir)
+    three_vote = []
+    for k in range(23):
+        A, B = z["t%d_first" % k], z["t%d_second" % (k + 1)]
+        ka, da = oracle.orb_detect_describe(A); kb, db = oracle.orb_detect_describe(B)
+        pairs, _ = oracle.bf_hamming_matches(da, db)
+        st, off, votes = oracle.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, 3)
+        assert st and votes >= 3, k
+        if votes == 3:
+            three_vote.append(k)
+            assert _overlap_ncc(A, B, off[0], off[1]) < 0.2, (k, off)
+            continue
+        s = surf[k][2]
+        assert abs(off[0] - s[1]) <= 2 and abs(off[1] - s[2]) <= 2, (k, off, s)
+        c = {(u, v): _overlap_ncc(A, B, off[0] + u, off[1] + v) for u in range(-2, 3) for v in range(-2, 3)}
+        assert max(c.values()) > 0.93 and c[(0, 0)] > 0.9, (k, c[(0, 0)])
+    assert three_vote == [8, 20], three_vote
