@@ -443,6 +443,17 @@ def test_surf_oracle_against_phase_and_ncc_on_zirconcl(oracle, golden_dir):
         c = {(u, v): _overlap_ncc(A, B, dx + u, dy + v) for u in (-2, -1, 0, 1, 2) for v in (-2, -1, 0, 1, 2)}
         best = max(c, key=c.get)
         assert c[(0, 0)] > 0.93 and max(abs(best[0]), abs(best[1])) <= 1, (k, c[(0, 0)], best)
+    # configs[0]'s pair (iron, 387 x 2584 strips, direction 1): 626 votes for [150, 0]; the phase peak, mirrored, says (149.9, -0.5)
+    iron = np.load(os.path.join(golden_dir, "demo_strips.npz"))
+    A, B = iron["d0_roiA"], iron["d0_roiB"]
+    ka, da = oracle.surf_detect_describe(A); kb, db = oracle.surf_detect_describe(B)
+    st, off, votes = oracle.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), oracle.bf_l2_ratio_matches(da, db, 0.75), 3)
+    px, py = rows[-1]["numpy_xy"]
+    assert rows[-1]["dataset"] == "iron" and st and off == [150, 0] and votes > 500
+    assert abs(off[0] + py) <= 1.5 and abs(off[1] + px) <= 1.5, (off, px, py)
+    c = {(u, v): _overlap_ncc(A, B, off[0] + u, off[1] + v) for u in (-2, -1, 0, 1, 2) for v in (-2, -1, 0, 1, 2)}
+    best = max(c, key=c.get)
+    assert c[(0, 0)] > 0.9 and max(abs(best[0]), abs(best[1])) <= 1, (c[(0, 0)], best)
 
 
 def test_orb_oracle_against_surf_and_ncc_on_zirconcl(oracle, golden_dir):
