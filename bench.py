@@ -368,7 +368,7 @@ def bench_from_files(args, eng, grid, torch):
             from imagestitch_amd.grid import GridRegistrar
             hs = [eng.tile_upload(ST._imread(f, False)) for f in files]
             reg = GridRegistrar(eng, method="surf", roiRatio=0.2, searchRatio=0.75, offsetEvaluate=args.offset_evaluate, directIncre=1,
-                                surfParams=eng.surf_params(), window=24)
+                                surfParams=eng.surf_params(), window=48)
             shapes = [(grid.th, grid.tw)] * grid.n_tiles
             reg.register(hs, shapes, 1)
             eng.sync(); t0 = time.perf_counter()
