@@ -740,7 +740,7 @@ def test_ingest_pipeline_reserved_tiles_filled_by_a_slow_decoder(engine):
     handles = [engine.tile_reserve(*s) for s in shapes]
     def decoder(fail_at=None):
         for k, (h, t) in enumerate(zip(handles, tiles)):
-            time.sleep(0.02)
+            time.sleep(0.05)                                   # several batch times: every batch sees at most the tiles decoded since the last one
             engine.tile_fill(h, None if k == fail_at else t)
     th = threading.Thread(target=decoder); th.start()
     try:
