@@ -325,11 +325,15 @@ def bench_from_files(args, eng, grid, torch):
     from imagestitch_amd import stitcher as ST
     if args.gpus != 1 or args.method != "surf":
         raise SystemExit("--from-files is a single-GPU SURF measurement")
-    nthreads = max(1, min(args.decode_threads or min(os.cpu_count() or 4, 16), grid.n_tiles, 64))
+    nthreads = max(1, min(args.decode_threads or min(os.cpu_count() or 4, 32), grid.n_tiles, 64))
+    color = bool(args.color)
     with tempfile.TemporaryDirectory(prefix="vfsms_bench_") as d:
         files = []
         for k, t in enumerate(grid.tiles(range(grid.n_tiles), threads=min(8, os.cpu_count() or 1))):
             f = os.path.join(d, "tile_%03d.jpg" % k)
+            if color:                                         # a tinted colour version: Cb / Cr planes that are not flat (4:2:0 like camera JPEGs)
+                ft = t.astype(np.float32)
+                t = np.clip(np.stack([0.6 * ft + 30, ft, 255 - 0.7 * ft], -1), 0, 255).astype(np.uint8)
             Image.fromarray(t).save(f, quality=90)
             files.append(f)
         mb = sum(os.path.getsize(f) for f in files) / 1e6
@@ -337,13 +341,18 @@ def bench_from_files(args, eng, grid, torch):
         old = (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate,
                isa.Stitcher.isColorMode, isa.Stitcher.fuseMethod)
         isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate = 1, 0.2, "surf", args.offset_evaluate
-        isa.Stitcher.isColorMode, isa.Stitcher.fuseMethod = True, "notFuse"      # (colour mosaics: the registration tiles are not kept for the canvas)
+        # --color: Main.py:14's default -- ONE decode per file gives the registration plane and the mosaic's B G R tile (vfsms_tile_fill_pair);
+        # the colour tiles stay resident for getStitchByOffset and are released here after every step.  Without it: gray tiles only.
+        isa.Stitcher.isColorMode, isa.Stitcher.fuseMethod = color, "notFuse"
         s.decodeThreads = nthreads
         truth = grid.true_offsets()
 
         def e2e():
             s.direction = 1
-            return s._registerBatched(files, s.calculateOffsetForFeatureSearchIncre)
+            out = s._registerBatched(files, s.calculateOffsetForFeatureSearchIncre)
+            for h, _shape in (s.__dict__.pop("_resident", None) or {}).values():
+                eng.tile_free(h)
+            return out
         try:
             status, end, offs, _desc = e2e()
             assert status and end == grid.n_pairs, (status, end)
@@ -359,10 +368,10 @@ def bench_from_files(args, eng, grid, torch):
             # decode only, same pool size
             with ThreadPoolExecutor(max_workers=nthreads) as ex:
                 t0 = time.perf_counter()
-                list(ex.map(lambda f: ST._imread_gray_pointer(f)[2], files))
+                list(ex.map(lambda f: ST._decode_once(f, color)[1], files))
                 dt_dec = time.perf_counter() - t0
             t0 = time.perf_counter()
-            ST._imread(files[0], False)
+            ST._decode_once(files[0], color)
             dt_one = time.perf_counter() - t0
             # registration only (tiles resident)
             from imagestitch_amd.grid import GridRegistrar
@@ -383,12 +392,14 @@ def bench_from_files(args, eng, grid, torch):
              isa.Stitcher.isColorMode, isa.Stitcher.fuseMethod) = old
     P = grid.n_pairs
     slower = max(dt_dec, dt_reg)
-    _jsonline({"metric": "image-pairs/sec, decode inclusive (2048x2048 grayscale JPEG files, SURF+BF)", "value": round(P / dt, 3), "unit": "image-pairs/s",
+    _jsonline({"metric": "image-pairs/sec, decode inclusive (2048x2048 %s JPEG files, SURF+BF)" % ("colour" if color else "grayscale"), "value": round(P / dt, 3), "unit": "image-pairs/s",
                "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic (JPEG quality 90 on local disk, %.0f MB for %d tiles)" % (mb, grid.n_tiles),
-               "config": {"workload": "synthetic %dx%d grid of %dx%d tiles as JPEG files -> Stitcher ingest pipeline (vfsms_tile_reserve / vfsms_tile_fill, "
-                                      "%d decoder threads) -> native registrar; SURF+BF-L2+mode as the default workload" % (args.rows, args.cols, args.tile, args.tile, nthreads),
-                          "pairs": P, "decode_threads": nthreads, "host_cores": os.cpu_count()},
+               "config": {"workload": "synthetic %dx%d grid of %dx%d tiles as %s JPEG files -> Stitcher ingest pipeline (vfsms_tile_reserve / %s, "
+                                      "%d decoder threads, one decode per file) -> native registrar; SURF+BF-L2+mode as the default workload"
+                                      % (args.rows, args.cols, args.tile, args.tile, "colour (isColorMode = True: gray plane + resident B G R tile from the same decode)" if color else "grayscale",
+                                         "vfsms_tile_fill_pair" if color else "vfsms_tile_fill", nthreads),
+                          "pairs": P, "decode_threads": nthreads, "host_cores": os.cpu_count(), "color": color},
                "max_abs_offset_error_px": int(worst),
                "decode_only_ms_per_step": round(dt_dec * 1e3, 2), "decode_only_tiles_per_s": round(grid.n_tiles / dt_dec, 1),
                "decode_one_tile_one_thread_ms": round(dt_one * 1e3, 2),
@@ -459,7 +470,8 @@ def main():
     ap.add_argument("--workload", default="grid", choices=["grid", "dendritic25"],
                     help="grid = the synthetic serpentine grid (BASELINE metric); dendritic25 = the 25 committed real pairs (N = 1, surf)")
     ap.add_argument("--from-files", action="store_true", help="N = 1: JPEG tiles on disk through Stitcher's ingest pipeline (decode inclusive)")
-    ap.add_argument("--decode-threads", type=int, default=0, help="decoder threads of --from-files (0 = one per host core, at most 64)")
+    ap.add_argument("--decode-threads", type=int, default=0, help="decoder threads of --from-files (0 = one per host core, at most 32)")
+    ap.add_argument("--color", action="store_true", help="--from-files with colour JPEGs and isColorMode = True (Main.py:14's default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -70,6 +70,9 @@ _SIGNATURES = {
     "vfsms_tile_upload_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "vfsms_tile_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "vfsms_tile_fill": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
+    "vfsms_tile_reserve_ch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "vfsms_tile_fill_pair": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int]),
+    "vfsms_canvas_blend_tile_resident": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vfsms_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vfsms_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vfsms_tile_wrap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
@@ -246,13 +249,27 @@ class Engine:
         self._check(self.lib.vfsms_tile_reserve(self.ctx, int(h), int(w), C.byref(hd)))
         return hd.value
 
+    def tile_reserve_color(self, h, w, ch=3):
+        """tile_reserve for an interleaved tile of `ch` channels (the mosaic's colour tiles)"""
+        hd = C.c_int64()
+        self._check(self.lib.vfsms_tile_reserve_ch(self.ctx, int(h), int(w), int(ch), C.byref(hd)))
+        return hd.value
+
     def tile_fill(self, handle, img):
-        """deliver (img: u8 2-D array, C-contiguous rows) or give up on (img is None) a reserved tile; safe from any thread"""
+        """deliver (img: u8 (h, w) or (h, w, ch) array, C-contiguous rows) or give up on (img is None) a reserved tile; safe from any thread"""
         if img is None:
             self._check(self.lib.vfsms_tile_fill(self.ctx, C.c_int64(handle), None, 0))
             return
-        assert img.dtype == np.uint8 and img.ndim == 2 and img.strides[1] == 1
+        assert img.dtype == np.uint8 and img.ndim in (2, 3) and img.strides[-1] == 1 and (img.ndim == 2 or img.strides[1] == img.shape[2])
         self._check(self.lib.vfsms_tile_fill(self.ctx, C.c_int64(handle), _ptr(img), img.strides[0]))
+
+    SRC_GRAY8, SRC_YCC24, SRC_YCCX32 = 0, 1, 2
+
+    def tile_fill_pair(self, gray_handle, color_handle, address, stride_bytes, fmt):
+        """One decoded image -> the reserved gray tile and / or the reserved BGR tile (vfsms_tile_fill_pair; either handle may be 0 / None);
+        `address`: raw host address of the decoder's output in format `fmt` (SRC_*), None gives both tiles up.  Safe from any thread."""
+        self._check(self.lib.vfsms_tile_fill_pair(self.ctx, C.c_int64(gray_handle or 0), C.c_int64(color_handle or 0),
+                                                  C.c_void_p(address) if address is not None else None, int(stride_bytes), int(fmt)))
 
     def tile_fill_ptr(self, handle, address, stride):
         """tile_fill from a raw host address (rows `stride` bytes apart); the caller keeps the memory alive until this returns"""
@@ -609,6 +626,12 @@ class Engine:
         self._check(self.lib.vfsms_canvas_blend_tile(self.ctx, C.c_int64(handle), _ptr(tile), tile.shape[0], tile.shape[1],
                                                      int(y0), int(x0), ry0, rx0, ry1, rx1, int(mode)))
 
+    def canvas_blend_tile_resident(self, handle, tile_handle, y0, x0, roi, mode):
+        """canvas_blend_tile with a tile that is already resident; enqueue only"""
+        ry0, rx0, ry1, rx1 = [int(v) for v in roi]
+        self._check(self.lib.vfsms_canvas_blend_tile_resident(self.ctx, C.c_int64(handle), C.c_int64(tile_handle), int(y0), int(x0),
+                                                              ry0, rx0, ry1, rx1, int(mode)))
+
     def canvas_paste_tile(self, handle, tile_handle, y0, x0):
         """paste of a single-channel tile that is already resident in HBM (tile_upload handle)."""
         self._check(self.lib.vfsms_canvas_paste_tile(self.ctx, C.c_int64(handle), C.c_int64(tile_handle), int(y0), int(x0)))
@@ -623,7 +646,7 @@ class Engine:
 
     def canvas_assemble_resident(self, handle, tile_handles, geom):
         """The mosaic walk over resident tiles as one call.  geom: int32 [n][9] = y0, x0, ry0, rx0, ry1, rx1, dx, dy, mode
-        (mode -1 paste, 0 fadeInAndFadeOut, 1 trigonometric); enqueue only, geometry errors surface in canvas_download."""
+        (mode -1 paste, 0 fadeInAndFadeOut, 1 trigonometric, 2 / 3 / 4 average / maximum / minimum); enqueue only, geometry errors surface in canvas_download."""
         th = np.ascontiguousarray(tile_handles, np.int64)
         g = np.ascontiguousarray(geom, np.int32).reshape(-1, 9)
         if len(th) != len(g):

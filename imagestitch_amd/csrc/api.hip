@@ -235,6 +235,7 @@ extern "C" int vfsms_ctx_destroy(vfsms_ctx *ctx)
     hipStreamSynchronize(ctx->copy_stream);
     for (auto &kv : ctx->tiles) { if (kv.second.owned) hipFree(kv.second.ptr); if (kv.second.ready) hipEventDestroy(kv.second.ready); }
     for (auto &pe : ctx->tile_pool) { hipFree(pe.ptr); if (pe.idle) hipEventDestroy(pe.idle); }
+    for (auto &sb : ctx->stage_pool) hipFree(sb.ptr);
     for (hipEvent_t ev : ctx->event_pool) hipEventDestroy(ev);
     hipStreamDestroy(ctx->copy_stream);
     for (auto &kv : ctx->canvases) { hipFree(kv.second.pix); hipFree(kv.second.mask); hipFree(kv.second.d_err); hipFree(kv.second.scratch); }
@@ -328,8 +329,11 @@ static int tile_upload_impl(vfsms_ctx *ctx, const uint8_t *img, int h, int w_px,
 // make the compute stream wait for a tile's asynchronous upload (once)
 static int tile_ready(vfsms_ctx *ctx, TileRec &t)
 {
+    // `fill` and `pending` are written by decoder threads (vfsms_tile_fill*): read them under the same mutex.  Everything else in a
+    // TileRec, the tile map's structure, the buffer / event pools and the arena belong to the context's own thread (reserve, upload,
+    // free and every batch call must come from it).
+    std::unique_lock<std::mutex> lk(ctx->tiles_mu);
     if (t.fill) {                                            // reserved: block until its decoder thread has handed the pixels over
-        std::unique_lock<std::mutex> lk(ctx->tiles_mu);
         ctx->tiles_cv.wait(lk, [&] { return t.fill != 1; });
         if (t.fill == 2) { vfsms_set_error("a reserved tile was never filled (its decoder reported a failure)"); return VFSMS_ERR_BAD_ARG; }
     }
@@ -361,22 +365,38 @@ extern "C" int vfsms_tile_upload_ch(vfsms_ctx *ctx, const uint8_t *img, int h, i
 }
 // ---- tiles whose pixels arrive later, from other threads: the ingest pipeline (Stitcher.py:68-69 decodes file after file BEFORE the
 // first pair is registered; here the registration of tiles 0, 1, ... starts while tile k is still being decoded) -------------------------
-extern "C" int vfsms_tile_reserve(vfsms_ctx *ctx, int h, int w, int64_t *handle)
+static int tile_reserve_impl(vfsms_ctx *ctx, int h, int w, int ch, int64_t *handle)
 {
-    CTX_ENTER(ctx);
-    if (!handle || h <= 0 || w <= 0) { vfsms_set_error("tile_reserve: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    if (!handle || h <= 0 || w <= 0 || ch < 1 || ch > 4) { vfsms_set_error("tile_reserve: bad arguments"); return VFSMS_ERR_BAD_ARG; }
     std::lock_guard<std::mutex> lk(ctx->tiles_mu);
-    TileRec t; t.h = h; t.w = w; t.stride = w; t.owned = true; t.ready = nullptr; t.pending = false; t.ch = 1; t.bytes = (size_t)h * w; t.fill = 1;
+    TileRec t; t.h = h; t.w = w; t.stride = w * ch; t.owned = true; t.ready = nullptr; t.pending = false; t.ch = ch; t.bytes = (size_t)h * w * ch; t.fill = 1;
     TRY(tile_buffer(ctx, t.bytes, &t.ptr, ctx->copy_stream));
     if (!ctx->event_pool.empty()) { t.ready = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
-    else HIP_TRY(hipEventCreateWithFlags(&t.ready, hipEventDisableTiming));
+    else {
+        hipError_t e = hipEventCreateWithFlags(&t.ready, hipEventDisableTiming);
+        if (e != hipSuccess) {                               // the buffer goes back to the pool instead of leaking
+            PoolEnt pe; pe.bytes = t.bytes; pe.ptr = t.ptr; pe.idle = nullptr;
+            ctx->tile_pool.push_back(pe); ctx->tile_pool_bytes += pe.bytes;
+            vfsms_set_error("tile_reserve: %s", hipGetErrorString(e)); return VFSMS_ERR_HIP;
+        }
+    }
     *handle = ctx->next_handle++;
     ctx->tiles[*handle] = t;
     return VFSMS_OK;
 }
+extern "C" int vfsms_tile_reserve(vfsms_ctx *ctx, int h, int w, int64_t *handle)
+{
+    CTX_ENTER(ctx);
+    return tile_reserve_impl(ctx, h, w, 1, handle);
+}
+extern "C" int vfsms_tile_reserve_ch(vfsms_ctx *ctx, int h, int w, int ch, int64_t *handle)
+{
+    CTX_ENTER(ctx);
+    return tile_reserve_impl(ctx, h, w, ch, handle);
+}
 // May be called from ANY thread, concurrently with batch calls on the context's own thread: copies the pixels on the copy stream and returns
 // when the copy has completed, so `img` (a decoder thread's staging buffer) can be reused at once.  img == NULL reports a failed decode:
-// the batch call waiting for the tile returns an error instead of waiting forever.
+// the batch call waiting for the tile returns an error instead of waiting forever.  `stride` in bytes; a row is w * ch bytes.
 extern "C" int vfsms_tile_fill(vfsms_ctx *ctx, int64_t handle, const uint8_t *img, int stride)
 {
     CTX_ENTER(ctx);
@@ -386,8 +406,8 @@ extern "C" int vfsms_tile_fill(vfsms_ctx *ctx, int64_t handle, const uint8_t *im
         auto it = ctx->tiles.find(handle);
         if (it == ctx->tiles.end() || it->second.fill != 1) { vfsms_set_error("tile_fill: not a reserved tile"); return VFSMS_ERR_BAD_ARG; }
         if (!img) { it->second.fill = 2; ctx->tiles_cv.notify_all(); return VFSMS_OK; }
-        if (stride < it->second.w) { vfsms_set_error("tile_fill: stride smaller than the tile width"); return VFSMS_ERR_BAD_ARG; }
-        ev = it->second.ready; dst = it->second.ptr; h = it->second.h; w = it->second.w;
+        if (stride < it->second.w * it->second.ch) { vfsms_set_error("tile_fill: stride smaller than a row of the tile"); return VFSMS_ERR_BAD_ARG; }
+        ev = it->second.ready; dst = it->second.ptr; h = it->second.h; w = it->second.w * it->second.ch;
     }
     hipError_t e = hipMemcpy2DAsync(dst, w, img, stride, w, h, hipMemcpyHostToDevice, ctx->copy_stream);
     if (e == hipSuccess) e = hipEventRecord(ev, ctx->copy_stream);
@@ -400,6 +420,65 @@ extern "C" int vfsms_tile_fill(vfsms_ctx *ctx, int64_t handle, const uint8_t *im
     }
     if (e != hipSuccess) { vfsms_set_error("tile_fill: %s", hipGetErrorString(e)); return VFSMS_ERR_HIP; }
     return VFSMS_OK;
+}
+// One decode, both planes (csrc/ingest_kernels.hip): `src` is what the decoder produced ONCE -- format 0: 8-bit gray, 1: Y Cb Cr interleaved,
+// 2: Y Cb Cr X (4 bytes per pixel) -- and fills the reserved gray tile `gray` (the registration plane, cv2.imdecode(..., 0) of Stitcher.py:68-69)
+// and / or the reserved 3-channel tile `color` (B G R, cv2.imdecode(..., IMREAD_COLOR) of Stitcher.py:382-403); either handle may be 0.
+// The source rows go to a device staging buffer on the copy stream, the split / colour conversion runs there too, and the call returns when
+// both tiles are complete.  Any thread.  src == NULL gives both tiles up.
+int ingest_source_pixel_bytes(int format);
+int launch_ingest_split(hipStream_t stream, const uint8_t *src, uint8_t *gray, uint8_t *bgr, long long n, int format);
+extern "C" int vfsms_tile_fill_pair(vfsms_ctx *ctx, int64_t gray, int64_t color, const uint8_t *src, int stride_bytes, int format)
+{
+    CTX_ENTER(ctx);
+    hipEvent_t ev = nullptr; uint8_t *dg = nullptr, *dc = nullptr; int h = 0, w = 0;
+    const int spx = ingest_source_pixel_bytes(format);
+    {
+        std::lock_guard<std::mutex> lk(ctx->tiles_mu);
+        TileRec *tg = nullptr, *tc = nullptr;
+        if (gray) { auto it = ctx->tiles.find(gray); if (it != ctx->tiles.end() && it->second.fill == 1 && it->second.ch == 1) tg = &it->second; }
+        if (color) { auto it = ctx->tiles.find(color); if (it != ctx->tiles.end() && it->second.fill == 1 && it->second.ch == 3) tc = &it->second; }
+        if ((gray && !tg) || (color && !tc) || (!tg && !tc)) {
+            vfsms_set_error("tile_fill_pair: needs a reserved 1-channel tile and / or a reserved 3-channel tile"); return VFSMS_ERR_BAD_ARG;
+        }
+        if (!src) { if (tg) tg->fill = 2; if (tc) tc->fill = 2; ctx->tiles_cv.notify_all(); return VFSMS_OK; }
+        if (tg && tc && (tg->h != tc->h || tg->w != tc->w)) { vfsms_set_error("tile_fill_pair: the two tiles differ in size"); return VFSMS_ERR_BAD_ARG; }
+        h = tg ? tg->h : tc->h; w = tg ? tg->w : tc->w;
+        if (!spx || stride_bytes < w * spx) { vfsms_set_error("tile_fill_pair: unknown format or stride smaller than a source row"); return VFSMS_ERR_BAD_ARG; }
+        ev = tg ? tg->ready : tc->ready; dg = tg ? tg->ptr : nullptr; dc = tc ? tc->ptr : nullptr;
+    }
+    // staging buffer for the packed source rows: a small pool of its own (the tile pool belongs to the context thread)
+    const size_t need = (size_t)h * w * spx;
+    StageBuf sb{nullptr, 0};
+    {
+        std::lock_guard<std::mutex> lk(ctx->stage_mu);
+        for (size_t k = 0; k < ctx->stage_pool.size(); k++)
+            if (ctx->stage_pool[k].bytes >= need) { sb = ctx->stage_pool[k]; ctx->stage_pool.erase(ctx->stage_pool.begin() + k); break; }
+    }
+    hipError_t e = hipSuccess;
+    if (!sb.ptr) { e = hipMalloc((void **)&sb.ptr, need); sb.bytes = need; }
+    int rc = VFSMS_OK;
+    if (e == hipSuccess) e = hipMemcpy2DAsync(sb.ptr, (size_t)w * spx, src, stride_bytes, (size_t)w * spx, h, hipMemcpyHostToDevice, ctx->copy_stream);
+    if (e == hipSuccess) rc = launch_ingest_split(ctx->copy_stream, sb.ptr, dg, dc, (long long)h * w, format);
+    if (e == hipSuccess && rc == VFSMS_OK) e = hipEventRecord(ev, ctx->copy_stream);
+    if (e == hipSuccess && rc == VFSMS_OK) e = hipEventSynchronize(ev);
+    if (sb.ptr) {
+        if (e != hipSuccess) hipStreamSynchronize(ctx->copy_stream);          // nothing may still read the staging buffer when it is reused
+        std::lock_guard<std::mutex> lk(ctx->stage_mu);
+        if (ctx->stage_pool.size() < 64) ctx->stage_pool.push_back(sb); else hipFree(sb.ptr);
+    }
+    const bool ok = e == hipSuccess && rc == VFSMS_OK;
+    {
+        std::lock_guard<std::mutex> lk(ctx->tiles_mu);
+        for (int64_t hd : { gray, color }) {
+            if (!hd) continue;
+            auto it = ctx->tiles.find(hd);
+            if (it != ctx->tiles.end()) { it->second.fill = ok ? 0 : 2; it->second.pending = false; }
+        }
+        ctx->tiles_cv.notify_all();
+    }
+    if (e != hipSuccess) { vfsms_set_error("tile_fill_pair: %s", hipGetErrorString(e)); return VFSMS_ERR_HIP; }
+    return rc;
 }
 
 extern "C" int vfsms_host_alloc(vfsms_ctx *ctx, size_t bytes, void **ptr)
@@ -432,7 +511,10 @@ extern "C" int vfsms_tile_free(vfsms_ctx *ctx, int64_t handle)
     CTX_ENTER(ctx);
     auto it = ctx->tiles.find(handle);
     if (it == ctx->tiles.end()) { vfsms_set_error("tile_free: unknown handle"); return VFSMS_ERR_BAD_ARG; }
-    if (it->second.fill == 1) { vfsms_set_error("tile_free: the tile is reserved and its decoder has not filled it yet"); return VFSMS_ERR_BAD_ARG; }
+    {
+        std::lock_guard<std::mutex> lk(ctx->tiles_mu);       // (fill is written by decoder threads)
+        if (it->second.fill == 1) { vfsms_set_error("tile_free: the tile is reserved and its decoder has not filled it yet"); return VFSMS_ERR_BAD_ARG; }
+    }
     // an upload may still be in flight; compute work on the tile may only be ENQUEUED (canvas paste / resident fuse return early)
     if (it->second.pending) HIP_TRY(hipEventSynchronize(it->second.ready));
     if (it->second.ready) ctx->event_pool.push_back(it->second.ready);
@@ -1383,13 +1465,28 @@ extern "C" int vfsms_canvas_fuse_tile_resident_m(vfsms_ctx *ctx, int64_t canvas,
     if (info) HIP_TRY(hipStreamSynchronize(ctx->stream));   // without a readback the call only enqueues (stream order keeps the canvas consistent)
     return VFSMS_OK;
 }
+// fuseMethod "average" / "maximum" / "minimum" (mode 0 / 1 / 2) with a resident tile; enqueue only
+extern "C" int vfsms_canvas_blend_tile_resident(vfsms_ctx *ctx, int64_t canvas, int64_t tile,
+                                                int y0, int x0, int ry0, int rx0, int ry1, int rx1, int mode)
+{
+    CTX_ENTER(ctx);
+    if (mode < 0 || mode > 2) { vfsms_set_error("canvas_blend_tile: mode must be 0 (average), 1 (maximum) or 2 (minimum)"); return VFSMS_ERR_BAD_ARG; }
+    CanvasRec *cv; TileRec *tr;
+    TRY(canvas_resident_args(ctx, canvas, tile, y0, x0, &cv, &tr));
+    if (ry1 > ry0 && rx1 > rx0 && (ry0 < y0 || rx0 < x0 || ry1 > y0 + tr->h || rx1 > x0 + tr->w)) {
+        vfsms_set_error("canvas_blend_tile: fuse ROI must lie inside the tile rectangle"); return VFSMS_ERR_BAD_ARG;
+    }
+    TRY(canvas_blend_device(ctx, cv, tr->ptr, tr->h, tr->w, y0, x0, ry0, rx0, ry1, rx1, mode));
+    return VFSMS_OK;
+}
 extern "C" int vfsms_canvas_fuse_tile_resident(vfsms_ctx *ctx, int64_t canvas, int64_t tile,
                                                int y0, int x0, int ry0, int rx0, int ry1, int rx1, int dx, int dy, int32_t *info)
 {
     return vfsms_canvas_fuse_tile_resident_m(ctx, canvas, tile, y0, x0, ry0, rx0, ry1, rx1, dx, dy, 0, info);
 }
 // The whole mosaic walk of Stitcher.getStitchByOffset (Stitcher.py:434-483) over resident tiles as ONE call: per tile nine ints
-// [y0, x0, ry0, rx0, ry1, rx1, dx, dy, mode] with mode -1 = paste (the first tile, notFuse), 0 = fadeInAndFadeOut, 1 = trigonometric.
+// [y0, x0, ry0, rx0, ry1, rx1, dx, dy, mode] with mode -1 = paste (the first tile, notFuse), 0 = fadeInAndFadeOut, 1 = trigonometric,
+// 2 / 3 / 4 = average / maximum / minimum.
 // Enqueue only (one library call per mosaic instead of one per tile; the device chain stays two launches per tile); geometry errors are latched
 // in the canvas and reported by the download, as with vfsms_canvas_fuse_tile_resident(info = NULL).
 extern "C" int vfsms_canvas_assemble_resident(vfsms_ctx *ctx, int64_t canvas, int n, const int64_t *tiles, const int32_t *geom)
@@ -1398,7 +1495,7 @@ extern "C" int vfsms_canvas_assemble_resident(vfsms_ctx *ctx, int64_t canvas, in
     if (n < 0 || (n > 0 && (!tiles || !geom))) { vfsms_set_error("canvas_assemble_resident: bad arguments"); return VFSMS_ERR_BAD_ARG; }
     for (int i = 0; i < n; i++) {                       // everything is checked before anything is enqueued
         const int32_t *g = geom + 9 * (size_t)i;
-        if (g[8] < -1 || g[8] > 1) { vfsms_set_error("canvas_assemble_resident: mode must be -1 (paste), 0 (fadeInAndFadeOut) or 1 (trigonometric)"); return VFSMS_ERR_BAD_ARG; }
+        if (g[8] < -1 || g[8] > 4) { vfsms_set_error("canvas_assemble_resident: mode must be -1 (paste), 0 (fadeInAndFadeOut), 1 (trigonometric), 2 / 3 / 4 (average / maximum / minimum)"); return VFSMS_ERR_BAD_ARG; }
         CanvasRec *cv; TileRec *tr;
         TRY(canvas_resident_args(ctx, canvas, tiles[i], g[0], g[1], &cv, &tr));
         if (g[8] >= 0 && g[4] > g[2] && g[5] > g[3] && (g[2] < g[0] || g[3] < g[1] || g[4] > g[0] + tr->h || g[5] > g[1] + tr->w)) {
@@ -1408,6 +1505,7 @@ extern "C" int vfsms_canvas_assemble_resident(vfsms_ctx *ctx, int64_t canvas, in
     for (int i = 0; i < n; i++) {
         const int32_t *g = geom + 9 * (size_t)i;
         if (g[8] < 0) TRY(vfsms_canvas_paste_tile(ctx, canvas, tiles[i], g[0], g[1]));
+        else if (g[8] >= 2) TRY(vfsms_canvas_blend_tile_resident(ctx, canvas, tiles[i], g[0], g[1], g[2], g[3], g[4], g[5], g[8] - 2));
         else TRY(vfsms_canvas_fuse_tile_resident_m(ctx, canvas, tiles[i], g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], nullptr));
     }
     return VFSMS_OK;

@@ -139,6 +139,7 @@ struct MatchDev {
 // pending: an async upload the compute stream has not yet waited for; bytes: size of an owned allocation;
 // fill: 0 filled (or being copied: `ready` is recorded), 1 reserved -- a decoder thread still owes the pixels (vfsms_tile_fill), 2 the decoder gave up
 struct TileRec { uint8_t *ptr; int h, w, stride; bool owned; hipEvent_t ready; bool pending; int ch = 1; size_t bytes = 0; int fill = 0; };
+struct StageBuf { uint8_t *ptr; size_t bytes; };                    // device staging of one decoded source image (vfsms_tile_fill_pair)
 struct PoolEnt { size_t bytes; uint8_t *ptr; hipEvent_t idle; };   // a freed tile buffer; idle: recorded on the compute stream when the tile was freed
 struct CanvasRec { uint8_t *pix; uint8_t *mask; int rows, cols, ch; int *d_err; void *scratch; };   // d_err: sticky "degenerate fuse geometry" flag for calls made without an info readback; scratch: the fuse's statistics records + ramps
 struct FftPlan { int M, N, nb; void *fwd, *inv, *fwd_info, *inv_info; size_t fwd_work, inv_work; };   // rocfft_plan / rocfft_execution_info
@@ -160,7 +161,8 @@ struct vfsms_ctx {
     void *d_area_tab = nullptr;          // INTER_AREA tables of every descriptor-window size (ctx_prepare_area_tab)
     vfsms_orb_params cur_orb; bool orb_valid; OrbTables *d_orb_tables;
     std::unordered_map<int64_t, TileRec> tiles;
-    std::mutex tiles_mu; std::condition_variable tiles_cv;   // reserved tiles are filled by other threads (vfsms_tile_fill): the map, the event pool and the copy stream are shared with them
+    std::mutex tiles_mu; std::condition_variable tiles_cv;   // reserved tiles are filled by other threads (vfsms_tile_fill*): they look tiles up and write TileRec::fill / pending under this mutex and enqueue on the copy stream; the map's structure, the buffer / event pools and the arena belong to the context's own thread
+    std::mutex stage_mu; std::vector<StageBuf> stage_pool;   // staging buffers of the decoder threads (vfsms_tile_fill_pair), the one pool they share
     hipStream_t copy_stream;                                  // H2D uploads of tiles, overlapped with compute (vfsms_tile_upload_async)
     std::vector<PoolEnt> tile_pool;      // freed tile buffers, reused by allocation size (no hipMalloc / hipFree per step)
     size_t tile_pool_bytes = 0;

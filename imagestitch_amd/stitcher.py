@@ -79,6 +79,7 @@ def _imread_gray_pointer(path):
     from PIL import Image
     im = Image.open(path)
     im.draft("L", im.size)
+    im.decodermaxblock = max(im.decodermaxblock, 1 << 24)    # the whole file in one read + decode call: fewer trips through the interpreter lock per tile
     im.load()
     if im.mode == "L" and hasattr(im, "__arrow_c_array__"):
         try:
@@ -91,6 +92,56 @@ def _imread_gray_pointer(path):
             pass
     a = np.ascontiguousarray(np.asarray(im.convert("L")))
     return a, a.ctypes.data, a.shape
+
+
+def _decode_once(path, want_color):
+    """ONE decode of a file for both uses the reference makes of it (cv2.imdecode(..., 0) at Stitcher.py:68-69 for registration and, with
+    isColorMode, cv2.imdecode(..., IMREAD_COLOR) at Stitcher.py:382-403 for the mosaic) -> (owner, (rows, cols), parts) with
+    parts = ("src", address, stride_bytes, fmt): what vfsms_tile_fill_pair takes -- fmt 0 a gray plane, 1 / 2 the JPEG's own Y Cb Cr planes
+          interleaved (libjpeg out_color_space = JCS_YCbCr: the colour conversion happens on the GPU, the Y plane IS the grayscale decode),
+          or ("arrays", gray (h, w), bgr (h, w, 3) | None): other formats / colour spaces, both planes from the one loaded image."""
+    from PIL import Image
+    if not want_color:
+        keep, addr, shape = _imread_gray_pointer(path)
+        return keep, shape, ("src", addr, shape[1], 0)
+    im = Image.open(path)
+    im.decodermaxblock = max(im.decodermaxblock, 1 << 24)
+    if im.format == "JPEG" and im.mode == "RGB":
+        try:
+            im.draft("YCbCr", im.size)
+            im.load()
+        except Exception:                                    # e.g. an Adobe RGB JPEG (no YCbCr planes): decode as it is
+            im = Image.open(path)
+    else:
+        im.draft("L", im.size)
+    im.load()
+    shape = (im.size[1], im.size[0])
+    if im.mode in ("L", "YCbCr"):
+        spx = 1 if im.mode == "L" else 4                     # Pillow stores 3-band pixels in 4 bytes
+        if hasattr(im, "__arrow_c_array__"):
+            try:
+                import pyarrow as pa
+                arr = pa.array(im)
+                buf = (arr.buffers()[1] if spx == 1 else arr.values.buffers()[1])
+                if buf is not None and buf.size == shape[0] * shape[1] * spx:
+                    return (arr, im), shape, ("src", buf.address, shape[1] * spx, 0 if spx == 1 else 2)
+            except Exception:                                # no pyarrow / image in several blocks: the copying path below
+                pass
+        a = np.ascontiguousarray(np.asarray(im))
+        return a, shape, ("src", a.ctypes.data, a.strides[0], 0 if spx == 1 else 1)
+    gray = np.ascontiguousarray(np.asarray(im.convert("L")))
+    bgr = np.ascontiguousarray(np.asarray(im.convert("RGB"))[:, :, ::-1])
+    return None, shape, ("arrays", gray, bgr)
+
+
+def _ycc_to_bgr(ycc):
+    """libjpeg's YCbCr -> RGB (jdcolor.c: 16-bit fixed-point tables), stored B G R: what cv2.imdecode(IMREAD_COLOR) yields from the planes
+    `_decode_once` hands to the GPU.  Host-side twin of csrc/ingest_kernels.hip for the tiles that are not resident (lone tiles)."""
+    y = ycc[..., 0].astype(np.int32); cb = ycc[..., 1].astype(np.int32) - 128; cr = ycc[..., 2].astype(np.int32) - 128
+    r = y + ((91881 * cr + 32768) >> 16)
+    g = y + ((-22554 * cb + 32768 - 46802 * cr) >> 16)
+    b = y + ((116130 * cb + 32768) >> 16)
+    return np.clip(np.stack([b, g, r], -1), 0, 255).astype(np.uint8)
 
 
 def _imshape(path):
@@ -246,28 +297,58 @@ class Stitcher(Utility.Method):
                             phaseResponseThreshold=self.phaseResponseThreshold, window=48,
                             enhance=self._enhanceSpec() if method in ("surf", "surf_full") else (0, 0.0, 0))
         reg.orbMaxDistance = self.orbMaxDistance if self.isGPUAvailable else -1
-        keep = (not self.isColorMode) and self.fuseMethod in ("notFuse", "fadeInAndFadeOut", "trigonometric") and hasattr(eng, "canvas_fuse_tile_resident")
-        handles, pool, futures, failed = [], None, [], False
+        device_fuse = (self.fuseMethod in ("notFuse", "fadeInAndFadeOut", "trigonometric") and hasattr(eng, "canvas_fuse_tile_resident")) or \
+                      (self.fuseMethod in ("average", "maximum", "minimum") and hasattr(eng, "canvas_blend_tile_resident"))
+        # the tiles the mosaic is assembled from stay in HBM: the registration planes themselves for gray mosaics, and for colour mosaics
+        # (Main.py:14's default) the B G R tiles the SAME decode produced -- every file is decoded exactly once (Stitcher.py:68-69, 382-403)
+        color = bool(self.isColorMode) and device_fuse and hasattr(eng, "tile_fill_pair")
+        keep = device_fuse and (color or not self.isColorMode) and len(set(fileList)) == len(fileList)
+        handles, chandles, pool, futures, failed, table = [], [], None, [], False, None
+        block_alloc = None
         try:
             if hasattr(eng, "tile_reserve"):
                 # Ingest pipeline.  The reference decodes the whole file list before the first pair is looked at, and each tile three
-                # times (Stitcher.py:68-69, 382-403).  Here every tile gets its device handle up front (vfsms_tile_reserve) and a pool
+                # times (Stitcher.py:68-69, 382-403).  Here every tile gets its device handle(s) up front (vfsms_tile_reserve) and a pool
                 # of decoder threads (Pillow releases the GIL while it decodes) fills them in path order; the native registrar starts
                 # at once and waits only for the tiles of the batch it is about to launch, so registration overlaps decoding and the
                 # decoded arrays never pile up on the host (a thread holds one tile at a time).
                 from concurrent.futures import ThreadPoolExecutor
-                handles = [eng.tile_reserve(s[0], s[1]) for s in shapes]
-                nthreads = max(1, min(int(self.decodeThreads or min(os.cpu_count() or 4, 16)), len(fileList), 64))
+                for s in shapes:                              # one by one: a reserve that fails midway leaves nothing behind (finally)
+                    handles.append(eng.tile_reserve(s[0], s[1]))
+                    if color:
+                        chandles.append(eng.tile_reserve_color(s[0], s[1], 3))
+                nthreads = max(1, min(int(self.decodeThreads or min(os.cpu_count() or 4, 32)), len(fileList), 64))
+                if color:
+                    try:                                      # 3-band images in ONE block, so that Pillow can hand the pixel block over without a copy
+                        from PIL import Image as _I
+                        block_alloc = _I.core.get_use_block_allocator()
+                        _I.core.set_use_block_allocator(1)
+                    except Exception:
+                        block_alloc = None
 
                 def ingest(k):
+                    hc = chandles[k] if color else 0
                     try:
-                        keep, addr, shape = _imread_gray_pointer(fileList[k])
-                        if shape != shapes[k]:
+                        owner, shape, parts = _decode_once(fileList[k], color)
+                        if tuple(shape) != tuple(shapes[k]):
                             raise ValueError("decoded size %s of %s differs from its header %s" % (shape, fileList[k], shapes[k]))
-                        eng.tile_fill_ptr(handles[k], addr, shape[1])
-                        del keep
+                        if parts[0] == "src":
+                            if hc or parts[3] != 0:
+                                eng.tile_fill_pair(handles[k], hc, parts[1], parts[2], parts[3])
+                            else:
+                                eng.tile_fill_ptr(handles[k], parts[1], parts[2])
+                        else:
+                            eng.tile_fill(handles[k], parts[1])
+                            if hc:
+                                eng.tile_fill(hc, parts[2])
+                        del owner
                     except BaseException:
-                        eng.tile_fill(handles[k], None)          # the batch waiting for this tile fails instead of hanging
+                        for h in (handles[k], hc):            # the batch waiting for this tile fails instead of hanging
+                            if h:
+                                try:
+                                    eng.tile_fill(h, None)
+                                except Exception:             # already filled (the second fill of an "arrays" pair failed)
+                                    pass
                         raise
                 pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="vfsms-decode")
                 futures = [pool.submit(ingest, k) for k in range(len(fileList))]
@@ -281,20 +362,47 @@ class Stitcher(Utility.Method):
             keep, failed = False, True
             raise
         finally:
+            # flowStitch discards everything behind a break (Stitcher.py:74-76) and the reference never opens those files: decodes that have
+            # not started are cancelled (their handles are given up so that they can be freed), and a file behind the last registered pair
+            # that fails to decode is not an error of this call
+            needed = len(fileList) if (failed or table is None) else min(len(table) + 1, len(fileList))
             err = None
-            for fu in futures:                                # every decoder has finished with its handle before any is freed
+            for k, fu in enumerate(futures):
+                if fu.cancel():
+                    for h in ([handles[k]] + ([chandles[k]] if color else [])):
+                        try:
+                            eng.tile_fill(h, None)
+                        except Exception:
+                            pass
+            for k, fu in enumerate(futures):                  # every running decoder has finished with its handles before any is freed
+                if fu.cancelled():
+                    continue
                 try:
                     fu.result()
                 except BaseException as e:                     # noqa: PERF203
-                    err = err or e
+                    if k < needed:
+                        err = err or e
             if pool is not None:
                 pool.shutdown(wait=True)
+            if block_alloc is not None:
+                try:
+                    from PIL import Image as _I
+                    _I.core.set_use_block_allocator(block_alloc)
+                except Exception:
+                    pass
             if keep and err is None:
-                # gray mosaics are assembled from these very tiles: getStitchByOffset takes them over (and frees them)
-                self._resident = dict(zip(fileList, zip(handles, shapes)))
-            else:
-                for h in handles:
+                # the mosaic is assembled from these very tiles: getStitchByOffset takes them over (and frees them)
+                kept = chandles if color else handles
+                self._resident = dict(zip(fileList, zip(kept, [(s[0], s[1], 3) if color else s for s in shapes])))
+                for h in (handles if color else []):
                     eng.tile_free(h)
+            else:
+                for h in handles + chandles:
+                    try:
+                        eng.tile_free(h)
+                    except Exception:                          # (a handle whose decoder never ran and could not be given up)
+                        if not failed and err is None:
+                            raise
             if err is not None and not failed:
                 raise err
         offsetList, endfileIndex, status, describtion = [], 0, True, ""
@@ -692,22 +800,37 @@ class Stitcher(Utility.Method):
         originOffsetList.insert(0, [0, 0])
         n = len(originOffsetList)
         eng = self.engine
-        # tiles the batched registration left in HBM (gray mosaics only): fused from where they are, no second decode / upload
+        # tiles the batched registration left in HBM (the gray planes, or the B G R tiles of the same decode): fused from where they are
         resident = self.__dict__.pop("_resident", None) or {}
         device_fuse = self.fuseMethod in ("notFuse", "fadeInAndFadeOut", "trigonometric")
         fmethod = 1 if self.fuseMethod == "trigonometric" else 0
-        handles = None
-        use_res = (not color) and device_fuse and all(fileList[i] in resident for i in range(n))
+        simple = {"average": 0, "maximum": 1, "minimum": 2}.get(self.fuseMethod)
+        if simple is not None and not hasattr(eng, "canvas_blend_tile"):
+            simple = None
+        handles = imageList = None
+        use_res = (device_fuse or (simple is not None and hasattr(eng, "canvas_blend_tile_resident"))) and \
+            all(fileList[i] in resident and (len(resident[fileList[i]][1]) == 3) == color for i in range(n))
         try:
+            if not use_res and (device_fuse or simple is not None) and hasattr(eng, "tile_reserve") and hasattr(eng, "tile_fill_pair") and \
+                    (simple is None or hasattr(eng, "canvas_blend_tile_resident")):
+                # not (all) resident -- a custom registration method ran pair by pair on host arrays: the mosaic's tiles go straight from a
+                # pool of decoder threads into reserved device tiles, never as a list on the host (the reference holds all of them,
+                # Stitcher.py:382-403)
+                for h, _shape in resident.values():
+                    eng.tile_free(h)
+                resident = {}
+                resident = self._ingestForMosaic([fileList[i] for i in range(n)], color) or {}
+                use_res = bool(resident)
             if use_res:
                 shapes = [resident[fileList[i]][1] for i in range(n)]
+                handles = [resident[fileList[i]][0] for i in range(n)]
             else:
                 imageList = [_imread(fileList[0], color)]
                 for i in range(1, n):
                     imageList.append(_imread(fileList[i], Stitcher.isColorMode))
                 shapes = [im.shape for im in imageList]
                 if device_fuse and hasattr(eng, "tile_upload_color") and len({im.ndim for im in imageList}) == 1:
-                    # colour (or not yet resident) tiles: all uploads are queued on the copy stream up front and the per-tile canvas
+                    # engines without the ingest entry points: all uploads are queued on the copy stream up front and the per-tile canvas
                     # calls below only enqueue work behind them -- no host synchronisation per tile (Stitcher.py:174-179, 434-483)
                     for h, _shape in resident.values():
                         eng.tile_free(h)
@@ -718,19 +841,14 @@ class Stitcher(Utility.Method):
                         resident[(i, fileList[i])] = (hnd, im.shape)
                     handles = [resident[(i, fileList[i])][0] for i in range(n)]
                     use_res = True
-            if use_res and handles is None:
-                handles = [resident[fileList[i]][0] for i in range(n)]
             offsetList, rangeX, rangeY, resultRow, resultCol = self._layout(shapes, originOffsetList)
             self.printAndWrite("  The rectified offsetList is " + str(offsetList))
-            simple = {"average": 0, "maximum": 1, "minimum": 2}.get(self.fuseMethod)
-            if simple is not None and not hasattr(eng, "canvas_blend_tile"):
-                simple = None
             if not device_fuse and simple is None:
                 return self._stitchWithHostFuse(fileList, imageList, originOffsetList, offsetList, rangeX, rangeY, resultRow, resultCol)
             ch = 3 if color else 1
             canvas = eng.canvas_create(resultRow, resultCol, ch)
             try:
-                one_call = use_res and simple is None and hasattr(eng, "canvas_assemble_resident")
+                one_call = use_res and hasattr(eng, "canvas_assemble_resident")
                 if one_call:
                     # every tile is resident: the walk below as ONE library call (the per-tile calls cost the host more than
                     # their two launches cost the device)
@@ -743,7 +861,8 @@ class Stitcher(Utility.Method):
                             geom[i] = (oy, ox, 0, 0, 0, 0, 0, 0, -1)
                         else:
                             geom[i] = (oy, ox, max(oy, rangeX[i - 1][0]), max(ox, rangeY[i - 1][0]), min(oy + th, rangeX[i - 1][1]),
-                                       min(ox + tw, rangeY[i - 1][1]), originOffsetList[i][0], originOffsetList[i][1], fmethod)
+                                       min(ox + tw, rangeY[i - 1][1]), originOffsetList[i][0], originOffsetList[i][1],
+                                       fmethod if simple is None else 2 + simple)
                     eng.canvas_assemble_resident(canvas, handles, geom)
                 for i in range(n if one_call else 0, n):
                     self.printAndWrite("  stitching " + str(fileList[i]))
@@ -757,7 +876,9 @@ class Stitcher(Utility.Method):
                         continue
                     roi = (max(oy, rangeX[i - 1][0]), max(ox, rangeY[i - 1][0]),
                            min(oy + th, rangeX[i - 1][1]), min(ox + tw, rangeY[i - 1][1]))
-                    if simple is not None:
+                    if simple is not None and use_res:
+                        eng.canvas_blend_tile_resident(canvas, handles[i], oy, ox, roi, simple)
+                    elif simple is not None:
                         eng.canvas_blend_tile(canvas, imageList[i], oy, ox, roi, simple)
                     elif use_res:
                         eng.canvas_fuse_tile_resident(canvas, handles[i], oy, ox, roi, originOffsetList[i][0], originOffsetList[i][1], method=fmethod)
@@ -777,6 +898,52 @@ class Stitcher(Utility.Method):
                 eng.sync_uploads()                           # the host tiles of asynchronous uploads may be released now
             for h, _shape in resident.values():
                 eng.tile_free(h)
+
+    def _ingestForMosaic(self, files, color):
+        """The mosaic's tiles from their files into reserved device tiles through a pool of decoder threads (one decode per file, the
+        colour conversion on the GPU) -> {file: (handle, shape)}."""
+        eng = self.engine
+        if len(set(files)) != len(files):                    # (a file listed twice: the host path keys nothing by name)
+            return None
+        shapes = [_imshape(f) for f in files]
+        from concurrent.futures import ThreadPoolExecutor
+        handles = []
+        try:
+            for s_ in shapes:
+                handles.append(eng.tile_reserve_color(s_[0], s_[1], 3) if color else eng.tile_reserve(s_[0], s_[1]))
+
+            def ingest(k):
+                try:
+                    owner, shape, parts = _decode_once(files[k], color)
+                    if tuple(shape) != tuple(shapes[k]):
+                        raise ValueError("decoded size %s of %s differs from its header %s" % (shape, files[k], shapes[k]))
+                    if parts[0] == "src":
+                        eng.tile_fill_pair(0 if color else handles[k], handles[k] if color else 0, parts[1], parts[2], parts[3])
+                    else:
+                        eng.tile_fill(handles[k], parts[2] if color else parts[1])
+                    del owner
+                except BaseException:
+                    try:
+                        eng.tile_fill(handles[k], None)
+                    except Exception:
+                        pass
+                    raise
+            nthreads = max(1, min(int(self.decodeThreads or min(os.cpu_count() or 4, 32)), len(files), 64))
+            with ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="vfsms-decode") as pool:
+                for fu in [pool.submit(ingest, k) for k in range(len(files))]:
+                    fu.result()
+        except BaseException:
+            for h in handles:
+                try:
+                    eng.tile_fill(h, None)
+                except Exception:
+                    pass
+                try:
+                    eng.tile_free(h)
+                except Exception:
+                    pass
+            raise
+        return dict(zip(files, zip(handles, [(s_[0], s_[1], 3) if color else s_ for s_ in shapes])))
 
     def _stitchWithHostFuse(self, fileList, imageList, originOffsetList, offsetList, rangeX, rangeY, resultRow, resultCol):
         """Fallback for engines without the canvas blend entry points (the CPU test doubles): same int64 / -1 canvas walk as

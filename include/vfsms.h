@@ -115,6 +115,21 @@ int vfsms_tile_upload_ch(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int c
  * waits for exactly that tile, so vfsms_pairs_offsets works on tiles 0, 1, ... while tile k is still being decoded.               */
 int vfsms_tile_reserve(vfsms_ctx *ctx, int h, int w, int64_t *handle);
 int vfsms_tile_fill(vfsms_ctx *ctx, int64_t handle, const uint8_t *img, int stride);
+/* the same for an interleaved tile of ch channels (the mosaic's colour tiles); vfsms_tile_fill takes its rows of w * ch bytes, `stride` in bytes */
+int vfsms_tile_reserve_ch(vfsms_ctx *ctx, int h, int w, int ch, int64_t *handle);
+/* ONE decode per file for both uses the reference makes of it: cv2.imdecode(..., 0) feeds the registration loop (Stitcher.py:68-69) and,
+ * with isColorMode (Main.py:14's default), cv2.imdecode(..., IMREAD_COLOR) feeds the mosaic (Stitcher.py:382-403).  Both are views of the
+ * same entropy decode: IMREAD_GRAYSCALE of a JPEG is its Y plane, IMREAD_COLOR is libjpeg's fixed-point YCbCr -> RGB (jdcolor.c) of the
+ * same planes, stored B G R.  `src` holds what the decoder produced once --
+ *   VFSMS_SRC_GRAY8   one byte per pixel (a grayscale file; the colour tile replicates it, as IMREAD_COLOR does)
+ *   VFSMS_SRC_YCC24   Y Cb Cr interleaved (libjpeg out_color_space = JCS_YCbCr: no colour conversion on the host)
+ *   VFSMS_SRC_YCCX32  Y Cb Cr X, four bytes per pixel (Pillow's pixel storage, handed over without a repack)
+ * -- and the device writes the reserved gray tile `gray` and the reserved 3-channel tile `color` (either may be 0).  Any thread; returns
+ * when both tiles are complete; src == NULL gives both up (a failed decode).                                                              */
+#define VFSMS_SRC_GRAY8 0
+#define VFSMS_SRC_YCC24 1
+#define VFSMS_SRC_YCCX32 2
+int vfsms_tile_fill_pair(vfsms_ctx *ctx, int64_t gray, int64_t color, const uint8_t *src, int stride_bytes, int format);
 /* pinned host staging memory for tiles (decoders write into it; uploads from it are asynchronous DMA)                          */
 int vfsms_host_alloc(vfsms_ctx *ctx, size_t bytes, void **ptr);
 int vfsms_host_free(vfsms_ctx *ctx, void *ptr);
@@ -298,6 +313,9 @@ int vfsms_canvas_blend_tile(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile,
  * With info == NULL the fuse only enqueues work (no host synchronisation per tile); a degenerate corner geometry -- where the
  * reference's getWeightsMatrix raises -- is then latched in the canvas and reported by vfsms_canvas_download.               */
 int vfsms_canvas_paste_tile(vfsms_ctx *ctx, int64_t canvas, int64_t tile, int y0, int x0);
+/* vfsms_canvas_blend_tile ("average" / "maximum" / "minimum", mode 0 / 1 / 2) for a resident tile; enqueue only                       */
+int vfsms_canvas_blend_tile_resident(vfsms_ctx *ctx, int64_t canvas, int64_t tile,
+                                     int y0, int x0, int ry0, int rx0, int ry1, int rx1, int mode);
 int vfsms_canvas_fuse_tile_resident(vfsms_ctx *ctx, int64_t canvas, int64_t tile,
                                     int y0, int x0, int ry0, int rx0, int ry1, int rx1,
                                     int dx, int dy, int32_t *info);
@@ -306,7 +324,7 @@ int vfsms_canvas_fuse_tile_resident_m(vfsms_ctx *ctx, int64_t canvas, int64_t ti
                                       int dx, int dy, int method, int32_t *info);
 /* The canvas walk of Stitcher.getStitchByOffset (Stitcher.py:434-483) over n resident tiles in one call.
  * geom: n x 9 ints [y0, x0, ry0, rx0, ry1, rx1, dx, dy, mode], mode -1 = paste (first tile / notFuse),
- * 0 = fadeInAndFadeOut, 1 = trigonometric.  Enqueue only: errors of a tile's geometry surface in the download. */
+ * 0 = fadeInAndFadeOut, 1 = trigonometric, 2 / 3 / 4 = average / maximum / minimum.  Enqueue only: errors of a tile's geometry surface in the download. */
 int vfsms_canvas_assemble_resident(vfsms_ctx *ctx, int64_t canvas, int n, const int64_t *tiles, const int32_t *geom);
 /* final image: empty -> 0 (Stitcher.py:485-486).  out: u8 [rows][cols][ch]                           */
 int vfsms_canvas_download(vfsms_ctx *ctx, int64_t canvas, uint8_t *out);

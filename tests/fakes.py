@@ -107,3 +107,117 @@ class OracleEngine:
         cv = self._canvases[h].copy()
         cv[cv == -1] = 0
         return cv.astype(np.uint8)
+
+
+class IngestOracleEngine(OracleEngine):
+    """OracleEngine plus the fused-attempt, ingest (tile_reserve / tile_fill / tile_fill_pair) and resident-canvas entry points, so that the
+    Stitcher's decode-once pipeline and its error paths run on a machine without a GPU.  Tiles are numpy arrays keyed by handle; a reserved
+    tile is an Event the attempts wait on.  tile_fill_pair restates csrc/ingest_kernels.hip with stitcher._ycc_to_bgr."""
+
+    def __init__(self, oracle, scripted=None):
+        super().__init__(oracle)
+        import threading
+        self.tiles, self.ready, self.failed, self.live = {}, {}, set(), set()
+        self.batches = 0
+        self.scripted = scripted                              # optional: f(job index in call order) -> row, instead of the oracle chain
+        self._mu = threading.Lock()
+
+    # tiles -------------------------------------------------------------------------------------------
+    def _new(self):
+        with self._mu:
+            h = self._next; self._next += 1
+            self.live.add(h)
+            return h
+
+    def tile_upload(self, img):
+        h = self._new(); self.tiles[h] = np.ascontiguousarray(img)
+        return h
+
+    def tile_reserve(self, h, w):
+        import threading
+        hd = self._new(); self.ready[hd] = threading.Event(); self.tiles[hd] = ("reserved", (h, w))
+        return hd
+
+    def tile_reserve_color(self, h, w, ch=3):
+        import threading
+        hd = self._new(); self.ready[hd] = threading.Event(); self.tiles[hd] = ("reserved", (h, w, ch))
+        return hd
+
+    def _deliver(self, hd, arr):
+        assert hd in self.ready and not self.ready[hd].is_set(), "not a reserved tile"
+        if arr is None:
+            self.failed.add(hd)
+        else:
+            assert arr.shape == self.tiles[hd][1], (arr.shape, self.tiles[hd][1])
+            self.tiles[hd] = np.array(arr, np.uint8)
+        self.ready[hd].set()
+
+    def tile_fill(self, hd, img):
+        self._deliver(hd, img)
+
+    def tile_fill_ptr(self, hd, address, stride):
+        import ctypes
+        h, w = self.tiles[hd][1]
+        buf = np.frombuffer((ctypes.c_uint8 * (h * stride)).from_address(address), np.uint8).reshape(h, stride)[:, :w]
+        self._deliver(hd, buf)
+
+    SRC_GRAY8, SRC_YCC24, SRC_YCCX32 = 0, 1, 2
+
+    def tile_fill_pair(self, gray, color, address, stride, fmt):
+        import ctypes
+        from imagestitch_amd.stitcher import _ycc_to_bgr
+        if address is None:
+            for hd in (gray, color):
+                if hd:
+                    self._deliver(hd, None)
+            return
+        h, w = self.tiles[gray or color][1][:2]
+        spx = {0: 1, 1: 3, 2: 4}[fmt]
+        buf = np.frombuffer((ctypes.c_uint8 * (h * stride)).from_address(address), np.uint8).reshape(h, stride)[:, :w * spx].reshape(h, w, spx)
+        if gray:
+            self._deliver(gray, buf[:, :, 0])
+        if color:
+            self._deliver(color, np.repeat(buf, 3, axis=2) if fmt == 0 else _ycc_to_bgr(buf[:, :, :3]))
+
+    def tile_free(self, hd):
+        with self._mu:
+            assert hd in self.live, "freed twice / unknown handle"
+            assert hd not in self.ready or self.ready[hd].is_set(), "tile_free: the tile is reserved and its decoder has not filled it yet"
+            self.live.remove(hd)
+            self.tiles.pop(hd, None)
+
+    def _tile(self, hd):
+        if hd in self.ready:
+            assert self.ready[hd].wait(30), "a reserved tile was never filled"
+            if hd in self.failed:
+                raise RuntimeError("a reserved tile was never filled (its decoder reported a failure)")
+        return self.tiles[hd]
+
+    def set_keypoint_capacity(self, n):
+        pass
+
+    # fused attempts ------------------------------------------------------------------------------------
+    def attempt_surf_batch(self, jobs, params=None, ratio=0.75, offset_evaluate=3):
+        self.batches += 1
+        out = np.zeros((len(jobs), 8), np.int32)
+        for n, job in enumerate(jobs):
+            ta, tb, ay0, ax0, by0, bx0, h, w = [int(v) for v in job]
+            A, B = self._tile(ta), self._tile(tb)
+            if self.scripted is not None:
+                out[n] = self.scripted(A, B, job)
+                continue
+            a = np.ascontiguousarray(A[ay0:ay0 + h, ax0:ax0 + w]); b = np.ascontiguousarray(B[by0:by0 + h, bx0:bx0 + w])
+            ka, da = self.surf_detect_describe(a); kb, db = self.surf_detect_describe(b)
+            if len(ka) == 0 or len(kb) == 0:
+                out[n] = [0, 0, 0, 0, len(ka), len(kb), 0, 0]; continue
+            pairs = self.bf_l2_ratio_matches(da, db, ratio)
+            st, off, votes = self.mode_offset(ka, kb, pairs, offset_evaluate) if len(pairs) else (False, [0, 0], 0)
+            out[n] = [int(st), off[0], off[1], votes, len(ka), len(kb), len(pairs), 0]
+        return out
+
+    # resident canvas calls ---------------------------------------------------------------------------------
+    def canvas_paste_tile(self, h, tile_handle, y0, x0):
+        self.canvas_paste(h, self._tile(tile_handle), y0, x0)
+
+    def canvas_fuse_tile_resident(self, h, tile_handle, y0, x0, roi, dx, dy, want_info=False, method=0):
+        self.canvas_fuse_tile(h, self._tile(tile_handle), y0, x0, roi, dx, dy, method=method)

@@ -329,28 +329,38 @@ def test_config0_iron_pair_end_to_end(engine, golden_dir):
         isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate = old
 
 
-def test_config4_tile_size_4096_pair(engine):
-    """BASELINE configs[4] tile geometry (4096 x 4096 tiles -> 819 x 4096 strips, ~4x the keypoints of the 2048 case): one
-    in-column pair and one turn pair through the grid registrar; offsets within 1 px of the synthetic ground truth, and the
-    fused attempt row identical to the per-operator chain (detect+describe -> exhaustive-arithmetic matcher -> mode vote)."""
+def test_config4_tile_size_4096_pair(engine, oracle):
+    """BASELINE configs[4] tile geometry (4096 x 4096 tiles -> 819 x 4096 strips, ~4x the keypoints of the 2048 case, window classes and
+    ticket / capacity paths the 409-row strips never reach): one in-column pair and one turn pair through the grid registrar; offsets
+    within 1 px of the synthetic ground truth, and the fused attempt row of the 819 x 4096 strips EQUAL TO THE ORACLE'S chain
+    (surf_detect_describe -> bf_l2_ratio_matches -> mode_offset: status, offset, votes, keypoint and match counts), with the keypoints and
+    descriptors of the strip themselves bit-identical to the oracle's."""
     from imagestitch_amd.grid import GridRegistrar
     g = SyntheticGrid(2, 2, 4096)
     tiles = g.tiles(threads=4)
     hs = [engine.tile_upload(t) for t in tiles]
-    reg = GridRegistrar(engine, method="surf", roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3, directIncre=1)
-    table, _d = reg.register(hs, [t.shape for t in tiles], 1)
-    truth = np.array(g.true_offsets())
-    assert np.all(table[:, 0] == 1) and np.abs(table[:, 1:3] - truth).max() <= 1, (table, truth)
-    ra = isa.roi_rect(tiles[0].shape, 1, "first", 0.2); rb = isa.roi_rect(tiles[1].shape, 1, "second", 0.2)
-    assert ra[2:] == (819, 4096)
-    row = engine.attempt_surf_batch([(hs[0], hs[1], ra[0], ra[1], rb[0], rb[1], ra[2], ra[3])])[0]
-    A = np.ascontiguousarray(tiles[0][ra[0]:ra[0] + ra[2]]); B = np.ascontiguousarray(tiles[1][:rb[2]])
-    ka, da = engine.surf_detect_describe(A); kb, db = engine.surf_detect_describe(B)
-    pairs = engine.bf_l2_ratio_matches(da, db, 0.75)
-    st, off, votes = engine.mode_offset(ka, kb, pairs, 3)
-    assert row[:7].tolist() == [int(st), off[0], off[1], votes, len(ka), len(kb), len(pairs)], (row, st, off, votes, len(ka), len(kb), len(pairs))
-    for h in hs:
-        engine.tile_free(h)
+    try:
+        reg = GridRegistrar(engine, method="surf", roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3, directIncre=1)
+        table, _d = reg.register(hs, [t.shape for t in tiles], 1)
+        truth = np.array(g.true_offsets())
+        assert np.all(table[:, 0] == 1) and np.abs(table[:, 1:3] - truth).max() <= 1, (table, truth)
+        ra = isa.roi_rect(tiles[0].shape, 1, "first", 0.2); rb = isa.roi_rect(tiles[1].shape, 1, "second", 0.2)
+        assert ra[2:] == (819, 4096)
+        row = engine.attempt_surf_batch([(hs[0], hs[1], ra[0], ra[1], rb[0], rb[1], ra[2], ra[3])])[0]
+        A = np.ascontiguousarray(tiles[0][ra[0]:ra[0] + ra[2]]); B = np.ascontiguousarray(tiles[1][:rb[2]])
+        ka, da = oracle.surf_detect_describe(A); kb, db = oracle.surf_detect_describe(B)
+        assert len(ka) > 20000 and len(kb) > 20000
+        pairs = oracle.bf_l2_ratio_matches(da, db, 0.75)
+        st, off, votes = oracle.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, 3)
+        assert row[:7].tolist() == [int(st), off[0], off[1], votes, len(ka), len(kb), len(pairs)], (row, st, off, votes, len(ka), len(kb), len(pairs))
+        full = off[0] + 4096 - int(0.2 * 4096)
+        assert st and abs(full - truth[0][0]) <= 1 and abs(off[1] - truth[0][1]) <= 1
+        kx, dd, kf = engine.surf_detect_describe(A, full=True)
+        assert np.array_equal(_kp_fields(kf), _kp_fields(ka)) and np.array_equal(kf["angle"], ka["angle"]) and np.array_equal(dd, da)
+        assert np.array_equal(engine.bf_l2_ratio_matches(da, db, 0.75), pairs)
+    finally:
+        for h in hs:
+            engine.tile_free(h)
 
 
 def test_config3_zirconcl_phase_incremental(engine, golden_dir):
@@ -796,7 +806,7 @@ def test_canvas_assemble_resident_equals_per_tile_calls(engine):
         cv = engine.canvas_create(rows, cols, 1)
         try:
             with pytest.raises(Exception):
-                engine.canvas_assemble_resident(cv, handles[:1], [(0, 0, 0, 0, 0, 0, 0, 0, 2)])
+                engine.canvas_assemble_resident(cv, handles[:1], [(0, 0, 0, 0, 0, 0, 0, 0, 5)])
         finally:
             engine.canvas_free(cv)
     finally:
@@ -1017,3 +1027,215 @@ def test_line_scan_batched_full_image_path(engine, tmp_path):
         (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate, isa.Stitcher.isEnhance,
          isa.Stitcher.isClahe, isa.Stitcher.isColorMode, isa.Stitcher.fuseMethod) = old
         isa.Stitcher.tempImageFeature.isBreak = True
+
+
+@pytest.mark.gpu
+def test_timed_mosaic_walk_equals_the_oracle_walk_at_2048(engine, oracle):
+    """What `bench.py --method fuse` times -- vfsms_canvas_assemble_resident over resident 2048 x 2048 tiles with the geometry rows
+    bench.py builds from Stitcher._layout -- against the reference's int64 / -1 canvas walk (Stitcher.py:434-483) with the oracle's
+    fuseByFadeInAndFadeOut: a 3 x 3 serpentine (strip ROIs inside the columns, corner ROIs after both turns, a tile that meets three
+    earlier ones), byte for byte."""
+    from fakes import OracleEngine
+    T = 2048
+    g = SyntheticGrid(3, 3, T)
+    tiles = g.tiles(threads=4)
+    n = len(tiles)
+    offs = [[0, 0]] + [list(map(int, o)) for o in g.true_offsets()]
+    offsetList, rangeX, rangeY, rows, cols = isa.Stitcher._layout([t.shape for t in tiles], offs)
+    rois = [None] + [(max(offsetList[i][0], rangeX[i - 1][0]), max(offsetList[i][1], rangeY[i - 1][0]),
+                      min(offsetList[i][0] + T, rangeX[i - 1][1]), min(offsetList[i][1] + T, rangeY[i - 1][1])) for i in range(1, n)]
+    handles = [engine.tile_upload(t) for t in tiles]
+    cv = engine.canvas_create(rows, cols, 1)
+    try:
+        geom = [(offsetList[0][0], offsetList[0][1], 0, 0, 0, 0, 0, 0, -1)]
+        geom += [(offsetList[i][0], offsetList[i][1]) + tuple(rois[i]) + (offs[i][0], offs[i][1], 0) for i in range(1, n)]
+        engine.canvas_assemble_resident(cv, handles, geom)
+        got = engine.canvas_download(cv, rows, cols, 1)
+    finally:
+        engine.canvas_free(cv)
+        for h in handles:
+            engine.tile_free(h)
+    ref = OracleEngine(oracle)
+    c = ref.canvas_create(rows, cols, 1)
+    ref.canvas_paste(c, tiles[0], offsetList[0][0], offsetList[0][1])
+    for i in range(1, n):
+        ref.canvas_fuse_tile(c, tiles[i], offsetList[i][0], offsetList[i][1], rois[i], offs[i][0], offs[i][1])
+    want = ref.canvas_download(c, rows, cols, 1)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert len({(r[2] - r[0] == T and r[3] - r[1] == T) for r in rois[1:]}) == 2          # both strip and whole-tile (corner) ROIs occurred
+
+
+def _colour_jpegs(tmp_path, g, tag, quality=92, **kw):
+    from PIL import Image
+    files = []
+    for k, t in enumerate(g.tiles(threads=2)):
+        f = t.astype(np.float32)
+        rgb = np.clip(np.stack([0.6 * f + 30, f, 255 - 0.7 * f], -1), 0, 255).astype(np.uint8)
+        p = os.path.join(str(tmp_path), "%s_%02d.jpg" % (tag, k))
+        Image.fromarray(rgb).save(p, quality=quality, **kw)
+        files.append(p)
+    return files
+
+
+def _tile_bytes(engine, handle, h, w, ch):
+    cv = engine.canvas_create(h, w, ch)
+    try:
+        engine.canvas_paste_tile(cv, handle, 0, 0)
+        return engine.canvas_download(cv, h, w, ch)
+    finally:
+        engine.canvas_free(cv)
+
+
+@pytest.mark.gpu
+def test_ingest_pair_fill_equals_the_two_decodes(engine, tmp_path):
+    """vfsms_tile_fill_pair (csrc/ingest_kernels.hip): from ONE decode of a JPEG to its Y Cb Cr planes the device writes the gray tile ==
+    the file's grayscale decode (cv2.imdecode(..., 0), Stitcher.py:68-69) and the B G R tile == its colour decode (IMREAD_COLOR,
+    Stitcher.py:382-403), byte for byte -- 4-byte and 3-byte source pixels, a grayscale file, image areas that are not multiples of 4,
+    4:2:0 and 4:4:4 files; giving a pair up fails the call that waits for it."""
+    from PIL import Image
+    from imagestitch_amd import stitcher as ST
+    rng = np.random.default_rng(11)
+    base = rng.integers(0, 256, (41, 57, 3), dtype=np.uint8)
+    for (w, h), kw in (((613, 407), dict(quality=90)), ((512, 384), dict(quality=95, subsampling=0)), ((333, 7), dict(quality=70))):
+        img = np.asarray(Image.fromarray(base).resize((w, h), Image.BICUBIC))
+        p = os.path.join(str(tmp_path), "c_%d.jpg" % w)
+        Image.fromarray(img).save(p, **kw)
+        want_gray, want_bgr = ST._imread(p, False), ST._imread(p, True)
+        ycc = Image.open(p); ycc.draft("YCbCr", ycc.size); ycc = np.ascontiguousarray(np.asarray(ycc))
+        assert ycc.shape == (h, w, 3)
+        x32 = np.ascontiguousarray(np.concatenate([ycc, np.full((h, w, 1), 255, np.uint8)], 2))
+        padded = np.zeros((h, w * 3 + 5), np.uint8); padded[:, :w * 3] = ycc.reshape(h, w * 3)       # a row stride wider than the row
+        for src, stride, fmt in ((ycc, w * 3, engine.SRC_YCC24), (x32, w * 4, engine.SRC_YCCX32), (padded, w * 3 + 5, engine.SRC_YCC24)):
+            hg, hc = engine.tile_reserve(h, w), engine.tile_reserve_color(h, w, 3)
+            try:
+                engine.tile_fill_pair(hg, hc, src.ctypes.data, stride, fmt)
+                assert np.array_equal(_tile_bytes(engine, hg, h, w, 1), want_gray)
+                assert np.array_equal(_tile_bytes(engine, hc, h, w, 3), want_bgr)
+            finally:
+                engine.tile_free(hg); engine.tile_free(hc)
+        # one plane only; a grayscale source replicated into the colour tile
+        hc = engine.tile_reserve_color(h, w, 3)
+        engine.tile_fill_pair(0, hc, ycc.ctypes.data, w * 3, engine.SRC_YCC24)
+        assert np.array_equal(_tile_bytes(engine, hc, h, w, 3), want_bgr)
+        engine.tile_free(hc)
+        hg, hc = engine.tile_reserve(h, w), engine.tile_reserve_color(h, w, 3)
+        engine.tile_fill_pair(hg, hc, want_gray.ctypes.data, w, engine.SRC_GRAY8)
+        assert np.array_equal(_tile_bytes(engine, hg, h, w, 1), want_gray)
+        assert np.array_equal(_tile_bytes(engine, hc, h, w, 3), np.repeat(want_gray[:, :, None], 3, 2))
+        engine.tile_free(hg); engine.tile_free(hc)
+    # the decoder's own hand-over (Pillow's pixel block through Arrow, or the array copy) is one of the formats above
+    owner, shape, parts = ST._decode_once(p, True)
+    hg, hc = engine.tile_reserve(*shape), engine.tile_reserve_color(shape[0], shape[1], 3)
+    engine.tile_fill_pair(hg, hc, parts[1], parts[2], parts[3])
+    assert np.array_equal(_tile_bytes(engine, hc, shape[0], shape[1], 3), want_bgr)
+    engine.tile_free(hg); engine.tile_free(hc)
+    # a pair that is given up
+    hg, hc = engine.tile_reserve(8, 8), engine.tile_reserve_color(8, 8, 3)
+    engine.tile_fill_pair(hg, hc, None, 0, 0)
+    cv = engine.canvas_create(8, 8, 3)
+    try:
+        with pytest.raises(Exception):
+            engine.canvas_paste_tile(cv, hc, 0, 0)
+    finally:
+        engine.canvas_free(cv); engine.tile_free(hg); engine.tile_free(hc)
+    with pytest.raises(Exception):
+        engine.tile_fill_pair(0, 0, x32.ctypes.data, 4, 2)
+
+
+class _NoIngest:
+    """the engine without its ingest entry points: the Stitcher then decodes gray for the pairs and colour for the mosaic, twice per file,
+    like the reference"""
+    def __init__(self, eng):
+        self._e = eng
+
+    def __getattr__(self, name):
+        if name in ("tile_reserve", "tile_fill_pair", "tile_reserve_color"):
+            raise AttributeError(name)
+        return getattr(self._e, name)
+
+
+@pytest.mark.gpu
+def test_colour_mode_driver_decodes_each_file_once(engine, tmp_path):
+    """Main.py as written (isColorMode = True, Main.py:14) on a folder of colour JPEG tiles through imageSetStitchWithMutiple: the decoder
+    runs exactly ONCE per file (counted) -- the registration plane and the mosaic's B G R tile come from the same decode and the colour
+    tiles stay in HBM for getStitchByOffset -- and the written mosaic equals, byte for byte, the run that decodes every file twice
+    (grayscale for the pairs, colour for the mosaic: Stitcher.py:68-69, 382-403), for fadeInAndFadeOut and for average."""
+    from PIL import Image
+    from imagestitch_amd import stitcher as ST
+    g = SyntheticGrid(3, 3, 768, overlap=0.15)
+    proj = tmp_path / "demo"; (proj / "1").mkdir(parents=True)
+    files = _colour_jpegs(proj / "1", g, "1")
+    old = (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod,
+           isa.Stitcher.fuseMethod, isa.Stitcher.offsetEvaluate)
+    counts = {"once": 0, "imread": 0}
+    real_once, real_imread = ST._decode_once, ST._imread
+
+    def once(path, color):
+        counts["once"] += 1
+        return real_once(path, color)
+
+    def imread(path, color):
+        counts["imread"] += 1
+        return real_imread(path, color)
+    try:
+        isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode = 1, 0.2, True
+        isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate = "surf", 3
+        for fuse in ("fadeInAndFadeOut", "average"):
+            isa.Stitcher.fuseMethod = fuse
+            outs = []
+            for once_only in (True, False):
+                st = isa.Stitcher(); st._engine = engine if once_only else _NoIngest(engine)
+                isa.Stitcher.direction = 1; st.direction = 1
+                msgs = []
+                st.printAndWrite = lambda c, msgs=msgs: msgs.append(c)
+                out = tmp_path / ("out_%s_%d" % (fuse, once_only))
+                counts["once"] = counts["imread"] = 0
+                ST._decode_once, ST._imread = once, imread
+                try:
+                    st.imageSetStitchWithMutiple(str(proj), str(out) + os.sep, 1, st.calculateOffsetForFeatureSearchIncre,
+                                                 startNum=1, fileExtension="jpg", outputfileExtension="png")
+                finally:
+                    ST._decode_once, ST._imread = real_once, real_imread
+                if once_only:
+                    assert counts == {"once": len(files), "imread": 0}, counts
+                else:
+                    assert counts["imread"] >= 2 * len(files) - 1, counts
+                outs.append(([m for m in msgs if "offset of stitching" in m], np.asarray(Image.open(str(out / "stitching_result_1.png")))))
+            assert outs[0][0] == outs[1][0] and len(outs[0][0]) == 8
+            assert outs[0][1].ndim == 3 and np.array_equal(outs[0][1], outs[1][1])
+            assert outs[0][1].shape[0] > 2 * 768 and outs[0][1][:, :, 0].std() > 5 and not np.array_equal(outs[0][1][:, :, 0], outs[0][1][:, :, 2])
+    finally:
+        (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod,
+         isa.Stitcher.fuseMethod, isa.Stitcher.offsetEvaluate) = old
+
+
+@pytest.mark.gpu
+def test_phase_batch_on_dendritic_crops_against_stitcher_py_87(engine, oracle, golden_dir):
+    """The HIP phase correlation (rocFFT batch + the four kernels) on the 25 committed dendriticCrystal strip pairs: every row equals the
+    oracle's (integer offsets exact, sub-pixel peak 1e-6, response 1e-9) AND, sign-fixed and axis-corrected as Stitcher.phaseSignFix does,
+    lies within 1.5 px of the reference's own offset list (Stitcher.py:87) modulo the padded strip."""
+    import json
+    from test_oracle_golden import phase87_residual
+    d = json.load(open(os.path.join(golden_dir, "dendritic_phase87.json")))["crops"]
+    z = np.load(os.path.join(golden_dir, "real_path_strips.npz"))
+    by_shape = {}
+    for r in d:
+        by_shape.setdefault(tuple(r["roi"]), []).append(r)
+    assert len(by_shape) == 2                                              # 387 x 640 row strips, 640 x 516 column strips
+    for shape, rows in by_shape.items():
+        hs, jobs = [], []
+        try:
+            for r in rows:
+                ha, hb = engine.tile_upload(np.ascontiguousarray(z[r["key_a"]])), engine.tile_upload(np.ascontiguousarray(z[r["key_b"]]))
+                hs += [ha, hb]
+                jobs.append((ha, hb, 0, 0, 0, 0, shape[0], shape[1]))
+            out = engine.attempt_phase_batch(jobs)                           # one launch for all pairs of a shape
+        finally:
+            for h in hs:
+                engine.tile_free(h)
+        for r, (x, y, resp) in zip(rows, out):
+            (ox, oy), orr = oracle.phase_correlate(np.ascontiguousarray(z[r["key_a"]]), np.ascontiguousarray(z[r["key_b"]]))
+            assert int(x) == int(ox) and int(y) == int(oy) and abs(x - ox) < 1e-6 and abs(y - oy) < 1e-6 and abs(resp - orr) < 1e-9, (r["a"], x, ox, y, oy)
+            ry, rx = phase87_residual(r, (x, y))
+            assert max(abs(ry), abs(rx)) <= 1.5, (r["a"], ry, rx)
+            assert bool(resp > 0.15) == r["accepted"]

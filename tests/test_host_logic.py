@@ -10,7 +10,7 @@ import pytest
 
 import imagestitch_amd as isa
 from imagestitch_amd import stitcher as st_mod
-from fakes import OracleEngine
+from fakes import OracleEngine, IngestOracleEngine
 
 
 def test_roi_rect_matches_reference(golden_dir):
@@ -369,3 +369,137 @@ def test_flow_stitch_releases_tiles_when_an_operator_raises(tmp_path):
     with pytest.raises(RuntimeError):
         st.flowStitch(files, st.calculateOffsetForFeatureSearchIncre)
     assert eng.calls == 2 and not eng.live
+
+
+# ---- ingest pipeline: one decode per file, both planes; error paths (CPU, IngestOracleEngine) ---------------------------------------------
+def _colour_tiles(g):
+    """colour versions of a synthetic grid's tiles: three differently weighted planes, so that Cb / Cr are not flat"""
+    out = []
+    for t in g.tiles(threads=1):
+        f = t.astype(np.float32)
+        out.append(np.clip(np.stack([0.6 * f + 30, f, 255 - 0.7 * f], -1), 0, 255).astype(np.uint8))
+    return out
+
+
+def _write_jpegs(tmp_path, tiles, tag, quality=92):
+    from PIL import Image
+    files = []
+    for k, t in enumerate(tiles):
+        p = os.path.join(str(tmp_path), "%s_%02d.jpg" % (tag, k))
+        Image.fromarray(t).save(p, quality=quality)           # (RGB order in the file; the engine's tiles are B G R like cv2's)
+        files.append(p)
+    return files
+
+
+def test_decode_once_planes_equal_the_two_decodes(tmp_path):
+    """The one decode of the ingest pipeline against the two the reference makes (Stitcher.py:68-69, 382-403): the Y plane of the JPEG's
+    YCbCr decode IS its grayscale decode, and jdcolor's fixed-point conversion of the same planes (stitcher._ycc_to_bgr, the host twin
+    of csrc/ingest_kernels.hip) IS its colour decode, byte for byte -- on 4:2:0 and 4:4:4 files, odd sizes, and a grayscale file."""
+    from PIL import Image
+    from imagestitch_amd import stitcher as ST
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    img = np.asarray(Image.fromarray(base).resize((211, 149), Image.BICUBIC))
+    for k, kw in enumerate((dict(quality=90), dict(quality=95, subsampling=0), dict(quality=60, subsampling=2))):
+        p = os.path.join(str(tmp_path), "c%d.jpg" % k)
+        Image.fromarray(img).save(p, **kw)
+        owner, shape, parts = ST._decode_once(p, True)
+        assert parts[0] == "src" and parts[3] in (1, 2) and shape == (149, 211)
+        spx = 3 if parts[3] == 1 else 4
+        import ctypes
+        buf = np.frombuffer((ctypes.c_uint8 * (shape[0] * parts[2])).from_address(parts[1]), np.uint8).reshape(shape[0], parts[2])
+        ycc = buf[:, :shape[1] * spx].reshape(shape[0], shape[1], spx)[:, :, :3]
+        assert np.array_equal(ycc[:, :, 0], ST._imread(p, False))
+        assert np.array_equal(ST._ycc_to_bgr(ycc), ST._imread(p, True))
+        del owner
+    p = os.path.join(str(tmp_path), "g.jpg")
+    Image.fromarray(img[:, :, 1]).save(p, quality=90)
+    owner, shape, parts = ST._decode_once(p, True)
+    assert parts[0] == "src" and parts[3] == 0
+    p = os.path.join(str(tmp_path), "c.png")
+    Image.fromarray(img).save(p)
+    owner, shape, parts = ST._decode_once(p, True)
+    assert parts[0] == "arrays" and np.array_equal(parts[1], ST._imread(p, False)) and np.array_equal(parts[2], ST._imread(p, True))
+
+
+def test_colour_mosaic_decodes_every_file_exactly_once(oracle, tmp_path):
+    """Main.py:14's default isColorMode = True through flowStitch: the ingest pipeline decodes each file ONCE (counted) for the
+    registration plane and the B G R mosaic tile, no file is read again for the mosaic, nothing stays in HBM, and the mosaic equals the
+    pair-by-pair run that decodes gray and colour separately like the reference (Stitcher.py:68-69, 382-403)."""
+    from imagestitch_amd.synthetic import SyntheticGrid
+    from imagestitch_amd import stitcher as ST
+    g = SyntheticGrid(2, 2, 256, overlap=0.25)
+    files = _write_jpegs(tmp_path, _colour_tiles(g), "col")
+    old = (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod)
+    counts = {"once": 0, "imread": 0}
+    real_once, real_imread = ST._decode_once, ST._imread
+
+    def once(path, color):
+        counts["once"] += 1
+        return real_once(path, color)
+
+    def imread(path, color):
+        counts["imread"] += 1
+        return real_imread(path, color)
+
+    class HostOnly(IngestOracleEngine):
+        """no ingest entry points: the Stitcher decodes gray for the pairs and colour for the mosaic, like the reference"""
+        @property
+        def tile_reserve(self):
+            raise AttributeError("tile_reserve")
+    try:
+        isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod = 1, 0.3, True, "surf"
+        runs = []
+        for batched in (True, False):
+            for fuse in ("fadeInAndFadeOut", "notFuse"):
+                eng = IngestOracleEngine(oracle) if batched else HostOnly(oracle)
+                s = isa.Stitcher(); s._engine = eng; s.batchRegistration = batched; s.isPrintLog = False
+                s.direction = 1; s.fuseMethod = fuse
+                counts["once"] = counts["imread"] = 0
+                ST._decode_once, ST._imread = once, imread
+                try:
+                    (status, mosaic) = s.flowStitch(list(files), s.calculateOffsetForFeatureSearchIncre)
+                finally:
+                    ST._decode_once, ST._imread = real_once, real_imread
+                assert status == (True, 3) and mosaic.ndim == 3
+                if batched:
+                    assert counts == {"once": len(files), "imread": 0}, counts
+                assert not eng.live, eng.live                          # every tile handle was released
+                runs.append(mosaic)
+        assert np.array_equal(runs[0], runs[2]) and np.array_equal(runs[1], runs[3])
+        assert runs[0].std() > 10
+    finally:
+        isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod = old
+
+
+def test_ingest_error_paths_free_every_handle(oracle, tmp_path):
+    """A file that cannot be decoded: the batch waiting for its tile fails, flowStitch raises the decoder's error and every reserved handle
+    (gray and colour) is released.  A corrupt file BEHIND a registration break is never an error -- the reference stops at the break and
+    does not open it (Stitcher.py:64-79) -- and its decode is cancelled or ignored."""
+    from imagestitch_amd.synthetic import SyntheticGrid
+    g = SyntheticGrid(1, 5, 128, overlap=0.25)
+    files = _write_jpegs(tmp_path, _colour_tiles(g), "err")
+    old = (isa.Stitcher.direction, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod)
+    try:
+        isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod = "surf", "notFuse"
+        for color in (True, False):
+            isa.Stitcher.isColorMode = color
+            bad = list(files)
+            bad[2] = os.path.join(str(tmp_path), "corrupt_%d.jpg" % color)
+            data = open(files[2], "rb").read()
+            open(bad[2], "wb").write(data[:len(data) // 3])                # header intact (the size is read from it), entropy data cut
+            accept = lambda A, B, job: [1, 5, -3, 9, 10, 10, 9, 0]
+            eng = IngestOracleEngine(oracle, scripted=accept)
+            s = isa.Stitcher(); s._engine = eng; s.isPrintLog = False; s.direction = 1; s.decodeThreads = 2
+            with pytest.raises(Exception):
+                s.flowStitch(list(bad), s.calculateOffsetForFeatureSearchIncre)
+            assert not eng.live, eng.live
+            # the same corrupt file behind a break at pair 0: not an error, nothing leaks, the lone first tile is the result
+            calls = []
+            refuse = lambda A, B, job: (calls.append(1), [0, 0, 0, 0, 10, 10, 0, 0])[1]
+            eng = IngestOracleEngine(oracle, scripted=refuse)
+            s = isa.Stitcher(); s._engine = eng; s.isPrintLog = False; s.direction = 1; s.decodeThreads = 1
+            (status, mosaic) = s.flowStitch([files[0], files[1], files[3], bad[2]], s.calculateOffsetForFeatureSearchIncre)
+            assert status == (False, 0) and mosaic.shape[:2] == (128, 128) and not eng.live
+    finally:
+        isa.Stitcher.direction, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod = old

@@ -479,3 +479,35 @@ def test_orb_oracle_against_surf_and_ncc_on_zirconcl(oracle, golden_dir):
         c = {(u, v): _overlap_ncc(A, B, off[0] + u, off[1] + v) for u in range(-2, 3) for v in range(-2, 3)}
         assert max(c.values()) > 0.93 and c[(0, 0)] > 0.9, (k, c[(0, 0)])
     assert three_vote == [8, 20], three_vote
+
+
+def phase87_residual(row, xy=None):
+    """(row residual, column residual) of the sign-fixed, axis-corrected sub-pixel phase peak against Stitcher.py:87's offset, wrapped to the
+    padded strip (the DFT is circular: an in-strip shift s and s - M are the same peak)"""
+    M, N = row["padded"]
+    x, y = xy if xy is not None else row["phase_xy"]
+    c, g = row["axis_correction"], row["gold"]
+    return ((-y + c[0] - g[0] + M / 2.0) % M - M / 2.0, (-x + c[1] - g[1] + N / 2.0) % N - N / 2.0)
+
+
+def test_phase_oracle_against_the_reference_offset_vector(oracle, golden_dir):
+    """The phase leg pinned to the one numeric vector the reference holds (Stitcher.py:87, the TRUE offsets of the dendriticCrystal path):
+    on the ROI strips of the accepted (direction, i) of EVERY pair (tiles 003..090; tools/capture_golden.py phase87) the oracle's
+    cv2.phaseCorrelate restatement, with the sign of the feature path (Stitcher.phaseSignFix) and the reference's axis correction
+    (Stitcher.py:244-251), lands on the gold offset within 1.5 px modulo the padded strip -- all 87 pairs, whatever the response; the
+    truncated integer form (Stitcher.py:231-232) within 2.  The 25 pairs whose strips are committed as crops are recomputed here."""
+    d = json.load(open(os.path.join(golden_dir, "dendritic_phase87.json")))
+    assert len(d["full"]) == 87 and len(d["crops"]) == 25
+    for r in d["full"] + d["crops"]:
+        ry, rx = phase87_residual(r)
+        assert max(abs(ry), abs(rx)) <= 1.5, (r["a"], ry, rx)
+        assert max(abs(v) for v in r["residual_mod_padded"]) <= 2, (r["a"], r["residual_mod_padded"])
+    assert sum(r["accepted"] for r in d["full"]) >= 80                      # the reference's own gate (response > 0.15) passes most of them
+    z = np.load(os.path.join(golden_dir, "real_path_strips.npz"))
+    for r in d["crops"]:
+        a, b = np.ascontiguousarray(z[r["key_a"]]), np.ascontiguousarray(z[r["key_b"]])
+        assert list(a.shape) == r["roi"]
+        (x, y), resp = oracle.phase_correlate(a, b)
+        assert abs(x - r["phase_xy"][0]) < 1e-9 and abs(y - r["phase_xy"][1]) < 1e-9 and abs(resp - r["response"]) < 1e-12, r["a"]
+        ry, rx = phase87_residual(r, (x, y))
+        assert max(abs(ry), abs(rx)) <= 1.5

@@ -665,11 +665,114 @@ def cap_phase_independent():
     print("zirconCL strips", os.path.getsize(os.path.join(OUT, "zirconcl_strips.npz")) // 1024, "KiB; pairs", len(rows))
 
 
+def _opt_dft(n):
+    m = max(int(n), 1)
+    while True:
+        k = m
+        for q in (2, 3, 5):
+            while k % q == 0:
+                k //= q
+        if k == 1:
+            return m
+        m += 1
+
+
+def cap_phase87():
+    """The phase leg against the reference-held vector (Stitcher.py:87 lists the TRUE offsets of the dendriticCrystal path): for every pair,
+    the oracle's cv2.phaseCorrelate restatement on the two ROI strips of the ACCEPTED (direction, i) of dendritic_path_oracle.json, as
+    Stitcher.calculateOffsetForPhaseCorrleateIncre slices them (Stitcher.py:224-229).  With the sign the feature path uses (phaseSignFix:
+    offset = -[int(y), int(x)] + axis correction, Stitcher.py:244-251) the result must be the gold offset -- modulo the padded strip
+    (the DFT is circular: a strip shift s and s - M are the same peak), wherever the correlation peak is the overlap's (response gate).
+    Two records per pair: the FULL strips (387 x 2584 / 1936 x 516; rows only -- the images are the reference's) and, for the 25 pairs
+    of real_path_strips.npz, the committed 640-px crops (what the CPU and GPU parity tests run)."""
+    from PIL import Image
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    from imagestitch_amd.utility import roi_rect
+    O.build()
+    path = json.load(open(os.path.join(OUT, "dendritic_path_oracle.json")))["rows"]
+    d = os.path.join(refshim.REF, "demoImages", "dendriticCrystal", "1")
+
+    def load(t):
+        im = Image.open(os.path.join(d, "1-%03d.jpg" % t)); im.draft("L", im.size)
+        return np.asarray(im.convert("L"))
+
+    def record(a, b, H, W, dd, ii, gold):
+        """phase-correlate strips a, b cut for (direction dd, growth ii) from H x W tiles -> row"""
+        (x, y), resp = O.phase_correlate(a, b)
+        corr = [0, 0]                                          # Stitcher.py:244-251 for the accepted direction
+        if dd == 1: corr[0] = H - int(ii * 0.2 * H)
+        elif dd == 2: corr[1] = W - int(ii * 0.2 * W)
+        elif dd == 3: corr[0] = -(H - int(ii * 0.2 * H))
+        elif dd == 4: corr[1] = -(W - int(ii * 0.2 * W))
+        M, N = _opt_dft(a.shape[0]), _opt_dft(a.shape[1])
+        fixed = [-int(y) + corr[0], -int(x) + corr[1]]        # phaseSignFix = True
+        asref = [int(y) + corr[0], int(x) + corr[1]]          # the reference as written (mirrored)
+        res = [(fixed[0] - gold[0] + M // 2) % M - M // 2, (fixed[1] - gold[1] + N // 2) % N - N // 2]
+        return dict(direction=dd, i=ii, gold=gold, roi=list(a.shape), padded=[M, N], phase_xy=[x, y], response=resp, axis_correction=corr,
+                    offset_sign_fixed=fixed, offset_as_written=asref, residual_mod_padded=res,
+                    in_strip_shift=[gold[0] - corr[0], gold[1] - corr[1]], accepted=bool(resp > 0.15))
+    rows = []
+    tile = {}
+    for r in path:
+        a_, b_ = r["a"], r["b"]
+        for t in (a_, b_):
+            if t not in tile:
+                tile[t] = load(t)
+        for old in [k for k in tile if k < a_]:
+            del tile[old]
+        A, B = tile[a_], tile[b_]
+        H, W = A.shape
+        ra = roi_rect((H, W), r["direction"], "first", r["i"] * 0.2); rb = roi_rect((H, W), r["direction"], "second", r["i"] * 0.2)
+        sa = np.ascontiguousarray(A[ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]]); sb = np.ascontiguousarray(B[rb[0]:rb[0] + rb[2], rb[1]:rb[1] + rb[3]])
+        row = record(sa, sb, H, W, r["direction"], r["i"], r["gold"])
+        row.update(a=a_, b=b_)
+        rows.append(row)
+        print("phase87 full", a_, r["direction"], r["gold"], row["offset_sign_fixed"], row["residual_mod_padded"], "%.3f" % row["response"], flush=True)
+    # the committed crops
+    meta = json.load(open(os.path.join(OUT, "real_path_strips.json")))["neighbourhoods"]
+    z = np.load(os.path.join(OUT, "real_path_strips.npz"))
+    crops = []
+    for nb in meta:
+        H, W = nb["shape"]
+        by_tile = {}
+        for s_ in nb["strips"]:
+            by_tile.setdefault(s_["tile"], []).append(s_)
+        for e in nb["expected"]:
+            a_ = e["a"]
+            # the strip of tile a cut as "first" and of tile a + 1 cut as "second" for the accepted direction: the crop whose origin matches
+            ra = roi_rect((H, W), e["direction"], "first", e["i"] * 0.2); rb = roi_rect((H, W), e["direction"], "second", e["i"] * 0.2)
+
+            def pick(t, rect):
+                for s_ in by_tile[t]:
+                    arr = z[s_["key"]]
+                    if rect[0] <= s_["y0"] and s_["y0"] + arr.shape[0] <= rect[0] + rect[2] and rect[1] <= s_["x0"] and s_["x0"] + arr.shape[1] <= rect[1] + rect[3]:
+                        return s_["key"], arr
+                raise KeyError((t, rect))
+            ka, sa = pick(a_, ra); kb, sb = pick(a_ + 1, rb)
+            assert sa.shape == sb.shape
+            row = record(np.ascontiguousarray(sa), np.ascontiguousarray(sb), H, W, e["direction"], e["i"], e["gold"])
+            row.update(a=a_, b=a_ + 1, key_a=ka, key_b=kb)
+            crops.append(row)
+            print("phase87 crop", a_, e["direction"], e["gold"], row["offset_sign_fixed"], row["residual_mod_padded"], "%.3f" % row["response"], flush=True)
+    ok_full = [r for r in rows if r["accepted"] and max(abs(v) for v in r["residual_mod_padded"]) <= 1]
+    ok_crop = [r for r in crops if r["accepted"] and max(abs(v) for v in r["residual_mod_padded"]) <= 1]
+    json.dump(dict(source="oracle phase correlation (oracle/vfsms_oracle.c) of the ROI strips of the accepted (direction, i) of every dendriticCrystal pair "
+                          "(tiles 003..090, Pillow draft-L decode) against gold = Stitcher.py:87; offset_sign_fixed = -[int(y), int(x)] + axis correction "
+                          "(Stitcher.phaseSignFix), residual_mod_padded = (offset_sign_fixed - gold) wrapped to the padded strip size; "
+                          "full = whole strips (rows only), crops = the committed 640-px crops of real_path_strips.npz",
+                   full=rows, crops=crops, full_accepted=sum(r["accepted"] for r in rows), full_within_one=len(ok_full),
+                   crops_accepted=sum(r["accepted"] for r in crops), crops_within_one=len(ok_crop)),
+              open(os.path.join(OUT, "dendritic_phase87.json"), "w"), indent=1)
+    print("phase87: full %d pairs, %d accepted, %d within 1 px mod padded; crops %d, %d accepted, %d within" %
+          (len(rows), sum(r["accepted"] for r in rows), len(ok_full), len(crops), sum(r["accepted"] for r in crops), len(ok_crop)))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["roi", "mode", "sm", "cache", "fuse", "stitch", "flow", "real", "realpath", "demo"]
     fns = dict(roi=cap_roi, mode=cap_mode, sm=cap_state_machine, cache=cap_feature_search_cache,
                fuse=cap_fuse, stitch=cap_stitch, flow=cap_flow, real=cap_real, realpath=cap_real_path, realpath_orb=cap_real_path_orb,
-               demo=cap_demo_strips, phase2=cap_phase_independent)
+               demo=cap_demo_strips, phase2=cap_phase_independent, phase87=cap_phase87)
     for w in which:
         fns[w]()
