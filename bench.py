@@ -365,6 +365,7 @@ def bench_from_files(args, eng, grid, torch):
                 e2e()
             torch.cuda.synchronize(); eng.sync()
             dt = (time.perf_counter() - t0) / args.steps
+            ist = dict(getattr(s, "_ingestStats", {}) or {})
             # decode only, same pool size
             with ThreadPoolExecutor(max_workers=nthreads) as ex:
                 t0 = time.perf_counter()
@@ -405,6 +406,9 @@ def bench_from_files(args, eng, grid, torch):
                "decode_one_tile_one_thread_ms": round(dt_one * 1e3, 2),
                "registration_only_ms_per_step": round(dt_reg * 1e3, 2), "registration_only_pairs_per_s": round(P / dt_reg, 1),
                "end_to_end_over_slower_stage": round(dt / slower, 3),
+               "ingest_thread_ms_per_tile": (dict(decode=round(ist["decode_s"] / max(ist["tiles"], 1) * 1e3, 2), hand_over=round(ist["fill_s"] / max(ist["tiles"], 1) * 1e3, 2))
+                                             if ist.get("tiles") else None),
+               "startup_bubble_note": "a path cannot start before its first tiles are decoded: end-to-end >= one tile's decode latency + the registration time",
                "roofline": None, "cpu_baseline": None})
     eng.close()
 

@@ -236,6 +236,7 @@ extern "C" int vfsms_ctx_destroy(vfsms_ctx *ctx)
     for (auto &kv : ctx->tiles) { if (kv.second.owned) hipFree(kv.second.ptr); if (kv.second.ready) hipEventDestroy(kv.second.ready); }
     for (auto &pe : ctx->tile_pool) { hipFree(pe.ptr); if (pe.idle) hipEventDestroy(pe.idle); }
     for (auto &sb : ctx->stage_pool) hipFree(sb.ptr);
+    for (auto &pb : ctx->pin_pool) hipHostFree(pb.ptr);
     for (hipEvent_t ev : ctx->event_pool) hipEventDestroy(ev);
     hipStreamDestroy(ctx->copy_stream);
     for (auto &kv : ctx->canvases) { hipFree(kv.second.pix); hipFree(kv.second.mask); hipFree(kv.second.d_err); hipFree(kv.second.scratch); }
@@ -365,6 +366,32 @@ extern "C" int vfsms_tile_upload_ch(vfsms_ctx *ctx, const uint8_t *img, int h, i
 }
 // ---- tiles whose pixels arrive later, from other threads: the ingest pipeline (Stitcher.py:68-69 decodes file after file BEFORE the
 // first pair is registered; here the registration of tiles 0, 1, ... starts while tile k is still being decoded) -------------------------
+// Pinned host staging for the decoder threads' hand-overs (vfsms_tile_fill*): the decoder's own memory is pageable, and an asynchronous copy
+// from pageable memory makes the runtime pin it on the fly (a trip through the kernel's memory-map lock per tile, contended by every
+// decoder thread and by the registrar's launches).  The rows are packed into a pinned buffer by the calling thread (a memcpy, in parallel
+// across the decoders) and leave by true DMA.  The pool is shared by the fill threads under stage_mu.
+static int stage_pinned_get(vfsms_ctx *ctx, size_t need, StageBuf *out)
+{
+    {
+        std::lock_guard<std::mutex> lk(ctx->stage_mu);
+        for (size_t k = 0; k < ctx->pin_pool.size(); k++)
+            if (ctx->pin_pool[k].bytes >= need) { *out = ctx->pin_pool[k]; ctx->pin_pool.erase(ctx->pin_pool.begin() + k); return VFSMS_OK; }
+    }
+    out->ptr = nullptr; out->bytes = need;
+    HIP_TRY(hipHostMalloc((void **)&out->ptr, need, hipHostMallocDefault));
+    return VFSMS_OK;
+}
+static void stage_pinned_put(vfsms_ctx *ctx, StageBuf b)
+{
+    if (!b.ptr) return;
+    std::lock_guard<std::mutex> lk(ctx->stage_mu);
+    if (ctx->pin_pool.size() < 64) ctx->pin_pool.push_back(b); else hipHostFree(b.ptr);
+}
+static void pack_rows(uint8_t *dst, const uint8_t *src, int stride, size_t row_bytes, int h)
+{
+    if ((size_t)stride == row_bytes) { memcpy(dst, src, row_bytes * h); return; }
+    for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * row_bytes, src + (size_t)y * stride, row_bytes);
+}
 static int tile_reserve_impl(vfsms_ctx *ctx, int h, int w, int ch, int64_t *handle)
 {
     if (!handle || h <= 0 || w <= 0 || ch < 1 || ch > 4) { vfsms_set_error("tile_reserve: bad arguments"); return VFSMS_ERR_BAD_ARG; }
@@ -409,9 +436,16 @@ extern "C" int vfsms_tile_fill(vfsms_ctx *ctx, int64_t handle, const uint8_t *im
         if (stride < it->second.w * it->second.ch) { vfsms_set_error("tile_fill: stride smaller than a row of the tile"); return VFSMS_ERR_BAD_ARG; }
         ev = it->second.ready; dst = it->second.ptr; h = it->second.h; w = it->second.w * it->second.ch;
     }
-    hipError_t e = hipMemcpy2DAsync(dst, w, img, stride, w, h, hipMemcpyHostToDevice, ctx->copy_stream);
+    StageBuf pb{nullptr, 0};
+    hipError_t e = hipSuccess;
+    if (stage_pinned_get(ctx, (size_t)w * h, &pb) == VFSMS_OK) {
+        pack_rows(pb.ptr, img, stride, (size_t)w, h);
+        e = hipMemcpyAsync(dst, pb.ptr, (size_t)w * h, hipMemcpyHostToDevice, ctx->copy_stream);
+    } else e = hipMemcpy2DAsync(dst, w, img, stride, w, h, hipMemcpyHostToDevice, ctx->copy_stream);   // no pinned memory left: straight from the caller's
     if (e == hipSuccess) e = hipEventRecord(ev, ctx->copy_stream);
     if (e == hipSuccess) e = hipEventSynchronize(ev);
+    else hipStreamSynchronize(ctx->copy_stream);
+    stage_pinned_put(ctx, pb);
     {
         std::lock_guard<std::mutex> lk(ctx->tiles_mu);
         auto it = ctx->tiles.find(handle);
@@ -458,12 +492,19 @@ extern "C" int vfsms_tile_fill_pair(vfsms_ctx *ctx, int64_t gray, int64_t color,
     hipError_t e = hipSuccess;
     if (!sb.ptr) { e = hipMalloc((void **)&sb.ptr, need); sb.bytes = need; }
     int rc = VFSMS_OK;
-    if (e == hipSuccess) e = hipMemcpy2DAsync(sb.ptr, (size_t)w * spx, src, stride_bytes, (size_t)w * spx, h, hipMemcpyHostToDevice, ctx->copy_stream);
+    StageBuf pb{nullptr, 0};
+    if (e == hipSuccess) {
+        if (stage_pinned_get(ctx, need, &pb) == VFSMS_OK) {
+            pack_rows(pb.ptr, src, stride_bytes, (size_t)w * spx, h);
+            e = hipMemcpyAsync(sb.ptr, pb.ptr, need, hipMemcpyHostToDevice, ctx->copy_stream);
+        } else e = hipMemcpy2DAsync(sb.ptr, (size_t)w * spx, src, stride_bytes, (size_t)w * spx, h, hipMemcpyHostToDevice, ctx->copy_stream);
+    }
     if (e == hipSuccess) rc = launch_ingest_split(ctx->copy_stream, sb.ptr, dg, dc, (long long)h * w, format);
     if (e == hipSuccess && rc == VFSMS_OK) e = hipEventRecord(ev, ctx->copy_stream);
     if (e == hipSuccess && rc == VFSMS_OK) e = hipEventSynchronize(ev);
+    if (e != hipSuccess || rc != VFSMS_OK) hipStreamSynchronize(ctx->copy_stream);   // nothing may still read the staging buffers when they are reused
+    stage_pinned_put(ctx, pb);
     if (sb.ptr) {
-        if (e != hipSuccess) hipStreamSynchronize(ctx->copy_stream);          // nothing may still read the staging buffer when it is reused
         std::lock_guard<std::mutex> lk(ctx->stage_mu);
         if (ctx->stage_pool.size() < 64) ctx->stage_pool.push_back(sb); else hipFree(sb.ptr);
     }

@@ -162,7 +162,8 @@ struct vfsms_ctx {
     vfsms_orb_params cur_orb; bool orb_valid; OrbTables *d_orb_tables;
     std::unordered_map<int64_t, TileRec> tiles;
     std::mutex tiles_mu; std::condition_variable tiles_cv;   // reserved tiles are filled by other threads (vfsms_tile_fill*): they look tiles up and write TileRec::fill / pending under this mutex and enqueue on the copy stream; the map's structure, the buffer / event pools and the arena belong to the context's own thread
-    std::mutex stage_mu; std::vector<StageBuf> stage_pool;   // staging buffers of the decoder threads (vfsms_tile_fill_pair), the one pool they share
+    std::mutex stage_mu; std::vector<StageBuf> stage_pool;   // device staging buffers of the decoder threads (vfsms_tile_fill_pair), the pools they share
+    std::vector<StageBuf> pin_pool;                          // pinned host staging of the same threads (also under stage_mu)
     hipStream_t copy_stream;                                  // H2D uploads of tiles, overlapped with compute (vfsms_tile_upload_async)
     std::vector<PoolEnt> tile_pool;      // freed tile buffers, reused by allocation size (no hipMalloc / hipFree per step)
     size_t tile_pool_bytes = 0;

@@ -29,6 +29,9 @@ typedef GAS float *g_f32;
 typedef GAS const float *g_cf32;
 typedef GAS int32_t *g_i32;
 __device__ __forceinline__ int cv_round_f(float v) { return (int)rintf(v); }      // round-half-even
+// (uchar)cvRound(v) for 0 <= v < 2^22 in ONE VOP2 add: v + 1.5 * 2^23 has an ulp of 1, so the sum is v rounded half-to-even and the integer
+// sits in the low mantissa bits -- the byte store takes it from there (v_rndne_f32 + v_cvt_i32_f32 before).
+__device__ __forceinline__ uint8_t round_u8_pos(float v) { return (uint8_t)__float_as_uint(v + 12582912.f); }
 __device__ __forceinline__ int cv_round_d(double v) { return (int)rint(v); }
 __device__ __forceinline__ int cv_floor_d(double v) { return (int)floor(v); }
 __device__ __forceinline__ int cv_ceil_d(double v) { return (int)ceil(v); }
@@ -1011,7 +1014,11 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
 #pragma unroll
             for (int u = 0; u < STAGE_ILP; u++) {
                 const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
+#if VFSMS_EXP & 2
                 drc[jc[u]] = (uint8_t)cv_round_f(bilinear_pk(top[u], a, b));
+#else
+                drc[jc[u]] = round_u8_pos(bilinear_pk(top[u], a, b));
+#endif
             }
             DT_UNIT_END(0);
             continue;
@@ -1122,6 +1129,9 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
         // so one lane of wave 0 walks x while one lane of wave 1 walks y.
         // sin/cos of the orientation were evaluated one thread per keypoint by k_desc_trig and parked behind the keypoint's
         // patch row (several workgroups may work on one large keypoint, so the patch bytes themselves cannot be borrowed).
+#if !(VFSMS_EXP & 1)
+        // (one lane of wave 0 walks x while one lane of wave 1 walks y; both chains in lanes 0 / 1 of ONE wave -- half the issue slots -- measured
+        //  0.7 % SLOWER on the fixed 16-pair batch: the prologue is latency, not issue, and the lane select lengthens the chain)
         if (threadIdx.x == 0 || threadIdx.x == 64) {
             const float sin_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[0];
             const float cos_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[1];
@@ -1135,6 +1145,20 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
                 origin_chain(sy_row, kp.y - win_offset * sin_dir + win_offset * cos_dir, cos_dir, need);
             }
         }
+#else
+        // lanes 0 and 1 of ONE wave: a wave instruction costs its issue slot whether 1 or 64 lanes are active, and this kernel is bound by
+        // instruction issue -- two waves walking one chain each issued the loop twice
+        if (threadIdx.x < 2) {
+            const float sin_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[0];
+            const float cos_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[1];
+            const float win_offset = -(float)(win - 1) / 2;
+            // a band ticket only needs the origins up to the last source row of its band
+            const int need = band >= 0 ? min(win, REC[band].j0 + REC[band].n) : win;
+            if (threadIdx.x == 0) { trig_s[0] = sin_dir; trig_s[1] = cos_dir; }
+            const float sx0 = kp.x + win_offset * cos_dir + win_offset * sin_dir, sy0 = kp.y - win_offset * sin_dir + win_offset * cos_dir;
+            origin_chain(threadIdx.x == 0 ? sx_row : sy_row, threadIdx.x == 0 ? sx0 : sy0, threadIdx.x == 0 ? sin_dir : cos_dir, need);
+        }
+#endif
     } else {
         const float win_offset = -(float)(win - 1) / 2;
         G.usx = cv_round_f(kp.x + win_offset);

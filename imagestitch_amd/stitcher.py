@@ -326,10 +326,14 @@ class Stitcher(Utility.Method):
                     except Exception:
                         block_alloc = None
 
+                istats = self._ingestStats = dict(tiles=0, decode_s=0.0, fill_s=0.0, threads=nthreads)   # summed over the decoder threads
+
                 def ingest(k):
                     hc = chandles[k] if color else 0
                     try:
+                        t0 = time.perf_counter()
                         owner, shape, parts = _decode_once(fileList[k], color)
+                        t1 = time.perf_counter()
                         if tuple(shape) != tuple(shapes[k]):
                             raise ValueError("decoded size %s of %s differs from its header %s" % (shape, fileList[k], shapes[k]))
                         if parts[0] == "src":
@@ -342,6 +346,7 @@ class Stitcher(Utility.Method):
                             if hc:
                                 eng.tile_fill(hc, parts[2])
                         del owner
+                        istats["tiles"] += 1; istats["decode_s"] += t1 - t0; istats["fill_s"] += time.perf_counter() - t1
                     except BaseException:
                         for h in (handles[k], hc):            # the batch waiting for this tile fails instead of hanging
                             if h:
