@@ -471,6 +471,7 @@ def main():
     ap.add_argument("--offset-evaluate", type=int, default=3, help="Method.offsetEvaluate (Main.py:12: 3)")
     ap.add_argument("--cpu-sample", type=int, default=12, help="pairs timed on the host cores for cpu_baseline (0 = skip)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-resident-tiles measurement")
+    ap.add_argument("--no-path-hint", action="store_true", help="N > 1: do not hand the scan pattern to the registrar (blind chunk starts, chunks by pair count)")
     ap.add_argument("--workload", default="grid", choices=["grid", "dendritic25"],
                     help="grid = the synthetic serpentine grid (BASELINE metric); dendritic25 = the 25 committed real pairs (N = 1, surf)")
     ap.add_argument("--from-files", action="store_true", help="N = 1: JPEG tiles on disk through Stitcher's ingest pipeline (decode inclusive)")
@@ -497,6 +498,15 @@ def main():
             dist.init_process_group(backend)
     coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     assert world == args.gpus, "launch with --nproc-per-node == --gpus"
+    if dist is not None:
+        # fail loudly BEFORE anything is measured: the process group must span exactly --gpus ranks and, under RCCL, every rank must
+        # sit on a GPU of its own (two ranks on one device would still produce a line -- of a job that is not the one asked for)
+        assert dist.get_world_size() == args.gpus, "process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus)
+        devs = [None] * world
+        dist.all_gather_object(devs, (os.environ.get("HOSTNAME", ""), int(torch.cuda.current_device()), torch.cuda.get_device_properties(local_rank).name))
+        if backend == "nccl":
+            assert len({(h, d) for h, d, _n in devs}) == world, "ranks share a GPU under the nccl backend: %r" % (devs,)
+            assert torch.cuda.device_count() >= world, "%d visible GPUs for %d ranks" % (torch.cuda.device_count(), world)
 
     import imagestitch_amd as isa
     from imagestitch_amd.grid import GridRegistrar
@@ -513,7 +523,13 @@ def main():
         return bench_from_files(args, eng, grid, torch)
     P = grid.n_pairs
     truth = np.array(grid.true_offsets(), np.int64)
-    bounds = GridRegistrar.chunk_bounds(P, world)
+    # N > 1: the stage's scan pattern (a column serpentine of known height -- the operator knows it, the bench built the grid from it) is
+    # handed to the registrar as a PREDICTION of the accepted directions: a rank inside the path then starts one chain with a primed
+    # predictor instead of four blind ones, and the chunks are cut by the attempts the pattern predicts.  Results never depend on it
+    # (tests/test_grid_registrar.py); --no-path-hint measures the blind form.
+    hint = None if (args.no_path_hint or world == 1) else [int(d) for d in grid.true_directions()]
+    _reg0 = GridRegistrar(eng, method=args.method if args.method in ("surf", "orb", "phase") else "surf", roiRatio=0.2, directIncre=1)
+    bounds = _reg0._bounds(P, world, None, hint, 1)
     lo, hi = bounds[rank]
     need = list(range(lo, hi + 1)) if hi > lo else []
     # tiles live in pinned host memory (what a decoder feeding this engine would write into): uploads from it are asynchronous DMA
@@ -537,7 +553,7 @@ def main():
     gather = make_all_gather(coll_device) if world > 1 else single_process_all_gather
 
     def step(hs=handles):
-        return reg.register_sharded(hs, shapes, 1, rank, world, gather)
+        return reg.register_sharded(hs, shapes, 1, rank, world, gather, hint=hint)
 
     def step_from_host():
         """the same step with the tiles in host memory at its start: asynchronous uploads in path order on the copy stream (the
@@ -731,7 +747,9 @@ def main():
                                    "direction 1, directIncre 1" % (args.rows, args.cols, args.tile, args.tile, 100 * args.overlap, P,
                                       {"surf": "SURF(100,4,3,64-d)+BF-L2 knn2 ratio 0.75 + mode vote", "orb": "ORB(5000,1.2,8)+BF-Hamming 1-NN + mode vote",
                                        "phase": "FFT phase correlation of the ROI strips"}[args.method], args.offset_evaluate),
-                       "pairs": P, "parallelism": "pairs%d" % world, "speculation_window": args.window},
+                       "pairs": P, "parallelism": "pairs%d" % world, "speculation_window": args.window,
+                       "path_hint": (None if hint is None else "scan pattern (column serpentine %dx%d) as predicted directions: hinted chunk starts, chunks cut by predicted attempts"
+                                     % (args.rows, args.cols))},
             "max_abs_offset_error_px": max_err, "pairs_failed": n_failed,
             "value_host_resident_tiles": round(P * args.steps / elapsed_host, 3) if elapsed_host else None,
             "ms_per_step_host_resident_tiles": round(elapsed_host / args.steps * 1e3, 3) if elapsed_host else None,
@@ -743,7 +761,8 @@ def main():
             "cpu_baseline": cpu,
             "stages": stages,
             "per_rank": per_rank,
-            "collective": (dict(backend=dist.get_backend(), world_size=dist.get_world_size(), device=str(coll_device),
+            "collective": (dict(backend=dist.get_backend(), world_size=dist.get_world_size(), device=str(coll_device), rank_devices=devs,
+                                hint_repair_rounds=getattr(reg, "hint_repairs", 0),
                                 op="one all_gather of the int32 offset tables per step") if dist is not None else None),
         }
         if args.method == "orb" and max_err > 1:

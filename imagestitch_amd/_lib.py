@@ -38,7 +38,8 @@ class GridParams(C.Structure):
     _fields_ = [("method", C.c_int32), ("offset_evaluate", C.c_int32), ("direct_incre", C.c_int32), ("window", C.c_int32),
                 ("orb_max_dist", C.c_int32), ("enhance_mode", C.c_int32), ("tile_grid", C.c_int32), ("reserved", C.c_int32),
                 ("roi_ratio", C.c_double), ("search_ratio", C.c_double), ("phase_threshold", C.c_double), ("clip_limit", C.c_double),
-                ("surf", SurfParams), ("orb", OrbParams)]
+                ("surf", SurfParams), ("orb", OrbParams),
+                ("path_hint", C.POINTER(C.c_int32)), ("path_hint_len", C.c_int32), ("reserved2", C.c_int32)]
 
 
 ATTEMPT_EVAL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(AttemptKey), C.c_int, C.POINTER(C.c_int32))
@@ -501,8 +502,13 @@ class Engine:
     # -- whole shooting paths ------------------------------------------------------------------------------------------------
     @staticmethod
     def grid_params(method="surf", roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3, directIncre=1, window=24, surf=None, orb=None,
-                    phaseResponseThreshold=0.15, orbMaxDistance=-1, enhance=(0, 0.0, 0)):
+                    phaseResponseThreshold=0.15, orbMaxDistance=-1, enhance=(0, 0.0, 0), hint=None):
         p = GridParams()
+        if hint is not None and len(hint):
+            arr = np.ascontiguousarray(hint, np.int32)
+            p._hint_keepalive = arr                          # the struct only holds the address
+            p.path_hint = arr.ctypes.data_as(C.POINTER(C.c_int32))
+            p.path_hint_len = len(arr)
         p.method = {"surf": 0, "orb": 1, "phase": 2}[method]
         p.offset_evaluate, p.direct_incre, p.window, p.orb_max_dist = int(offsetEvaluate), int(directIncre), int(window), int(orbMaxDistance)
         p.enhance_mode, p.clip_limit, p.tile_grid = int(enhance[0]), float(enhance[1]), int(enhance[2])

@@ -108,6 +108,28 @@ struct Chain {
         int run_len = 0, slow = 1, prev_d = 0, d = d_in;
         std::map<int, int> ring_hint;                        // direction -> ring position that resolved the last turn from it
         std::map<std::pair<int, int>, int> trans2;           // (direction before, direction) -> direction the next turn led to
+        if (P->path_hint && P->path_hint_len > 0 && first > 0) {
+            // A chain that starts inside the path: the predictor is primed with the history the PREDICTED directions imply for the pairs
+            // before `first` (run lengths, the direction each turn led to, the ring position that resolved it), as if this chain had
+            // registered them itself.  Bookkeeping only -- nothing is evaluated, nothing cached.
+            int hd = P->path_hint[0];
+            const int upto = std::min(first, (int)P->path_hint_len);
+            for (int k = 0; k < upto && hd >= 1 && hd <= 4; k++) {
+                const int nd = P->path_hint[k];
+                if (nd < 1 || nd > 4) break;
+                if (nd == hd) { run_len += 1; slow = std::min(2 * slow, window); }
+                else {
+                    runs.push_back(run_len);
+                    run_len = 1; slow = 1;
+                    trans2[std::make_pair(prev_d, hd)] = nd;
+                    const std::vector<std::pair<int, int>> rg = ring(hd, 1);
+                    for (size_t q = 0; q < rg.size(); q++) if (rg[q].first == nd) { ring_hint[hd] = (int)q; break; }
+                    prev_d = hd;
+                }
+                hd = nd;
+            }
+            if (hd != d_in) { runs.clear(); run_len = 0; slow = 1; prev_d = 0; ring_hint.clear(); trans2.clear(); }   // entered differently than predicted: no basis
+        }
         for (int k = first; k < last; k++) {
           Row row; int d_next;
           const auto mem = memo.find(std::make_pair(k, d));

@@ -143,7 +143,7 @@ class GridRegistrar:
         return dx, dy
 
     # -- sequentially-equivalent chain over pairs [first, last) ------------------------------------------------------
-    def chain(self, handles, shapes, first, last, d_in, memo=None, cache=None, midpath=False, stop_on_fail=False):
+    def chain(self, handles, shapes, first, last, d_in, memo=None, cache=None, midpath=False, stop_on_fail=False, hint=None):
         """-> (int32[last-first, 6], d_out).
 
         An attempt is a pure function of (pair, direction, i), so WHICH attempts are evaluated together is free;
@@ -166,6 +166,28 @@ class GridRegistrar:
         runs, run_len, slow, ring_hint = [], 0, 1, {}
         trans2 = {}                                   # (direction before, direction) -> direction the next turn led to
         prev_d = 0
+        if hint is not None and len(hint) and first > 0:
+            # a chain that starts inside the path: prime the predictor with the history the predicted directions imply for the pairs
+            # before `first` (csrc/grid.hip does the same); bookkeeping only
+            hd = int(hint[0])
+            for kk in range(min(first, len(hint))):
+                nd = int(hint[kk])
+                if not (1 <= hd <= 4 and 1 <= nd <= 4):
+                    break
+                if nd == hd:
+                    run_len += 1
+                    slow = min(2 * slow, self.window)
+                else:
+                    runs.append(run_len)
+                    run_len, slow = 1, 1
+                    trans2[(prev_d, hd)] = nd
+                    ring0 = [c[0] for c in self.rings(hd)[0]]
+                    if nd in ring0:
+                        ring_hint[hd] = ring0.index(nd)
+                    prev_d = hd
+                hd = nd
+            if hd != d_in:                            # entered differently than predicted: no basis
+                runs, run_len, slow, ring_hint, trans2, prev_d = [], 0, 1, {}, {}, 0
         d = d_in
         k = first
 
@@ -256,11 +278,12 @@ class GridRegistrar:
 
     native = True      # run whole chains inside the library (vfsms_pairs_offsets) when the engine offers it; chain() is the same machine in Python
 
-    def _grid_params(self):
+    def _grid_params(self, hint=None):
+        kw = dict(hint=hint) if hint is not None else {}
         return self.eng.grid_params(method=self.method, roiRatio=self.roiRatio, searchRatio=self.searchRatio, offsetEvaluate=self.offsetEvaluate,
                                     directIncre=self.directIncre, window=self.window, surf=self.params if self.method == "surf" else None,
                                     orb=self.params if self.method == "orb" else None, phaseResponseThreshold=self.phaseThr,
-                                    orbMaxDistance=getattr(self, "orbMaxDistance", -1), enhance=self.enhance)
+                                    orbMaxDistance=getattr(self, "orbMaxDistance", -1), enhance=self.enhance, **kw)
 
     def _native_stats(self, st):
         self.stats["attempts"] += st[0]; self.stats["batches"] += st[1]
@@ -277,25 +300,82 @@ class GridRegistrar:
         return self.chain(handles, shapes, 0, len(handles) - 1, direction, stop_on_fail=stop_on_fail)
 
     # -- pair-sharded ---------------------------------------------------------------------------------------------------
-    @staticmethod
-    def chunk_bounds(n_pairs, world):
-        # balanced contiguous chunks; the remainder goes to the lowest ranks (rank 0 is the cheapest: it knows its incoming direction)
-        base, extra = divmod(n_pairs, world)
-        bounds, lo = [], 0
-        for r in range(world):
-            hi = lo + base + (1 if r < extra else 0)
-            bounds.append((lo, hi))
-            lo = hi
-        return bounds
+    BLIND_START_COST = 3.0     # a chunk entered with an unknown direction tries four first candidates instead of one
 
-    def shard_payload(self, handles, shapes, direction, rank, world):
+    @staticmethod
+    def chunk_bounds(n_pairs, world, weights=None, blind_cost=None):
+        """Contiguous chunks of the path, one per rank.  Without `weights`: balanced by pair count (the remainder goes to the lowest ranks;
+        rank 0 is the cheapest, it knows its incoming direction).  With weights (expected attempts per pair, path_weights): the partition
+        that minimises the most loaded rank (every rank but 0 carrying `blind_cost`, the price of a start with an unknown direction) --
+        a pair that changes the direction costs 2-4 attempts, so chunks by pair count leave the ranks that hold the turns over the mean.
+        Deterministic: every rank computes the same."""
+        if weights is None or world <= 1 or n_pairs <= 0:
+            base, extra = divmod(n_pairs, world)
+            bounds, lo = [], 0
+            for r in range(world):
+                hi = lo + base + (1 if r < extra else 0)
+                bounds.append((lo, hi))
+                lo = hi
+            return bounds
+        w = [float(v) for v in weights]
+        if len(w) != n_pairs:
+            raise ValueError("chunk_bounds: one weight per pair")
+        blind = GridRegistrar.BLIND_START_COST if blind_cost is None else float(blind_cost)
+
+        def cuts(limit):
+            """greedy: every rank takes pairs while it stays within `limit` -> bounds, or None when the path does not fit"""
+            bounds, lo = [], 0
+            for r in range(world):
+                acc, hi = (blind if r > 0 else 0.0), lo
+                while hi < n_pairs and acc + w[hi] <= limit:
+                    acc += w[hi]; hi += 1
+                bounds.append((lo, hi))
+                lo = hi
+            return bounds if lo == n_pairs else None
+        lo_l, hi_l = 0.0, sum(w) + blind
+        for _ in range(60):                                 # bisection on the bottleneck load
+            mid = 0.5 * (lo_l + hi_l)
+            if cuts(mid) is None:
+                lo_l = mid
+            else:
+                hi_l = mid
+        return cuts(hi_l)
+
+    def path_weights(self, directions, direction_in=1):
+        """Expected attempts per pair from a PREDICTION of the accepted directions (e.g. the stage's scan pattern: a column serpentine of
+        known height): a pair that keeps the direction costs one attempt, a pair that changes it the candidates the rotation tries up to
+        the new direction (Stitcher.py:319-351: 1 + rotation steps) -- what a chain with a primed predictor evaluates (BASELINE
+        configs[1]'s serpentine: 89 pairs, 16 direction changes, 123 attempts).  Only the work split depends on it."""
+        w, d = [], int(direction_in)
+        for nd in directions:
+            nd = int(nd)
+            steps, c = 0, d
+            while c != nd and steps < 4 and self.directIncre != 0:
+                c = _rotate(c, self.directIncre); steps += 1
+            w.append(1.0 + steps)
+            d = nd
+        return w
+
+    def _bounds(self, P, world, weights, hint, direction):
+        """the work split of the sharded form: by the caller's weights, else -- with a hint -- by the attempts the hint predicts (a hinted
+        start costs nothing extra), else by pair count"""
+        if weights is None and hint is not None and len(hint) == P and world > 1:
+            return self.chunk_bounds(P, world, self.path_weights(hint, direction), blind_cost=0.0)
+        return self.chunk_bounds(P, world, weights)
+
+    def shard_payload(self, handles, shapes, direction, rank, world, weights=None, hint=None, blind=False):
         """This rank's offset table: int32[4 * per * 6 + 4] = results for each possible incoming direction
-        (only the true one on rank 0 / when directIncre == 0) followed by the direction each chain ends in."""
+        (only the true one on rank 0 / when directIncre == 0) followed by the direction each chain ends in (0: chain not evaluated).
+        hint: predicted accepted direction of every pair (the stage's scan pattern).  A rank > 0 then follows ONLY the chain entered with
+        the direction the hint gives its predecessor pair -- one first candidate instead of four; a wrong hint is found out by assemble()
+        (the chain it needs is marked missing) and repaired by register_sharded in a second round.  Results never depend on the hint."""
         P = len(shapes) - 1
-        bounds = self.chunk_bounds(P, world)
+        bounds = self._bounds(P, world, weights, hint, direction)
         lo, hi = bounds[rank]
         per = max(b - a for a, b in bounds)
         dirs = [direction] if (self.directIncre == 0 or rank == 0) else [1, 2, 3, 4]
+        if len(dirs) > 1 and hint is not None and not blind and 0 < lo <= len(hint) and int(hint[lo - 1]) in (1, 2, 3, 4):
+            dirs = [int(hint[lo - 1])]
         table = np.zeros((4, per, RESULT_INTS), np.int32)
         d_out = np.zeros(4, np.int32)
         memo, cache = {}, {}
@@ -311,21 +391,23 @@ class GridRegistrar:
                 cache[it] = r
         for d_in in dirs:
             if hi > lo and len(dirs) == 1 and self.native and hasattr(self.eng, "pairs_offsets"):
-                res, dn, st = self.eng.pairs_offsets(handles, shapes, self._grid_params(), lo, hi, d_in, rank > 0, False)
+                res, dn, st = self.eng.pairs_offsets(handles, shapes, self._grid_params(hint if rank > 0 else None), lo, hi, d_in, rank > 0, False)
                 self._native_stats(st)
                 table[d_in - 1, :hi - lo] = res
             elif hi > lo:
-                res, dn = self.chain(handles, shapes, lo, hi, d_in, memo, cache, midpath=rank > 0)
+                res, dn = self.chain(handles, shapes, lo, hi, d_in, memo, cache, midpath=rank > 0, hint=hint if (rank > 0 and len(dirs) == 1) else None)
                 table[d_in - 1, :hi - lo] = res
             else:
                 dn = d_in
             d_out[d_in - 1] = dn
         return np.concatenate([table.reshape(-1), d_out])
 
-    def assemble(self, gathered, n_pairs, world, direction):
-        """Walk the gathered tables rank by rank, selecting the chain consistent with the true incoming direction."""
+    def assemble(self, gathered, n_pairs, world, direction, weights=None, missing=None, hint=None):
+        """Walk the gathered tables rank by rank, selecting the chain consistent with the true incoming direction.
+        missing (a list): receives the ranks whose table lacks the chain the walk needs (a hinted start that guessed wrong); the walk
+        stops at the first of them and the result is then incomplete."""
         P = n_pairs
-        bounds = self.chunk_bounds(P, world)
+        bounds = self._bounds(P, world, weights, hint, direction)
         per = max(b - a for a, b in bounds)
         full = np.zeros((P, RESULT_INTS), np.int32)
         d = direction
@@ -333,18 +415,45 @@ class GridRegistrar:
             a, b = bounds[r]
             t = np.asarray(gathered[r][:-4]).reshape(4, per, RESULT_INTS)
             dn = gathered[r][-4:]
+            if b > a and int(dn[d - 1]) == 0:
+                if missing is None:
+                    raise RuntimeError("rank %d did not evaluate the chain entered with direction %d" % (r, d))
+                missing.append(r)
+                return full, d
             full[a:b] = t[d - 1, :b - a]
             d = int(dn[d - 1]) if b > a else d
         return full, d
 
-    def register_sharded(self, handles, shapes, direction, rank, world, all_gather):
+    def register_sharded(self, handles, shapes, direction, rank, world, all_gather, weights=None, hint=None):
         """handles/shapes are indexed by GLOBAL tile index (only this rank's chunk + halo need be valid).
         all_gather(int32 ndarray [C]) -> int32 ndarray [world, C]   (the single collective of the path).
+        weights: expected attempts per pair (path_weights) for the work split; hint: predicted accepted directions (shard_payload);
+        every rank must pass the same.  With a hint that turns out wrong for some rank, ONE repair round follows: the ranks whose
+        chunk was entered with another direction than they assumed register it again for all four (the blind form) and the tables are
+        gathered a second time -- every rank sees the same tables, so all of them take the same decision.
         Returns the same (int32[P, 6], final direction) on every rank."""
         P = len(shapes) - 1
-        payload = self.shard_payload(handles, shapes, direction, rank, world)
+        payload = self.shard_payload(handles, shapes, direction, rank, world, weights, hint)
         gathered = all_gather(payload)
-        return self.assemble(gathered, P, world, direction)
+        if len(gathered) != world:
+            raise RuntimeError("all_gather returned %d payloads for a world of %d ranks" % (len(gathered), world))
+        if hint is None:
+            return self.assemble(gathered, P, world, direction, weights)
+        missing = []
+        full, d = self.assemble(gathered, P, world, direction, weights, missing, hint)
+        if not missing:
+            return full, d
+        # repair: every rank that followed a single hinted chain is a suspect (a wrong direction upstream changes what enters the ranks
+        # behind it); those whose assumption is not confirmed by the first walk redo their chunk blind.  One extra collective.
+        self.hint_repairs = getattr(self, "hint_repairs", 0) + 1
+        gathered = np.array(gathered, np.int32, copy=True)
+        confirmed = set(range(missing[0]))                   # the walk reached these ranks with the direction they had assumed
+        if rank in confirmed or rank == 0:
+            mine = payload
+        else:                                                # the same chunk (the hint's work split), now for every incoming direction
+            mine = self.shard_payload(handles, shapes, direction, rank, world, weights, hint, blind=True)
+        gathered = all_gather(mine)
+        return self.assemble(gathered, P, world, direction, weights, None, hint)
 
 
 def split_segments(results):

@@ -184,6 +184,111 @@ class NpyBandWriter:
             self._mm = None
 
 
+class PngBandWriter:
+    """A `Stitcher.mosaicSink` that encodes the bands into ONE PNG as they leave the device (cv2.imwrite's job at Stitcher.py:174-179,
+    without the whole mosaic in host memory): IHDR, then every band deflated into IDAT chunks by a streaming zlib compressor (filter 0
+    on every row), IEND.  Bands are B G R like the canvas; the file is R G B."""
+
+    def __init__(self, path, level=1):
+        self.path, self.level, self._f, self._z = path, level, None, None
+
+    @staticmethod
+    def _chunk(f, tag, data):
+        import struct
+        import zlib
+        f.write(struct.pack(">I", len(data))); f.write(tag); f.write(data)
+        f.write(struct.pack(">I", zlib.crc32(data, zlib.crc32(tag)) & 0xffffffff))
+
+    def __call__(self, row0, band, full_shape):
+        import struct
+        import zlib
+        if self._f is None:
+            d = os.path.dirname(self.path)
+            if d and not os.path.exists(d):
+                os.makedirs(d)
+            self._f = open(self.path, "wb")
+            self._f.write(b"\x89PNG\r\n\x1a\n")
+            ch = full_shape[2] if len(full_shape) == 3 else 1
+            self._chunk(self._f, b"IHDR", struct.pack(">IIBBBBB", full_shape[1], full_shape[0], 8, 2 if ch == 3 else 0, 0, 0, 0))
+            self._z = zlib.compressobj(self.level)
+        band = np.asarray(band)
+        if band.ndim == 3:
+            band = band[:, :, ::-1]
+        rows = np.empty((band.shape[0], 1 + band.shape[1] * (band.shape[2] if band.ndim == 3 else 1)), np.uint8)
+        rows[:, 0] = 0                                           # filter type None
+        rows[:, 1:] = band.reshape(band.shape[0], -1)
+        data = self._z.compress(rows.tobytes())
+        if data:
+            self._chunk(self._f, b"IDAT", data)
+        if row0 + band.shape[0] >= full_shape[0]:
+            data = self._z.flush()
+            if data:
+                self._chunk(self._f, b"IDAT", data)
+            self._chunk(self._f, b"IEND", b"")
+            self._f.close()
+            self._f = self._z = None
+
+
+class TiffBandWriter:
+    """A `Stitcher.mosaicSink` for uncompressed baseline TIFF (BigTIFF beyond 4 GB): one strip per band, the directory written behind the
+    last band.  R G B (or gray) 8-bit samples."""
+
+    def __init__(self, path):
+        self.path, self._f, self._strips = path, None, []
+
+    def __call__(self, row0, band, full_shape):
+        import struct
+        rows, cols = full_shape[0], full_shape[1]
+        ch = full_shape[2] if len(full_shape) == 3 else 1
+        big = rows * cols * ch + (1 << 20) >= (1 << 32)
+        if self._f is None:
+            d = os.path.dirname(self.path)
+            if d and not os.path.exists(d):
+                os.makedirs(d)
+            self._f = open(self.path, "wb")
+            self._f.write(struct.pack("<2sHHHQ", b"II", 43, 8, 0, 0) if big else struct.pack("<2sHI", b"II", 42, 0))
+            self._strips, self._band_rows = [], band.shape[0]
+        band = np.asarray(band)
+        if band.ndim == 3:
+            band = band[:, :, ::-1]
+        self._strips.append((self._f.tell(), band.size))
+        self._f.write(np.ascontiguousarray(band).tobytes())
+        if row0 + band.shape[0] < rows:
+            return
+        f, n = self._f, len(self._strips)
+        if f.tell() & 1:
+            f.write(b"\0")
+        fmt_off = "<%dQ" % n if big else "<%dI" % n
+        off_pos = f.tell(); f.write(struct.pack(fmt_off, *[o for o, _c in self._strips]))
+        cnt_pos = f.tell(); f.write(struct.pack(fmt_off, *[c for _o, c in self._strips]))
+        bps_pos = f.tell(); f.write(struct.pack("<3H", 8, 8, 8)); f.write(b"\0\0")
+        ifd = f.tell()
+        ltype = 16 if big else 4                                 # LONG8 / LONG
+        tags = [(256, ltype, 1, cols), (257, ltype, 1, rows), (258, 3, ch, bps_pos if ch == 3 else 8), (259, 3, 1, 1),
+                (262, 3, 1, 2 if ch == 3 else 1), (273, ltype, n, off_pos if n > 1 else self._strips[0][0]), (277, 3, 1, ch),
+                (278, ltype, 1, self._band_rows), (279, ltype, n, cnt_pos if n > 1 else self._strips[0][1])]
+        if big:
+            f.write(struct.pack("<Q", len(tags)))
+            for t, ty, c, v in tags:
+                f.write(struct.pack("<HHQQ", t, ty, c, v))
+            f.write(struct.pack("<Q", 0))
+            f.seek(8); f.write(struct.pack("<Q", ifd))
+        else:
+            f.write(struct.pack("<H", len(tags)))
+            for t, ty, c, v in tags:
+                f.write(struct.pack("<HHII", t, ty, c, v))
+            f.write(struct.pack("<I", 0))
+            f.seek(4); f.write(struct.pack("<I", ifd))
+        f.close()
+        self._f = None
+
+
+def band_writer_for(path):
+    """the streaming encoder for an output file name, or None when its format has none here (JPEG: written whole through Pillow)"""
+    ext = os.path.splitext(path)[1].lower()
+    return PngBandWriter(path) if ext == ".png" else TiffBandWriter(path) if ext in (".tif", ".tiff") else NpyBandWriter(path) if ext == ".npy" else None
+
+
 def _list_images(folder, extension):
     """glob(folder/*.ext): the reference relies on Windows semantics (case-insensitive, name order)."""
     ext = "." + extension.lower()
@@ -264,8 +369,30 @@ class Stitcher(Utility.Method):
             self.printAndWrite(describtion)
         return ((status, endfileIndex), stitchImage)
 
+    streamOutput = False         # imageSetStitch*: encode PNG / TIFF / NPY results band by band as they leave the device (mosaics beyond host memory)
     batchRegistration = True     # let flowStitch register a whole file list in fused device batches when the stock search is used
     decodeThreads = 0            # decoder threads of the ingest pipeline (0: one per host core, at most 16 -- beyond that Pillow's Python-side work and the registrar's own host thread get in each other's way)
+
+    def _streamTo(self, paths, pattern=None):
+        """install a mosaicSink that opens one streaming encoder per mosaic: `paths` names the files (pattern is None) or collects the
+        part files made from `pattern % n`; returns None (and installs nothing) when the format has no band encoder"""
+        probe = pattern % 0 if pattern else paths[0]
+        if band_writer_for(probe) is None:
+            return None
+        state = {"w": None, "n": 0}
+
+        def sink(row0, band, full_shape):
+            if state["w"] is None:
+                path = (pattern % state["n"]) if pattern else paths[state["n"]]
+                if pattern:
+                    paths.append(path)
+                state["n"] += 1
+                state["w"] = band_writer_for(path)
+            state["w"](row0, band, full_shape)
+            if row0 + band.shape[0] >= full_shape[0]:
+                state["w"] = None
+        self.mosaicSink = sink
+        return sink
 
     def _registerBatched(self, fileList, caculateOffsetMethod):
         """The pair loop of flowStitch (Stitcher.py:64-79) through grid.GridRegistrar when `caculateOffsetMethod` is this
@@ -471,9 +598,15 @@ class Stitcher(Utility.Method):
             if not os.path.exists(outDir):
                 os.makedirs(outDir)
             Stitcher.outputAddress = outDir if outDir.endswith(os.sep) else outDir + os.sep
-            (status, result) = self.flowStitch(fileList, caculateOffsetMethod)
+            outPath = os.path.join(outDir, "stitching_result_" + str(i) + "." + outputfileExtension)
+            streamed = self._streamTo([outPath]) if self.streamOutput else None
+            try:
+                (status, result) = self.flowStitch(fileList, caculateOffsetMethod)
+            finally:
+                if streamed is not None:
+                    self.__dict__.pop("mosaicSink", None)
             self.tempImageFeature.isBreak = True
-            _imwrite(os.path.join(outDir, "stitching_result_" + str(i) + "." + outputfileExtension), result)
+            _imwrite(outPath, result)
             if status == False:
                 self.printAndWrite("stitching Failed")
 
@@ -487,13 +620,22 @@ class Stitcher(Utility.Method):
             if not os.path.exists(outDir):
                 os.makedirs(outDir)
             Stitcher.outputAddress = outDir if outDir.endswith(os.sep) else outDir + os.sep   # printAndWrite appends the file name
-            result = self.flowStitchWithMutiple(fileList, caculateOffsetMethod)
+            parts = []
+            streamed = self._streamTo(parts, os.path.join(outDir, ".stitching_part_" + str(i) + "_%d." + outputfileExtension)) if self.streamOutput else None
+            try:
+                result = self.flowStitchWithMutiple(fileList, caculateOffsetMethod)
+            finally:
+                if streamed is not None:
+                    self.__dict__.pop("mosaicSink", None)
             self.tempImageFeature.isBreak = True
-            if len(result) == 1:
-                _imwrite(os.path.join(outDir, "stitching_result_" + str(i) + "." + outputfileExtension), result[0])
-            else:
-                for j in range(0, len(result)):
-                    _imwrite(os.path.join(outDir, "stitching_result_" + str(i) + "_" + str(j + 1) + "." + outputfileExtension), result[j])
+            names = ([os.path.join(outDir, "stitching_result_" + str(i) + "." + outputfileExtension)] if len(result) == 1 else
+                     [os.path.join(outDir, "stitching_result_" + str(i) + "_" + str(j + 1) + "." + outputfileExtension) for j in range(len(result))])
+            streamedParts = iter(parts)
+            for j in range(0, len(result)):
+                if result[j] is None:                         # streamed while it was assembled: the part file takes the reference's name
+                    os.replace(next(streamedParts), names[j])
+                else:
+                    _imwrite(names[j], result[j])
             endTime = time.time()
             print("Time Consuming for " + fileAddress + " is " + str(endTime - startTime))
 

@@ -245,6 +245,12 @@ typedef struct {
     double clip_limit;               /* Method.clipLimit                                                                           */
     vfsms_surf_params surf;
     vfsms_orb_params orb;
+    /* optional PREDICTION of the accepted direction of every pair of the path (the stage's scan pattern: e.g. a column serpentine of known
+     * height), path_hint[k] in 1..4 for pair k, or NULL.  It only primes the speculation predictor of a chain that starts inside the path
+     * (a rank of the pair-sharded form knows nothing of the runs before its chunk) -- results never depend on it.                       */
+    const int32_t *path_hint;
+    int32_t path_hint_len;
+    int32_t reserved2;
 } vfsms_grid_params;
 int vfsms_pairs_offsets(vfsms_ctx *ctx, const int64_t *tiles, const int32_t *shapes_hw, int n_tiles, int first_pair, int last_pair,
                         int direction_in, int midpath, int stop_on_fail, const vfsms_grid_params *p, int32_t *out,

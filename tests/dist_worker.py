@@ -24,12 +24,21 @@ accept = random_truth(rng, n_pairs, 0.2) if n_pairs < 100 else serpentine_truth(
 SHAPE = (1000, 1400)
 eng = ScriptedAttemptEngine(SHAPE, 0.2, accept)
 reg = GridRegistrar(eng, roiRatio=0.2, directIncre=1, window=window)
-full, d = reg.register_sharded(list(range(len(accept) + 1)), [SHAPE] * (len(accept) + 1), 1, rank, world, make_all_gather(torch.device("cpu")))
+# argv[5]: "hint" = the serpentine's own directions as the scan-pattern hint, "badhint" = the same with wrong entries (forces the repair round)
+hint = None
+mode = sys.argv[5] if len(sys.argv) > 5 else ""
+if mode in ("hint", "badhint"):
+    hint = [min(a_, key=lambda c: (c[1], c[0]))[0] if a_ else 1 for a_ in accept]
+    if mode == "badhint":
+        for k in range(7, len(hint), 97):
+            hint[k] = hint[k] % 4 + 1
+full, d = reg.register_sharded(list(range(len(accept) + 1)), [SHAPE] * (len(accept) + 1), 1, rank, world, make_all_gather(torch.device("cpu")), hint=hint)
 stats = torch.tensor([reg.stats["attempts"], reg.stats["batches"]], dtype=torch.int64)
 allstats = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
 dist.all_gather(allstats, stats)
 if rank == 0:
-    json.dump(dict(rows=full.tolist(), direction=int(d), attempts=[int(s[0]) for s in allstats], batches=[int(s[1]) for s in allstats]),
+    json.dump(dict(rows=full.tolist(), direction=int(d), attempts=[int(s[0]) for s in allstats], batches=[int(s[1]) for s in allstats],
+                   repairs=int(getattr(reg, "hint_repairs", 0))),
               open(sys.argv[1], "w"))
 dist.barrier()
 dist.destroy_process_group()

@@ -221,3 +221,8 @@ class IngestOracleEngine(OracleEngine):
 
     def canvas_fuse_tile_resident(self, h, tile_handle, y0, x0, roi, dx, dy, want_info=False, method=0):
         self.canvas_fuse_tile(h, self._tile(tile_handle), y0, x0, roi, dx, dy, method=method)
+
+    def canvas_download_bands(self, h, rows, cols, ch, band_rows=4096):
+        img = self.canvas_download(h, rows, cols, ch)
+        for r0 in range(0, rows, band_rows):
+            yield r0, img[r0:r0 + band_rows]

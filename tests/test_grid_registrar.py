@@ -199,3 +199,136 @@ def test_native_blind_chains_equal_python_twin():
         for d_in in (1, 2, 3, 4):                              # every chain is the sequential search of the chunk entered with d_in
             seq, d_end, _ = sequential(accept[lo:hi], roiRatio, incre, d_in)
             assert [list(r[:4]) for r in res[d_in - 1][:hi - lo].tolist()] == seq and int(dn[d_in - 1]) == d_end, (seed, d_in)
+
+
+def _lockstep_sharded(accept, roiRatio, incre, d0, world, window, hint, native=False):
+    """register_sharded on `world` threads with an in-process all-gather (a barrier + a shared list): the collective protocol -- including
+    the repair round of a wrong hint -- exactly as the ranks of a torch.distributed job run it"""
+    import threading
+    P = len(accept)
+    handles, shapes = list(range(P + 1)), [SHAPE] * (P + 1)
+    bar = threading.Barrier(world)
+    slots, outs, regs, errs = [None] * world, [None] * world, [None] * world, []
+
+    def work(rank):
+        try:
+            eng = ScriptedAttemptEngine(SHAPE, roiRatio, accept)
+            reg = GridRegistrar(eng, roiRatio=roiRatio, directIncre=incre, window=window)
+            reg.native = native
+            regs[rank] = reg
+
+            def all_gather(payload):
+                slots[rank] = np.asarray(payload, np.int32)
+                bar.wait()
+                g = np.stack(slots)
+                bar.wait()
+                return g
+            outs[rank] = reg.register_sharded(handles, shapes, d0, rank, world, all_gather, hint=hint)
+        except BaseException as e:                            # noqa: BLE001
+            errs.append(e); bar.abort()
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    if errs:
+        raise errs[0]
+    return outs, regs
+
+
+def test_hinted_shards_equal_sequential_whatever_the_hint():
+    """A scan-pattern hint lets a rank > 0 follow ONE chain (the predicted incoming direction, predictor primed with the predicted history)
+    instead of four blind ones.  Results never depend on it: right, random or partly wrong hints all give the sequential table -- a wrong
+    one through the repair round (one extra all-gather, the same decision on every rank)."""
+    repaired = 0
+    for seed in range(25):
+        rng = np.random.default_rng(4000 + seed)
+        roiRatio = float(rng.choice([0.1, 0.2])); incre = int(rng.choice([-1, 1])); d0 = int(rng.integers(1, 5))
+        P = int(rng.integers(6, 60)); world = int(rng.integers(2, 6)); window = int(rng.choice([3, 8, 24]))
+        accept = random_truth(rng, P, roiRatio)
+        seq, d_end, _ = sequential(accept, roiRatio, incre, d0)
+        true_dirs = [r[3] for r in seq]
+        kinds = [true_dirs, [int(rng.integers(1, 5)) for _ in range(P)], [d if rng.random() < 0.8 else d % 4 + 1 for d in true_dirs], None]
+        for hint in kinds:
+            outs, regs = _lockstep_sharded(accept, roiRatio, incre, d0, world, window, hint)
+            for full, d in outs:
+                assert d == d_end and [list(r[:4]) for r in full.tolist()] == seq, (seed, world, hint)
+            assert len({getattr(r, "hint_repairs", 0) for r in regs}) == 1            # every rank took the same decision
+            repaired += getattr(regs[0], "hint_repairs", 0)
+    assert repaired > 5
+
+
+def test_hint_removes_the_blind_start_cost_on_the_serpentine():
+    """BASELINE configs[1]'s path (10 x 9 column serpentine, 89 pairs) over 8 ranks: with the scan pattern as hint the ranks together
+    evaluate exactly the attempts of the sequential search (no blind starts, no slow speculation inside a chunk) and the busiest rank
+    stays within 20 % of the mean -- 162 attempts, busiest 22 against a mean of 15.4 sequential, without the hint.  The native chains
+    (csrc/grid.hip through vfsms_pairs_offsets_eval) take the same decisions as the Python twin."""
+    accept, dirs = [], []
+    for c in range(9):
+        d_col = 1 if c % 2 == 0 else 3
+        accept += [{(d_col, i): (3, 4) for i in range(1, 4)} for _ in range(9)]; dirs += [d_col] * 9
+        if c < 8:
+            accept.append({(2, i): (3, 4) for i in range(1, 4)}); dirs.append(2)
+    seq, d_end, n_seq = sequential(accept, 0.2, 1, 1)
+    res = {}
+    for hint in (None, dirs):
+        outs, regs = _lockstep_sharded(accept, 0.2, 1, 1, 8, 48, hint)
+        assert all([list(r[:4]) for r in full.tolist()] == seq for full, _d in outs)
+        res[hint is not None] = [r.stats["attempts"] for r in regs]
+    ref = GridRegistrar(ScriptedAttemptEngine(SHAPE, 0.2, accept), roiRatio=0.2, directIncre=1, window=48)
+    ref.native = False
+    ref.chain(list(range(90)), [SHAPE] * 90, 0, 89, 1)
+    one_gpu = ref.stats["attempts"]
+    assert sum(res[True]) == one_gpu and max(res[True]) <= 1.2 * one_gpu / 8, (res, one_gpu)
+    assert sum(res[False]) > 1.25 * one_gpu and max(res[False]) > max(res[True])
+
+
+def test_native_midpath_chain_primed_by_hint_equals_python_twin():
+    """vfsms_grid_params.path_hint (csrc/grid.hip) against GridRegistrar.chain(hint=...): a chain that starts inside the path with its
+    predictor primed by the predicted history evaluates the same batches in the same order in both, and the rows are the sequential
+    search of the chunk -- for right and for wrong hints."""
+    from imagestitch_amd._lib import pairs_offsets_eval, Engine
+    for seed in range(30):
+        rng = np.random.default_rng(9000 + seed)
+        roiRatio = float(rng.choice([0.1, 0.2])); incre = int(rng.choice([-1, 1]))
+        P = int(rng.integers(8, 70)); window = int(rng.choice([3, 8, 24, 48]))
+        accept = random_truth(rng, P, roiRatio, p_fail=0.0, p_false=0.1)
+        seq, _d, _n = sequential(accept, roiRatio, incre, 1)
+        true_dirs = [r[3] for r in seq]
+        hint = true_dirs if seed % 3 else [int(rng.integers(1, 5)) for _ in range(P)]
+        lo = int(rng.integers(1, P - 2)); hi = int(rng.integers(lo + 1, P + 1))
+        d_in = true_dirs[lo - 1]
+        eng = ScriptedAttemptEngine(SHAPE, roiRatio, accept)
+        reg = GridRegistrar(eng, roiRatio=roiRatio, directIncre=incre, window=window)
+        res_py, d_py = reg.chain(list(range(P + 1)), [SHAPE] * (P + 1), lo, hi, d_in, midpath=True, hint=hint)
+        log = []
+
+        def attempts(items, accept=accept, log=log):
+            rows = []
+            for (k, d, i) in items:
+                log.append((k, d, i))
+                acc = accept[k]
+                ok = (d, i) in acc
+                raw = acc[(d, i)] if ok else (7, -3)
+                rows.append([int(ok), raw[0], raw[1], 5 if ok else 1, 100, 100, 10, 0])
+            return rows
+        params = Engine.grid_params(method="surf", roiRatio=roiRatio, directIncre=incre, window=window, hint=hint)
+        res_c, d_c, st = pairs_offsets_eval(attempts, [SHAPE] * (P + 1), params, lo, hi, d_in, True)
+        assert np.array_equal(res_c, res_py) and d_c == d_py, seed
+        assert log == eng.log and st[1] == reg.stats["batches"], (seed, len(log), len(eng.log))
+        assert [list(r[:4]) for r in res_c.tolist()] == seq[lo:hi]
+
+
+def test_two_process_gloo_hinted_with_repair(tmp_path):
+    """world_size 2 over gloo with a scan-pattern hint that is wrong in places: the repair round (a second all-gather) runs on both ranks and
+    the table is the sequential one; with the right hint there is no repair."""
+    from scripted import serpentine_truth
+    worker = os.path.join(os.path.dirname(__file__), "dist_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    accept = serpentine_truth(32, 32, 0.2)
+    seq, d_end, _ = sequential(accept, 0.2, 1, 1)
+    for mode, port in (("hint", "29623"), ("badhint", "29625")):
+        out = os.path.join(str(tmp_path), "res_%s.json" % mode)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", port, worker, out, "1023", "5", "24", mode]
+        subprocess.check_call(cmd, env=env, timeout=900)
+        got = json.load(open(out))
+        assert got["direction"] == d_end and [r[:4] for r in got["rows"]] == seq
+        assert (got["repairs"] >= 1) == (mode == "badhint"), (mode, got["repairs"])

@@ -503,3 +503,64 @@ def test_ingest_error_paths_free_every_handle(oracle, tmp_path):
             assert status == (False, 0) and mosaic.shape[:2] == (128, 128) and not eng.live
     finally:
         isa.Stitcher.direction, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod = old
+
+
+def test_png_and_tiff_band_writers_round_trip(tmp_path):
+    """Stitcher.mosaicSink encoders behind the band stream (cv2.imwrite's place, Stitcher.py:174-179): bands of a gray and of a B G R mosaic
+    go in, Pillow reads the same pixels back (R G B in the file), for band heights that do and do not divide the image."""
+    from PIL import Image
+    rng = np.random.default_rng(21)
+    for shape in ((157, 203), (90, 131, 3)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        for ext in ("png", "tif"):
+            for band in (32, 157, 500):
+                path = os.path.join(str(tmp_path), "sub", "m%d_%d.%s" % (len(shape), band, ext))
+                sink = isa.band_writer_for(path)
+                for r0 in range(0, shape[0], band):
+                    sink(r0, img[r0:r0 + band], shape)
+                back = np.asarray(Image.open(path))
+                want = img[:, :, ::-1] if img.ndim == 3 else img
+                assert back.shape == want.shape and np.array_equal(back, want), (shape, ext, band)
+    assert isa.band_writer_for("x.jpg") is None
+
+
+def test_streamed_output_names_and_bytes_equal_the_whole_image_write(oracle, tmp_path):
+    """streamOutput: imageSetStitchWithMutiple encodes every mosaic band by band while it leaves the canvas; the files carry the reference's
+    names (stitching_result_<i>[_<j>].<ext>, Stitcher.py:174-179) and the same pixels as the whole-image write -- also across a
+    registration break (two segments, the part files renamed at the end)."""
+    from PIL import Image
+    from imagestitch_amd.synthetic import SyntheticGrid
+    g = SyntheticGrid(1, 4, 128, overlap=0.25)
+    proj = tmp_path / "p"; (proj / "1").mkdir(parents=True)
+    for k, t in enumerate(_colour_tiles(g)):
+        Image.fromarray(t).save(str(proj / "1" / ("t%02d.png" % k)))
+    old = (isa.Stitcher.direction, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod)
+    try:
+        isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod = True, "surf", "notFuse"
+        for breaks in (False, True):
+            outs = {}
+            for stream in (False, True):
+                eng = IngestOracleEngine(oracle, scripted=(lambda A, B, job: [1, 96, 0, 9, 10, 10, 9, 0]) if not breaks else _break_at_second_pair())
+                s = isa.Stitcher(); s._engine = eng; s.isPrintLog = False; s.direction = 2; isa.Stitcher.direction = 2
+                s.streamOutput = stream; s.mosaicBandRows = 50
+                out = tmp_path / ("o%d%d" % (breaks, stream))
+                s.imageSetStitchWithMutiple(str(proj), str(out) + os.sep, 1, s.calculateOffsetForFeatureSearchIncre, fileExtension="png", outputfileExtension="png")
+                names = sorted(n for n in os.listdir(str(out)) if not n.startswith("."))
+                outs[stream] = {n: np.asarray(Image.open(str(out / n))) for n in names if n.endswith(".png")}
+                assert not [n for n in os.listdir(str(out)) if n.startswith(".stitching_part")] and not eng.live
+            assert sorted(outs[False]) == sorted(outs[True]) and len(outs[True]) == (2 if breaks else 1), (breaks, sorted(outs[True]))
+            for n in outs[False]:
+                assert np.array_equal(outs[False][n], outs[True][n]), n
+    finally:
+        isa.Stitcher.direction, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod = old
+
+
+def _break_at_second_pair():
+    """scripted attempts: every attempt of the pair (tile 1, tile 2) fails -- a registration break in the middle of four tiles"""
+    seen = {}
+
+    def script(A, B, job):
+        key = (int(job[0]), int(job[1]))
+        order = seen.setdefault(key, len(seen))
+        return [0, 0, 0, 0, 10, 10, 0, 0] if order == 1 else [1, 96, 0, 9, 10, 10, 9, 0]
+    return script
