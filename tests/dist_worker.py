@@ -30,7 +30,7 @@ mode = sys.argv[5] if len(sys.argv) > 5 else ""
 if mode in ("hint", "badhint"):
     hint = [min(a_, key=lambda c: (c[1], c[0]))[0] if a_ else 1 for a_ in accept]
     if mode == "badhint":
-        for k in range(7, len(hint), 97):
+        for k in range(len(hint) // 2 - 120, len(hint) // 2 + 120):   # wrong wherever a 2-rank split can put its cut
             hint[k] = hint[k] % 4 + 1
 full, d = reg.register_sharded(list(range(len(accept) + 1)), [SHAPE] * (len(accept) + 1), 1, rank, world, make_all_gather(torch.device("cpu")), hint=hint)
 stats = torch.tensor([reg.stats["attempts"], reg.stats["batches"]], dtype=torch.int64)
