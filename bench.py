@@ -325,7 +325,7 @@ def bench_from_files(args, eng, grid, torch):
     from imagestitch_amd import stitcher as ST
     if args.gpus != 1 or args.method != "surf":
         raise SystemExit("--from-files is a single-GPU SURF measurement")
-    nthreads = max(1, min(args.decode_threads or min(os.cpu_count() or 4, 32), grid.n_tiles, 64))
+    nthreads = max(1, min(args.decode_threads or min(os.cpu_count() or 4, 16), grid.n_tiles, 64))
     color = bool(args.color)
     with tempfile.TemporaryDirectory(prefix="vfsms_bench_") as d:
         files = []
@@ -366,8 +366,9 @@ def bench_from_files(args, eng, grid, torch):
             torch.cuda.synchronize(); eng.sync()
             dt = (time.perf_counter() - t0) / args.steps
             ist = dict(getattr(s, "_ingestStats", {}) or {})
-            # decode only, same pool size
-            with ThreadPoolExecutor(max_workers=nthreads) as ex:
+            # decode only, same pool size (and the same Pillow block cache as the Stitcher's pool)
+            with ST._PillowBlocks(nthreads, grid.th * grid.tw * (4 if color else 1)), ThreadPoolExecutor(max_workers=nthreads) as ex:
+                list(ex.map(lambda f: ST._decode_once(f, color)[1], files[:nthreads]))
                 t0 = time.perf_counter()
                 list(ex.map(lambda f: ST._decode_once(f, color)[1], files))
                 dt_dec = time.perf_counter() - t0
@@ -381,6 +382,7 @@ def bench_from_files(args, eng, grid, torch):
                                 surfParams=eng.surf_params(), window=48)
             shapes = [(grid.th, grid.tw)] * grid.n_tiles
             reg.register(hs, shapes, 1)
+            reg.register(hs, shapes, 1)                       # (the second one runs on the learned scan pattern: arena and clocks settled)
             eng.sync(); t0 = time.perf_counter()
             for _ in range(args.steps):
                 reg.register(hs, shapes, 1)
@@ -471,7 +473,9 @@ def main():
     ap.add_argument("--offset-evaluate", type=int, default=3, help="Method.offsetEvaluate (Main.py:12: 3)")
     ap.add_argument("--cpu-sample", type=int, default=12, help="pairs timed on the host cores for cpu_baseline (0 = skip)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-resident-tiles measurement")
-    ap.add_argument("--no-path-hint", action="store_true", help="N > 1: do not hand the scan pattern to the registrar (blind chunk starts, chunks by pair count)")
+    ap.add_argument("--no-cold-leg", action="store_true", help="N = 1: skip the extra K steps without path memory (value_cold_path)")
+    ap.add_argument("--no-path-memory", action="store_true", help="do not let the registrar use the scan pattern it learned from the previous step "
+                    "(every step cold: history-driven speculation, blind chunk starts and chunks by pair count at N > 1)")
     ap.add_argument("--workload", default="grid", choices=["grid", "dendritic25"],
                     help="grid = the synthetic serpentine grid (BASELINE metric); dendritic25 = the 25 committed real pairs (N = 1, surf)")
     ap.add_argument("--from-files", action="store_true", help="N = 1: JPEG tiles on disk through Stitcher's ingest pipeline (decode inclusive)")
@@ -523,15 +527,14 @@ def main():
         return bench_from_files(args, eng, grid, torch)
     P = grid.n_pairs
     truth = np.array(grid.true_offsets(), np.int64)
-    # N > 1: the stage's scan pattern (a column serpentine of known height -- the operator knows it, the bench built the grid from it) is
-    # handed to the registrar as a PREDICTION of the accepted directions: a rank inside the path then starts one chain with a primed
-    # predictor instead of four blind ones, and the chunks are cut by the attempts the pattern predicts.  Results never depend on it
-    # (tests/test_grid_registrar.py); --no-path-hint measures the blind form.
-    hint = None if (args.no_path_hint or world == 1) else [int(d) for d in grid.true_directions()]
-    _reg0 = GridRegistrar(eng, method=args.method if args.method in ("surf", "orb", "phase") else "surf", roiRatio=0.2, directIncre=1)
-    bounds = _reg0._bounds(P, world, None, hint, 1)
+    # Path memory (GridRegistrar.path_memory): the accepted directions of the previous registration of this scan pattern -- the warm-up
+    # step -- are the speculation prior of the timed steps (batches planned over the whole predicted path from the first pair on; with
+    # N > 1 one primed chain per rank instead of four blind ones, chunks cut by the predicted attempts).  Nothing comes from the ground
+    # truth, every attempt is still evaluated, results never depend on it; --no-path-memory measures every step cold.
+    bounds = GridRegistrar.chunk_bounds(P, world)
     lo, hi = bounds[rank]
-    need = list(range(lo, hi + 1)) if hi > lo else []
+    # (N > 1: the learned pattern moves the chunk boundaries after the first step, so every rank keeps all tiles resident)
+    need = list(range(grid.n_tiles)) if world > 1 else (list(range(lo, hi + 1)) if hi > lo else [])
     # tiles live in pinned host memory (what a decoder feeding this engine would write into): uploads from it are asynchronous DMA
     tiles = {}
     for k, t in zip(need, grid.tiles(need, threads=min(8, os.cpu_count() or 1))):
@@ -550,19 +553,25 @@ def main():
     reg = GridRegistrar(eng, method=args.method, roiRatio=0.2, searchRatio=0.75, offsetEvaluate=args.offset_evaluate, directIncre=1,
                         surfParams=eng.surf_params() if args.method == "surf" else eng.orb_params() if args.method == "orb" else None,
                         window=args.window)
+    reg.remember = not args.no_path_memory
     gather = make_all_gather(coll_device) if world > 1 else single_process_all_gather
 
     def step(hs=handles):
-        return reg.register_sharded(hs, shapes, 1, rank, world, gather, hint=hint)
+        return reg.register_sharded(hs, shapes, 1, rank, world, gather)
+
+    def my_tiles():
+        a, b = reg._bounds(P, world, None, reg._prediction(P, None), 1)[rank]
+        return list(range(a, b + 1)) if b > a else []
 
     def step_from_host():
         """the same step with the tiles in host memory at its start: asynchronous uploads in path order on the copy stream (the
         first batch waits only for the tiles it names), registration, release of the device copies"""
         hs = [None] * grid.n_tiles
-        for k in need:
+        mine = my_tiles()
+        for k in mine:
             hs[k] = eng.tile_upload_async(tiles[k])
         out = step(hs)
-        for k in need:
+        for k in mine:
             eng.tile_free(hs[k])
         return out
 
@@ -621,6 +630,20 @@ def main():
             step_from_host()
         fence()
         elapsed_host = time.perf_counter() - t0
+    elapsed_cold = None
+    if world == 1 and not args.no_path_memory and not args.no_cold_leg:
+        reg_c = GridRegistrar(eng, method=args.method, roiRatio=0.2, searchRatio=0.75, offsetEvaluate=args.offset_evaluate, directIncre=1,
+                              surfParams=reg.params, window=args.window)
+        reg_c.remember = False
+        res_c, _d = reg_c.register_sharded(handles, shapes, 1, 0, 1, single_process_all_gather)
+        assert np.array_equal(res_c, res)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            reg_c.register_sharded(handles, shapes, 1, 0, 1, single_process_all_gather)
+        fence()
+        elapsed_cold = time.perf_counter() - t0
+        cold_stats = dict(reg_c.stats)
     per_rank = None
     if dist is not None:
         mine = dict(rank=rank, pairs=hi - lo, attempts_per_step=st["attempts"] / max(args.steps, 1), batches_per_step=st["batches"] / max(args.steps, 1),
@@ -748,9 +771,15 @@ def main():
                                       {"surf": "SURF(100,4,3,64-d)+BF-L2 knn2 ratio 0.75 + mode vote", "orb": "ORB(5000,1.2,8)+BF-Hamming 1-NN + mode vote",
                                        "phase": "FFT phase correlation of the ROI strips"}[args.method], args.offset_evaluate),
                        "pairs": P, "parallelism": "pairs%d" % world, "speculation_window": args.window,
-                       "path_hint": (None if hint is None else "scan pattern (column serpentine %dx%d) as predicted directions: hinted chunk starts, chunks cut by predicted attempts"
-                                     % (args.rows, args.cols))},
+                       "path_prediction": ("none (--no-path-memory): every step registers the path cold" if args.no_path_memory else
+                                           "path memory: the accepted directions of the previous registration of this scan pattern (the warm-up step) drive the "
+                                           "speculation plan of the timed steps; nothing from the ground truth, every attempt evaluated")},
             "max_abs_offset_error_px": max_err, "pairs_failed": n_failed,
+            "value_cold_path": round(P * args.steps / elapsed_cold, 3) if elapsed_cold else None,
+            "cold_path": (dict(ms_per_step=round(elapsed_cold / args.steps * 1e3, 3), attempts_per_step=cold_stats["attempts"] / (args.steps + 1),
+                               batches_per_step=cold_stats["batches"] / (args.steps + 1),
+                               note="the same K steps by a registrar WITHOUT path memory: every path learned from scratch (history-driven speculation), "
+                                    "rounds 1-3's headline configuration") if elapsed_cold else None),
             "value_host_resident_tiles": round(P * args.steps / elapsed_host, 3) if elapsed_host else None,
             "ms_per_step_host_resident_tiles": round(elapsed_host / args.steps * 1e3, 3) if elapsed_host else None,
             "h2d_ms_rank0_blocking": round(t_up * 1e3, 2),
@@ -762,7 +791,7 @@ def main():
             "stages": stages,
             "per_rank": per_rank,
             "collective": (dict(backend=dist.get_backend(), world_size=dist.get_world_size(), device=str(coll_device), rank_devices=devs,
-                                hint_repair_rounds=getattr(reg, "hint_repairs", 0),
+                                prediction_repair_rounds=getattr(reg, "hint_repairs", 0),
                                 op="one all_gather of the int32 offset tables per step") if dist is not None else None),
         }
         if args.method == "orb" and max_err > 1:

@@ -138,9 +138,27 @@ struct Chain {
             // ---- predicted continuation of the path as one batch (up to `window` attempts)
             if (!cache.count(Key(k, d, 1))) {
                 std::vector<Key> items;
+                if (P->path_hint && P->path_hint_len > 0) {
+                    // the predicted directions as the plan itself: the run at the current direction up to the predicted change, the candidate
+                    // ring of that pair up to the predicted new direction, the next run, ... (grid.py: plan_hint)
+                    int cd = d;
+                    for (int kk = k; kk < last && kk < (int)P->path_hint_len && (int)items.size() < window; kk++) {
+                        const int hd = P->path_hint[kk];
+                        if (hd < 1 || hd > 4) break;
+                        const std::vector<std::pair<int, int>> rg = ring(cd, 1);
+                        int at = -1;
+                        for (size_t q = 0; q < rg.size(); q++) if (rg[q].first == hd) { at = (int)q; break; }
+                        if (hd == cd || at < 0) items.push_back(Key(kk, cd, 1));
+                        else {
+                            for (int q = 0; q <= at; q++) items.push_back(Key(kk, rg[q].first, rg[q].second));
+                            cd = hd;
+                        }
+                    }
+                }
+                const bool hinted = !items.empty();           // else: the plan from this chain's own history
                 std::vector<int> R(runs);
                 int rl = run_len, cd = d, cp = prev_d, kk = k;
-                while (kk < last && (int)items.size() < window) {
+                while (!hinted && kk < last && (int)items.size() < window) {
                     if (R.size() < 2) break;
                     const int pred = R[R.size() - 2];
                     const int remaining = pred - rl;

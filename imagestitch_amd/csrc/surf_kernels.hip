@@ -290,7 +290,12 @@ __global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const L
     constexpr int OCT = STEP == 1 ? 0 : 1;
     constexpr int MAXSZ = 33 * STEP;                              // size of the octave's coarsest layer: (9 + 6*4) << o
     constexpr int LW = (TW - 1) * STEP + MAXSZ + 1, LH = (TH - 1) * STEP + MAXSZ + 1;
-    __shared__ int32_t tile[LH * LW];
+    // STEP 2: the lanes of a wave sample every second column, so a row-major window is read with a stride of two dwords -- two lanes per
+    // LDS bank on every tap, and the taps are what bounds this kernel.  The window is therefore kept as two planes, even and odd columns:
+    // column 2 lx + dx of a tap lies in plane dx & 1 at lx + (dx >> 1) -- unit stride across the lanes, both still immediates.
+    constexpr int LWH = STEP == 2 ? (LW + 1) / 2 : LW;            // row pitch (of a plane)
+    constexpr int PLANE = STEP == 2 ? LH * LWH + 1 : 0;           // (+1: the two planes start in different banks)
+    __shared__ int32_t tile[STEP == 2 ? 2 * (LH * LWH + 1) : LH * LW];
     const RoiDev &R = rois[blockIdx.z];
     const int sw = R.w + 1, sh = R.h + 1;
     const int j0 = blockIdx.x * TW, i0 = blockIdx.y * TH;          // sample coordinates of the tile origin
@@ -300,7 +305,9 @@ __global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const L
     for (int t = tid; t < LH * LW; t += 256) {
         const int ty = t / LW, tx = t - ty * LW;
         const int gy = min(i0 * STEP + ty, sh - 1), gx = min(j0 * STEP + tx, sw - 1);
-        tile[t] = S[(size_t)gy * sw + gx];
+        const int32_t v = S[(size_t)gy * sw + gx];
+        if (STEP == 2) tile[(tx & 1) * PLANE + ty * LWH + (tx >> 1)] = v;
+        else tile[t] = v;
     }
     __syncthreads();
     const int lcols = R.w / STEP;
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const L
             const int ly = e / TW, lx = e - ly * TW;
             const int i = i0 + ly, j = j0 + lx;
             if (i >= samples_i || j >= samples_j) continue;
-            const int32_t *sp = tile + (ly * STEP) * LW + lx * STEP;
+            const int32_t *sp = STEP == 2 ? tile + (ly * STEP) * LWH + lx : tile + (ly * STEP) * LW + lx * STEP;
             float d3[3];
 #pragma unroll
             for (int g = 0; g < 3; g++) {
@@ -330,7 +337,12 @@ __global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const L
                 for (int k = k0; k < k0 + n; k++) {
                     const int dx1 = vfsms_haar_corner(size, k, 0), dy1 = vfsms_haar_corner(size, k, 1);
                     const int dx2 = vfsms_haar_corner(size, k, 2), dy2 = vfsms_haar_corner(size, k, 3);
-                    const int v = sp[dy1 * LW + dx1] + sp[dy2 * LW + dx2] - sp[dy2 * LW + dx1] - sp[dy1 * LW + dx2];
+                    int v;
+                    if (STEP == 2)
+                        v = sp[(dx1 & 1) * PLANE + dy1 * LWH + (dx1 >> 1)] + sp[(dx2 & 1) * PLANE + dy2 * LWH + (dx2 >> 1)]
+                          - sp[(dx1 & 1) * PLANE + dy2 * LWH + (dx1 >> 1)] - sp[(dx2 & 1) * PLANE + dy1 * LWH + (dx2 >> 1)];
+                    else
+                        v = sp[dy1 * LW + dx1] + sp[dy2 * LW + dx2] - sp[dy2 * LW + dx1] - sp[dy1 * LW + dx2];
                     d += (double)((float)v * w[k]);
                 }
                 d3[g] = (float)d;
@@ -339,6 +351,69 @@ __global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const L
             det[o] = d3[0] * d3[1] - 0.81f * d3[2] * d3[2];
         }
     }
+}
+
+// Coarse octaves (2, 3) with the stock five layers: the (tile + wavelet) window of an octave-2 tile would be 120-200 KB of LDS, so the taps
+// stay gathers from the L2-resident integral image -- but none of their addresses is computed per tap.  Layer and octave are template
+// parameters, so the corner offsets (vfsms_haar_corner) are constants: a tap is `global_load_dword v, v_lane_offset, s[row base] offset:dx*4`
+// -- the row base (y + dy) * pitch is one scalar multiply-add per corner ROW, the lane offset x * 4 is computed once per thread.  (The
+// generic k_hessian walks LayerPat tables: its scalar unit issued 3.4 instructions per VALU instruction, PMC round 3.)
+// 64 x 4 samples per workgroup; arithmetic and its order are those of k_hessian.
+template <int OCT, int L>
+__device__ __forceinline__ void hessian_coarse_body(const RoiDev &R, const LayerPat *pats, int layers_per_octave, int ti, int tj)
+{
+    constexpr int STEP = 1 << OCT;
+    constexpr int size = (9 + 6 * L) << OCT;
+    if (size > R.h || size > R.w) return;
+    const int samples_i = 1 + (R.h - size) / STEP, samples_j = 1 + (R.w - size) / STEP;
+    const int i = ti * 4 + (int)threadIdx.y, j = tj * 64 + (int)threadIdx.x;
+    if (i >= samples_i || j >= samples_j) return;
+    const int li = OCT * layers_per_octave + L;
+    const LayerPat &P = pats[li];
+    const uint32_t sw = (uint32_t)(R.w + 1);
+    const GAS char *S = (const GAS char *)R.sum;
+    const uint32_t voff = (uint32_t)(j * STEP) * 4u;                 // the lane's column, bytes
+    const uint32_t row0 = (uint32_t)(i * STEP);                      // (threadIdx.y is not wave-uniform in general: blockDim = (64, 4) makes it so)
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0);
+    float d3[3];
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        const int k0 = g == 0 ? 0 : g == 1 ? 3 : 6, n = g == 2 ? 4 : 3;
+        double d = 0;
+#pragma unroll
+        for (int k = k0; k < k0 + n; k++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int dx1 = vfsms_haar_corner(size, k, 0), dy1 = vfsms_haar_corner(size, k, 1);
+            const int dx2 = vfsms_haar_corner(size, k, 2), dy2 = vfsms_haar_corner(size, k, 3);
+            const GAS char *ra = S + (size_t)((r0 + (uint32_t)dy1) * sw) * 4u;      // scalar: row bases of the two corner rows
+            const GAS char *rb = S + (size_t)((r0 + (uint32_t)dy2) * sw) * 4u;
+            const int v = ((const GAS int32_t *)(ra + voff))[dx1] + ((const GAS int32_t *)(rb + voff))[dx2]
+                        - ((const GAS int32_t *)(rb + voff))[dx1] - ((const GAS int32_t *)(ra + voff))[dx2];
+            d += (double)((float)v * P.w[k]);
+        }
+        d3[g] = (float)d;
+    }
+    const int margin = (size / 2) / STEP;
+    const int lcols = R.w / STEP;
+    ((g_f32)R.det[li])[(size_t)(i + margin) * lcols + (j + margin)] = d3[0] * d3[1] - 0.81f * d3[2] * d3[2];
+}
+
+__global__ __launch_bounds__(256) void k_hessian_coarse(const RoiDev *rois, const LayerPat *pats, int layers_per_octave, HessPlan plan, int nrois)
+{
+    unsigned roi, inner;
+    xcd_roi_map(blockIdx.x, (unsigned)(plan.first[plan.noct] * 5), (unsigned)nrois, roi, inner);
+    const int l = (int)(inner % 5u);
+    int t = (int)(inner / 5u);
+    int q = 0;
+    while (q + 1 < plan.noct && t >= plan.first[q + 1]) q++;
+    t -= plan.first[q];
+    const RoiDev &R = rois[roi];
+    const int tj = t % plan.tiles_x[q], ti = t / plan.tiles_x[q];
+    const int o = plan.o0 + q;
+#define HC(O, LL) hessian_coarse_body<O, LL>(R, pats, layers_per_octave, ti, tj)
+    if (o == 2) { switch (l) { case 0: HC(2, 0); break; case 1: HC(2, 1); break; case 2: HC(2, 2); break; case 3: HC(2, 3); break; default: HC(2, 4); } }
+    else { switch (l) { case 0: HC(3, 0); break; case 1: HC(3, 1); break; case 2: HC(3, 2); break; case 3: HC(3, 3); break; default: HC(3, 4); } }
+#undef HC
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1737,8 +1812,13 @@ int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_roi
             plan.noct++;
             step *= 2;
         }
-        if (plan.noct > 0 && plan.first[plan.noct] > 0)
-            hipLaunchKernelGGL(k_hessian, dim3((unsigned)plan.first[plan.noct] * lpo * nrois), dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo, plan, nrois);
+        static const bool generic = getenv("VFSMS_HESSIAN_GENERIC") && atoi(getenv("VFSMS_HESSIAN_GENERIC")) != 0;
+        if (plan.noct > 0 && plan.first[plan.noct] > 0) {
+            if (lpo == 5 && plan.o0 == 2 && plan.o0 + plan.noct <= 4 && !generic)       // the stock pyramid: constant-offset taps
+                hipLaunchKernelGGL(k_hessian_coarse, dim3((unsigned)plan.first[plan.noct] * lpo * nrois), dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo, plan, nrois);
+            else
+                hipLaunchKernelGGL(k_hessian, dim3((unsigned)plan.first[plan.noct] * lpo * nrois), dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo, plan, nrois);
+        }
     }
     {
         ProfScope ps(ctx, "nms");

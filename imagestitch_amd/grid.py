@@ -45,6 +45,12 @@ class GridRegistrar:
         self.window = max(1, int(window))
         self.enhance = tuple(enhance)                     # (mode, clipLimit, tileSize) of Method.isEnhance (Stitcher.py:327-334)
         self.stats = dict(attempts=0, batches=0, sum_nq_nt=0, sum_nq_plus_nt=0, sum_nq=0, roi_px=0)
+        # Path memory: the accepted directions of the last path this registrar registered are the PREDICTION for the next one of the same
+        # length (a session shoots one scan pattern after the other: Main.py loops over its datasets with one setting) -- they drive the
+        # speculation plan from the first pair on and, in the sharded form, the chunk starts.  A prior like a branch predictor's: every
+        # attempt is still evaluated, results never depend on it (tests/test_grid_registrar.py).
+        self.remember = True
+        self.path_memory = None
 
     # -- candidate order of Stitcher.py:319-351 --------------------------------------------------------------
     def maxI(self):
@@ -221,13 +227,34 @@ class GridRegistrar:
                 kk += 1
             return items
 
+        def plan_hint(k0, d0):
+            """The predicted directions as the plan itself: the run at the current direction up to the predicted change, the candidate ring
+            of that pair up to the predicted new direction, the next run, ... -- what the history-driven plan arrives at after two
+            serpentine periods, available from the first pair on."""
+            items, cd, kk = [], d0, k0
+            while kk < last and kk < len(hint) and len(items) < self.window:
+                hd = int(hint[kk])
+                if not 1 <= hd <= 4:
+                    break
+                ring = self.rings(cd)[0]
+                ds = [c[0] for c in ring]
+                if hd == cd or hd not in ds:
+                    items.append((kk, cd, 1))
+                else:
+                    items += [(kk,) + c for c in ring[:ds.index(hd) + 1]]
+                    cd = hd
+                kk += 1
+            return items
+
         while k < last:
             if (k, d) in memo:
                 row, d_next = memo[(k, d)]
             else:
                 rings = self.rings(d)
                 if (k, d, 1) not in cache:
-                    items = plan(k, d, prev_d)
+                    items = plan_hint(k, d) if hint is not None and len(hint) else []
+                    if not items:
+                        items = plan(k, d, prev_d)
                     if not items:                              # no history yet: slow start
                         items = [(kk, d, 1) for kk in range(k, min(k + slow, last)) if (kk, d) not in memo]
                     evaluate(items)
@@ -290,14 +317,31 @@ class GridRegistrar:
         self.capacity_retries = getattr(self, "capacity_retries", 0) + st[2]
         self.stats["sum_nq_nt"] += st[3]; self.stats["sum_nq_plus_nt"] += st[4]; self.stats["roi_px"] += st[5]
 
-    def register(self, handles, shapes, direction=1, stop_on_fail=False):
+    def _prediction(self, P, hint):
+        """the caller's hint, else what the last path of the same length taught this registrar"""
+        if hint is not None:
+            return hint
+        m = self.path_memory
+        return m if (self.remember and m is not None and len(m) == P) else None
+
+    def _learn(self, table):
+        if self.remember and len(table):
+            self.path_memory = [int(r[3]) if 1 <= int(r[3]) <= 4 else 1 for r in table]
+
+    def register(self, handles, shapes, direction=1, stop_on_fail=False, hint=None):
         """All P = len(handles)-1 consecutive pairs on this GPU.  -> (int32[P, 6], final direction).
-        stop_on_fail: stop behind the first pair that cannot be registered (rows after it stay zero)."""
+        stop_on_fail: stop behind the first pair that cannot be registered (rows after it stay zero).
+        hint: predicted accepted directions (default: the path memory)."""
+        P = len(handles) - 1
+        hint = self._prediction(P, hint)
         if self.native and hasattr(self.eng, "pairs_offsets"):
-            out, d, st = self.eng.pairs_offsets(handles, shapes, self._grid_params(), 0, len(handles) - 1, direction, False, stop_on_fail)
+            out, d, st = self.eng.pairs_offsets(handles, shapes, self._grid_params(hint), 0, P, direction, False, stop_on_fail)
             self._native_stats(st)
-            return out, d
-        return self.chain(handles, shapes, 0, len(handles) - 1, direction, stop_on_fail=stop_on_fail)
+        else:
+            out, d = self.chain(handles, shapes, 0, P, direction, stop_on_fail=stop_on_fail, hint=hint)
+        if not stop_on_fail or bool(np.all(out[:, 0] == 1)):
+            self._learn(out)
+        return out, d
 
     # -- pair-sharded ---------------------------------------------------------------------------------------------------
     BLIND_START_COST = 3.0     # a chunk entered with an unknown direction tries four first candidates instead of one
@@ -391,11 +435,11 @@ class GridRegistrar:
                 cache[it] = r
         for d_in in dirs:
             if hi > lo and len(dirs) == 1 and self.native and hasattr(self.eng, "pairs_offsets"):
-                res, dn, st = self.eng.pairs_offsets(handles, shapes, self._grid_params(hint if rank > 0 else None), lo, hi, d_in, rank > 0, False)
+                res, dn, st = self.eng.pairs_offsets(handles, shapes, self._grid_params(hint), lo, hi, d_in, rank > 0, False)
                 self._native_stats(st)
                 table[d_in - 1, :hi - lo] = res
             elif hi > lo:
-                res, dn = self.chain(handles, shapes, lo, hi, d_in, memo, cache, midpath=rank > 0, hint=hint if (rank > 0 and len(dirs) == 1) else None)
+                res, dn = self.chain(handles, shapes, lo, hi, d_in, memo, cache, midpath=rank > 0, hint=hint if len(dirs) == 1 else None)
                 table[d_in - 1, :hi - lo] = res
             else:
                 dn = d_in
@@ -433,15 +477,19 @@ class GridRegistrar:
         gathered a second time -- every rank sees the same tables, so all of them take the same decision.
         Returns the same (int32[P, 6], final direction) on every rank."""
         P = len(shapes) - 1
+        hint = self._prediction(P, hint)
         payload = self.shard_payload(handles, shapes, direction, rank, world, weights, hint)
         gathered = all_gather(payload)
         if len(gathered) != world:
             raise RuntimeError("all_gather returned %d payloads for a world of %d ranks" % (len(gathered), world))
         if hint is None:
-            return self.assemble(gathered, P, world, direction, weights)
+            full, d = self.assemble(gathered, P, world, direction, weights)
+            self._learn(full)
+            return full, d
         missing = []
         full, d = self.assemble(gathered, P, world, direction, weights, missing, hint)
         if not missing:
+            self._learn(full)
             return full, d
         # repair: every rank that followed a single hinted chain is a suspect (a wrong direction upstream changes what enters the ranks
         # behind it); those whose assumption is not confirmed by the first walk redo their chunk blind.  One extra collective.
@@ -453,7 +501,9 @@ class GridRegistrar:
         else:                                                # the same chunk (the hint's work split), now for every incoming direction
             mine = self.shard_payload(handles, shapes, direction, rank, world, weights, hint, blind=True)
         gathered = all_gather(mine)
-        return self.assemble(gathered, P, world, direction, weights, None, hint)
+        full, d = self.assemble(gathered, P, world, direction, weights, None, hint)
+        self._learn(full)
+        return full, d
 
 
 def split_segments(results):

@@ -94,6 +94,43 @@ def _imread_gray_pointer(path):
     return a, a.ctypes.data, a.shape
 
 
+class _PillowBlocks:
+    """Pillow's image storage for the decoder pool: blocks large enough for a whole decoded tile (so that the pixel block can be handed to
+    the engine without a copy: _decode_once) and a cache of freed blocks (every decode otherwise maps and unmaps 4-17 MB of fresh
+    memory, and a pool of threads page-faulting in one address space serialises on the kernel's memory-map lock: the per-tile decode
+    time grew 20-40 % from 16 to 32 threads).  Restores the process-wide settings on exit."""
+
+    def __init__(self, nthreads, tile_bytes):
+        self.nthreads, self.tile_bytes, self.saved = nthreads, tile_bytes, None
+
+    def __enter__(self):
+        try:
+            from PIL import Image
+            core = Image.core
+            self.saved = (core.get_block_size(), core.get_blocks_max())
+            want = 1 << 24
+            while want < self.tile_bytes and want < (1 << 28):
+                want <<= 1
+            if want != self.saved[0]:
+                core.set_blocks_max(0)                       # (the size can only change while nothing is cached)
+                core.set_block_size(want)
+            core.set_blocks_max(max(self.saved[1], min(2 * self.nthreads + 4, (4 << 30) // want)))
+        except Exception:                                    # an older Pillow: the copying hand-over still works
+            self.saved = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.saved is not None:
+            try:
+                from PIL import Image
+                Image.core.set_blocks_max(0)
+                Image.core.set_block_size(self.saved[0])
+                Image.core.set_blocks_max(self.saved[1])
+            except Exception:
+                pass
+        return False
+
+
 def _decode_once(path, want_color):
     """ONE decode of a file for both uses the reference makes of it (cv2.imdecode(..., 0) at Stitcher.py:68-69 for registration and, with
     isColorMode, cv2.imdecode(..., IMREAD_COLOR) at Stitcher.py:382-403 for the mosaic) -> (owner, (rows, cols), parts) with
@@ -424,6 +461,9 @@ class Stitcher(Utility.Method):
                             phaseResponseThreshold=self.phaseResponseThreshold, window=48,
                             enhance=self._enhanceSpec() if method in ("surf", "surf_full") else (0, 0.0, 0))
         reg.orbMaxDistance = self.orbMaxDistance if self.isGPUAvailable else -1
+        # the scan pattern the previous dataset taught this stitcher (accepted directions, same number of tiles): the speculation prior of
+        # this one (GridRegistrar.path_memory; Main.py runs its datasets through ONE Stitcher with one setting)
+        reg.path_memory = self.__dict__.get("_pathMemory")
         device_fuse = (self.fuseMethod in ("notFuse", "fadeInAndFadeOut", "trigonometric") and hasattr(eng, "canvas_fuse_tile_resident")) or \
                       (self.fuseMethod in ("average", "maximum", "minimum") and hasattr(eng, "canvas_blend_tile_resident"))
         # the tiles the mosaic is assembled from stay in HBM: the registration planes themselves for gray mosaics, and for colour mosaics
@@ -444,14 +484,9 @@ class Stitcher(Utility.Method):
                     handles.append(eng.tile_reserve(s[0], s[1]))
                     if color:
                         chandles.append(eng.tile_reserve_color(s[0], s[1], 3))
-                nthreads = max(1, min(int(self.decodeThreads or min(os.cpu_count() or 4, 32)), len(fileList), 64))
-                if color:
-                    try:                                      # 3-band images in ONE block, so that Pillow can hand the pixel block over without a copy
-                        from PIL import Image as _I
-                        block_alloc = _I.core.get_use_block_allocator()
-                        _I.core.set_use_block_allocator(1)
-                    except Exception:
-                        block_alloc = None
+                nthreads = max(1, min(int(self.decodeThreads or min(os.cpu_count() or 4, 16)), len(fileList), 64))
+                block_alloc = _PillowBlocks(nthreads, shapes[0][0] * shapes[0][1] * (4 if color else 1))
+                block_alloc.__enter__()
 
                 istats = self._ingestStats = dict(tiles=0, decode_s=0.0, fill_s=0.0, threads=nthreads)   # summed over the decoder threads
 
@@ -490,6 +525,8 @@ class Stitcher(Utility.Method):
                 table = self._fullImageTable(handles)
             else:
                 table, _d = reg.register(handles, shapes, self.direction, stop_on_fail=True)
+                if reg.path_memory is not None:
+                    self._pathMemory = reg.path_memory
         except BaseException:
             keep, failed = False, True
             raise
@@ -517,11 +554,7 @@ class Stitcher(Utility.Method):
             if pool is not None:
                 pool.shutdown(wait=True)
             if block_alloc is not None:
-                try:
-                    from PIL import Image as _I
-                    _I.core.set_use_block_allocator(block_alloc)
-                except Exception:
-                    pass
+                block_alloc.__exit__(None, None, None)
             if keep and err is None:
                 # the mosaic is assembled from these very tiles: getStitchByOffset takes them over (and frees them)
                 kept = chandles if color else handles
@@ -1075,10 +1108,11 @@ class Stitcher(Utility.Method):
                     except Exception:
                         pass
                     raise
-            nthreads = max(1, min(int(self.decodeThreads or min(os.cpu_count() or 4, 32)), len(files), 64))
-            with ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="vfsms-decode") as pool:
-                for fu in [pool.submit(ingest, k) for k in range(len(files))]:
-                    fu.result()
+            nthreads = max(1, min(int(self.decodeThreads or min(os.cpu_count() or 4, 16)), len(files), 64))
+            with _PillowBlocks(nthreads, shapes[0][0] * shapes[0][1] * (4 if color else 1)):
+                with ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="vfsms-decode") as pool:
+                    for fu in [pool.submit(ingest, k) for k in range(len(files))]:
+                        fu.result()
         except BaseException:
             for h in handles:
                 try:
