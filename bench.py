@@ -367,7 +367,7 @@ def bench_from_files(args, eng, grid, torch):
             dt = (time.perf_counter() - t0) / args.steps
             ist = dict(getattr(s, "_ingestStats", {}) or {})
             # decode only, same pool size (and the same Pillow block cache as the Stitcher's pool)
-            with ST._PillowBlocks(nthreads, grid.th * grid.tw * (4 if color else 1)), ThreadPoolExecutor(max_workers=nthreads) as ex:
+            with ST._PillowBlocks(color), ThreadPoolExecutor(max_workers=nthreads) as ex:
                 list(ex.map(lambda f: ST._decode_once(f, color)[1], files[:nthreads]))
                 t0 = time.perf_counter()
                 list(ex.map(lambda f: ST._decode_once(f, color)[1], files))

@@ -972,24 +972,31 @@ static int attempt_surf_impl(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, 
     // counters of all ROIs and results of all jobs live in two contiguous blocks: one memset, two D2H copies per batch
     int *cblock = (int *)ctx_arena_alloc(ctx, sizeof(int) * 16 * 2 * n);
     int32_t *rblock = (int32_t *)ctx_arena_alloc(ctx, sizeof(int32_t) * VFSMS_ATTEMPT_INTS * n);
-    for (int k = 0; k < n; k++) {
+    // ROIs of one shape next to each other (the column strips, then the strips of the turn candidates): the kernels whose grid follows the
+    // image size are launched per shape run (surf_kernels.hip: shape_runs).  Slot s of the batch holds job ord[s]; results go to the job's row.
+    std::vector<int> ord(n);
+    for (int k = 0; k < n; k++) ord[k] = k;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a_, int b_) {
+        return jobs[a_].h != jobs[b_].h ? jobs[a_].h < jobs[b_].h : jobs[a_].w < jobs[b_].w; });
+    for (int s_ = 0; s_ < n; s_++) {
+        const int k = ord[s_];
         const uint8_t *pa, *pb; int sa, sb;
         TRY(resolve_job(ctx, jobs[k], &pa, &sa, &pb, &sb));
         if (enh_mode) {            // Stitcher.py:327-334: the ROI strips are equalised / CLAHE'd before detectAndDescribe
-            TRY(enhance_carve(ctx, &E[2 * k], pa, sa, jobs[k].h, jobs[k].w, enh_mode, tile_grid));
-            TRY(enhance_carve(ctx, &E[2 * k + 1], pb, sb, jobs[k].h, jobs[k].w, enh_mode, tile_grid));
-            pa = E[2 * k].dst; sa = jobs[k].w; pb = E[2 * k + 1].dst; sb = jobs[k].w;
+            TRY(enhance_carve(ctx, &E[2 * s_], pa, sa, jobs[k].h, jobs[k].w, enh_mode, tile_grid));
+            TRY(enhance_carve(ctx, &E[2 * s_ + 1], pb, sb, jobs[k].h, jobs[k].w, enh_mode, tile_grid));
+            pa = E[2 * s_].dst; sa = jobs[k].w; pb = E[2 * s_ + 1].dst; sb = jobs[k].w;
         }
-        TRY(surf_roi_carve(ctx, &R[2 * k], pa, sa, jobs[k].h, jobs[k].w, caps[k], params));
-        TRY(surf_roi_carve(ctx, &R[2 * k + 1], pb, sb, jobs[k].h, jobs[k].w, caps[k], params));
-        R[2 * k].counters = cblock + 16 * (2 * k); R[2 * k + 1].counters = cblock + 16 * (2 * k + 1);
-        memset(&M[k], 0, sizeof(MatchDev));
-        TRY(match_carve(ctx, &M[k], caps[k], dim, ns));
-        if (filtered) TRY(match_filter_carve(ctx, &M[k], caps[k], caps[k], cns));
-        M[k].result = rblock + VFSMS_ATTEMPT_INTS * k;
-        M[k].q = R[2 * k].desc; M[k].t = R[2 * k + 1].desc;
-        M[k].nq_ptr = R[2 * k].counters + 1; M[k].nt_ptr = R[2 * k + 1].counters + 1;
-        M[k].kq = R[2 * k].kps_xy; M[k].kt = R[2 * k + 1].kps_xy;
+        TRY(surf_roi_carve(ctx, &R[2 * s_], pa, sa, jobs[k].h, jobs[k].w, caps[k], params));
+        TRY(surf_roi_carve(ctx, &R[2 * s_ + 1], pb, sb, jobs[k].h, jobs[k].w, caps[k], params));
+        R[2 * s_].counters = cblock + 16 * (2 * s_); R[2 * s_ + 1].counters = cblock + 16 * (2 * s_ + 1);
+        memset(&M[s_], 0, sizeof(MatchDev));
+        TRY(match_carve(ctx, &M[s_], caps[k], dim, ns));
+        if (filtered) TRY(match_filter_carve(ctx, &M[s_], caps[k], caps[k], cns));
+        M[s_].result = rblock + VFSMS_ATTEMPT_INTS * k;
+        M[s_].q = R[2 * s_].desc; M[s_].t = R[2 * s_ + 1].desc;
+        M[s_].nq_ptr = R[2 * s_].counters + 1; M[s_].nt_ptr = R[2 * s_ + 1].counters + 1;
+        M[s_].kq = R[2 * s_].kps_xy; M[s_].kt = R[2 * s_ + 1].kps_xy;
     }
     RoiDev *dR; MatchDev *dM;
     TRY(upload_pinned(ctx, R.data(), sizeof(RoiDev) * 2 * n, (void **)&dR));
@@ -1653,21 +1660,27 @@ extern "C" int vfsms_attempt_orb_batch(vfsms_ctx *ctx, const vfsms_roi_pair *job
     // counters of all ROIs and results of all jobs live in two contiguous blocks: two D2H copies per batch
     int *cblock = (int *)ctx_arena_alloc(ctx, sizeof(int) * 64 * 2 * n);
     int32_t *rblock = (int32_t *)ctx_arena_alloc(ctx, sizeof(int32_t) * VFSMS_ATTEMPT_INTS * n);
-    for (int k = 0; k < n; k++) {
+    // ROIs of one shape next to each other: the image-sized kernels are launched per shape run (launch_orb); slot s holds job ord[s]
+    std::vector<int> ord(n);
+    for (int k = 0; k < n; k++) ord[k] = k;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a_, int b_) {
+        return jobs[a_].h != jobs[b_].h ? jobs[a_].h < jobs[b_].h : jobs[a_].w < jobs[b_].w; });
+    for (int s_ = 0; s_ < n; s_++) {
+        const int k = ord[s_];
         const uint8_t *pa, *pb; int sa, sb;
         TRY(resolve_job(ctx, jobs[k], &pa, &sa, &pb, &sb));
-        TRY(orb_roi_carve(ctx, &R[2 * k], pa, sa, jobs[k].h, jobs[k].w, params, c1, c2, c));
-        TRY(orb_roi_carve(ctx, &R[2 * k + 1], pb, sb, jobs[k].h, jobs[k].w, params, c1, c2, c));
+        TRY(orb_roi_carve(ctx, &R[2 * s_], pa, sa, jobs[k].h, jobs[k].w, params, c1, c2, c));
+        TRY(orb_roi_carve(ctx, &R[2 * s_ + 1], pb, sb, jobs[k].h, jobs[k].w, params, c1, c2, c));
         for (int e = 0; e < 2; e++) {
-            OrbDev &r = R[2 * k + e];
-            r.counters = cblock + 64 * (2 * k + e); r.thr1 = r.counters + 16; r.n1 = r.counters + 32; r.n2 = r.counters + 48;
+            OrbDev &r = R[2 * s_ + e];
+            r.counters = cblock + 64 * (2 * s_ + e); r.thr1 = r.counters + 16; r.n1 = r.counters + 32; r.n2 = r.counters + 48;
         }
-        memset(&M[k], 0, sizeof(MatchDev));
-        TRY(match_carve(ctx, &M[k], c, 32, hns));
-        M[k].result = rblock + VFSMS_ATTEMPT_INTS * k;
-        M[k].q = (const float *)R[2 * k].desc; M[k].t = (const float *)R[2 * k + 1].desc;
-        M[k].nq_ptr = R[2 * k].counters + 1; M[k].nt_ptr = R[2 * k + 1].counters + 1;
-        M[k].kq = R[2 * k].kps_xy; M[k].kt = R[2 * k + 1].kps_xy;
+        memset(&M[s_], 0, sizeof(MatchDev));
+        TRY(match_carve(ctx, &M[s_], c, 32, hns));
+        M[s_].result = rblock + VFSMS_ATTEMPT_INTS * k;
+        M[s_].q = (const float *)R[2 * s_].desc; M[s_].t = (const float *)R[2 * s_ + 1].desc;
+        M[s_].nq_ptr = R[2 * s_].counters + 1; M[s_].nt_ptr = R[2 * s_ + 1].counters + 1;
+        M[s_].kq = R[2 * s_].kps_xy; M[s_].kt = R[2 * s_ + 1].kps_xy;
     }
     ctx->pinned_off = 0;
     OrbDev *dR; MatchDev *dM;

@@ -102,12 +102,24 @@ __device__ __forceinline__ int corner_score16(const int *d /* 25 differences v -
 // atomics on the same few addresses were the bulk of this stage).
 #define FT_W 64
 #define FT_H 16
-__global__ __launch_bounds__(256) void k_orb_fast_nms(const OrbDev *rois, int nlevels, int threshold, int edge)
+// blockIdx.x walks the tiles of level 0, then level 1, ... of ONE ROI shape (first[l] = tiles before level l): a grid cut from the level-0
+// size for every level dispatched 2.4 times the workgroups the pyramid has tiles
+struct OrbPlan { int first[VFSMS_ORB_MAX_LEVELS + 1]; int tiles_x[VFSMS_ORB_MAX_LEVELS]; };
+__device__ __forceinline__ void orb_plan_tile(const OrbPlan &plan, int nlevels, int &level, int &tx, int &ty)
 {
-    const OrbDev &R = rois[blockIdx.z / nlevels];
-    const int level = blockIdx.z % nlevels;
+    int t = blockIdx.x;
+    level = 0;
+    while (level + 1 < nlevels && t >= plan.first[level + 1]) level++;
+    t -= plan.first[level];
+    ty = t / plan.tiles_x[level]; tx = t - ty * plan.tiles_x[level];
+}
+__global__ __launch_bounds__(256) void k_orb_fast_nms(const OrbDev *rois, int nlevels, int threshold, int edge, OrbPlan plan)
+{
+    const OrbDev &R = rois[blockIdx.y];
+    int level, tile_x, tile_y;
+    orb_plan_tile(plan, nlevels, level, tile_x, tile_y);
     const int w = R.lw[level], h = R.lh[level], st = R.ls[level];
-    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    const int x0 = tile_x * FT_W, y0 = tile_y * FT_H;
     if (x0 >= w || y0 >= h) return;
     __shared__ uint8_t img[FT_H + 8][FT_W + 8];
     __shared__ uint8_t sc[FT_H + 2][FT_W + 2 + 2];
@@ -431,12 +443,13 @@ __global__ __launch_bounds__(256) void k_orb_angle(const OrbDev *rois, int nleve
 
 
 // ---- GaussianBlur(7x7, sigma 2, REFLECT_101) as the 8-bit fixed-point separable filter: 32x32 tile + 3 px halo in LDS ---------------
-__global__ __launch_bounds__(256) void k_orb_blur(const OrbDev *rois, int nlevels, const OrbTables *T)
+__global__ __launch_bounds__(256) void k_orb_blur(const OrbDev *rois, int nlevels, const OrbTables *T, OrbPlan plan)
 {
-    const OrbDev &R = rois[blockIdx.z / nlevels];
-    const int level = blockIdx.z % nlevels;
+    const OrbDev &R = rois[blockIdx.y];
+    int level, tile_x, tile_y;
+    orb_plan_tile(plan, nlevels, level, tile_x, tile_y);
     const int w = R.lw[level], h = R.lh[level], st = R.ls[level];
-    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    const int x0 = tile_x * 32, y0 = tile_y * 32;
     if (x0 >= w || y0 >= h) return;
     __shared__ uint8_t src[38][40];
     __shared__ int rowp[38][32];
@@ -636,20 +649,41 @@ int launch_orb(vfsms_ctx *ctx, const OrbDev *d_rois, const OrbDev *h_rois, int n
     }
     int maxcap1 = 0;
     for (int r = 0; r < nrois; r++) maxcap1 = h_rois[r].cap1 > maxcap1 ? h_rois[r].cap1 : maxcap1;
+    // Runs of consecutive ROIs of one shape: the kernels whose grid is cut from the image size are launched once per run (a batch of the
+    // incremental search mixes 409 x 2048 and 2048 x 409 strips; a grid for the largest height AND width dispatched five times the
+    // workgroups either shape needs).  vfsms_attempt_orb_batch orders its ROIs by shape.
+    struct Run { int first, count, h, w; };
+    std::vector<Run> runs;
+    for (int r = 0; r < nrois; r++) {
+        if (!runs.empty() && runs.back().h == h_rois[r].h && runs.back().w == h_rois[r].w) runs.back().count++;
+        else { Run q; q.first = r; q.count = 1; q.h = h_rois[r].h; q.w = h_rois[r].w; runs.push_back(q); }
+    }
+    (void)maxw; (void)maxh;
     hipLaunchKernelGGL(k_orb_clear, dim3(nrois), dim3(256), 0, ctx->stream, d_rois, nl);
     {
         ProfScope ps(ctx, "orb_pyramid");
-        for (int l = 1; l < nl; l++) {
-            int lw[VFSMS_ORB_MAX_LEVELS], lh[VFSMS_ORB_MAX_LEVELS]; float ls[VFSMS_ORB_MAX_LEVELS];
-            orb_level_dims(p, maxh, maxw, lw, lh, ls);
-            if (lw[l] <= 0 || lh[l] <= 0) continue;
-            hipLaunchKernelGGL(k_orb_resize, dim3((lw[l] + 256) / 256, lh[l] + 1, nrois), dim3(256), 0, ctx->stream, d_rois, l);
-        }
+        for (int l = 1; l < nl; l++)
+            for (const Run &q : runs) {
+                int lw[VFSMS_ORB_MAX_LEVELS], lh[VFSMS_ORB_MAX_LEVELS]; float ls[VFSMS_ORB_MAX_LEVELS];
+                orb_level_dims(p, q.h, q.w, lw, lh, ls);
+                if (lw[l] <= 0 || lh[l] <= 0) continue;
+                hipLaunchKernelGGL(k_orb_resize, dim3((lw[l] + 256) / 256, lh[l] + 1, q.count), dim3(256), 0, ctx->stream, d_rois + q.first, l);
+            }
     }
     {
         ProfScope ps(ctx, "orb_fast");
-        hipLaunchKernelGGL(k_orb_fast_nms, dim3((maxw + FT_W - 1) / FT_W, (maxh + FT_H - 1) / FT_H, nrois * nl), dim3(256), 0, ctx->stream, d_rois, nl,
-                           p->fast_threshold < 0 ? 0 : p->fast_threshold > 255 ? 255 : p->fast_threshold, p->edge_threshold);
+        for (const Run &q : runs) {
+            int lw[VFSMS_ORB_MAX_LEVELS], lh[VFSMS_ORB_MAX_LEVELS]; float ls[VFSMS_ORB_MAX_LEVELS];
+            orb_level_dims(p, q.h, q.w, lw, lh, ls);
+            OrbPlan plan; plan.first[0] = 0;
+            for (int l = 0; l < nl; l++) {
+                const int tx = std::max((lw[l] + FT_W - 1) / FT_W, 1), ty = std::max((lh[l] + FT_H - 1) / FT_H, 0);
+                plan.tiles_x[l] = tx; plan.first[l + 1] = plan.first[l] + tx * ty;
+            }
+            if (plan.first[nl] > 0)
+                hipLaunchKernelGGL(k_orb_fast_nms, dim3(plan.first[nl], q.count), dim3(256), 0, ctx->stream, d_rois + q.first, nl,
+                                   p->fast_threshold < 0 ? 0 : p->fast_threshold > 255 ? 255 : p->fast_threshold, p->edge_threshold, plan);
+        }
         hipLaunchKernelGGL(k_orb_threshold, dim3((nrois * nl + 63) / 64), dim3(64), 0, ctx->stream, d_rois, nrois, nl, ctx->d_orb_tables);
     }
     {
@@ -663,7 +697,17 @@ int launch_orb(vfsms_ctx *ctx, const OrbDev *d_rois, const OrbDev *h_rois, int n
     }
     {
         ProfScope ps(ctx, "orb_describe");
-        hipLaunchKernelGGL(k_orb_blur, dim3((maxw + 31) / 32, (maxh + 31) / 32, nrois * nl), dim3(256), 0, ctx->stream, d_rois, nl, ctx->d_orb_tables);
+        for (const Run &q : runs) {
+            int lw[VFSMS_ORB_MAX_LEVELS], lh[VFSMS_ORB_MAX_LEVELS]; float ls[VFSMS_ORB_MAX_LEVELS];
+            orb_level_dims(p, q.h, q.w, lw, lh, ls);
+            OrbPlan plan; plan.first[0] = 0;
+            for (int l = 0; l < nl; l++) {
+                const int tx = std::max((lw[l] + 31) / 32, 1), ty = std::max((lh[l] + 31) / 32, 0);
+                plan.tiles_x[l] = tx; plan.first[l + 1] = plan.first[l] + tx * ty;
+            }
+            if (plan.first[nl] > 0)
+                hipLaunchKernelGGL(k_orb_blur, dim3(plan.first[nl], q.count), dim3(256), 0, ctx->stream, d_rois + q.first, nl, ctx->d_orb_tables, plan);
+        }
         hipLaunchKernelGGL(k_orb_describe, dim3((maxcap2 + 7) / 8, 1, nrois * nl), dim3(256), 0, ctx->stream, d_rois, nl, ctx->d_orb_tables);
     }
     HIP_TRY(hipGetLastError());

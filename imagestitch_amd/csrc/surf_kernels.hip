@@ -202,10 +202,24 @@ __global__ __launch_bounds__(256) void k_integral_final(const RoiDev *rois)
     }
 }
 
+// Kernels whose grid is cut from the image size are launched once per RUN of consecutive ROIs of one shape: a batch of the incremental search
+// mixes the 409 x 2048 strips of the column pairs with the 2048 x 409 strips of the turn candidates, and a grid sized for the largest height
+// AND the largest width of the batch dispatched five times the workgroups either shape needs (empty ones exit at once, but a batch of 96 ROIs
+// paid 1.3 ms per launch for dispatching them).  Callers order their ROIs by shape (attempt_surf_impl).
+struct ShapeRun { int first, count, h, w; };
+static std::vector<ShapeRun> shape_runs(const RoiDev *h_rois, int nrois)
+{
+    std::vector<ShapeRun> runs;
+    for (int r = 0; r < nrois; r++) {
+        if (!runs.empty() && runs.back().h == h_rois[r].h && runs.back().w == h_rois[r].w) runs.back().count++;
+        else { ShapeRun q; q.first = r; q.count = 1; q.h = h_rois[r].h; q.w = h_rois[r].w; runs.push_back(q); }
+    }
+    return runs;
+}
+
 int launch_integral(vfsms_ctx *ctx, const RoiDev *d_rois, int nrois, int maxh, int maxw)
 {
     if (nrois <= 0) return VFSMS_OK;
-    ProfScope ps(ctx, "integral");
     const int nb = (maxh + INT_TH - 1) / INT_TH;
     hipLaunchKernelGGL(k_integral_bandsum, dim3((maxw + 1023) / 1024, nb, nrois), dim3(256), 0, ctx->stream, d_rois);
     hipLaunchKernelGGL(k_integral_bandscan, dim3((maxw + 3 + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
@@ -1779,62 +1793,67 @@ int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_roi
 {
     if (nrois <= 0) return VFSMS_OK;
     const int lpo = p->n_octave_layers + 2;
-    int maxh = 0, maxw = 0, maxcap = 0;
+    int maxcap = 0;
     // (the caller zeroes the ROI counters; det layers need no clearing: the non-maximum search only ever reads cells
     //  that k_hessian wrote -- its margins are those of the layer above -- so the 53 B/px layer memset is gone)
-    for (int r = 0; r < nrois; r++) {
-        maxh = h_rois[r].h > maxh ? h_rois[r].h : maxh;
-        maxw = h_rois[r].w > maxw ? h_rois[r].w : maxw;
-        maxcap = h_rois[r].cap > maxcap ? h_rois[r].cap : maxcap;
+    for (int r = 0; r < nrois; r++) maxcap = h_rois[r].cap > maxcap ? h_rois[r].cap : maxcap;
+    const std::vector<ShapeRun> runs = shape_runs(h_rois, nrois);
+    {
+        ProfScope ps(ctx, "integral");
+        for (const ShapeRun &q : runs) TRY(launch_integral(ctx, d_rois + q.first, q.count, q.h, q.w));
     }
-    TRY(launch_integral(ctx, d_rois, nrois, maxh, maxw));
     {
         ProfScope ps(ctx, "hessian");
-        int step = 1, o = 0;
-        if (lpo == 5) {                                                // the two fine octaves: LDS-tiled
-            for (; o < p->n_octaves && o < 2; o++) {
-                const int lrows = maxh / step, lcols = maxw / step;
-                if (lrows > 0 && lcols > 0) {
-                    if (o == 0)
-                        hipLaunchKernelGGL((k_hessian_lds<1, 64>), dim3((lcols + 63) / 64, (lrows + 15) / 16, nrois), dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo, o);
-                    else
-                        hipLaunchKernelGGL((k_hessian_lds<2, 32>), dim3((lcols + 31) / 32, (lrows + 15) / 16, nrois), dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo, o);
+        static const bool generic = getenv("VFSMS_HESSIAN_GENERIC") && atoi(getenv("VFSMS_HESSIAN_GENERIC")) != 0;
+        for (const ShapeRun &q : runs) {
+            const RoiDev *dq = d_rois + q.first;
+            int step = 1, o = 0;
+            if (lpo == 5) {                                                // the two fine octaves: LDS-tiled
+                for (; o < p->n_octaves && o < 2; o++) {
+                    const int lrows = q.h / step, lcols = q.w / step;
+                    if (lrows > 0 && lcols > 0) {
+                        if (o == 0)
+                            hipLaunchKernelGGL((k_hessian_lds<1, 64>), dim3((lcols + 63) / 64, (lrows + 15) / 16, q.count), dim3(64, 4), 0, ctx->stream, dq, ctx->d_layers, lpo, o);
+                        else
+                            hipLaunchKernelGGL((k_hessian_lds<2, 32>), dim3((lcols + 31) / 32, (lrows + 15) / 16, q.count), dim3(64, 4), 0, ctx->stream, dq, ctx->d_layers, lpo, o);
+                    }
+                    step *= 2;
                 }
+            }
+            HessPlan plan; plan.o0 = o; plan.noct = 0; plan.first[0] = 0;
+            for (; o < p->n_octaves && plan.noct < VFSMS_MAX_OCTAVES; o++) {
+                const int lrows = q.h / step, lcols = q.w / step;
+                const int tx = (lcols + 63) / 64, ty = (lrows + 3) / 4;
+                plan.tiles_x[plan.noct] = tx > 0 ? tx : 1;
+                plan.first[plan.noct + 1] = plan.first[plan.noct] + tx * ty;
+                plan.noct++;
                 step *= 2;
             }
-        }
-        HessPlan plan; plan.o0 = o; plan.noct = 0; plan.first[0] = 0;
-        for (; o < p->n_octaves && plan.noct < VFSMS_MAX_OCTAVES; o++) {
-            const int lrows = maxh / step, lcols = maxw / step;
-            const int tx = (lcols + 63) / 64, ty = (lrows + 3) / 4;
-            plan.tiles_x[plan.noct] = tx > 0 ? tx : 1;
-            plan.first[plan.noct + 1] = plan.first[plan.noct] + tx * ty;
-            plan.noct++;
-            step *= 2;
-        }
-        static const bool generic = getenv("VFSMS_HESSIAN_GENERIC") && atoi(getenv("VFSMS_HESSIAN_GENERIC")) != 0;
-        if (plan.noct > 0 && plan.first[plan.noct] > 0) {
-            if (lpo == 5 && plan.o0 == 2 && plan.o0 + plan.noct <= 4 && !generic)       // the stock pyramid: constant-offset taps
-                hipLaunchKernelGGL(k_hessian_coarse, dim3((unsigned)plan.first[plan.noct] * lpo * nrois), dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo, plan, nrois);
-            else
-                hipLaunchKernelGGL(k_hessian, dim3((unsigned)plan.first[plan.noct] * lpo * nrois), dim3(64, 4), 0, ctx->stream, d_rois, ctx->d_layers, lpo, plan, nrois);
+            if (plan.noct > 0 && plan.first[plan.noct] > 0) {
+                if (lpo == 5 && plan.o0 == 2 && plan.o0 + plan.noct <= 4 && !generic)       // the stock pyramid: constant-offset taps
+                    hipLaunchKernelGGL(k_hessian_coarse, dim3((unsigned)plan.first[plan.noct] * lpo * q.count), dim3(64, 4), 0, ctx->stream, dq, ctx->d_layers, lpo, plan, q.count);
+                else
+                    hipLaunchKernelGGL(k_hessian, dim3((unsigned)plan.first[plan.noct] * lpo * q.count), dim3(64, 4), 0, ctx->stream, dq, ctx->d_layers, lpo, plan, q.count);
+            }
         }
     }
     {
         ProfScope ps(ctx, "nms");
-        NmsPlan plan; plan.noct = 0; plan.first[0] = 0;
-        int step = 1;
-        for (int o = 0; o < p->n_octaves && o < VFSMS_MAX_OCTAVES; o++) {
-            const int lrows = maxh / step, lcols = maxw / step;
-            const int tx = (lcols + 63) / 64, ty = (lrows + NMS_TH - 1) / NMS_TH;
-            plan.tiles_x[o] = tx > 0 ? tx : 1;
-            plan.first[o + 1] = plan.first[o] + tx * ty;
-            plan.noct = o + 1;
-            step *= 2;
+        for (const ShapeRun &q : runs) {
+            NmsPlan plan; plan.noct = 0; plan.first[0] = 0;
+            int step = 1;
+            for (int o = 0; o < p->n_octaves && o < VFSMS_MAX_OCTAVES; o++) {
+                const int lrows = q.h / step, lcols = q.w / step;
+                const int tx = (lcols + 63) / 64, ty = (lrows + NMS_TH - 1) / NMS_TH;
+                plan.tiles_x[o] = tx > 0 ? tx : 1;
+                plan.first[o + 1] = plan.first[o] + tx * ty;
+                plan.noct = o + 1;
+                step *= 2;
+            }
+            if (plan.noct > 0 && plan.first[plan.noct] > 0)
+                hipLaunchKernelGGL(k_nms, dim3(plan.first[plan.noct], q.count * p->n_octave_layers), dim3(64, 4), 0, ctx->stream, d_rois + q.first,
+                                   ctx->d_layers, lpo, p->n_octave_layers, plan, p->hessian_threshold);
         }
-        if (plan.noct > 0 && plan.first[plan.noct] > 0)
-            hipLaunchKernelGGL(k_nms, dim3(plan.first[plan.noct], nrois * p->n_octave_layers), dim3(64, 4), 0, ctx->stream, d_rois,
-                               ctx->d_layers, lpo, p->n_octave_layers, plan, p->hessian_threshold);
     }
     {
         ProfScope ps(ctx, "sort");
@@ -1922,9 +1941,8 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
         int *tickets = (int *)ctx_arena_alloc(ctx, sizeof(int) * 2 * DESC_HEADS * DESC_HEAD_STRIDE);
         if (!tickets) { vfsms_set_error("arena exhausted (descriptor tickets)"); return VFSMS_ERR_CAPACITY; }
         HIP_TRY(hipMemsetAsync(tickets, 0, sizeof(int) * 2 * DESC_HEADS * DESC_HEAD_STRIDE, ctx->stream));
-        int maxh = 0, maxw = 0;
-        for (int r = 0; r < nrois; r++) { maxh = std::max(maxh, h_rois[r].h); maxw = std::max(maxw, h_rois[r].w); }
-        hipLaunchKernelGGL(k_pair_rows, dim3((maxw + 1023) / 1024, maxh, nrois), dim3(256), 0, ctx->stream, d_rois);
+        for (const ShapeRun &q : shape_runs(h_rois, nrois))
+            hipLaunchKernelGGL(k_pair_rows, dim3((q.w + 1023) / 1024, q.h, q.count), dim3(256), 0, ctx->stream, d_rois + q.first);
         hipLaunchKernelGGL(k_desc_order, dim3(nrois), dim3(1024), 0, ctx->stream, d_rois);
         if (!p->upright) hipLaunchKernelGGL(k_desc_trig, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
         hipLaunchKernelGGL(k_describe, dim3(256 * DESC_WGS), dim3(256), 0, ctx->stream, d_rois, nrois, tickets,

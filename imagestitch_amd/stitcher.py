@@ -95,37 +95,29 @@ def _imread_gray_pointer(path):
 
 
 class _PillowBlocks:
-    """Pillow's image storage for the decoder pool: blocks large enough for a whole decoded tile (so that the pixel block can be handed to
-    the engine without a copy: _decode_once) and a cache of freed blocks (every decode otherwise maps and unmaps 4-17 MB of fresh
-    memory, and a pool of threads page-faulting in one address space serialises on the kernel's memory-map lock: the per-tile decode
-    time grew 20-40 % from 16 to 32 threads).  Restores the process-wide settings on exit."""
+    """Pillow keeps 3-band images in 4-byte pixels: a 2048 x 2048 tile is 16.7 MB, more than one 16 MB storage block, and only an image in ONE
+    block can be handed to the engine without a copy (_decode_once).  While the decoder pool runs, colour images are allocated as single
+    blocks (process-wide switch, restored on exit).  (Measured and rejected: a cache of freed 32 MB blocks for the pool -- Image.core.
+    set_blocks_max -- made the per-tile decode 20 % slower on the 256-thread host, gray and colour alike.)"""
 
-    def __init__(self, nthreads, tile_bytes):
-        self.nthreads, self.tile_bytes, self.saved = nthreads, tile_bytes, None
+    def __init__(self, color):
+        self.color, self.saved = color, None
 
     def __enter__(self):
-        try:
-            from PIL import Image
-            core = Image.core
-            self.saved = (core.get_block_size(), core.get_blocks_max())
-            want = 1 << 24
-            while want < self.tile_bytes and want < (1 << 28):
-                want <<= 1
-            if want != self.saved[0]:
-                core.set_blocks_max(0)                       # (the size can only change while nothing is cached)
-                core.set_block_size(want)
-            core.set_blocks_max(max(self.saved[1], min(2 * self.nthreads + 4, (4 << 30) // want)))
-        except Exception:                                    # an older Pillow: the copying hand-over still works
-            self.saved = None
+        if self.color:
+            try:
+                from PIL import Image
+                self.saved = Image.core.get_use_block_allocator()
+                Image.core.set_use_block_allocator(1)
+            except Exception:                                # an older Pillow: the copying hand-over still works
+                self.saved = None
         return self
 
     def __exit__(self, *exc):
         if self.saved is not None:
             try:
                 from PIL import Image
-                Image.core.set_blocks_max(0)
-                Image.core.set_block_size(self.saved[0])
-                Image.core.set_blocks_max(self.saved[1])
+                Image.core.set_use_block_allocator(self.saved)
             except Exception:
                 pass
         return False
@@ -485,7 +477,7 @@ class Stitcher(Utility.Method):
                     if color:
                         chandles.append(eng.tile_reserve_color(s[0], s[1], 3))
                 nthreads = max(1, min(int(self.decodeThreads or min(os.cpu_count() or 4, 16)), len(fileList), 64))
-                block_alloc = _PillowBlocks(nthreads, shapes[0][0] * shapes[0][1] * (4 if color else 1))
+                block_alloc = _PillowBlocks(color)
                 block_alloc.__enter__()
 
                 istats = self._ingestStats = dict(tiles=0, decode_s=0.0, fill_s=0.0, threads=nthreads)   # summed over the decoder threads
@@ -1109,7 +1101,7 @@ class Stitcher(Utility.Method):
                         pass
                     raise
             nthreads = max(1, min(int(self.decodeThreads or min(os.cpu_count() or 4, 16)), len(files), 64))
-            with _PillowBlocks(nthreads, shapes[0][0] * shapes[0][1] * (4 if color else 1)):
+            with _PillowBlocks(color):
                 with ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="vfsms-decode") as pool:
                     for fu in [pool.submit(ingest, k) for k in range(len(files))]:
                         fu.result()
