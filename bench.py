@@ -17,6 +17,12 @@ stream, overlapped with the registration of earlier pairs (SURVEY 8d's reading: 
 With N > 1 the pairs are sharded in contiguous chunks, one process per GPU, and ONE all-gather (RCCL) of the int32 offset
 tables closes the step ("strong" scaling: total work is fixed).  Prints ONE JSON line on rank 0.
 
+Path memory (round 4): the registrar remembers the accepted directions of the path it registered last and plans the speculative batches of
+the next path of the same length from them (GridRegistrar.path_memory; a prior like a branch predictor's: every attempt is still evaluated,
+results never depend on it).  The warm-up step teaches it the grid's scan pattern, the K timed steps run on it: 3 batches per step instead
+of 13, one primed chain per rank at N > 1.  `value_cold_path` (N = 1) is the same K steps by a registrar without memory -- the
+configuration of rounds 1-3; --no-path-memory makes it the headline.
+
 --method orb | phase | fuse time the other paths of the scope table on the same grid (each with its own roofline object);
 the default, surf, is the BASELINE metric.
 --workload dendritic25 (N = 1): the 25 committed pairs of the reference's dendriticCrystal set (tests/golden/real_path_strips.*), a second
@@ -37,8 +43,12 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak of gfx950 (v_mfma_f32_32x32x16_bf16), MI355X_MICROARCH.md
 FP32_PEAK_TFLOPS = 157.3       # dense FP32 MFMA peak of gfx950 (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md
-# VALU issue peak in lane-operations: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.  (157.3 TFLOP/s = this x 2 flop per FMA x 2 for packed
-# FP32; SQ_INSTS_VALU == SQ_ACTIVE_INST_VALU quad-cycles in profiles/r02_pmc_describe.txt: one wave64 VALU instruction = 4 cycles.)
+# VALU issue peak in lane-operations: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T/s, i.e. one wave64 VALU instruction occupies its SIMD
+# for 4 cycles.  CALIBRATED on the box (tools/valu_peak.hip, every SIMD filled with 1-8 waves of independent chains,
+# profiles/r04_valu_peak.txt): v_fma_f32 38.3, v_fma_f64 33.2, v_add_f64 36.9, v_cvt_f32_ubyte0 37.8, v_cvt_i32_f64 37.5, v_cvt_f32_f64 36.8,
+# v_pk_mul_f32 33.1 T lane-ops/s -- the 4-cycle rate (0.84-0.97 of 39.3) for every VOP3 / conversion / f64 / packed instruction the
+# descriptor kernels lean on; MI355X_MICROARCH.md's "SIMD-32, 2 cycles" (78.6 T/s) is NOT reached by them.  Only plain VOP2 operations run
+# faster: v_mul_f32 56.4, v_add_u32 60.7 T/s (~2.7 cycles).  157.3 TFLOP/s = 39.3 T x 2 flop per FMA x 2 for packed FP32.
 VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # VALU instructions per bilinear sample of k_describe's staging loop, counted in its gfx950 assembly (interior path: index + v_cvt_f64,
 # 2 v_fma_f64, 2 v_cvt_i32_f64, 2 address, 2 v_fract_f64, 2 v_cvt_f32_f64, 2 v_sub, 4 v_cvt_f32_ubyte, 4 v_pk_mul (+2 moves), 3 v_add,
@@ -554,6 +564,10 @@ def main():
                         surfParams=eng.surf_params() if args.method == "surf" else eng.orb_params() if args.method == "orb" else None,
                         window=args.window)
     reg.remember = not args.no_path_memory
+    if os.environ.get("VFSMS_BENCH_PRIME", "0") not in ("", "0"):
+        # PROFILING AID (tools/profile_round.sh, PMC passes of one step): start with the scan pattern already learned, so that every launch
+        # of the short run is a steady-state launch.  Never set for a measured line.
+        reg.path_memory = [int(d) for d in grid.true_directions()]
     gather = make_all_gather(coll_device) if world > 1 else single_process_all_gather
 
     def step(hs=handles):
@@ -690,7 +704,8 @@ def main():
                              "instructions k_describe issues (PMC SQ_INSTS_VALU, profiles/) keep its SIMDs busy for valu_busy_frac_pmc of the "
                              "launch (lane padding of 8 x 32-sample units, INTER_AREA reduction, row-origin chains, tickets)"
                              % (100.0 * de_ms / max(sum(v[0] for v in prof.values()), 1e-9)),
-                        valu_insts_per_launch_pmc=valu_insts, valu_busy_frac_pmc=valu_busy,
+                        valu_insts_per_launch_pmc=valu_insts, valu_busy_frac_pmc=valu_busy, ta_busy_frac_pmc=pmc_value("k_describe", "ta_busy_frac")[0],
+                        valu_peak_source="profiles/r04_valu_peak.txt (tools/valu_peak.hip on the MI355X box: 4-cycle class instructions 33-38 T lane-ops/s)",
                         ops_per_sample_lower_bound=DESC_OPS_LOWER_BOUND,
                         valu_insts_lower_bound_per_launch=round(kps * spk * DESC_OPS_LOWER_BOUND / 64.0),
                         valu_issued_over_lower_bound=(round((valu_insts + (pmc_value("k_describe_small", "INSTS_VALU")[0] or 0.0)) /
@@ -725,7 +740,11 @@ def main():
     he_ms, he_n = prof.get("hessian", (0.0, 0))
     if he_n:
         # reads S once per octave pass 4 (h+1)(w+1) x 4 + writes det + trace 8 x sum_o 5 (h/2^o)(w/2^o) = 69.1 B/px
-        extra["hessian_hbm"] = hbm_roofline("k_hessian_lds<1,64>+k_hessian_lds<2,32>+k_hessian(octaves 2..)", st["roi_px"] / he_n * 69.1, he_ms / he_n, he_n)
+        extra["hessian_hbm"] = hbm_roofline("k_hessian_lds<1,64>+k_hessian_lds<2,32>+k_hessian_coarse(octaves 2, 3)", st["roi_px"] / he_n * 69.1, he_ms / he_n, he_n)
+        hv, _s = pmc_value("void k_hessian_lds<1, 64>", "INSTS_VALU"); hb, _s = pmc_value("void k_hessian_lds<1, 64>", "BUSY_CYCLES")
+        extra["hessian_hbm"]["valu_busy_frac_pmc_octave0"] = round(hv * 4.0 / (hb / 32.0 * 1024.0), 3) if hv and hb else None
+        extra["hessian_hbm"]["note"] = ("bytes = SURVEY 8d's 69.1 B/px (it still counts the trace layers, no longer written); the fine octaves are bound by VALU "
+                                        "issue + LDS taps (valu_busy_frac_pmc_octave0), not by HBM")
     if args.method == "phase":
         ph_ms, ph_n = prof.get("phase", (0.0, 0))
         if ph_n:
@@ -775,6 +794,7 @@ def main():
                                            "path memory: the accepted directions of the previous registration of this scan pattern (the warm-up step) drive the "
                                            "speculation plan of the timed steps; nothing from the ground truth, every attempt evaluated")},
             "max_abs_offset_error_px": max_err, "pairs_failed": n_failed,
+            "path_memory_primed_for_profiling": os.environ.get("VFSMS_BENCH_PRIME", "0") not in ("", "0"),
             "value_cold_path": round(P * args.steps / elapsed_cold, 3) if elapsed_cold else None,
             "cold_path": (dict(ms_per_step=round(elapsed_cold / args.steps * 1e3, 3), attempts_per_step=cold_stats["attempts"] / (args.steps + 1),
                                batches_per_step=cold_stats["batches"] / (args.steps + 1),
