@@ -1114,8 +1114,25 @@ extern "C" int vfsms_features_surf(vfsms_ctx *ctx, int64_t tile, int y0, int x0,
 // calculateOffsetForFeatureSearch pair after pair (Stitcher.py:260-304); with all tiles of a scan in HBM every tile is described once, up to
 // 16 per launch sequence, and the N - 1 matches + mode votes run as one batch (vfsms_features_match_offset_batch) -- one host synchronisation
 // per 16 tiles instead of two per tile.
+static int features_surf_batch_impl(vfsms_ctx *ctx, const int64_t *tiles, int n, const vfsms_surf_params *params,
+                                    int enhance_mode, double clip_limit, int tile_grid, int64_t *feats, int *counts);
+extern "C" int vfsms_features_free(vfsms_ctx *ctx, int64_t feat);
 extern "C" int vfsms_features_surf_batch(vfsms_ctx *ctx, const int64_t *tiles, int n, const vfsms_surf_params *params,
                                          int enhance_mode, double clip_limit, int tile_grid, int64_t *feats, int *counts)
+{
+    const int rc = features_surf_batch_impl(ctx, tiles, n, params, enhance_mode, clip_limit, tile_grid, feats, counts);
+    if (rc != VFSMS_OK && ctx && feats && n > 0) {
+        // an error in chunk 2 or later (e.g. VFSMS_ERR_CAPACITY): the sets of the earlier chunks never reach the caller -- release them
+        // (and their shared block) here; the error text of the failure is kept
+        char msg[512]; vfsms_last_error(msg, sizeof(msg));
+        for (int k = 0; k < n; k++)
+            if (feats[k] && ctx->feats.count(feats[k])) { vfsms_features_free(ctx, feats[k]); feats[k] = 0; }
+        vfsms_set_error("%s", msg);
+    }
+    return rc;
+}
+static int features_surf_batch_impl(vfsms_ctx *ctx, const int64_t *tiles, int n, const vfsms_surf_params *params,
+                                    int enhance_mode, double clip_limit, int tile_grid, int64_t *feats, int *counts)
 {
     CTX_ENTER(ctx);
     if (n < 0 || (n && (!tiles || !feats || !counts)) || !params) { vfsms_set_error("features_surf_batch: bad arguments"); return VFSMS_ERR_BAD_ARG; }

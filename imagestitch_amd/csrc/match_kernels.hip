@@ -776,6 +776,9 @@ __global__ __launch_bounds__(256) void k_votes_from_pairs(const MatchDev *jobs, 
 // in O(M) instead of the O(M^2) equality count (100 us per launch on SURF batches, 230 us on ORB's 5000 unconditional votes).
 #define MODE_SLOTS 8192
 #define MODE_HASH_MAX 5600
+// three uint32[8192] tables = 96 KB of static LDS: this kernel needs gfx950's 160 KB per CU (the library is gfx950-only: README, Makefile);
+// a 64 KB-LDS target would have to shrink MODE_SLOTS and send more votes through the O(M^2) fallback above MODE_HASH_MAX
+static_assert(3 * MODE_SLOTS * sizeof(uint32_t) <= 160 * 1024 - 16 * 1024, "k_scan_mode's hash tables are sized for the 160 KB LDS of gfx950");
 __global__ __launch_bounds__(1024) void k_scan_mode(const MatchDev *jobs, int offset_evaluate)
 {
     const MatchDev &J = jobs[blockIdx.x];

@@ -557,9 +557,15 @@ class Stitcher(Utility.Method):
                 for h in handles + chandles:
                     try:
                         eng.tile_free(h)
-                    except Exception:                          # (a handle whose decoder never ran and could not be given up)
-                        if not failed and err is None:
-                            raise
+                    except Exception:
+                        # still reserved: its decoder never ran (a reserve further down the list failed before the pool started) -- give it
+                        # up first, a reserved tile cannot be freed
+                        try:
+                            eng.tile_fill(h, None)
+                            eng.tile_free(h)
+                        except Exception:
+                            if not failed and err is None:
+                                raise
             if err is not None and not failed:
                 raise err
         offsetList, endfileIndex, status, describtion = [], 0, True, ""

@@ -564,3 +564,27 @@ def _break_at_second_pair():
         order = seen.setdefault(key, len(seen))
         return [0, 0, 0, 0, 10, 10, 0, 0] if order == 1 else [1, 96, 0, 9, 10, 10, 9, 0]
     return script
+
+
+def test_reserve_failure_midway_leaks_nothing(oracle, tmp_path):
+    """HBM exhausted while the ingest pipeline reserves its tiles (a long file list): the handles reserved so far -- still unfilled, which
+    vfsms_tile_free refuses -- are given up and freed, and the error reaches the caller."""
+    from imagestitch_amd.synthetic import SyntheticGrid
+    g = SyntheticGrid(1, 4, 128, overlap=0.25)
+    files = _write_jpegs(tmp_path, _colour_tiles(g), "oom")
+
+    class Exhausted(IngestOracleEngine):
+        def tile_reserve(self, h, w):
+            if len(self.live) >= 3:
+                raise MemoryError("hipMalloc: out of memory")
+            return super().tile_reserve(h, w)
+    old = (isa.Stitcher.direction, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod)
+    try:
+        isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod, isa.Stitcher.isColorMode = "surf", "notFuse", True
+        eng = Exhausted(oracle, scripted=lambda A, B, job: [1, 5, -3, 9, 10, 10, 9, 0])
+        s = isa.Stitcher(); s._engine = eng; s.isPrintLog = False; s.direction = 1
+        with pytest.raises(MemoryError):
+            s.flowStitch(list(files), s.calculateOffsetForFeatureSearchIncre)
+        assert not eng.live, eng.live
+    finally:
+        isa.Stitcher.direction, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod = old
