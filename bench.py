@@ -70,15 +70,41 @@ def pmc_value(kernel, key):
     import re
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.txt")), reverse=True):
         for line in open(path):
-            if line.startswith(kernel + " ") and "launches=" in line:
+            if line.startswith(kernel + " ") and ("launches=" in line or kernel == "pmc_run"):
                 m = re.search(re.escape(key) + r"=([0-9.e+]+)", line)
                 if m:
                     return float(m.group(1)), os.path.relpath(path, ROOT)
     return None, None
 
 
+def pmc_total(kernel, key):
+    """per-launch figure x launches of `kernel` in the newest PMC summary -> (total, launches)"""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.txt")), reverse=True):
+        for line in open(path):
+            if line.startswith(kernel + " ") and "launches=" in line:
+                m = re.search(re.escape(key) + r"=([0-9.e+]+)", line)
+                n = re.search(r"launches=(\d+)", line)
+                if m and n:
+                    return float(m.group(1)) * int(n.group(1)), int(n.group(1))
+    return None, None
+
+
 def pmc_traffic(kernel):
     return pmc_value(kernel, "total(x2 rule)")
+
+
+def valu_over_bound(spk_live):
+    """SQ_INSTS_VALU of k_describe + k_describe_small over the whole PMC run / (the keypoints that run described x samples per keypoint x 26
+    lane-ops / 64 lanes): counter totals against an algorithmic count, independent of launch sizes"""
+    a, _n = pmc_total("k_describe", "INSTS_VALU")
+    b, _n = pmc_total("k_describe_small", "INSTS_VALU")
+    kp, _s = pmc_value("pmc_run", "keypoints")
+    sp, _s = pmc_value("pmc_run", "samples_per_keypoint")
+    if not (a and kp):
+        return None
+    return round((a + (b or 0.0)) / (kp * (sp or spk_live) * DESC_OPS_LOWER_BOUND / 64.0), 3)
 
 
 def sum_or_none(vals):
@@ -708,8 +734,9 @@ def main():
                         valu_peak_source="profiles/r04_valu_peak.txt (tools/valu_peak.hip on the MI355X box: 4-cycle class instructions 33-38 T lane-ops/s)",
                         ops_per_sample_lower_bound=DESC_OPS_LOWER_BOUND,
                         valu_insts_lower_bound_per_launch=round(kps * spk * DESC_OPS_LOWER_BOUND / 64.0),
-                        valu_issued_over_lower_bound=(round((valu_insts + (pmc_value("k_describe_small", "INSTS_VALU")[0] or 0.0)) /
-                                                            (kps * spk * DESC_OPS_LOWER_BOUND / 64.0), 3) if valu_insts and kps * spk > 0 else None))
+                        valu_issued_over_lower_bound=valu_over_bound(spk),
+                        per_launch_pmc_note="PMC figures are per launch OF THE PMC RUN (its launches need not have this run's size); the ratio "
+                                            "valu_issued_over_lower_bound is formed from counter TOTALS and the keypoints that run described (pmc_run line)")
     bf_ms, bf_n = prof.get("bf_mfma", (0.0, 0))
     if bf_n:
         dur = bf_ms / bf_n * 1e-3

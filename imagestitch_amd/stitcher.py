@@ -440,6 +440,9 @@ class Stitcher(Utility.Method):
         elif (fn is Stitcher.calculateOffsetForFeatureSearch and self._usesStockOperators() and self.featureMethod == "surf"
               and self.offsetCaculate == "mode" and hasattr(self.engine, "features_surf_batch")):
             method = "surf_full"                              # the line scans of Main.py:29-51: whole-tile features, no ROI search
+        elif (fn is Stitcher.calculateOffsetForFeatureSearch and self._usesStockOperators() and self.featureMethod == "orb"
+              and self.offsetCaculate == "mode" and not self.isEnhance and hasattr(self.engine, "attempt_orb_batch")):
+            method = "orb_full"                               # the same scans with featureMethod = "orb"
         else:
             return None
         eng = self.engine
@@ -447,8 +450,8 @@ class Stitcher(Utility.Method):
         if any(s != shapes[0] for s in shapes):
             return None
         from .grid import GridRegistrar
-        params = None if method == "phase" else (self._orbParams() if method == "orb" else self._surfParams())
-        reg = GridRegistrar(eng, method="surf" if method == "surf_full" else method, roiRatio=self.roiRatio, searchRatio=self.searchRatio, offsetEvaluate=self.offsetEvaluate,
+        params = None if method == "phase" else (self._orbParams() if method in ("orb", "orb_full") else self._surfParams())
+        reg = GridRegistrar(eng, method="surf" if method == "surf_full" else "orb" if method == "orb_full" else method, roiRatio=self.roiRatio, searchRatio=self.searchRatio, offsetEvaluate=self.offsetEvaluate,
                             directIncre=self.directIncre, surfParams=params,
                             phaseResponseThreshold=self.phaseResponseThreshold, window=48,
                             enhance=self._enhanceSpec() if method in ("surf", "surf_full") else (0, 0.0, 0))
@@ -515,6 +518,8 @@ class Stitcher(Utility.Method):
                 handles = [eng.tile_upload(_imread(f, False)) for f in fileList]
             if method == "surf_full":
                 table = self._fullImageTable(handles)
+            elif method == "orb_full":
+                table = self._fullImageTableOrb(handles, shapes)
             else:
                 table, _d = reg.register(handles, shapes, self.direction, stop_on_fail=True)
                 if reg.path_memory is not None:
@@ -575,7 +580,7 @@ class Stitcher(Utility.Method):
                 status = False
                 describtion = "  " + str(fileList[k]) + " and " + str(fileList[k + 1]) + " can not be stitched"
                 break
-            if method != "surf_full":
+            if method not in ("surf_full", "orb_full"):
                 self.direction = int(row[3])
             self.printAndWrite("  The offset of stitching: dx is " + str(int(row[1])) + " dy is " + str(int(row[2])))
             offsetList.append([int(row[1]), int(row[2])])
@@ -600,6 +605,25 @@ class Stitcher(Utility.Method):
             table.append([int(r[0]), int(r[1]), int(r[2]), 0, 0, int(r[3])])
             if not r[0]:
                 break
+        self.tempImageFeature.isBreak = True                  # the scan owns no cached set afterwards
+        return table
+
+    def _fullImageTableOrb(self, handles, shapes, chunk=16):
+        """calculateOffsetForFeatureSearch (Stitcher.py:260-304) with featureMethod = "orb" over consecutive resident tiles: the N - 1
+        whole-tile attempts (ORB of both tiles, BF-Hamming 1-NN, mode vote) as fused batches of `chunk` pairs.  A tile is described as B of
+        one pair and again as A of the next -- the reference reuses B's features (Stitcher.py:278-290), which are the same numbers -- so the
+        rows are those of the pair loop; nothing behind the first pair that cannot be matched is reported (flowStitch breaks there)."""
+        eng = self.engine
+        max_dist = self.orbMaxDistance if self.isGPUAvailable else -1
+        table = []
+        for c0 in range(0, len(handles) - 1, chunk):
+            jobs = [(handles[k], handles[k + 1], 0, 0, 0, 0, shapes[k][0], shapes[k][1]) for k in range(c0, min(c0 + chunk, len(handles) - 1))]
+            for r in eng.attempt_orb_batch(jobs, self._orbParams(), max_dist, self.offsetEvaluate):
+                ok = bool(r[0]) and r[4] > 0 and r[5] > 0          # an image without keypoints: featuresX is None, status stays False
+                table.append([int(ok), int(r[1]), int(r[2]), 0, 0, int(r[3])])
+                if not ok:
+                    self.tempImageFeature.isBreak = True
+                    return table
         self.tempImageFeature.isBreak = True                  # the scan owns no cached set afterwards
         return table
 

@@ -1241,3 +1241,52 @@ def test_phase_batch_on_dendritic_crops_against_stitcher_py_87(engine, oracle, g
             ry, rx = phase87_residual(r, (x, y))
             assert max(abs(ry), abs(rx)) <= 1.5, (r["a"], ry, rx)
             assert bool(resp > 0.15) == r["accepted"]
+
+
+@pytest.mark.gpu
+def test_line_scan_batched_full_image_path_orb(engine, oracle, tmp_path):
+    """The same scans with featureMethod = "orb" (Stitcher.py:260-304 over ImageUtility.py:260, 297-302): the batched whole-tile path
+    (N - 1 fused ORB attempts) reports what the pair-by-pair mirror reports -- status, offsets, log lines, the break -- and its first rows
+    equal the oracle's chain (ORB of both tiles, BF-Hamming 1-NN, mode vote) on the same tiles."""
+    from PIL import Image
+    tiles, truth = _line_scan()
+    tiles = tiles[:5]
+    files = []
+    for k, t in enumerate(tiles):
+        f = os.path.join(str(tmp_path), "oscan_%02d.png" % k)
+        Image.fromarray(t).save(f); files.append(f)
+    old = (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate, isa.Stitcher.isEnhance,
+           isa.Stitcher.isColorMode, isa.Stitcher.fuseMethod)
+    try:
+        isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate = 4, 0, "orb", 10
+        isa.Stitcher.isColorMode, isa.Stitcher.fuseMethod, isa.Stitcher.isEnhance = False, "notFuse", False
+        seq = isa.Stitcher(); seq._engine = engine; seq.isPrintLog = False
+        seq.tempImageFeature.isBreak = True
+        want = [seq.calculateOffsetForFeatureSearch([tiles[k], tiles[k + 1]]) for k in range(len(tiles) - 1)]
+        seq.releaseTiles()
+        st = isa.Stitcher(); st._engine = engine
+        msgs = []
+        st.printAndWrite = lambda c, msgs=msgs: msgs.append(c)
+        got = st._registerBatched(files, st.calculateOffsetForFeatureSearch)
+        assert got is not None, "the batched ORB full-image path did not engage"
+        status, end, offs, _desc = got
+        for h, _s in (st.__dict__.pop("_resident", None) or {}).values():
+            engine.tile_free(h)
+        assert all(w[0] for w in want) and status and end == len(tiles) - 1 and offs == [w[1] for w in want], (offs, want)
+        for k, o in enumerate(offs):
+            assert abs(o[0] - truth[k][0]) <= 1 and abs(o[1] - truth[k][1]) <= 1
+            assert "  The offset of stitching: dx is %d dy is %d" % (o[0], o[1]) in msgs
+        ka, da = oracle.orb_detect_describe(tiles[0]); kb, db = oracle.orb_detect_describe(tiles[1])
+        pairs, _ = oracle.bf_hamming_matches(da, db)
+        ost, ooff, _votes = oracle.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, 10)
+        assert ost and list(ooff) == offs[0]
+        Image.fromarray(np.zeros_like(tiles[0])).save(files[3])
+        st = isa.Stitcher(); st._engine = engine; st.isPrintLog = False
+        status, end, offs, desc = st._registerBatched(files, st.calculateOffsetForFeatureSearch)
+        for h, _s in (st.__dict__.pop("_resident", None) or {}).values():
+            engine.tile_free(h)
+        assert status is False and end == 2 and len(offs) == 2 and "can not be stitched" in desc
+    finally:
+        (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate, isa.Stitcher.isEnhance,
+         isa.Stitcher.isColorMode, isa.Stitcher.fuseMethod) = old
+        isa.Stitcher.tempImageFeature.isBreak = True

@@ -64,6 +64,17 @@ for k in sorted(ta, key=lambda k:-ta[k].get('TA_TA_BUSY',0)):
             k[:28],n,ta[k].get('TA_TA_BUSY',0)/n,ta[k].get('TA_FLAT_READ_WAVEFRONTS_sum',ta[k].get('TA_FLAT_READ_WAVEFRONTS',0))/n,
             (ta[k].get('TA_TA_BUSY',0)/n/256.0)/busy if busy else 0, m.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/nm,
             (m.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/nm/1024.0)/busy if busy else 0, m.get('SQ_WAIT_INST_ANY',0)/nm, m.get('SQ_ACTIVE_INST_VALU',0)/nm))
+# what the PMC runs described, so that counter TOTALS can be set against an algorithmic count whatever the launch sizes were: the SQ pass ran
+# (warm-up-0 step + 1 timed step) of the bench line stored next to it, plus one single-ROI call (the samples-per-keypoint probe)
+import json
+try:
+    b=json.loads(open('$OUT/pmc_sq_bench.json').read().strip().splitlines()[-1])
+    steps=b['steps']+max(b['warmup'],1)
+    kps=2.0*b['attempts_per_step']*b['keypoints_per_roi']*steps+b['keypoints_per_roi']
+    out.write('\n# the SQ pass as a whole (for ratios of counter totals to algorithmic counts)\n')
+    out.write('pmc_run steps=%d attempts=%.0f keypoints=%.0f samples_per_keypoint=%.1f\n' % (steps, b['attempts_per_step']*steps, kps, b['roofline']['samples_per_keypoint']))
+except Exception as e:
+    out.write('# pmc_run: %s\n' % e)
 out.close()
 print(open('$OUT/pmc_summary.txt').read())
 PY
