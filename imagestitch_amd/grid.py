@@ -506,6 +506,19 @@ class GridRegistrar:
         return full, d
 
 
+def serpentine_directions(rows, cols, first=1, across=2):
+    """Predicted accepted directions of a column-major serpentine of rows x cols tiles (rows - 1 pairs down, one across, rows - 1 up, ...):
+    a scan-pattern hint for GridRegistrar.register(hint=...) / Stitcher.pathHint.  first: direction of the first column (1: the next tile
+    lies below), across: direction of the step to the next column."""
+    back = {1: 3, 3: 1, 2: 4, 4: 2}[first]
+    out = []
+    for c in range(cols):
+        out += [first if c % 2 == 0 else back] * (rows - 1)
+        if c < cols - 1:
+            out.append(across)
+    return out
+
+
 def split_segments(results):
     """flowStitchWithMutiple's segmentation (Stitcher.py:96-127) from a per-pair result table:
     -> [(first tile, last tile inclusive, [[dx, dy], ...])]."""

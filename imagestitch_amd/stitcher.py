@@ -440,6 +440,7 @@ class Stitcher(Utility.Method):
             self.printAndWrite(describtion)
         return ((status, endfileIndex), stitchImage)
 
+    pathHint = None              # optional PREDICTION of the accepted direction of every pair (a scan pattern the operator knows, e.g. from grid.serpentine_directions); the speculation prior of the FIRST dataset -- later ones use what the previous one taught (GridRegistrar.path_memory).  Results never depend on it.
     streamOutput = False         # imageSetStitch*: encode PNG / TIFF / NPY results band by band as they leave the device (mosaics beyond host memory)
     batchRegistration = True     # let flowStitch register a whole file list in fused device batches when the stock search is used
     decodeThreads = 0            # decoder threads of the ingest pipeline (0: one per host core, at most 16 -- beyond that Pillow's Python-side work and the registrar's own host thread get in each other's way)
@@ -501,6 +502,8 @@ class Stitcher(Utility.Method):
         # the scan pattern the previous dataset taught this stitcher (accepted directions, same number of tiles): the speculation prior of
         # this one (GridRegistrar.path_memory; Main.py runs its datasets through ONE Stitcher with one setting)
         reg.path_memory = self.__dict__.get("_pathMemory")
+        if reg.path_memory is None and self.pathHint is not None and len(self.pathHint) == len(fileList) - 1:
+            reg.path_memory = [int(d) for d in self.pathHint]
         device_fuse = (self.fuseMethod in ("notFuse", "fadeInAndFadeOut", "trigonometric") and hasattr(eng, "canvas_fuse_tile_resident")) or \
                       (self.fuseMethod in ("average", "maximum", "minimum") and hasattr(eng, "canvas_blend_tile_resident"))
         # the tiles the mosaic is assembled from stay in HBM: the registration planes themselves for gray mosaics, and for colour mosaics

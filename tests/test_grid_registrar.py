@@ -336,6 +336,26 @@ def test_two_process_gloo_hinted_with_repair(tmp_path):
         assert (got["repairs"] >= 1) == (mode == "badhint"), (mode, got["repairs"])
 
 
+def test_serpentine_hint_on_the_first_path():
+    """grid.serpentine_directions as the hint of a path registered for the FIRST time: the sequential number of attempts in three batches,
+    the sequential table."""
+    from imagestitch_amd.grid import serpentine_directions
+    accept = []
+    for c in range(9):
+        d_col = 1 if c % 2 == 0 else 3
+        accept += [{(d_col, i): (3, 4) for i in range(1, 4)} for _ in range(9)]
+        if c < 8:
+            accept.append({(2, i): (3, 4) for i in range(1, 4)})
+    hint = serpentine_directions(10, 9)
+    assert len(hint) == len(accept) == 89
+    seq, d_end, n_seq = sequential(accept, 0.2, 1, 1)
+    eng = ScriptedAttemptEngine(SHAPE, 0.2, accept)
+    reg = GridRegistrar(eng, roiRatio=0.2, directIncre=1, window=48)
+    res, d = reg.register(list(range(90)), [SHAPE] * 90, 1, hint=hint)
+    assert [list(r[:4]) for r in res.tolist()] == seq and d == d_end
+    assert reg.stats["attempts"] == n_seq and reg.stats["batches"] == 3, reg.stats
+
+
 def test_path_memory_is_a_prior_never_a_result():
     """GridRegistrar.path_memory: the second registration of a scan pattern plans its batches from what the first one taught it -- the
     sequential number of attempts in a handful of batches instead of a learning phase of a dozen small ones -- and a DIFFERENT path of
