@@ -573,7 +573,7 @@ def main():
     need = list(range(grid.n_tiles)) if world > 1 else (list(range(lo, hi + 1)) if hi > lo else [])
     # tiles live in pinned host memory (what a decoder feeding this engine would write into): uploads from it are asynchronous DMA
     tiles = {}
-    for k, t in zip(need, grid.tiles(need, threads=min(8, os.cpu_count() or 1))):
+    for k, t in zip(need, grid.tiles(need, threads=min(8 if grid.n_tiles <= 128 else 48, os.cpu_count() or 1))):
         buf = eng.pinned_empty(t.shape)
         buf[...] = t
         tiles[k] = buf

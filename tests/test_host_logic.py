@@ -610,3 +610,33 @@ def test_fast_header_reader_equals_pillow(tmp_path):
         with Image.open(p) as im:
             want = (im.size[1], im.size[0])
         assert ST._imshape(p) == want, p
+
+
+def test_decode_once_on_the_reference_demo_tiles():
+    """The same identity on the reference's own micrographs, where they are present (this container; the GPU box has no /root/reference and
+    no `-m gpu` test reads it): one file per demo dataset -- 4:2:0 colour JPEGs from the microscope cameras and the grayscale zircon scans --
+    decoded ONCE to planes gives the grayscale decode (Y) and the colour decode (jdcolor arithmetic) byte for byte."""
+    import ctypes
+    import glob
+    from imagestitch_amd import stitcher as ST
+    root = "/root/reference/demoImages"
+    if not os.path.isdir(root):
+        pytest.skip("the reference checkout is not present here")
+    seen = 0
+    for d in sorted(glob.glob(os.path.join(root, "*", "1"))):
+        files = sorted(f for f in glob.glob(os.path.join(d, "*")) if f.lower().endswith((".jpg", ".jpeg")))
+        if not files:
+            continue
+        p = files[len(files) // 2]
+        owner, shape, parts = ST._decode_once(p, True)
+        assert parts[0] == "src" and shape == ST._imshape(p)
+        spx = {0: 1, 1: 3, 2: 4}[parts[3]]
+        buf = np.frombuffer((ctypes.c_uint8 * (shape[0] * parts[2])).from_address(parts[1]), np.uint8).reshape(shape[0], parts[2])
+        px = buf[:, :shape[1] * spx].reshape(shape[0], shape[1], spx)
+        assert np.array_equal(px[:, :, 0], ST._imread(p, False)), p
+        want = ST._imread(p, True)
+        got = np.repeat(px[:, :, :1], 3, 2) if parts[3] == 0 else ST._ycc_to_bgr(px[:, :, :3])
+        assert np.array_equal(got, want), p
+        del owner
+        seen += 1
+    assert seen >= 4
