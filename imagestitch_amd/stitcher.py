@@ -510,7 +510,7 @@ class Stitcher(Utility.Method):
         # (Main.py:14's default) the B G R tiles the SAME decode produced -- every file is decoded exactly once (Stitcher.py:68-69, 382-403)
         color = bool(self.isColorMode) and device_fuse and hasattr(eng, "tile_fill_pair")
         keep = device_fuse and (color or not self.isColorMode) and len(set(fileList)) == len(fileList)
-        handles, chandles, pool, futures, failed, table = [], [], None, [], False, None
+        handles, chandles, pool, futures, failed, table, todo = [], [], None, [], False, None, []
         block_alloc = None
         try:
             if hasattr(eng, "tile_reserve"):
@@ -520,10 +520,26 @@ class Stitcher(Utility.Method):
                 # at once and waits only for the tiles of the batch it is about to launch, so registration overlaps decoding and the
                 # decoded arrays never pile up on the host (a thread holds one tile at a time).
                 from concurrent.futures import ThreadPoolExecutor
-                for s in shapes:                              # one by one: a reserve that fails midway leaves nothing behind (finally)
+                # Tiles a previous segment of this file list decoded but did not use (they lay behind its registration break,
+                # flowStitchWithMutiple): taken over as they are -- a file is decoded once even when the path breaks (the reference
+                # decodes the remaining list again after every break, Stitcher.py:96-127).
+                cache = self.__dict__.get("_ingestCache") or {}
+                have = []
+                for s, f in zip(shapes, fileList):            # one by one: a reserve that fails midway leaves nothing behind (finally)
+                    ent = cache.get(f)
+                    if ent is not None and tuple(ent[2]) == tuple(s) and (bool(ent[1]) or not color):
+                        del cache[f]
+                        handles.append(ent[0])
+                        if color:
+                            chandles.append(ent[1])
+                        elif ent[1]:
+                            eng.tile_free(ent[1])
+                        have.append(True)
+                        continue
                     handles.append(eng.tile_reserve(s[0], s[1]))
                     if color:
                         chandles.append(eng.tile_reserve_color(s[0], s[1], 3))
+                    have.append(False)
                 nthreads = max(1, min(int(self.decodeThreads or min(os.cpu_count() or 4, 16)), len(fileList), 64))
                 block_alloc = _PillowBlocks(color)
                 block_alloc.__enter__()
@@ -558,7 +574,8 @@ class Stitcher(Utility.Method):
                                     pass
                         raise
                 pool = _decoder_pool(nthreads)
-                futures = [pool.submit(ingest, k) for k in range(len(fileList))]
+                todo = [k for k in range(len(fileList)) if not have[k]]
+                futures = [pool.submit(ingest, k) for k in todo]
             else:
                 handles = [eng.tile_upload(_imread(f, False)) for f in fileList]
             if method == "surf_full":
@@ -577,32 +594,40 @@ class Stitcher(Utility.Method):
             # not started are cancelled (their handles are given up so that they can be freed), and a file behind the last registered pair
             # that fails to decode is not an error of this call
             needed = len(fileList) if (failed or table is None) else min(len(table) + 1, len(fileList))
-            err = None
-            for k, fu in enumerate(futures):
+            err, unfilled = None, set()
+            for k, fu in zip(todo, futures):
                 if fu.cancel():
+                    unfilled.add(k)
                     for h in ([handles[k]] + ([chandles[k]] if color else [])):
                         try:
                             eng.tile_fill(h, None)
                         except Exception:
                             pass
-            for k, fu in enumerate(futures):                  # every running decoder has finished with its handles before any is freed
+            for k, fu in zip(todo, futures):                  # every running decoder has finished with its handles before any is freed
                 if fu.cancelled():
                     continue
                 try:
                     fu.result()
                 except BaseException as e:                     # noqa: PERF203
+                    unfilled.add(k)
                     if k < needed:
                         err = err or e
             if block_alloc is not None:
                 block_alloc.__exit__(None, None, None)
-            if keep and err is None:
-                # the mosaic is assembled from these very tiles: getStitchByOffset takes them over (and frees them)
-                kept = chandles if color else handles
-                self._resident = dict(zip(fileList, zip(kept, [(s[0], s[1], 3) if color else s for s in shapes])))
-                for h in (handles if color else []):
-                    eng.tile_free(h)
-            else:
-                for h in handles + chandles:
+            # tiles of this segment: 0 .. (leading registered pairs); the rest lies behind the break
+            n_used = len(fileList)
+            if table is not None and not failed:
+                n_used = 1
+                for row in table:
+                    if not row[0]:
+                        break
+                    n_used += 1
+                n_used = min(n_used, len(fileList))
+            stash = self.__dict__.get("_ingestCache") if (not failed and err is None) else None
+            mine = list(range(len(handles)))
+
+            def release(k):
+                for h in ([handles[k]] + ([chandles[k]] if k < len(chandles) else [])):
                     try:
                         eng.tile_free(h)
                     except Exception:
@@ -614,6 +639,20 @@ class Stitcher(Utility.Method):
                         except Exception:
                             if not failed and err is None:
                                 raise
+            if keep and err is None:
+                # the mosaic is assembled from these very tiles: getStitchByOffset takes them over (and frees them)
+                kept = chandles if color else handles
+                self._resident = {fileList[k]: (kept[k], (shapes[k][0], shapes[k][1], 3) if color else shapes[k]) for k in range(n_used)}
+                for k in range(n_used):
+                    if color:
+                        eng.tile_free(handles[k])
+                mine = list(range(n_used, len(handles)))
+            for k in mine:
+                if stash is not None and k >= n_used and k not in unfilled and fileList[k] not in stash and k < len(handles) and \
+                        (not color or k < len(chandles)):
+                    stash[fileList[k]] = (handles[k], chandles[k] if color else 0, shapes[k])      # decoded, unused: the next segment takes it over
+                else:
+                    release(k)
             if err is not None and not failed:
                 raise err
         offsetList, endfileIndex, status, describtion = [], 0, True, ""
@@ -675,18 +714,42 @@ class Stitcher(Utility.Method):
         result = []
         totalNum = len(fileList)
         startNum = 0
-        while 1:
-            (status, stitchResult) = self.flowStitch(fileList[startNum: totalNum], caculateOffsetMethod)
-            result.append(stitchResult)
-            self.tempImageFeature.isBreak = True
-            startNum = startNum + status[1] + 1
-            if startNum == totalNum:
-                break
-            if startNum == (totalNum - 1):
-                result.append(_imread(fileList[startNum], self.isColorMode))
-                break
-            self.printAndWrite("stitching Break, start from " + str(fileList[startNum]) + " again")
+        self._ingestCache = {}                                # tiles decoded behind a break wait here for the segment that uses them
+        try:
+            while 1:
+                (status, stitchResult) = self.flowStitch(fileList[startNum: totalNum], caculateOffsetMethod)
+                result.append(stitchResult)
+                self.tempImageFeature.isBreak = True
+                startNum = startNum + status[1] + 1
+                if startNum == totalNum:
+                    break
+                if startNum == (totalNum - 1):
+                    result.append(self._loneTile(fileList[startNum]))
+                    break
+                self.printAndWrite("stitching Break, start from " + str(fileList[startNum]) + " again")
+        finally:
+            for g, c, _shape in self.__dict__.pop("_ingestCache", {}).values():
+                for h in (g, c):
+                    if h:
+                        try:
+                            self.engine.tile_free(h)
+                        except Exception:
+                            pass
         return result
+
+    def _loneTile(self, path):
+        """the trailing tile that is a result of its own (Stitcher.py:119-121): from the device copy a broken segment left behind, else decoded"""
+        ent = (self.__dict__.get("_ingestCache") or {}).get(path)
+        eng = self.engine
+        if ent is not None and hasattr(eng, "canvas_paste_tile") and (bool(ent[1]) or not self.isColorMode):
+            h, ch = (ent[1], 3) if self.isColorMode else (ent[0], 1)
+            cv = eng.canvas_create(ent[2][0], ent[2][1], ch)
+            try:
+                eng.canvas_paste_tile(cv, h, 0, 0)
+                return eng.canvas_download(cv, ent[2][0], ent[2][1], ch)
+            finally:
+                eng.canvas_free(cv)
+        return _imread(path, self.isColorMode)
 
     def imageSetStitch(self, projectAddress, outputAddress, fileNum, caculateOffsetMethod, startNum=1, fileExtension="jpg", outputfileExtension="jpg"):
         """Stitcher.py:129-151."""

@@ -640,3 +640,53 @@ def test_decode_once_on_the_reference_demo_tiles():
         del owner
         seen += 1
     assert seen >= 4
+
+
+def test_a_registration_break_does_not_decode_a_file_twice(oracle, tmp_path):
+    """flowStitchWithMutiple restarts behind every pair that cannot be registered (Stitcher.py:96-127) and the reference decodes the remaining
+    list again each time.  Here the tiles the first segment's pipeline had already decoded behind the break wait in HBM for the segment
+    that uses them: every file is decoded exactly once across the break, a trailing lone tile comes back from its device copy, and nothing
+    stays in HBM -- gray and colour."""
+    from imagestitch_amd.synthetic import SyntheticGrid
+    from imagestitch_amd import stitcher as ST
+    g = SyntheticGrid(1, 6, 128, overlap=0.25)
+    files = _write_jpegs(tmp_path, _colour_tiles(g), "brk")
+    old = (isa.Stitcher.direction, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod)
+    counts = {"once": 0, "imread": 0}
+    real_once, real_imread = ST._decode_once, ST._imread
+
+    def once(path, color):
+        counts["once"] += 1
+        return real_once(path, color)
+
+    def imread(path, color):
+        counts["imread"] += 1
+        return real_imread(path, color)
+
+    try:
+        isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod = "surf", "notFuse"
+        for color in (True, False):
+            isa.Stitcher.isColorMode = color
+            for nfiles, bad, want_results in ((6, (2,), 2), (4, (2,), 2), (5, (0, 3), 3)):
+                sub = files[:nfiles]
+                ref_tiles = [ST._imread(f, False) for f in sub]
+
+                def script(A, B, job, ref_tiles=ref_tiles, bad=bad):
+                    ka = [i for i, t in enumerate(ref_tiles) if t.shape == np.asarray(A).shape and np.array_equal(t, A)][0]
+                    return [0, 0, 0, 0, 10, 10, 0, 0] if ka in bad else [1, 96, 0, 9, 10, 10, 9, 0]
+                eng = IngestOracleEngine(oracle, scripted=script)
+                s = isa.Stitcher(); s._engine = eng; s.isPrintLog = False; s.direction = 2; isa.Stitcher.direction = 2
+                counts["once"] = counts["imread"] = 0
+                ST._decode_once, ST._imread = once, imread
+                try:
+                    results = s.flowStitchWithMutiple(list(sub), s.calculateOffsetForFeatureSearchIncre)
+                finally:
+                    ST._decode_once, ST._imread = real_once, real_imread
+                assert len(results) == want_results, (color, nfiles, bad, len(results))
+                assert counts["once"] == nfiles and counts["imread"] == 0, (color, nfiles, bad, counts)
+                assert not eng.live and "_ingestCache" not in s.__dict__
+                assert all(r is not None and r.ndim == (3 if color else 2) for r in results)
+                if nfiles == 4:                                     # tiles 0-2 | tile 3 alone: the lone tile equals its decode
+                    assert np.array_equal(results[1], ST._imread(sub[3], color))
+    finally:
+        isa.Stitcher.direction, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod = old
