@@ -1290,3 +1290,55 @@ def test_line_scan_batched_full_image_path_orb(engine, oracle, tmp_path):
         (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate, isa.Stitcher.isEnhance,
          isa.Stitcher.isColorMode, isa.Stitcher.fuseMethod) = old
         isa.Stitcher.tempImageFeature.isBreak = True
+
+
+@pytest.mark.gpu
+def test_driver_with_registration_breaks_decodes_once_and_matches_the_pair_loop(engine, tmp_path):
+    """imageSetStitchWithMutiple over a folder whose middle tile is blank (two pairs cannot be registered: three segments, Stitcher.py:96-127),
+    colour JPEGs: the batched path decodes every file ONCE across both restarts (the tiles behind a break wait in HBM for their segment)
+    and writes the files -- names and bytes -- of the pair-by-pair run that decodes gray and colour separately."""
+    from PIL import Image
+    from imagestitch_amd import stitcher as ST
+    g = SyntheticGrid(1, 5, 512, overlap=0.2)
+    proj = tmp_path / "brk"; (proj / "1").mkdir(parents=True)
+    files = _colour_jpegs(proj / "1", g, "1")
+    Image.fromarray(np.full((512, 512, 3), 90, np.uint8)).save(files[2], quality=92)          # nothing to match in tile 2
+    old = (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod,
+           isa.Stitcher.fuseMethod, isa.Stitcher.offsetEvaluate)
+    counts = {"once": 0, "imread": 0}
+    real_once, real_imread = ST._decode_once, ST._imread
+
+    def once(path, color):
+        counts["once"] += 1
+        return real_once(path, color)
+
+    def imread(path, color):
+        counts["imread"] += 1
+        return real_imread(path, color)
+    try:
+        isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode = 1, 0.2, True
+        isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate, isa.Stitcher.fuseMethod = "surf", 3, "fadeInAndFadeOut"
+        outs = []
+        for once_only in (True, False):
+            st = isa.Stitcher(); st._engine = engine if once_only else _NoIngest(engine); st.isPrintLog = False
+            st.batchRegistration = once_only
+            isa.Stitcher.direction = 2; st.direction = 2
+            out = tmp_path / ("o%d" % once_only)
+            counts["once"] = counts["imread"] = 0
+            ST._decode_once, ST._imread = once, imread
+            try:
+                st.imageSetStitchWithMutiple(str(proj), str(out) + os.sep, 1, st.calculateOffsetForFeatureSearchIncre,
+                                             startNum=1, fileExtension="jpg", outputfileExtension="png")
+            finally:
+                ST._decode_once, ST._imread = real_once, real_imread
+            if once_only:
+                assert counts == {"once": len(files), "imread": 0}, counts
+            names = sorted(n for n in os.listdir(str(out)) if n.endswith(".png"))
+            outs.append({n: np.asarray(Image.open(str(out / n))) for n in names})
+        assert sorted(outs[0]) == sorted(outs[1]) == ["stitching_result_1_1.png", "stitching_result_1_2.png", "stitching_result_1_3.png"], sorted(outs[0])
+        for n in outs[0]:
+            assert outs[0][n].shape == outs[1][n].shape and np.array_equal(outs[0][n], outs[1][n]), n
+        assert outs[0]["stitching_result_1_2.png"].shape[:2] == (512, 512)                    # the blank tile alone
+    finally:
+        (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod,
+         isa.Stitcher.fuseMethod, isa.Stitcher.offsetEvaluate) = old
