@@ -8,7 +8,6 @@ What differs is where the work happens: registration attempts run as fused devic
 in HBM; see imagestitch_amd/csrc.
 """
 import copy
-import glob
 import os
 import time
 
@@ -519,7 +518,6 @@ class Stitcher(Utility.Method):
                 # of decoder threads (Pillow releases the GIL while it decodes) fills them in path order; the native registrar starts
                 # at once and waits only for the tiles of the batch it is about to launch, so registration overlaps decoding and the
                 # decoded arrays never pile up on the host (a thread holds one tile at a time).
-                from concurrent.futures import ThreadPoolExecutor
                 # Tiles a previous segment of this file list decoded but did not use (they lay behind its registration break,
                 # flowStitchWithMutiple): taken over as they are -- a file is decoded once even when the path breaks (the reference
                 # decodes the remaining list again after every break, Stitcher.py:96-127).
@@ -1214,7 +1212,6 @@ class Stitcher(Utility.Method):
         if len(set(files)) != len(files):                    # (a file listed twice: the host path keys nothing by name)
             return None
         shapes = [_imshape(f) for f in files]
-        from concurrent.futures import ThreadPoolExecutor
         handles = []
         try:
             for s_ in shapes:
