@@ -347,7 +347,13 @@ int tile_is_filled(vfsms_ctx *ctx, int64_t handle)
 {
     std::lock_guard<std::mutex> lk(ctx->tiles_mu);
     auto it = ctx->tiles.find(handle);
-    return it == ctx->tiles.end() || it->second.fill != 1;
+    if (it == ctx->tiles.end()) return 1;
+    if (it->second.fill == 1) return 0;
+    // an asynchronous upload that has not landed yet (vfsms_tile_upload_async: ninety tiles queued on the copy stream in front of a path): the
+    // speculative part of a batch takes what is there, like with tiles a decoder still owes -- the first batch does not wait for a whole
+    // window of copies
+    if (it->second.pending && it->second.ready && hipEventQuery(it->second.ready) != hipSuccess) return 0;
+    return 1;
 }
 extern "C" int vfsms_tile_upload(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int64_t *handle)
 {
