@@ -270,14 +270,11 @@ def bench_dendritic25(args, eng, torch):
     P = 25
     bf_ms, bf_n = prof.get("bf_mfma", (0.0, 0))
     de_ms, de_n = prof.get("describe", (0.0, 0))
+    # A FIXTURE-SHAPED line, not configs[1]'s cost: 640-px crops of the accepted ROI strips in otherwise empty frames give 2.6 k keypoints per ROI
+    # and many small batches.  No roofline is claimed for it; what it establishes is the keypoint DENSITY of real dendrite texture (per kpx of
+    # textured ROI), which equals the synthetic grid's -- the headline workload is representative per pixel.
     roof = None
-    if bf_n:
-        dur = bf_ms / bf_n * 1e-3
-        flops = 2.0 * 64 * st["sum_nq_nt"] / bf_n
-        roof = dict(kernel="k_bf_split16+k_bf_mfma16_d64", bound="mfma", achieved=round(flops / dur / 1e12, 3), peak=BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(flops / dur / 1e12 / BF16_PEAK_TFLOPS, 4), traffic=None, avg_launch_ms=round(dur * 1e3, 4), flops_per_launch=flops, launches=bf_n,
-                    note="the BF filter at the real keypoint density (the describe stage is reported under stages; its roofline is the grid workload's)")
-    _jsonline({"metric": "image-pairs/sec (dendriticCrystal neighbourhoods, SURF+BF)", "value": round(P / dt, 3), "unit": "image-pairs/s", "n_gpus": 1,
+    _jsonline({"metric": "image-pairs/sec (FIXTURE: 640-px crops of dendriticCrystal ROI strips in empty frames, SURF+BF; not configs[1]'s cost)", "value": round(P / dt, 3), "unit": "image-pairs/s", "n_gpus": 1,
                "steps": args.steps, "warmup": args.warmup, "warmup_extra_steps_until_1p5s": warm_extra, "ms_per_step": round(dt * 1e3, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "real (committed crops of the reference's demo tiles)",
                "config": {"workload": "the 25 committed pairs of demoImages/dendriticCrystal (5 neighbourhoods x 6 tiles of 1936x2584, 640-px crops of the "
@@ -287,6 +284,8 @@ def bench_dendritic25(args, eng, torch):
                "attempts_per_step": st["attempts"] / max(args.steps, 1), "batches_per_step": st["batches"] / max(args.steps, 1),
                "keypoints_per_roi": round(st["sum_nq_plus_nt"] / max(2 * st["attempts"], 1), 1),
                "keypoints_per_kpx_of_textured_roi": round(st["sum_nq_plus_nt"] / max(2 * st["attempts"], 1) / (640 * 387 / 1000.0), 2),
+               "note": "fixture-shaped: rows == oracle and within 1 px of Stitcher.py:87 on real texture; keypoints_per_kpx_of_textured_roi is the figure to "
+                       "compare with the synthetic grid (10.4 per kpx) -- the rate and the stage times describe the fixture, not the dataset",
                "roofline": roof, "cpu_baseline": None, "stages": stages})
     eng.close()
 
