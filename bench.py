@@ -239,10 +239,15 @@ def bench_dendritic25(args, eng, torch):
             frames[s_["tile"]][s_["y0"]:s_["y0"] + a.shape[0], s_["x0"]:s_["x0"] + a.shape[1]] = a
         fr = [frames[t] for t in nb["tiles"]]
         nbs.append(dict(nb=nb, hs=[eng.tile_upload(f) for f in fr], shapes=[f.shape for f in fr]))
-    reg = GridRegistrar(eng, method="surf", roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3, directIncre=1, surfParams=eng.surf_params(), window=args.window)
+    # one registrar per neighbourhood: each remembers ITS path (the five have the same length and different turns -- a shared memory would hand
+    # every neighbourhood the previous one's pattern, which costs attempts)
+    regs = [GridRegistrar(eng, method="surf", roiRatio=0.2, searchRatio=0.75, offsetEvaluate=3, directIncre=1, surfParams=eng.surf_params(), window=args.window)
+            for _ in nbs]
+
+    reg = regs[0]
 
     def step():
-        return [reg.register(n["hs"], n["shapes"], n["nb"]["incoming_direction"])[0] for n in nbs]
+        return [r.register(n["hs"], n["shapes"], n["nb"]["incoming_direction"])[0] for r, n in zip(regs, nbs)]
     tables = step()
     worst = 0
     for n, tb in zip(nbs, tables):
@@ -255,8 +260,9 @@ def bench_dendritic25(args, eng, torch):
         step()
     while time.perf_counter() - t_w < MIN_WARM_S and warm_extra < 400:
         step(); warm_extra += 1
-    for k in reg.stats:
-        reg.stats[k] = 0
+    for r in regs:
+        for k in r.stats:
+            r.stats[k] = 0
     eng.profile_enable(True); eng.profile_read(reset=True)
     torch.cuda.synchronize(); eng.sync()
     t0 = time.perf_counter()
@@ -265,7 +271,7 @@ def bench_dendritic25(args, eng, torch):
     torch.cuda.synchronize(); eng.sync()
     dt = (time.perf_counter() - t0) / args.steps
     prof = eng.profile_read(reset=True); eng.profile_enable(False)
-    st = dict(reg.stats)
+    st = {k: sum(r.stats[k] for r in regs) for k in reg.stats}
     stages = {k: dict(ms=round(v[0], 3), launches=v[1], ms_per_launch=round(v[0] / max(v[1], 1), 4)) for k, v in prof.items()}
     P = 25
     bf_ms, bf_n = prof.get("bf_mfma", (0.0, 0))
