@@ -95,6 +95,17 @@ def pmc_traffic(kernel):
     return pmc_value(kernel, "total(x2 rule)")
 
 
+def pmc_traffic_scaled(kernel, attempts_per_group):
+    """HBM traffic of `kernel` for ONE launch group of this run: the counter total of the PMC run / the attempts that run evaluated (pmc_run
+    line) x this run's attempts per group.  (Per-launch figures of the summary are per KERNEL launch of the PMC run: since round 4 a group
+    launches an image-sized kernel once per shape run, and PMC runs need not have this run's batch sizes.)"""
+    tot, _n = pmc_total(kernel, "total(x2 rule)")
+    att, src = pmc_value("pmc_run", "attempts")
+    if not (tot and att):
+        return pmc_traffic(kernel)
+    return tot / (att + 0.5) * attempts_per_group, src
+
+
 def valu_over_bound(spk_live):
     """SQ_INSTS_VALU of k_describe + k_describe_small over the whole PMC run / (the keypoints that run described x samples per keypoint x 26
     lane-ops / 64 lanes): counter totals against an algorithmic count, independent of launch sizes"""
@@ -721,7 +732,7 @@ def main():
         kps = st["sum_nq_plus_nt"] / de_n                                   # keypoints described per launch
         dur = de_ms / de_n * 1e-3
         laneops = kps * spk * DESC_VALU_PER_SAMPLE
-        traffic, traffic_src = pmc_traffic("k_describe")
+        traffic, traffic_src = pmc_traffic_scaled("k_describe", st["attempts"] / de_n)
         valu_insts, _src = pmc_value("k_describe", "INSTS_VALU")
         busy, _src2 = pmc_value("k_describe", "BUSY_CYCLES")            # summed over the 32 shader engines: / 32 = cycles of the launch
         valu_busy = round(valu_insts * 4.0 / (busy / 32.0 * 1024.0), 3) if valu_insts and busy else None
@@ -753,7 +764,7 @@ def main():
         extra["bf_l2_mfma"] = dict(kernel=kname, bound="mfma", achieved=round(flops / dur / 1e12, 3), peak=peak,
                                    unit="TFLOP/s", frac=round(flops / dur / 1e12 / peak, 4),
                                    traffic=(pmc_traffic("k_bf_mfma_d64")[0] if f32_filter else
-                                            sum_or_none([pmc_traffic("void k_bf_mfma16_d64<%d>" % q)[0] for q in (0, 1)])),
+                                            sum_or_none([pmc_traffic_scaled("void k_bf_mfma16_d64<%d>" % q, st["attempts"] / bf_n)[0] for q in (0, 1)])),
                                    avg_launch_ms=round(dur * 1e3, 4), flops_per_launch=flops, launches=bf_n,
                                    issued_mfma_flops_per_launch=flops if f32_filter else flops * 4.5,
                                    note=("v_mfma_f32_32x32x2_f32 candidate filter (peak = dense f32 MFMA)" if f32_filter else
@@ -767,16 +778,20 @@ def main():
     if in_n:
         # algorithmic bytes of cv::integral per ROI: h*w (u8 in) + 4 (h+1)(w+1) (i32 out) ~ 5 B/px
         extra["integral_hbm"] = hbm_roofline("k_integral_final+k_integral_bandsum+k_integral_bandscan", st["roi_px"] / in_n * 5.0, in_ms / in_n, in_n)
-        tr = [pmc_traffic(k)[0] for k in ("k_integral_final", "k_integral_bandsum", "k_integral_bandscan")]
+        tr = [pmc_traffic_scaled(k, st["attempts"] / in_n)[0] for k in ("k_integral_final", "k_integral_bandsum", "k_integral_bandscan")]
         extra["integral_hbm"]["traffic"] = sum(tr) if all(v is not None for v in tr) else None
     he_ms, he_n = prof.get("hessian", (0.0, 0))
     if he_n:
         # reads S once per octave pass 4 (h+1)(w+1) x 4 + writes det + trace 8 x sum_o 5 (h/2^o)(w/2^o) = 69.1 B/px
         extra["hessian_hbm"] = hbm_roofline("k_hessian_lds<1,64>+k_hessian_lds<2,32>+k_hessian_coarse(octaves 2, 3)", st["roi_px"] / he_n * 69.1, he_ms / he_n, he_n)
         hv, _s = pmc_value("void k_hessian_lds<1, 64>", "INSTS_VALU"); hb, _s = pmc_value("void k_hessian_lds<1, 64>", "BUSY_CYCLES")
-        extra["hessian_hbm"]["valu_busy_frac_pmc_octave0"] = round(hv * 4.0 / (hb / 32.0 * 1024.0), 3) if hv and hb else None
+        extra["hessian_hbm"]["valu_insts_x4_over_simd_cycles_octave0"] = round(hv * 4.0 / (hb / 32.0 * 1024.0), 3) if hv and hb else None
+        htr = [pmc_traffic_scaled(k, st["attempts"] / he_n)[0] for k in ("void k_hessian_lds<1, 64>", "void k_hessian_lds<2, 32>", "k_hessian_coarse")]
+        extra["hessian_hbm"]["traffic"] = sum(htr) if all(v is not None for v in htr) else None
         extra["hessian_hbm"]["note"] = ("bytes = SURVEY 8d's 69.1 B/px (it still counts the trace layers, no longer written); the fine octaves are bound by VALU "
-                                        "issue + LDS taps (valu_busy_frac_pmc_octave0), not by HBM")
+                                        "issue + LDS taps, not by HBM: SQ_INSTS_VALU x 4 cycles EXCEEDS the SIMD cycles of octave 0's launches "
+                                        "(valu_insts_x4_over_simd_cycles_octave0 > 1) -- part of its instructions are plain VOP2 integer adds, which issue in "
+                                        "~2.7 cycles (profiles/r04_valu_peak.txt): the kernel has no idle issue slots")
     if args.method == "phase":
         ph_ms, ph_n = prof.get("phase", (0.0, 0))
         if ph_n:
