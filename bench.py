@@ -702,7 +702,8 @@ def main():
         cold_stats = dict(reg_c.stats)
     per_rank = None
     if dist is not None:
-        mine = dict(rank=rank, pairs=hi - lo, attempts_per_step=st["attempts"] / max(args.steps, 1), batches_per_step=st["batches"] / max(args.steps, 1),
+        lo_t, hi_t = reg._bounds(P, world, None, reg._prediction(P, None), 1)[rank]      # the chunk of the timed steps (cut by the predicted attempts)
+        mine = dict(rank=rank, pairs=hi_t - lo_t, attempts_per_step=st["attempts"] / max(args.steps, 1), batches_per_step=st["batches"] / max(args.steps, 1),
                     gpu_ms_per_step=round(sum(v[0] for v in prof.values()) / max(args.steps, 1), 3), wall_ms_per_step=round(elapsed / args.steps * 1e3, 3))
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
