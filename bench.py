@@ -418,14 +418,31 @@ def bench_from_files(args, eng, grid, torch):
             torch.cuda.synchronize(); eng.sync()
             dt = (time.perf_counter() - t0) / args.steps
             ist = dict(getattr(s, "_ingestStats", {}) or {})
-            # decode only, same pool size (and the same Pillow block cache as the Stitcher's pool)
-            with ST._PillowBlocks(color), ThreadPoolExecutor(max_workers=nthreads) as ex:
-                list(ex.map(lambda f: ST._decode_once(f, color)[1], files[:nthreads]))
+            # decode only, same pool size, the decoder the pipeline used: the library's own (libjpeg-turbo into a buffer kept per thread) when
+            # every tile of the last step went through vfsms_tile_fill_jpeg, else Pillow (with the block allocator the Stitcher's pool sets)
+            native = ist.get("native", 0) == ist.get("tiles", -1)
+            if native:
+                import ctypes, threading
+                tl = threading.local()
+
+                def decode_only(f):
+                    if not hasattr(tl, "buf"):
+                        tl.buf = np.empty(grid.th * grid.tw * 3, np.uint8)
+                    data = open(f, "rb").read()
+                    h_, w_, c_ = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+                    rc = eng.lib.vfsms_jpeg_decode(data, len(data), int(color), tl.buf.ctypes.data_as(ctypes.c_void_p), tl.buf.nbytes,
+                                                   ctypes.byref(h_), ctypes.byref(w_), ctypes.byref(c_))
+                    assert rc == 0 and (h_.value, w_.value) == (grid.th, grid.tw), rc
+            else:
+                def decode_only(f):
+                    ST._decode_once(f, color)
+            with ST._PillowBlocks(color and not native), ThreadPoolExecutor(max_workers=nthreads) as ex:
+                list(ex.map(decode_only, files[:nthreads]))
                 t0 = time.perf_counter()
-                list(ex.map(lambda f: ST._decode_once(f, color)[1], files))
+                list(ex.map(decode_only, files))
                 dt_dec = time.perf_counter() - t0
             t0 = time.perf_counter()
-            ST._decode_once(files[0], color)
+            decode_only(files[0])
             dt_one = time.perf_counter() - t0
             # registration only (tiles resident)
             from imagestitch_amd.grid import GridRegistrar
@@ -453,8 +470,10 @@ def bench_from_files(args, eng, grid, torch):
                "config": {"workload": "synthetic %dx%d grid of %dx%d tiles as %s JPEG files -> Stitcher ingest pipeline (vfsms_tile_reserve / %s, "
                                       "%d decoder threads, one decode per file) -> native registrar; SURF+BF-L2+mode as the default workload"
                                       % (args.rows, args.cols, args.tile, args.tile, "colour (isColorMode = True: gray plane + resident B G R tile from the same decode)" if color else "grayscale",
-                                         "vfsms_tile_fill_pair" if color else "vfsms_tile_fill", nthreads),
-                          "pairs": P, "decode_threads": nthreads, "host_cores": os.cpu_count(), "color": color},
+                                         "vfsms_tile_fill_jpeg" if native else "vfsms_tile_fill_pair" if color else "vfsms_tile_fill", nthreads),
+                          "pairs": P, "decode_threads": nthreads, "host_cores": os.cpu_count(), "color": color,
+                          "decoder": ("libjpeg-turbo inside libvfsms (vfsms_tile_fill_jpeg: pinned staging, no interpreter lock)" if native
+                                      else "Pillow (VFSMS_NATIVE_JPEG=0 or no libjpeg.so.8) + %s" % ("vfsms_tile_fill_pair" if color else "vfsms_tile_fill"))},
                "max_abs_offset_error_px": int(worst),
                "decode_only_ms_per_step": round(dt_dec * 1e3, 2), "decode_only_tiles_per_s": round(grid.n_tiles / dt_dec, 1),
                "decode_one_tile_one_thread_ms": round(dt_one * 1e3, 2),

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvfsms.so")
 
 VFSMS_OK = 0
+VFSMS_ERR_BAD_ARG, VFSMS_ERR_CAPACITY, VFSMS_ERR_UNSUPPORTED = -1, -2, -6
 ATTEMPT_INTS = 8
 
 
@@ -73,6 +74,8 @@ _SIGNATURES = {
     "vfsms_tile_fill": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
     "vfsms_tile_reserve_ch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "vfsms_tile_fill_pair": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int]),
+    "vfsms_tile_fill_jpeg": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_size_t]),
+    "vfsms_jpeg_decode": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vfsms_canvas_blend_tile_resident": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vfsms_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vfsms_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -271,6 +274,17 @@ class Engine:
         `address`: raw host address of the decoder's output in format `fmt` (SRC_*), None gives both tiles up.  Safe from any thread."""
         self._check(self.lib.vfsms_tile_fill_pair(self.ctx, C.c_int64(gray_handle or 0), C.c_int64(color_handle or 0),
                                                   C.c_void_p(address) if address is not None else None, int(stride_bytes), int(fmt)))
+
+    def tile_fill_jpeg(self, gray_handle, color_handle, data):
+        """A JPEG file's bytes -> the reserved gray tile and / or the reserved BGR tile, decoded by the library itself (vfsms_tile_fill_jpeg:
+        libjpeg-turbo into pinned staging, colour conversion on the device).  True when the tiles are filled; False when this decoder does
+        not take the file (no libjpeg.so.8, an unusual colour space, a damaged file, a size other than the tiles'): the tiles are STILL
+        RESERVED and the caller decodes some other way.  Safe from any thread."""
+        rc = self.lib.vfsms_tile_fill_jpeg(self.ctx, C.c_int64(gray_handle or 0), C.c_int64(color_handle or 0), data, len(data))
+        if rc in (VFSMS_ERR_UNSUPPORTED, VFSMS_ERR_BAD_ARG):
+            return False
+        self._check(rc)
+        return True
 
     def tile_fill_ptr(self, handle, address, stride):
         """tile_fill from a raw host address (rows `stride` bytes apart); the caller keeps the memory alive until this returns"""
@@ -681,6 +695,21 @@ class Engine:
 
 
 _default_engine = None
+
+
+def jpeg_decode(data, want_planes=False):
+    """vfsms_jpeg_decode: the library's own JPEG decode (system libjpeg-turbo), no GPU involved -> u8 (h, w) -- the grayscale decode -- or,
+    with want_planes and a three-component file, u8 (h, w, 3) Y Cb Cr.  None when the library does not take the file (see tile_fill_jpeg)."""
+    lib = load_library()
+    h, w, c = C.c_int(), C.c_int(), C.c_int()
+    rc = lib.vfsms_jpeg_decode(data, len(data), int(bool(want_planes)), None, 0, C.byref(h), C.byref(w), C.byref(c))
+    if rc != VFSMS_ERR_CAPACITY:
+        return None
+    out = np.empty((h.value, w.value, c.value), np.uint8)
+    rc = lib.vfsms_jpeg_decode(data, len(data), int(bool(want_planes)), out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(h), C.byref(w), C.byref(c))
+    if rc != VFSMS_OK:
+        return None
+    return out[:, :, 0] if c.value == 1 else out
 
 
 def default_engine():

@@ -468,48 +468,45 @@ extern "C" int vfsms_tile_fill(vfsms_ctx *ctx, int64_t handle, const uint8_t *im
 // both tiles are complete.  Any thread.  src == NULL gives both tiles up.
 int ingest_source_pixel_bytes(int format);
 int launch_ingest_split(hipStream_t stream, const uint8_t *src, uint8_t *gray, uint8_t *bgr, long long n, int format);
-extern "C" int vfsms_tile_fill_pair(vfsms_ctx *ctx, int64_t gray, int64_t color, const uint8_t *src, int stride_bytes, int format)
+// the reserved tiles of a pair fill, looked up under the lock: 0 and the geometry, or an error with both tiles left as they were
+static int fill_pair_lookup(vfsms_ctx *ctx, int64_t gray, int64_t color, bool give_up, const char *who, int *h, int *w, hipEvent_t *ev, uint8_t **dg, uint8_t **dc)
 {
-    CTX_ENTER(ctx);
-    hipEvent_t ev = nullptr; uint8_t *dg = nullptr, *dc = nullptr; int h = 0, w = 0;
+    std::lock_guard<std::mutex> lk(ctx->tiles_mu);
+    TileRec *tg = nullptr, *tc = nullptr;
+    if (gray) { auto it = ctx->tiles.find(gray); if (it != ctx->tiles.end() && it->second.fill == 1 && it->second.ch == 1) tg = &it->second; }
+    if (color) { auto it = ctx->tiles.find(color); if (it != ctx->tiles.end() && it->second.fill == 1 && it->second.ch == 3) tc = &it->second; }
+    if ((gray && !tg) || (color && !tc) || (!tg && !tc)) {
+        vfsms_set_error("%s: needs a reserved 1-channel tile and / or a reserved 3-channel tile", who); return VFSMS_ERR_BAD_ARG;
+    }
+    if (give_up) { if (tg) tg->fill = 2; if (tc) tc->fill = 2; ctx->tiles_cv.notify_all(); *h = *w = 0; return VFSMS_OK; }
+    if (tg && tc && (tg->h != tc->h || tg->w != tc->w)) { vfsms_set_error("%s: the two tiles differ in size", who); return VFSMS_ERR_BAD_ARG; }
+    *h = tg ? tg->h : tc->h; *w = tg ? tg->w : tc->w;
+    *ev = tg ? tg->ready : tc->ready; *dg = tg ? tg->ptr : nullptr; *dc = tc ? tc->ptr : nullptr;
+    return VFSMS_OK;
+}
+// `host` (h * w pixels of `format`, densely packed; pinned when `host_pinned`) -> the device staging buffer -> the split kernel -> both tiles
+// complete (or both given up, on an error) when this returns
+static int fill_pair_upload(vfsms_ctx *ctx, int64_t gray, int64_t color, const uint8_t *host, int h, int w, int format, hipEvent_t ev, uint8_t *dg, uint8_t *dc,
+                            const char *who)
+{
     const int spx = ingest_source_pixel_bytes(format);
-    {
-        std::lock_guard<std::mutex> lk(ctx->tiles_mu);
-        TileRec *tg = nullptr, *tc = nullptr;
-        if (gray) { auto it = ctx->tiles.find(gray); if (it != ctx->tiles.end() && it->second.fill == 1 && it->second.ch == 1) tg = &it->second; }
-        if (color) { auto it = ctx->tiles.find(color); if (it != ctx->tiles.end() && it->second.fill == 1 && it->second.ch == 3) tc = &it->second; }
-        if ((gray && !tg) || (color && !tc) || (!tg && !tc)) {
-            vfsms_set_error("tile_fill_pair: needs a reserved 1-channel tile and / or a reserved 3-channel tile"); return VFSMS_ERR_BAD_ARG;
-        }
-        if (!src) { if (tg) tg->fill = 2; if (tc) tc->fill = 2; ctx->tiles_cv.notify_all(); return VFSMS_OK; }
-        if (tg && tc && (tg->h != tc->h || tg->w != tc->w)) { vfsms_set_error("tile_fill_pair: the two tiles differ in size"); return VFSMS_ERR_BAD_ARG; }
-        h = tg ? tg->h : tc->h; w = tg ? tg->w : tc->w;
-        if (!spx || stride_bytes < w * spx) { vfsms_set_error("tile_fill_pair: unknown format or stride smaller than a source row"); return VFSMS_ERR_BAD_ARG; }
-        ev = tg ? tg->ready : tc->ready; dg = tg ? tg->ptr : nullptr; dc = tc ? tc->ptr : nullptr;
-    }
-    // staging buffer for the packed source rows: a small pool of its own (the tile pool belongs to the context thread)
     const size_t need = (size_t)h * w * spx;
+    hipError_t e = hipSuccess; int rc = VFSMS_OK;
     StageBuf sb{nullptr, 0};
-    {
-        std::lock_guard<std::mutex> lk(ctx->stage_mu);
-        for (size_t k = 0; k < ctx->stage_pool.size(); k++)
-            if (ctx->stage_pool[k].bytes >= need) { sb = ctx->stage_pool[k]; ctx->stage_pool.erase(ctx->stage_pool.begin() + k); break; }
+    if (format == VFSMS_SRC_GRAY8 && !dc) e = hipMemcpyAsync(dg, host, need, hipMemcpyHostToDevice, ctx->copy_stream);      // nothing to convert
+    else {
+        {   // staging buffer for the packed source rows: a small pool of its own (the tile pool belongs to the context thread)
+            std::lock_guard<std::mutex> lk(ctx->stage_mu);
+            for (size_t k = 0; k < ctx->stage_pool.size(); k++)
+                if (ctx->stage_pool[k].bytes >= need) { sb = ctx->stage_pool[k]; ctx->stage_pool.erase(ctx->stage_pool.begin() + k); break; }
+        }
+        if (!sb.ptr) { e = hipMalloc((void **)&sb.ptr, need); sb.bytes = need; if (e != hipSuccess) sb.ptr = nullptr; }
+        if (e == hipSuccess) e = hipMemcpyAsync(sb.ptr, host, need, hipMemcpyHostToDevice, ctx->copy_stream);
+        if (e == hipSuccess) rc = launch_ingest_split(ctx->copy_stream, sb.ptr, dg, dc, (long long)h * w, format);
     }
-    hipError_t e = hipSuccess;
-    if (!sb.ptr) { e = hipMalloc((void **)&sb.ptr, need); sb.bytes = need; }
-    int rc = VFSMS_OK;
-    StageBuf pb{nullptr, 0};
-    if (e == hipSuccess) {
-        if (stage_pinned_get(ctx, need, &pb) == VFSMS_OK) {
-            pack_rows(pb.ptr, src, stride_bytes, (size_t)w * spx, h);
-            e = hipMemcpyAsync(sb.ptr, pb.ptr, need, hipMemcpyHostToDevice, ctx->copy_stream);
-        } else e = hipMemcpy2DAsync(sb.ptr, (size_t)w * spx, src, stride_bytes, (size_t)w * spx, h, hipMemcpyHostToDevice, ctx->copy_stream);
-    }
-    if (e == hipSuccess) rc = launch_ingest_split(ctx->copy_stream, sb.ptr, dg, dc, (long long)h * w, format);
     if (e == hipSuccess && rc == VFSMS_OK) e = hipEventRecord(ev, ctx->copy_stream);
     if (e == hipSuccess && rc == VFSMS_OK) e = hipEventSynchronize(ev);
     if (e != hipSuccess || rc != VFSMS_OK) hipStreamSynchronize(ctx->copy_stream);   // nothing may still read the staging buffers when they are reused
-    stage_pinned_put(ctx, pb);
     if (sb.ptr) {
         std::lock_guard<std::mutex> lk(ctx->stage_mu);
         if (ctx->stage_pool.size() < 64) ctx->stage_pool.push_back(sb); else hipFree(sb.ptr);
@@ -524,7 +521,56 @@ extern "C" int vfsms_tile_fill_pair(vfsms_ctx *ctx, int64_t gray, int64_t color,
         }
         ctx->tiles_cv.notify_all();
     }
-    if (e != hipSuccess) { vfsms_set_error("tile_fill_pair: %s", hipGetErrorString(e)); return VFSMS_ERR_HIP; }
+    if (e != hipSuccess) { vfsms_set_error("%s: %s", who, hipGetErrorString(e)); return VFSMS_ERR_HIP; }
+    return rc;
+}
+extern "C" int vfsms_tile_fill_pair(vfsms_ctx *ctx, int64_t gray, int64_t color, const uint8_t *src, int stride_bytes, int format)
+{
+    CTX_ENTER(ctx);
+    hipEvent_t ev = nullptr; uint8_t *dg = nullptr, *dc = nullptr; int h = 0, w = 0;
+    const int spx = ingest_source_pixel_bytes(format);
+    TRY(fill_pair_lookup(ctx, gray, color, src == nullptr, "tile_fill_pair", &h, &w, &ev, &dg, &dc));
+    if (!src) return VFSMS_OK;
+    if (!spx || stride_bytes < w * spx) { vfsms_set_error("tile_fill_pair: unknown format or stride smaller than a source row"); return VFSMS_ERR_BAD_ARG; }
+    const size_t need = (size_t)h * w * spx;
+    StageBuf pb{nullptr, 0};
+    const uint8_t *host = src;
+    std::vector<uint8_t> packed;
+    if (stage_pinned_get(ctx, need, &pb) == VFSMS_OK) { pack_rows(pb.ptr, src, stride_bytes, (size_t)w * spx, h); host = pb.ptr; }
+    else if ((size_t)stride_bytes != (size_t)w * spx) {      // no pinned memory left: straight from the caller's rows, packed first when they are strided
+        pb.ptr = nullptr;
+        packed.resize(need); pack_rows(packed.data(), src, stride_bytes, (size_t)w * spx, h); host = packed.data();
+    } else pb.ptr = nullptr;
+    const int rc = fill_pair_upload(ctx, gray, color, host, h, w, format, ev, dg, dc, "tile_fill_pair");
+    stage_pinned_put(ctx, pb);
+    return rc;
+}
+
+// A JPEG file's bytes -> the reserved gray tile and / or the reserved B G R tile, ONE decode (csrc/jpeg_host.hip: the system's libjpeg-turbo,
+// straight into a pinned staging buffer that is reused from call to call; Y only when no colour tile is asked for, the Y Cb Cr planes
+// otherwise, colour conversion on the device).  Any thread; blocks until the tiles are complete.  When the decode cannot be done here
+// (VFSMS_ERR_UNSUPPORTED: no libjpeg.so.8 on the host, not a 1- / 3-component JPEG; VFSMS_ERR_BAD_ARG: a damaged file, or a file whose size
+// is not the tiles') BOTH TILES STAY RESERVED: the caller decodes some other way and fills them, or gives them up.
+int jpeg_decode_host(const unsigned char *jpeg, size_t nbytes, int want_planes, unsigned char *out, size_t cap, int *h_out, int *w_out, int *comp_out);
+extern "C" int vfsms_tile_fill_jpeg(vfsms_ctx *ctx, int64_t gray, int64_t color, const uint8_t *jpeg, size_t nbytes)
+{
+    CTX_ENTER(ctx);
+    if (!jpeg || !nbytes) { vfsms_set_error("tile_fill_jpeg: no data"); return VFSMS_ERR_BAD_ARG; }
+    hipEvent_t ev = nullptr; uint8_t *dg = nullptr, *dc = nullptr; int h = 0, w = 0;
+    TRY(fill_pair_lookup(ctx, gray, color, false, "tile_fill_jpeg", &h, &w, &ev, &dg, &dc));
+    const size_t cap = (size_t)h * w * (dc ? 3 : 1);
+    StageBuf pb{nullptr, 0};
+    std::vector<uint8_t> pageable;
+    uint8_t *host = nullptr;
+    if (stage_pinned_get(ctx, cap, &pb) == VFSMS_OK) host = pb.ptr;
+    else { pb.ptr = nullptr; pageable.resize(cap); host = pageable.data(); }
+    int jh = 0, jw = 0, comp = 0;
+    int rc = jpeg_decode_host(jpeg, nbytes, dc != nullptr, host, cap, &jh, &jw, &comp);
+    if (rc == VFSMS_ERR_CAPACITY || (rc == VFSMS_OK && (jh != h || jw != w))) {
+        vfsms_set_error("tile_fill_jpeg: the file is %d x %d, the reserved tiles %d x %d", jh, jw, h, w); rc = VFSMS_ERR_BAD_ARG;
+    }
+    if (rc == VFSMS_OK) rc = fill_pair_upload(ctx, gray, color, host, h, w, comp == 3 ? VFSMS_SRC_YCC24 : VFSMS_SRC_GRAY8, ev, dg, dc, "tile_fill_jpeg");
+    stage_pinned_put(ctx, pb);
     return rc;
 }
 

@@ -174,6 +174,21 @@ def _decode_once(path, want_color):
     return None, shape, ("arrays", gray, bgr)
 
 
+def _fill_from_jpeg(eng, path, gray_handle, color_handle):
+    """JPEG files are decoded by the library itself when it can (vfsms_tile_fill_jpeg: the system's libjpeg-turbo writes into pinned staging
+    memory that is reused from tile to tile, outside the interpreter lock; one decode, colour conversion on the GPU) -> True, both tiles
+    filled.  False: not a JPEG, an engine without the entry point, a file this decoder does not take (CMYK, RGB-coded, damaged, ...), or
+    VFSMS_NATIVE_JPEG=0 -- the tiles are still reserved and `_decode_once` (Pillow) decodes the file."""
+    fill = getattr(eng, "tile_fill_jpeg", None)
+    if fill is None or os.environ.get("VFSMS_NATIVE_JPEG", "1") == "0":
+        return False
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:2] != b"\xff\xd8":
+        return False
+    return bool(fill(gray_handle, color_handle, data))
+
+
 def _ycc_to_bgr(ycc):
     """libjpeg's YCbCr -> RGB (jdcolor.c: 16-bit fixed-point tables), stored B G R: what cv2.imdecode(IMREAD_COLOR) yields from the planes
     `_decode_once` hands to the GPU.  Host-side twin of csrc/ingest_kernels.hip for the tiles that are not resident (lone tiles)."""
@@ -548,6 +563,9 @@ class Stitcher(Utility.Method):
                     hc = chandles[k] if color else 0
                     try:
                         t0 = time.perf_counter()
+                        if _fill_from_jpeg(eng, fileList[k], handles[k], hc):
+                            istats["tiles"] += 1; istats["native"] = istats.get("native", 0) + 1; istats["decode_s"] += time.perf_counter() - t0
+                            return
                         owner, shape, parts = _decode_once(fileList[k], color)
                         t1 = time.perf_counter()
                         if tuple(shape) != tuple(shapes[k]):
@@ -1219,6 +1237,8 @@ class Stitcher(Utility.Method):
 
             def ingest(k):
                 try:
+                    if _fill_from_jpeg(eng, files[k], 0 if color else handles[k], handles[k] if color else 0):
+                        return
                     owner, shape, parts = _decode_once(files[k], color)
                     if tuple(shape) != tuple(shapes[k]):
                         raise ValueError("decoded size %s of %s differs from its header %s" % (shape, files[k], shapes[k]))

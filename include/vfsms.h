@@ -130,6 +130,17 @@ int vfsms_tile_reserve_ch(vfsms_ctx *ctx, int h, int w, int ch, int64_t *handle)
 #define VFSMS_SRC_YCC24 1
 #define VFSMS_SRC_YCCX32 2
 int vfsms_tile_fill_pair(vfsms_ctx *ctx, int64_t gray, int64_t color, const uint8_t *src, int stride_bytes, int format);
+/* The decode itself, for JPEG files (what cv2.imread / cv2.imdecode do on the reference's host: Stitcher.py:68-69, 382-403): the FILE'S
+ * BYTES in, both tiles out.  The system's libjpeg-turbo (libjpeg.so.8, loaded at first use) decodes straight into the library's pinned
+ * staging memory -- the Y plane alone when only `gray` is given (IMREAD_GRAYSCALE), the upsampled Y Cb Cr planes when `color` is given --
+ * and the device finishes as in vfsms_tile_fill_pair.  Any thread; returns when both tiles are complete.  VFSMS_ERR_UNSUPPORTED (no
+ * libjpeg.so.8 on this host; not a 1- or 3-component YCbCr / gray JPEG) and VFSMS_ERR_BAD_ARG (a damaged file; a file that is not the
+ * size of the reserved tiles) leave BOTH TILES RESERVED: decode some other way and fill them, or give them up.                          */
+int vfsms_tile_fill_jpeg(vfsms_ctx *ctx, int64_t gray, int64_t color, const uint8_t *jpeg, size_t nbytes);
+/* the same decode into the caller's memory, no context and no GPU: rows of *w * *comp bytes, comp = 3 (Y Cb Cr interleaved) when
+ * want_planes != 0 and the file has three components, else 1 (the grayscale decode).  VFSMS_ERR_CAPACITY (with *h, *w, *comp set) when
+ * `cap` bytes are too few -- call with out == NULL to ask for the size.                                                                 */
+int vfsms_jpeg_decode(const uint8_t *jpeg, size_t nbytes, int want_planes, uint8_t *out, size_t cap, int *h, int *w, int *comp);
 /* pinned host staging memory for tiles (decoders write into it; uploads from it are asynchronous DMA)                          */
 int vfsms_host_alloc(vfsms_ctx *ctx, size_t bytes, void **ptr);
 int vfsms_host_free(vfsms_ctx *ctx, void *ptr);

@@ -226,3 +226,27 @@ class IngestOracleEngine(OracleEngine):
         img = self.canvas_download(h, rows, cols, ch)
         for r0 in range(0, rows, band_rows):
             yield r0, img[r0:r0 + band_rows]
+
+
+class NativeJpegEngine(IngestOracleEngine):
+    """IngestOracleEngine plus vfsms_tile_fill_jpeg: the decode is the PRODUCT's own host decoder (vfsms_jpeg_decode in libvfsms.so -- no GPU
+    involved), the device half (plane split + colour conversion) is the restatement of tile_fill_pair.  Counts what it decoded."""
+
+    def __init__(self, oracle, scripted=None):
+        super().__init__(oracle, scripted)
+        self.native, self.refused = [], []
+
+    def tile_fill_jpeg(self, gray, color, data):
+        from imagestitch_amd import _lib
+        from imagestitch_amd.stitcher import _ycc_to_bgr
+        out = _lib.jpeg_decode(data, want_planes=bool(color))
+        shape = self.tiles[gray or color][1][:2]
+        if out is None or out.shape[:2] != tuple(shape):
+            self.refused.append(len(data))
+            return False
+        self.native.append(len(data))
+        if gray:
+            self._deliver(gray, out if out.ndim == 2 else out[:, :, 0])
+        if color:
+            self._deliver(color, np.repeat(out[:, :, None], 3, axis=2) if out.ndim == 2 else _ycc_to_bgr(out))
+        return True

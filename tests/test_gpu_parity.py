@@ -1144,6 +1144,71 @@ def test_ingest_pair_fill_equals_the_two_decodes(engine, tmp_path):
         engine.tile_fill_pair(0, 0, x32.ctypes.data, 4, 2)
 
 
+@pytest.mark.gpu
+def test_tile_fill_jpeg_equals_the_two_decodes(engine, tmp_path):
+    """vfsms_tile_fill_jpeg: the FILE'S BYTES in -- libjpeg-turbo inside the library, pinned staging, plane split and colour conversion on the
+    device -- the gray tile == the file's grayscale decode (cv2.imdecode(..., 0), Stitcher.py:68-69) and the B G R tile == its colour decode
+    (Stitcher.py:382-403), byte for byte: 4:2:0 / 4:4:4 / progressive / grayscale files, areas that are not multiples of 4, one plane at a
+    time, many threads at once; a file it refuses (truncated, wrong size, PNG) leaves the tiles RESERVED for another decoder."""
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from imagestitch_amd import stitcher as ST
+    rng = np.random.default_rng(12)
+    base = rng.integers(0, 256, (41, 57, 3), dtype=np.uint8)
+    cases = []
+    for (w, h), kw in (((613, 407), dict(quality=90)), ((512, 384), dict(quality=95, subsampling=0)), ((333, 7), dict(quality=70)),
+                       ((1021, 767), dict(quality=85, progressive=True))):
+        img = np.asarray(Image.fromarray(base).resize((w, h), Image.BICUBIC))
+        p = os.path.join(str(tmp_path), "j_%d.jpg" % w)
+        Image.fromarray(img).save(p, **kw)
+        cases.append((p, h, w, ST._imread(p, False), ST._imread(p, True)))
+    p = os.path.join(str(tmp_path), "j_gray.jpg")
+    Image.fromarray(np.asarray(Image.fromarray(base[:, :, 0]).resize((301, 203), Image.BICUBIC))).save(p, quality=90)
+    g = ST._imread(p, False)
+    cases.append((p, 203, 301, g, np.repeat(g[:, :, None], 3, 2)))
+    hg0, hc0 = engine.tile_reserve(8, 8), engine.tile_reserve_color(8, 8, 3)
+    probe = io.BytesIO(); Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(probe, "JPEG")
+    if not engine.tile_fill_jpeg(hg0, hc0, probe.getvalue()):
+        engine.tile_fill_pair(hg0, hc0, None, 0, 0); engine.tile_free(hg0); engine.tile_free(hc0)
+        pytest.skip("no libjpeg.so.8 on this host: the Stitcher decodes with Pillow")
+    engine.tile_free(hg0); engine.tile_free(hc0)
+
+    def one(case, which):
+        p, h, w, want_gray, want_bgr = case
+        data = open(p, "rb").read()
+        hg = engine.tile_reserve(h, w) if which != "color" else 0
+        hc = engine.tile_reserve_color(h, w, 3) if which != "gray" else 0
+        assert engine.tile_fill_jpeg(hg, hc, data)
+        return hg, hc
+    for case in cases:
+        for which in ("both", "gray", "color"):
+            hg, hc = one(case, which)
+            if hg:
+                assert np.array_equal(_tile_bytes(engine, hg, case[1], case[2], 1), case[3]), (case[0], which)
+                engine.tile_free(hg)
+            if hc:
+                assert np.array_equal(_tile_bytes(engine, hc, case[1], case[2], 3), case[4]), (case[0], which)
+                engine.tile_free(hc)
+    with ThreadPoolExecutor(8) as ex:                          # the decoder pool's use: any thread, concurrently
+        got = list(ex.map(lambda k: one(cases[k % len(cases)], "both"), range(24)))
+    for k, (hg, hc) in enumerate(got):
+        c = cases[k % len(cases)]
+        assert np.array_equal(_tile_bytes(engine, hg, c[1], c[2], 1), c[3]) and np.array_equal(_tile_bytes(engine, hc, c[1], c[2], 3), c[4])
+        engine.tile_free(hg); engine.tile_free(hc)
+    # refused files: the tiles are still reserved, and another decoder's hand-over fills them
+    p, h, w, want_gray, want_bgr = cases[0]
+    data = open(p, "rb").read()
+    png = io.BytesIO(); Image.fromarray(want_bgr[:, :, ::-1]).save(png, "PNG")
+    for bad in (data[:len(data) // 2], open(cases[1][0], "rb").read(), png.getvalue()):
+        hg, hc = engine.tile_reserve(h, w), engine.tile_reserve_color(h, w, 3)
+        assert engine.tile_fill_jpeg(hg, hc, bad) is False
+        owner, shape, parts = ST._decode_once(p, True)
+        engine.tile_fill_pair(hg, hc, parts[1], parts[2], parts[3])
+        assert np.array_equal(_tile_bytes(engine, hg, h, w, 1), want_gray) and np.array_equal(_tile_bytes(engine, hc, h, w, 3), want_bgr)
+        engine.tile_free(hg); engine.tile_free(hc)
+
+
 class _NoIngest:
     """the engine without its ingest entry points: the Stitcher then decodes gray for the pairs and colour for the mosaic, twice per file,
     like the reference"""
@@ -1179,6 +1244,12 @@ def test_colour_mode_driver_decodes_each_file_once(engine, tmp_path):
     def imread(path, color):
         counts["imread"] += 1
         return real_imread(path, color)
+    real_native = ST._fill_from_jpeg
+
+    def native(eng, path, hg, hc):                             # the library's own decoder took the file: that is its one decode
+        ok = real_native(eng, path, hg, hc)
+        counts["once"] += bool(ok)
+        return ok
     try:
         isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode = 1, 0.2, True
         isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate = "surf", 3
@@ -1192,12 +1263,14 @@ def test_colour_mode_driver_decodes_each_file_once(engine, tmp_path):
                 st.printAndWrite = lambda c, msgs=msgs: msgs.append(c)
                 out = tmp_path / ("out_%s_%d" % (fuse, once_only))
                 counts["once"] = counts["imread"] = 0
-                ST._decode_once, ST._imread = once, imread
+                ST._decode_once, ST._imread, ST._fill_from_jpeg = once, imread, native
+                os.environ["VFSMS_NATIVE_JPEG"] = "1" if fuse == "fadeInAndFadeOut" else "0"      # either decoder: the library's, Pillow's
                 try:
                     st.imageSetStitchWithMutiple(str(proj), str(out) + os.sep, 1, st.calculateOffsetForFeatureSearchIncre,
                                                  startNum=1, fileExtension="jpg", outputfileExtension="png")
                 finally:
-                    ST._decode_once, ST._imread = real_once, real_imread
+                    ST._decode_once, ST._imread, ST._fill_from_jpeg = real_once, real_imread, real_native
+                    os.environ.pop("VFSMS_NATIVE_JPEG", None)
                 if once_only:
                     assert counts == {"once": len(files), "imread": 0}, counts
                 else:
@@ -1315,6 +1388,12 @@ def test_driver_with_registration_breaks_decodes_once_and_matches_the_pair_loop(
     def imread(path, color):
         counts["imread"] += 1
         return real_imread(path, color)
+    real_native = ST._fill_from_jpeg
+
+    def native(eng, path, hg, hc):                             # the library's own decoder took the file: that is its one decode
+        ok = real_native(eng, path, hg, hc)
+        counts["once"] += bool(ok)
+        return ok
     try:
         isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode = 1, 0.2, True
         isa.Stitcher.featureMethod, isa.Stitcher.offsetEvaluate, isa.Stitcher.fuseMethod = "surf", 3, "fadeInAndFadeOut"
@@ -1325,12 +1404,12 @@ def test_driver_with_registration_breaks_decodes_once_and_matches_the_pair_loop(
             isa.Stitcher.direction = 2; st.direction = 2
             out = tmp_path / ("o%d" % once_only)
             counts["once"] = counts["imread"] = 0
-            ST._decode_once, ST._imread = once, imread
+            ST._decode_once, ST._imread, ST._fill_from_jpeg = once, imread, native
             try:
                 st.imageSetStitchWithMutiple(str(proj), str(out) + os.sep, 1, st.calculateOffsetForFeatureSearchIncre,
                                              startNum=1, fileExtension="jpg", outputfileExtension="png")
             finally:
-                ST._decode_once, ST._imread = real_once, real_imread
+                ST._decode_once, ST._imread, ST._fill_from_jpeg = real_once, real_imread, real_native
             if once_only:
                 assert counts == {"once": len(files), "imread": 0}, counts
             names = sorted(n for n in os.listdir(str(out)) if n.endswith(".png"))

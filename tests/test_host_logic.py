@@ -472,6 +472,110 @@ def test_colour_mosaic_decodes_every_file_exactly_once(oracle, tmp_path):
         isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod = old
 
 
+def test_library_jpeg_decoder_equals_pillow_and_refuses_what_it_does_not_take(tmp_path):
+    """vfsms_jpeg_decode (csrc/jpeg_host.hip: the system's libjpeg-turbo behind a self-declared ABI) against Pillow's decode of the same
+    bytes -- the grayscale decode and the Y Cb Cr planes, for the chroma subsamplings, progressive files and a grayscale file -- byte for
+    byte; files it must hand back to the caller (truncated, CMYK, not a JPEG) come back as None, never as a wrong image."""
+    import io
+    from PIL import Image, ImageFilter
+    from imagestitch_amd import _lib
+    rng = np.random.default_rng(5)
+    base = np.asarray(Image.fromarray((rng.random((203, 331, 3)) * 255).astype(np.uint8)).filter(ImageFilter.GaussianBlur(1.5)))
+    if _lib.jpeg_decode(_jpeg_bytes(base), False) is None:
+        pytest.skip("no libjpeg.so.8 on this host: the Stitcher decodes with Pillow")
+    blobs = [(ss, prog, _jpeg_bytes(base, subsampling=ss, progressive=prog)) for ss in (0, 1, 2) for prog in (False, True)]
+    for ss, prog, b in blobs:
+        im = Image.open(io.BytesIO(b)); im.draft("YCbCr", im.size); im.load()
+        assert im.mode == "YCbCr"
+        planes = _lib.jpeg_decode(b, True)
+        assert planes.shape == (203, 331, 3) and np.array_equal(planes, np.asarray(im)), (ss, prog)
+        im = Image.open(io.BytesIO(b)); im.draft("L", im.size); im.load()
+        gray = _lib.jpeg_decode(b, False)
+        assert gray.shape == (203, 331) and np.array_equal(gray, np.asarray(im)), (ss, prog)
+        assert np.array_equal(gray, planes[:, :, 0])                       # IMREAD_GRAYSCALE of a JPEG is its Y plane
+    g = _jpeg_bytes(base[:, :, 1])
+    for want in (False, True):                                             # a grayscale file has one plane, whatever is asked for
+        out = _lib.jpeg_decode(g, want)
+        assert out.ndim == 2 and np.array_equal(out, np.asarray(Image.open(io.BytesIO(g))))
+    b = blobs[0][2]
+    assert _lib.jpeg_decode(b[:len(b) // 2], True) is None                 # truncated: libjpeg would pad it with gray
+    assert _lib.jpeg_decode(b"not a jpeg at all" * 20, False) is None
+    bio = io.BytesIO(); Image.fromarray(base).convert("CMYK").save(bio, "JPEG")
+    assert _lib.jpeg_decode(bio.getvalue(), True) is None                  # four components
+    bio = io.BytesIO(); Image.fromarray(base).save(bio, "PNG")
+    assert _lib.jpeg_decode(bio.getvalue(), False) is None
+    # many threads at once, one buffer each (the decoder pool's use): same bytes as alone
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(8) as ex:
+        outs = list(ex.map(lambda k: _lib.jpeg_decode(blobs[k % len(blobs)][2], True), range(32)))
+    ref = [_lib.jpeg_decode(bb[2], True) for bb in blobs]
+    assert all(np.array_equal(o, ref[k % len(blobs)]) for k, o in enumerate(outs))
+
+
+def _jpeg_bytes(arr, **kw):
+    import io
+    from PIL import Image
+    bio = io.BytesIO()
+    Image.fromarray(arr).save(bio, "JPEG", quality=kw.pop("quality", 90), **kw)
+    return bio.getvalue()
+
+
+def test_jpeg_files_are_decoded_by_the_library_once_and_pillow_takes_the_rest(oracle, tmp_path):
+    """The ingest pipeline hands JPEG files to vfsms_tile_fill_jpeg: one decode per file inside the library, `_decode_once` (Pillow) is not
+    called at all; a file the library refuses (here: a PNG, and a CMYK JPEG) goes through `_decode_once` -- once; VFSMS_NATIVE_JPEG=0 sends
+    everything through Pillow.  The three runs give the same mosaic as the engine without the entry point."""
+    from PIL import Image
+    from imagestitch_amd.synthetic import SyntheticGrid
+    from imagestitch_amd import stitcher as ST
+    from imagestitch_amd import _lib
+    from fakes import NativeJpegEngine
+    if _lib.jpeg_decode(_jpeg_bytes(np.zeros((16, 16), np.uint8)), False) is None:
+        pytest.skip("no libjpeg.so.8 on this host")
+    g = SyntheticGrid(2, 2, 256, overlap=0.25)
+    tiles = _colour_tiles(g)
+    files = _write_jpegs(tmp_path, tiles, "nat")
+    mixed = list(files)
+    mixed[1] = os.path.join(str(tmp_path), "nat_1.png")
+    Image.fromarray(np.asarray(Image.open(files[1]).convert("RGB"))).save(mixed[1])          # the decoded JPEG, losslessly: same pixels
+    old = (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod)
+    counts = {"once": 0}
+    real_once = ST._decode_once
+
+    def once(path, color):
+        counts["once"] += 1
+        return real_once(path, color)
+    env_old = os.environ.get("VFSMS_NATIVE_JPEG")
+    try:
+        isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod = 1, 0.3, "surf", "fadeInAndFadeOut"
+        for color in (True, False):
+            isa.Stitcher.isColorMode = color
+            runs = []
+            for flist, env, cls, want_native, want_once in ((files, "1", NativeJpegEngine, 4, 0), (files, "0", NativeJpegEngine, 0, 4),
+                                                            (files, "1", IngestOracleEngine, 0, 4), (mixed, "1", NativeJpegEngine, 3, 1)):
+                os.environ["VFSMS_NATIVE_JPEG"] = env
+                eng = cls(oracle)
+                s = isa.Stitcher(); s._engine = eng; s.isPrintLog = False; s.direction = 1
+                counts["once"] = 0
+                ST._decode_once = once
+                try:
+                    (status, mosaic) = s.flowStitch(list(flist), s.calculateOffsetForFeatureSearchIncre)
+                finally:
+                    ST._decode_once = real_once
+                assert status == (True, 3)
+                assert len(getattr(eng, "native", [])) == want_native and counts["once"] == want_once, (env, cls.__name__, getattr(eng, "native", None), counts)
+                assert not eng.live, eng.live
+                runs.append(mosaic)
+            assert all(np.array_equal(runs[0], r) for r in runs[1:3])
+            # (the PNG holds the JPEG's RGB pixels, not its planes: the mixed run differs by the rounding of RGB -> gray / YCC -> RGB -> BGR only)
+            assert runs[3].shape == runs[0].shape and np.abs(runs[3].astype(int) - runs[0].astype(int)).max() <= 4
+    finally:
+        if env_old is None:
+            os.environ.pop("VFSMS_NATIVE_JPEG", None)
+        else:
+            os.environ["VFSMS_NATIVE_JPEG"] = env_old
+        isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod = old
+
+
 def test_ingest_error_paths_free_every_handle(oracle, tmp_path):
     """A file that cannot be decoded: the batch waiting for its tile fails, flowStitch raises the decoder's error and every reserved handle
     (gray and colour) is released.  A corrupt file BEHIND a registration break is never an error -- the reference stops at the break and
