@@ -377,7 +377,8 @@ def bench_from_files(args, eng, grid, torch):
     from imagestitch_amd import stitcher as ST
     if args.gpus != 1 or args.method != "surf":
         raise SystemExit("--from-files is a single-GPU SURF measurement")
-    nthreads = max(1, min(args.decode_threads or min(os.cpu_count() or 4, 16), grid.n_tiles, 64))
+    # (the Stitcher's own default: 32 decoder threads with the library's JPEG decoder, 16 with Pillow -- Stitcher._decoderThreads)
+    nthreads = max(1, min(args.decode_threads or min(os.cpu_count() or 4, 32 if os.environ.get("VFSMS_NATIVE_JPEG", "1") != "0" else 16), grid.n_tiles, 64))
     color = bool(args.color)
     with tempfile.TemporaryDirectory(prefix="vfsms_bench_") as d:
         files = []
@@ -550,7 +551,7 @@ def main():
     ap.add_argument("--workload", default="grid", choices=["grid", "dendritic25"],
                     help="grid = the synthetic serpentine grid (BASELINE metric); dendritic25 = the 25 committed real pairs (N = 1, surf)")
     ap.add_argument("--from-files", action="store_true", help="N = 1: JPEG tiles on disk through Stitcher's ingest pipeline (decode inclusive)")
-    ap.add_argument("--decode-threads", type=int, default=0, help="decoder threads of --from-files (0 = one per host core, at most 32)")
+    ap.add_argument("--decode-threads", type=int, default=0, help="decoder threads of --from-files (0 = the Stitcher's default: one per host core, at most 32; 16 with VFSMS_NATIVE_JPEG=0)")
     ap.add_argument("--color", action="store_true", help="--from-files with colour JPEGs and isColorMode = True (Main.py:14's default)")
     args = ap.parse_args()
 
