@@ -10,7 +10,7 @@ behind the C ABI of include/vfsms.h (imagestitch_amd/lib/libvfsms.so, loaded wit
 from ._lib import Engine, VfsmsError, default_engine, load_library, LIB_PATH  # noqa: F401
 from .utility import Method, roi_rect  # noqa: F401
 from .fusion import ImageFusion  # noqa: F401
-from .stitcher import Stitcher, ImageFeature, NpyBandWriter, PngBandWriter, TiffBandWriter, band_writer_for  # noqa: F401
+from .stitcher import Stitcher, ImageFeature, NpyBandWriter, PngBandWriter, TiffBandWriter, JpegBandWriter, band_writer_for  # noqa: F401
 
 __all__ = ["Stitcher", "ImageFusion", "Method", "ImageFeature", "Engine", "VfsmsError", "default_engine",
-           "load_library", "roi_rect", "NpyBandWriter", "PngBandWriter", "TiffBandWriter", "band_writer_for"]
+           "load_library", "roi_rect", "NpyBandWriter", "PngBandWriter", "TiffBandWriter", "JpegBandWriter", "band_writer_for"]

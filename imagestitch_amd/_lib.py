@@ -76,6 +76,8 @@ _SIGNATURES = {
     "vfsms_tile_fill_pair": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int]),
     "vfsms_tile_fill_jpeg": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_size_t]),
     "vfsms_jpeg_decode": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vfsms_jpeg_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "vfsms_jpeg_join": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "vfsms_canvas_blend_tile_resident": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vfsms_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vfsms_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -710,6 +712,53 @@ def jpeg_decode(data, want_planes=False):
     if rc != VFSMS_OK:
         return None
     return out[:, :, 0] if c.value == 1 else out
+
+
+def _last_error(lib):
+    buf = C.create_string_buffer(512)
+    lib.vfsms_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def jpeg_encode(img, bgr=True, quality=95):
+    """vfsms_jpeg_encode: u8 (h, w) or (h, w, 3) rows (B G R when `bgr`, the canvas order) -> a complete baseline JPEG stream as a u8 array,
+    libjpeg defaults + `quality` (cv2.imwrite's: 95) -- byte for byte what Pillow / cv2 write for the same pixels.  None when the host has
+    no libjpeg.so.8 (the caller writes through Pillow).  No GPU involved; releases the interpreter lock."""
+    lib = load_library()
+    assert img.dtype == np.uint8 and img.ndim in (2, 3) and img.strides[-1] == 1 and (img.ndim == 2 or (img.shape[2] == 3 and img.strides[1] == 3))
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else 3
+    cap = max(1 << 16, h * w * ch // 4)
+    n = C.c_size_t()
+    for _ in range(2):
+        out = np.empty(cap, np.uint8)
+        rc = lib.vfsms_jpeg_encode(img.ctypes.data_as(C.c_void_p), h, w, ch, img.strides[0], int(bool(bgr)), int(quality),
+                                   out.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+        if rc == VFSMS_OK:
+            return out[:n.value]
+        if rc == VFSMS_ERR_UNSUPPORTED:
+            return None
+        if rc != VFSMS_ERR_CAPACITY:
+            raise VfsmsError("libvfsms error %d: %s" % (rc, _last_error(lib)))
+        cap = n.value
+    raise VfsmsError("jpeg_encode: the stream did not fit the size the library asked for")
+
+
+def jpeg_join(parts, stripe_rows, total_rows):
+    """vfsms_jpeg_join: the streams of consecutive stripes (jpeg_encode of rows [k * stripe_rows, (k + 1) * stripe_rows) of one image) -> ONE
+    JPEG whose restart intervals are the stripes; u8 array."""
+    lib = load_library()
+    n = len(parts)
+    ptrs = (C.c_void_p * n)(*[p.ctypes.data for p in parts])
+    sizes = (C.c_size_t * n)(*[p.size for p in parts])
+    need = C.c_size_t()
+    rc = lib.vfsms_jpeg_join(ptrs, sizes, n, int(stripe_rows), int(total_rows), None, 0, C.byref(need))
+    if rc == VFSMS_OK:
+        out = np.empty(need.value, np.uint8)
+        rc = lib.vfsms_jpeg_join(ptrs, sizes, n, int(stripe_rows), int(total_rows), out.ctypes.data_as(C.c_void_p), out.size, C.byref(need))
+    if rc != VFSMS_OK:
+        raise VfsmsError("libvfsms error %d: %s" % (rc, _last_error(lib)))
+    return out
 
 
 def default_engine():

@@ -10,6 +10,13 @@
 // wanted: out_color_space = JCS_YCbCr, the upsampled planes interleaved, no colour conversion on the host; the device derives the gray and
 // the B G R tile (csrc/ingest_kernels.hip).
 //
+// The other direction, for the mosaic (cv2.imwrite at Stitcher.py:149, 175-179; Main.py writes every result as .jpg): vfsms_jpeg_encode
+// turns a horizontal STRIPE of an image into a complete baseline JPEG stream with cv2.imwrite's settings (libjpeg defaults: 4:2:0, standard
+// Huffman tables, quality 95 unless told otherwise).  Stripes whose heights are multiples of the MCU height share no state -- the DCT
+// blocks, the 2x2 chroma box filter and the quantisation are local to an MCU row -- so the host encodes them on as many threads as it
+// likes and joins their entropy-coded segments into ONE file as restart intervals (vfsms_jpeg_join: DRI = the MCUs of a stripe, an RSTn
+// marker between two stripes).  The coefficients, hence the decoded pixels, are those of the one-thread encode of the whole image.
+//
 // ABI knowledge used (libjpeg 8 / libjpeg-turbo 2.x on x86-64, `boolean` = int): the public head of jpeg_decompress_struct up to
 // output_scanline and the layout of jpeg_error_mgr -- restated below field by field.  Two guards make a mismatch a clean refusal
 // (VFSMS_ERR_UNSUPPORTED -> the host falls back to Pillow) instead of a wrong image: the struct SIZE is taken from the library itself
@@ -19,6 +26,7 @@
 #include <dlfcn.h>
 #include <setjmp.h>
 #include <string.h>
+#include <stdlib.h>
 #include <atomic>
 
 namespace {
@@ -55,7 +63,14 @@ static_assert(offsetof(jdec_head_abi, image_width) == 48 && offsetof(jdec_head_a
               offsetof(jdec_head_abi, output_width) == 136 && offsetof(jdec_head_abi, output_components) == 148 && offsetof(jdec_head_abi, output_scanline) == 168,
               "jpeg_decompress_struct head: unexpected layout");
 static_assert(offsetof(jerr_abi, msg_parm) == 44 && offsetof(jerr_abi, num_warnings) == 128 && sizeof(jerr_abi) == 168, "jpeg_error_mgr: unexpected layout");
-enum { JCS_GRAYSCALE_ = 1, JCS_YCbCr_ = 3 };
+struct jcomp_head_abi {                 // struct jpeg_compress_struct, its public head
+    jerr_abi *err; void *mem; void *progress; void *client_data; int is_decompressor; int global_state;
+    void *dest;
+    unsigned image_width, image_height; int input_components; int in_color_space;
+    double input_gamma;
+};
+static_assert(offsetof(jcomp_head_abi, image_width) == 48 && offsetof(jcomp_head_abi, in_color_space) == 60, "jpeg_compress_struct head: unexpected layout");
+enum { JCS_GRAYSCALE_ = 1, JCS_RGB_ = 2, JCS_YCbCr_ = 3 };
 #define JPEG_ABI_VERSION 80
 #define JPEG_CINFO_BYTES 2048           // room for the whole struct (632 bytes in libjpeg-turbo 2.1, ABI 8)
 
@@ -70,6 +85,17 @@ struct JpegApi {
     void (*destroy)(void *);
     size_t cinfo_size;                  // as the library reports it
     bool ok;
+    // the compressor
+    void (*c_create)(void *, int, size_t);
+    void (*c_mem_dest)(void *, unsigned char **, unsigned long *);
+    void (*c_defaults)(void *);
+    void (*c_quality)(void *, int, int);
+    void (*c_start)(void *, int);
+    unsigned (*c_write)(void *, unsigned char **, unsigned);
+    void (*c_finish)(void *);
+    void (*c_destroy)(void *);
+    size_t c_size;
+    bool c_ok;
 };
 struct Guard { jmp_buf jb; int code; int parm0, parm1; char text[200]; };
 
@@ -111,6 +137,23 @@ const JpegApi &api()
         if (g.parm1 != 7 || g.parm0 < (int)sizeof(jdec_head_abi) || g.parm0 > JPEG_CINFO_BYTES) return a;    // not the size error, or an implausible size
         a.cinfo_size = (size_t)g.parm0;
         a.ok = true;
+        a.c_create = (void (*)(void *, int, size_t))dlsym(h, "jpeg_CreateCompress");
+        a.c_mem_dest = (void (*)(void *, unsigned char **, unsigned long *))dlsym(h, "jpeg_mem_dest");
+        a.c_defaults = (void (*)(void *))dlsym(h, "jpeg_set_defaults");
+        a.c_quality = (void (*)(void *, int, int))dlsym(h, "jpeg_set_quality");
+        a.c_start = (void (*)(void *, int))dlsym(h, "jpeg_start_compress");
+        a.c_write = (unsigned (*)(void *, unsigned char **, unsigned))dlsym(h, "jpeg_write_scanlines");
+        a.c_finish = (void (*)(void *))dlsym(h, "jpeg_finish_compress");
+        a.c_destroy = (void (*)(void *))dlsym(h, "jpeg_destroy_compress");
+        if (!a.c_create || !a.c_mem_dest || !a.c_defaults || !a.c_quality || !a.c_start || !a.c_write || !a.c_finish || !a.c_destroy) return a;
+        memset(cinfo, 0, sizeof(cinfo)); memset(&err, 0, sizeof(err)); memset(&g.code, 0, sizeof(g) - sizeof(g.jb));
+        c->err = a.std_error(&err);
+        err.error_exit = on_error; err.output_message = on_message;
+        c->client_data = &g;
+        if (setjmp(g.jb) == 0) { a.c_create(cinfo, JPEG_ABI_VERSION, 7); return a; }
+        if (g.parm1 != 7 || g.parm0 < (int)sizeof(jcomp_head_abi) || g.parm0 > JPEG_CINFO_BYTES) return a;
+        a.c_size = (size_t)g.parm0;
+        a.c_ok = true;
         return a;
     }();
     return A;
@@ -207,4 +250,181 @@ extern "C" int vfsms_jpeg_decode(const uint8_t *jpeg, size_t nbytes, int want_pl
 {
     if (!h || !w || !comp) { vfsms_set_error("jpeg_decode: bad arguments"); return VFSMS_ERR_BAD_ARG; }
     return jpeg_decode_host(jpeg, nbytes, want_planes, out, cap, h, w, comp);
+}
+
+// ---- encode -----------------------------------------------------------------------------------------------------------------------------
+namespace {
+// the segments of a baseline stream this library wrote: [2, sos_end) = the headers up to and including the SOS header, [sos_end, n - 2) =
+// the entropy-coded segment, and where the frame header keeps its size
+struct StreamMap { size_t sof, sos, sos_end; int h, w, nc, vmax; };
+bool map_stream(const unsigned char *p, size_t n, StreamMap *m)
+{
+    if (n < 6 || p[0] != 0xFF || p[1] != 0xD8 || p[n - 2] != 0xFF || p[n - 1] != 0xD9) return false;
+    size_t q = 2; m->sof = 0;
+    while (q + 4 <= n) {
+        if (p[q] != 0xFF) return false;
+        const unsigned mk = p[q + 1];
+        const size_t seg = ((size_t)p[q + 2] << 8) | p[q + 3];
+        if (q + 2 + seg > n) return false;
+        if (mk == 0xC0) {                                        // baseline frame header
+            if (seg < 8 + 3) return false;
+            m->sof = q; m->h = (p[q + 5] << 8) | p[q + 6]; m->w = (p[q + 7] << 8) | p[q + 8]; m->nc = p[q + 9];
+            if (seg < 8 + 3u * m->nc) return false;
+            m->vmax = 1;
+            for (int c = 0; c < m->nc; c++) { const int v = p[q + 11 + 3 * c] & 15; if (v > m->vmax) m->vmax = v; }
+        } else if (mk == 0xDD) return false;                      // a stripe is ONE restart interval: it must not bring a DRI of its own
+        else if (mk == 0xDA) { m->sos = q; m->sos_end = q + 2 + seg; return m->sof != 0 && m->sos_end <= n - 2; }
+        q += 2 + seg;
+    }
+    return false;
+}
+}  // namespace
+
+namespace {
+enum { IN_RGB = 0, IN_BGR_SWAP = 1, IN_BGR_EXT = 2 };
+#define JCS_EXT_BGR_ 8                  // libjpeg-turbo's extension: B G R input, converted by the same SIMD routine as R G B
+// one image -> a malloc'ed stream (*mem, *memsize; the caller frees it)
+int encode_impl(const uint8_t *rows, int n_rows, int cols, int channels, int stride, int input, int quality, unsigned char **mem, unsigned long *memsize)
+{
+    const JpegApi &A = api();
+    alignas(16) unsigned char cinfo[JPEG_CINFO_BYTES]; memset(cinfo, 0, sizeof(cinfo));
+    jerr_abi err; memset(&err, 0, sizeof(err));
+    Guard g; memset(&g.code, 0, sizeof(g) - sizeof(g.jb));
+    jcomp_head_abi *c = (jcomp_head_abi *)cinfo;
+    unsigned char *volatile swap = nullptr;
+    volatile bool created = false;
+    *mem = nullptr; *memsize = 0;                             // (jpeg_mem_dest allocates and grows the buffer with malloc)
+    if (setjmp(g.jb)) {
+        if (created) A.c_destroy(cinfo);
+        free(*mem); *mem = nullptr; free(swap);
+        vfsms_set_error("jpeg_encode: %s", g.text[0] ? g.text : "encoder error");
+        return VFSMS_ERR_BAD_ARG;
+    }
+    c->err = A.std_error(&err);
+    err.error_exit = on_error; err.output_message = on_message;
+    c->client_data = &g;
+    A.c_create(cinfo, JPEG_ABI_VERSION, A.c_size);
+    created = true;
+    c->client_data = &g;
+    A.c_mem_dest(cinfo, mem, memsize);
+    c->image_width = (unsigned)cols; c->image_height = (unsigned)n_rows; c->input_components = channels;
+    c->in_color_space = channels == 1 ? JCS_GRAYSCALE_ : input == IN_BGR_EXT ? JCS_EXT_BGR_ : JCS_RGB_;
+    A.c_defaults(cinfo);
+    A.c_quality(cinfo, quality, 1);
+    A.c_start(cinfo, 1);
+    const int CH = 16;
+    if (channels == 3 && input == IN_BGR_SWAP) {
+        swap = (unsigned char *)malloc((size_t)CH * cols * 3);
+        if (!swap) { A.c_destroy(cinfo); free(*mem); *mem = nullptr; vfsms_set_error("jpeg_encode: out of memory"); return VFSMS_ERR_CAPACITY; }
+    }
+    for (int y0 = 0; y0 < n_rows; y0 += CH) {
+        const int nr = n_rows - y0 < CH ? n_rows - y0 : CH;
+        unsigned char *ptr[CH];
+        for (int r = 0; r < nr; r++) {
+            const uint8_t *src = rows + (size_t)(y0 + r) * stride;
+            if (swap) {
+                unsigned char *d = swap + (size_t)r * cols * 3;
+                for (int x = 0; x < cols; x++) { d[3 * x] = src[3 * x + 2]; d[3 * x + 1] = src[3 * x + 1]; d[3 * x + 2] = src[3 * x]; }
+                ptr[r] = d;
+            } else ptr[r] = (unsigned char *)src;
+        }
+        int done = 0;
+        while (done < nr) {
+            const unsigned k = A.c_write(cinfo, ptr + done, (unsigned)(nr - done));
+            if (k == 0) { g.text[0] = 0; longjmp(g.jb, 1); }      // (cannot happen with a memory destination)
+            done += (int)k;
+        }
+    }
+    A.c_finish(cinfo);
+    A.c_destroy(cinfo);
+    created = false;
+    free(swap); swap = nullptr;
+    return VFSMS_OK;
+}
+// does this libjpeg take B G R rows directly (libjpeg-turbo does), with the very bytes of the swapped encode?  Probed once.
+bool ext_bgr_ok()
+{
+    static std::atomic<int> state{0};
+    int st = state.load();
+    if (st == 0) {
+        uint8_t img[16 * 16 * 3];
+        for (int k = 0; k < 16 * 16 * 3; k++) img[k] = (uint8_t)((k * 37 + (k / 48) * 11) & 255);
+        unsigned char *m1 = nullptr, *m2 = nullptr; unsigned long n1 = 0, n2 = 0;
+        const int r1 = encode_impl(img, 16, 16, 3, 48, IN_BGR_SWAP, 90, &m1, &n1);
+        const int r2 = encode_impl(img, 16, 16, 3, 48, IN_BGR_EXT, 90, &m2, &n2);
+        st = (r1 == VFSMS_OK && r2 == VFSMS_OK && n1 == n2 && n1 > 0 && memcmp(m1, m2, n1) == 0) ? 1 : -1;
+        free(m1); free(m2);
+        state.store(st);
+    }
+    return st == 1;
+}
+}  // namespace
+
+// `rows`: n_rows x cols pixels of `channels` (1: gray, 3: R G B, or B G R with bgr != 0 -- the canvas order), `stride` bytes apart -> a
+// complete baseline JPEG in `out` (cap bytes; *nbytes = the size needed, also on VFSMS_ERR_CAPACITY).  libjpeg defaults + `quality`: what
+// cv2.imwrite(path, img) writes (quality 95).
+extern "C" int vfsms_jpeg_encode(const uint8_t *rows, int n_rows, int cols, int channels, int stride, int bgr, int quality, uint8_t *out, size_t cap, size_t *nbytes)
+{
+    const JpegApi &A = api();
+    if (!A.c_ok) { vfsms_set_error("jpeg_encode: libjpeg.so.8 (ABI 8) is not available on this host"); return VFSMS_ERR_UNSUPPORTED; }
+    if (!rows || !nbytes || n_rows <= 0 || cols <= 0 || n_rows > 65500 || cols > 65500 || (channels != 1 && channels != 3) || stride < cols * channels || quality < 1 || quality > 100) {
+        vfsms_set_error("jpeg_encode: bad arguments (1 or 3 channels, at most 65500 pixels a side)"); return VFSMS_ERR_BAD_ARG;
+    }
+    const int input = (channels == 3 && bgr) ? (ext_bgr_ok() ? IN_BGR_EXT : IN_BGR_SWAP) : IN_RGB;
+    unsigned char *mem = nullptr; unsigned long memsize = 0;
+    int rc = encode_impl(rows, n_rows, cols, channels, stride, input, quality, &mem, &memsize);
+    if (rc != VFSMS_OK) return rc;
+    StreamMap m;
+    const bool sane = mem && map_stream(mem, memsize, &m) && m.h == n_rows && m.w == cols && m.nc == channels;     // the witness for the struct offsets
+    *nbytes = memsize;
+    if (!sane) { vfsms_set_error("jpeg_encode: libjpeg.so.8 does not have the expected struct layout"); rc = VFSMS_ERR_UNSUPPORTED; }
+    else if (!out || cap < memsize) { vfsms_set_error("jpeg_encode: output buffer too small"); rc = VFSMS_ERR_CAPACITY; }
+    else memcpy(out, mem, memsize);
+    free(mem);
+    return rc;
+}
+
+// Join stripes encoded by vfsms_jpeg_encode (same width, channels and quality; every stripe but the last `stripe_rows` high, a multiple of
+// the MCU height: 16 for colour, 8 for gray) into ONE JPEG of `total_rows` rows: the headers of stripe 0 with the frame height patched and a
+// DRI segment (restart interval = the MCUs of one stripe, at most 65535), then the entropy-coded segments with RSTn between them.
+// `streams[k]`, `sizes[k]`: stripe k.  With out == NULL only the size is computed.
+extern "C" int vfsms_jpeg_join(const uint8_t *const *streams, const size_t *sizes, int n_stripes, int stripe_rows, int total_rows, uint8_t *out, size_t cap, size_t *nbytes)
+{
+    if (!streams || !sizes || !nbytes || n_stripes < 1 || stripe_rows < 1 || total_rows < 1 || total_rows > 65500) { vfsms_set_error("jpeg_join: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    StreamMap m0;
+    if (!streams[0] || !map_stream(streams[0], sizes[0], &m0)) { vfsms_set_error("jpeg_join: stripe 0 is not a stream of vfsms_jpeg_encode"); return VFSMS_ERR_BAD_ARG; }
+    const int mcu_h = 8 * m0.vmax, mcu_w = m0.nc == 1 ? 8 : 16;
+    const long long interval = (long long)((m0.w + mcu_w - 1) / mcu_w) * (stripe_rows / mcu_h);
+    if (n_stripes > 1 && (stripe_rows % mcu_h || interval > 65535 || (m0.nc == 3 && m0.vmax != 2))) {
+        vfsms_set_error("jpeg_join: stripes of %d rows cannot be restart intervals of this image (MCU %d x %d, %lld MCUs per stripe)", stripe_rows, mcu_w, mcu_h, interval);
+        return VFSMS_ERR_BAD_ARG;
+    }
+    size_t need = m0.sos_end + (n_stripes > 1 ? 6 : 0) + 2;
+    long long rows = 0;
+    for (int k = 0; k < n_stripes; k++) {
+        StreamMap m;
+        if (!streams[k] || !map_stream(streams[k], sizes[k], &m) || m.w != m0.w || m.nc != m0.nc || (k + 1 < n_stripes && m.h != stripe_rows) ||
+            m.sof != m0.sof || m.sos != m0.sos || m.sos_end != m0.sos_end || memcmp(streams[k] + 2, streams[0] + 2, m0.sof - 2) ||       // same tables in front of the frame header
+            memcmp(streams[k] + m.sof + 9, streams[0] + m0.sof + 9, m0.sos_end - m0.sof - 9)) {                                        // same components, Huffman tables, scan header
+            vfsms_set_error("jpeg_join: stripe %d does not continue stripe 0 (size, channels, tables or height)", k); return VFSMS_ERR_BAD_ARG;
+        }
+        rows += m.h;
+        need += sizes[k] - 2 - m.sos_end + (k ? 2 : 0);
+    }
+    if (rows != total_rows) { vfsms_set_error("jpeg_join: the stripes hold %lld rows, not %d", rows, total_rows); return VFSMS_ERR_BAD_ARG; }
+    *nbytes = need;
+    if (!out) return VFSMS_OK;
+    if (cap < need) { vfsms_set_error("jpeg_join: output buffer too small"); return VFSMS_ERR_CAPACITY; }
+    uint8_t *o = out;
+    memcpy(o, streams[0], m0.sos); o += m0.sos;                                         // SOI .. DHT
+    out[m0.sof + 5] = (uint8_t)(total_rows >> 8); out[m0.sof + 6] = (uint8_t)total_rows;
+    if (n_stripes > 1) { const uint8_t dri[6] = { 0xFF, 0xDD, 0, 4, (uint8_t)(interval >> 8), (uint8_t)interval }; memcpy(o, dri, 6); o += 6; }
+    memcpy(o, streams[0] + m0.sos, m0.sos_end - m0.sos); o += m0.sos_end - m0.sos;      // the scan header
+    for (int k = 0; k < n_stripes; k++) {
+        if (k) { *o++ = 0xFF; *o++ = (uint8_t)(0xD0 + ((k - 1) & 7)); }
+        const size_t n = sizes[k] - 2 - m0.sos_end;
+        memcpy(o, streams[k] + m0.sos_end, n); o += n;
+    }
+    *o++ = 0xFF; *o++ = 0xD9;
+    return (size_t)(o - out) == need ? VFSMS_OK : VFSMS_ERR_BAD_ARG;
 }

@@ -241,13 +241,30 @@ def _imwrite(path, img):
         return
     from PIL import Image
     img = np.asarray(img)
-    if img.ndim == 3:
-        img = img[:, :, ::-1]
     d = os.path.dirname(path)
     if d and not os.path.exists(d):
         os.makedirs(d)
+    if path.lower().endswith((".jpg", ".jpeg")) and _imwrite_jpeg_stripes(path, img):
+        return
+    if img.ndim == 3:
+        img = img[:, :, ::-1]
     kw = {"quality": 95} if path.lower().endswith((".jpg", ".jpeg")) else {}     # cv2.imwrite's JPEG default (Pillow's is 75)
     Image.fromarray(np.ascontiguousarray(img)).save(path, **kw)
+
+
+def _imwrite_jpeg_stripes(path, img):
+    """a .jpg result through the library's encoder (JpegBandWriter: the stripes of the image on all cores) -> True; False = not written
+    (no libjpeg.so.8, VFSMS_NATIVE_JPEG=0, an image libjpeg cannot hold): Pillow writes it."""
+    if os.environ.get("VFSMS_NATIVE_JPEG", "1") == "0" or img.dtype != np.uint8 or img.ndim not in (2, 3) or (img.ndim == 3 and img.shape[2] != 3):
+        return False
+    if max(img.shape[:2]) > 65500 or min(img.shape[:2]) < 1:
+        return False
+    w = JpegBandWriter(path)
+    try:
+        w(0, img, img.shape)
+    except _NoNativeJpeg:
+        return False
+    return True
 
 
 class NpyBandWriter:
@@ -314,6 +331,101 @@ class PngBandWriter:
             self._f = self._z = None
 
 
+class _NoNativeJpeg(Exception):
+    pass
+
+
+_ENCODER_POOL = {}
+
+
+def _encoder_pool(nthreads):
+    from concurrent.futures import ThreadPoolExecutor
+    pool = _ENCODER_POOL.get(nthreads)
+    if pool is None:
+        pool = _ENCODER_POOL[nthreads] = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="vfsms-encode")
+    return pool
+
+
+class JpegBandWriter:
+    """A `Stitcher.mosaicSink` for the reference's own output format (Main.py:21-51 writes every result as .jpg; cv2.imwrite at
+    Stitcher.py:149, 175-179): the bands are cut into STRIPES whose height is a multiple of the MCU height, every stripe is encoded on a pool
+    of threads by the library (vfsms_jpeg_encode: the system's libjpeg-turbo with cv2.imwrite's settings, quality 95, no interpreter lock)
+    while the next band is still leaving the device, and the stripes are joined into ONE baseline JPEG as restart intervals
+    (vfsms_jpeg_join).  The DCT coefficients -- hence the decoded pixels -- are those of cv2.imwrite's / Pillow's one-thread encode of the
+    whole mosaic; the file is a few bytes per stripe longer (RSTn markers + one DRI segment).  Only the compressed stripes are kept in
+    host memory.  Bands are B G R like the canvas."""
+
+    def __init__(self, path, quality=95, threads=None, stripe_rows=None):
+        self.path, self.quality = path, int(quality)
+        self.threads = int(threads or min(os.cpu_count() or 4, 32))
+        self.stripe_rows = stripe_rows
+        self._reset()
+
+    def _reset(self):
+        self._futures, self._carry, self._rows_in, self._stripe, self._shape = [], None, 0, None, None
+
+    def _encode(self, rows):
+        from . import _lib
+        out = _lib.jpeg_encode(rows, bgr=True, quality=self.quality)
+        if out is None:
+            raise _NoNativeJpeg("no libjpeg.so.8 on this host")
+        return out
+
+    def _submit(self, rows):
+        if len(self._futures) >= 4 * self.threads:             # encoders far behind the band stream: do not pile the bands up in host memory
+            self._futures[len(self._futures) - 4 * self.threads].result()
+        self._futures.append(_encoder_pool(self.threads).submit(self._encode, rows))
+
+    def __call__(self, row0, band, full_shape):
+        band = np.asarray(band)
+        if self._shape is None:
+            rows, cols = int(full_shape[0]), int(full_shape[1])
+            ch = int(full_shape[2]) if len(full_shape) == 3 else 1
+            if ch not in (1, 3) or max(rows, cols) > 65500:
+                raise ValueError("JPEG holds 1- or 3-channel images of at most 65500 pixels a side (this one: %s)" % (tuple(full_shape),))
+            mcu = 16 if ch == 3 else 8
+            per_row = (cols + mcu - 1) // mcu
+            k = max(1, min((int(self.stripe_rows) if self.stripe_rows else 256) // mcu, 65535 // per_row))    # a stripe is one restart interval: <= 65535 MCUs
+            self._stripe, self._shape = k * mcu, (rows, cols, ch)
+        rows, cols, ch = self._shape
+        assert row0 == self._rows_in and band.shape[1] == cols, "bands arrive in order"
+        self._rows_in += band.shape[0]
+        last = self._rows_in >= rows
+        try:
+            if self._carry is not None:
+                band = np.concatenate([self._carry, band], 0)
+                self._carry = None
+            if not band.flags.c_contiguous:
+                band = np.ascontiguousarray(band)
+            S, n = self._stripe, band.shape[0]
+            full = n if last else (n // S) * S
+            for r in range(0, full, S):
+                self._submit(band[r:min(r + S, full)])
+            if full < n:
+                self._carry = band[full:].copy()
+            if not last:
+                return
+            from . import _lib
+            parts = [f.result() for f in self._futures]
+            data = _lib.jpeg_join(parts, S, rows)
+            d = os.path.dirname(self.path)
+            if d and not os.path.exists(d):
+                os.makedirs(d)
+            with open(self.path, "wb") as f:
+                f.write(memoryview(data))
+            self._reset()
+        except BaseException:
+            for f in self._futures:
+                f.cancel()
+            for f in self._futures:
+                try:
+                    f.result()
+                except BaseException:                          # noqa: PERF203
+                    pass
+            self._reset()
+            raise
+
+
 class TiffBandWriter:
     """A `Stitcher.mosaicSink` for uncompressed baseline TIFF (BigTIFF beyond 4 GB): one strip per band, the directory written behind the
     last band.  R G B (or gray) 8-bit samples."""
@@ -368,9 +480,23 @@ class TiffBandWriter:
         self._f = None
 
 
+def _native_jpeg_encoder():
+    """does the library encode JPEG on this host (libjpeg.so.8 present, not switched off)?"""
+    if os.environ.get("VFSMS_NATIVE_JPEG", "1") == "0":
+        return False
+    try:
+        from . import _lib
+        return _lib.jpeg_encode(np.zeros((8, 8), np.uint8)) is not None
+    except Exception:
+        return False
+
+
 def band_writer_for(path):
-    """the streaming encoder for an output file name, or None when its format has none here (JPEG: written whole through Pillow)"""
+    """the streaming encoder for an output file name, or None when its format has none here (JPEG without libjpeg.so.8 on the host: written
+    whole through Pillow)"""
     ext = os.path.splitext(path)[1].lower()
+    if ext in (".jpg", ".jpeg"):
+        return JpegBandWriter(path) if _native_jpeg_encoder() else None
     return PngBandWriter(path) if ext == ".png" else TiffBandWriter(path) if ext in (".tif", ".tiff") else NpyBandWriter(path) if ext == ".npy" else None
 
 

@@ -141,6 +141,18 @@ int vfsms_tile_fill_jpeg(vfsms_ctx *ctx, int64_t gray, int64_t color, const uint
  * want_planes != 0 and the file has three components, else 1 (the grayscale decode).  VFSMS_ERR_CAPACITY (with *h, *w, *comp set) when
  * `cap` bytes are too few -- call with out == NULL to ask for the size.                                                                 */
 int vfsms_jpeg_decode(const uint8_t *jpeg, size_t nbytes, int want_planes, uint8_t *out, size_t cap, int *h, int *w, int *comp);
+/* The way out, for the mosaic: replaces cv2.imwrite(path, result) for .jpg results (Stitcher.py:149, 175-179; Main.py:21-51 writes every
+ * result as jpg).  vfsms_jpeg_encode: n_rows x cols pixels of 1 or 3 channels (R G B, or B G R -- the canvas order -- with bgr != 0), rows
+ * `stride_bytes` apart -> a complete baseline JPEG stream with cv2.imwrite's settings (libjpeg defaults, `quality`: 95).  No context, no GPU,
+ * any thread.  *nbytes = the stream's size, also on VFSMS_ERR_CAPACITY.  A horizontal STRIPE of an image encodes independently of the
+ * others when its height is a multiple of the MCU height (16 rows for colour, 8 for gray), so a host encodes the stripes of a mosaic on all
+ * its cores -- while the bands are still leaving the device -- and vfsms_jpeg_join makes ONE file of them: the headers of stripe 0 with the
+ * full height, a DRI segment (restart interval = the MCUs of a stripe, <= 65535) and the stripes' entropy-coded segments separated by RSTn
+ * markers.  Same DCT coefficients, hence the same decoded pixels, as the one-thread encode of the whole image.  out == NULL: size only.   */
+int vfsms_jpeg_encode(const uint8_t *rows, int n_rows, int cols, int channels, int stride_bytes, int bgr, int quality,
+                      uint8_t *out, size_t cap, size_t *nbytes);
+int vfsms_jpeg_join(const uint8_t *const *streams, const size_t *sizes, int n_stripes, int stripe_rows, int total_rows,
+                    uint8_t *out, size_t cap, size_t *nbytes);
 /* pinned host staging memory for tiles (decoders write into it; uploads from it are asynchronous DMA)                          */
 int vfsms_host_alloc(vfsms_ctx *ctx, size_t bytes, void **ptr);
 int vfsms_host_free(vfsms_ctx *ctx, void *ptr);

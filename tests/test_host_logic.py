@@ -662,7 +662,96 @@ def test_png_and_tiff_band_writers_round_trip(tmp_path):
                 back = np.asarray(Image.open(path))
                 want = img[:, :, ::-1] if img.ndim == 3 else img
                 assert back.shape == want.shape and np.array_equal(back, want), (shape, ext, band)
-    assert isa.band_writer_for("x.jpg") is None
+
+
+def _restart_layout(data):
+    """(restart interval of the DRI segment or 0, number of RSTn markers in the entropy-coded data) of a baseline JPEG"""
+    dri, p = 0, 2
+    while data[p + 1] != 0xDA:
+        seg = int.from_bytes(data[p + 2:p + 4], "big")
+        if data[p + 1] == 0xDD:
+            dri = int.from_bytes(data[p + 4:p + 6], "big")
+        p += 2 + seg
+    body = bytes(data[p:])
+    return dri, sum(body.count(bytes([0xFF, 0xD0 + k])) for k in range(8))
+
+
+def test_jpeg_band_writer_writes_what_cv2_imwrite_writes(tmp_path):
+    """The reference writes every mosaic as .jpg (Main.py:21-51 -> cv2.imwrite at Stitcher.py:149, 175-179: libjpeg defaults, quality 95).
+    vfsms_jpeg_encode of a whole image is that file BYTE FOR BYTE (Pillow's quality-95 save is the stand-in for cv2.imwrite: same libjpeg
+    settings); the band writer's file -- stripes encoded on a thread pool, joined as restart intervals -- decodes to exactly the same pixels,
+    for colour and gray, band heights that do not divide anything, stripes of 16 to 256 rows, and an image smaller than a stripe; the
+    restart layout is what the header promises."""
+    import io
+    from PIL import Image, ImageFilter
+    from imagestitch_amd import _lib
+    if _lib.jpeg_encode(np.zeros((8, 8), np.uint8)) is None:
+        pytest.skip("no libjpeg.so.8 on this host: .jpg results are written through Pillow")
+    rng = np.random.default_rng(8)
+    for shape in ((700, 531, 3), (333, 1001), (40, 57, 3), (512, 256, 3)):
+        small = rng.integers(0, 256, (shape[0] // 6 + 2, shape[1] // 6 + 2) + shape[2:], dtype=np.uint8)
+        img = np.asarray(Image.fromarray(small).resize((shape[1], shape[0]), Image.BICUBIC).filter(ImageFilter.GaussianBlur(0.7)))
+        assert img.shape == shape
+        bgr = np.ascontiguousarray(img[:, :, ::-1]) if img.ndim == 3 else img
+        ref = io.BytesIO(); Image.fromarray(img).save(ref, "JPEG", quality=95)
+        want = np.asarray(Image.open(io.BytesIO(ref.getvalue())))
+        assert _lib.jpeg_encode(bgr, bgr=True, quality=95).tobytes() == ref.getvalue()
+        if img.ndim == 3:
+            assert _lib.jpeg_encode(img, bgr=False, quality=95).tobytes() == ref.getvalue()
+        for band, stripe in ((4096, None), (100, 64), (37, 16), (shape[0], 256)):
+            path = os.path.join(str(tmp_path), "j", "m%d_%d_%d.jpg" % (shape[0], band, stripe or 0))
+            sink = isa.JpegBandWriter(path, stripe_rows=stripe, threads=4)
+            for r0 in range(0, shape[0], band):
+                sink(r0, bgr[r0:r0 + band], shape)
+            data = open(path, "rb").read()
+            back = np.asarray(Image.open(io.BytesIO(data)))
+            assert back.shape == want.shape and np.array_equal(back, want), (shape, band, stripe)
+            mcu = 16 if img.ndim == 3 else 8
+            S = max(1, (stripe or 256) // mcu) * mcu
+            n_stripes = -(-shape[0] // S)
+            dri, rst = _restart_layout(data)
+            assert (dri, rst) == ((0, 0) if n_stripes == 1 else (-(-shape[1] // mcu) * (S // mcu), n_stripes - 1)), (shape, band, stripe, dri, rst)
+            if n_stripes == 1:
+                assert data == ref.getvalue()
+            got = _lib.jpeg_decode(data, True)                             # and through the library's own decoder: the planes of the one-thread file
+            assert got is not None and np.array_equal(got, _lib.jpeg_decode(ref.getvalue(), True))
+    assert isinstance(isa.band_writer_for("x.jpg"), isa.JpegBandWriter)
+    # a stripe that is not a whole number of MCU rows cannot be a restart interval; neither can streams of different images
+    a, b = _lib.jpeg_encode(bgr[:24]), _lib.jpeg_encode(bgr[24:48])
+    with pytest.raises(Exception):
+        _lib.jpeg_join([a, b], 24, 48)
+    with pytest.raises(Exception):
+        _lib.jpeg_join([_lib.jpeg_encode(bgr[:32]), _lib.jpeg_encode(bgr[32:64, :100])], 32, 64)
+    with pytest.raises(Exception):
+        _lib.jpeg_join([_lib.jpeg_encode(bgr[:32]), _lib.jpeg_encode(bgr[32:64], quality=80)], 32, 64)
+    with pytest.raises(ValueError):
+        isa.JpegBandWriter(os.path.join(str(tmp_path), "big.jpg"))(0, np.zeros((4, 8), np.uint8), (70000, 8))
+
+
+def test_imwrite_jpg_goes_through_the_stripe_encoder(tmp_path):
+    """_imwrite (cv2.imwrite's place) for .jpg: the library's encoder on all cores when the host has libjpeg-turbo, Pillow with quality 95
+    under VFSMS_NATIVE_JPEG=0 -- the same decoded pixels either way (B G R in, R G B in the file)."""
+    from PIL import Image
+    from imagestitch_amd import stitcher as ST
+    rng = np.random.default_rng(4)
+    img = np.asarray(Image.fromarray(rng.integers(0, 256, (90, 70, 3), dtype=np.uint8)).resize((420, 540), Image.BICUBIC))
+    old = os.environ.get("VFSMS_NATIVE_JPEG")
+    try:
+        outs = []
+        for env in ("1", "0"):
+            os.environ["VFSMS_NATIVE_JPEG"] = env
+            for arr, tag in ((img, "c"), (np.ascontiguousarray(img[:, :, 1]), "g")):
+                p = os.path.join(str(tmp_path), "w", "%s%s.jpg" % (tag, env))
+                ST._imwrite(p, arr)
+                outs.append(np.asarray(Image.open(p)))
+        assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[1], outs[3])
+        right, wrong = np.abs(outs[0].astype(int) - img[:, :, ::-1]).mean(), np.abs(outs[0].astype(int) - img).mean()
+        assert right < 8 and wrong > 4 * right and outs[1].shape == (540, 420), (right, wrong)       # (4:2:0 at quality 95 on a noisy image)
+    finally:
+        if old is None:
+            os.environ.pop("VFSMS_NATIVE_JPEG", None)
+        else:
+            os.environ["VFSMS_NATIVE_JPEG"] = old
 
 
 def test_streamed_output_names_and_bytes_equal_the_whole_image_write(oracle, tmp_path):
@@ -678,16 +767,16 @@ def test_streamed_output_names_and_bytes_equal_the_whole_image_write(oracle, tmp
     old = (isa.Stitcher.direction, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod)
     try:
         isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod = True, "surf", "notFuse"
-        for breaks in (False, True):
+        for breaks, oext in ((False, "png"), (True, "png"), (False, "jpg"), (True, "jpg")):      # (.jpg: Main.py's own output format)
             outs = {}
             for stream in (False, True):
                 eng = IngestOracleEngine(oracle, scripted=(lambda A, B, job: [1, 96, 0, 9, 10, 10, 9, 0]) if not breaks else _break_at_second_pair())
                 s = isa.Stitcher(); s._engine = eng; s.isPrintLog = False; s.direction = 2; isa.Stitcher.direction = 2
                 s.streamOutput = stream; s.mosaicBandRows = 50
-                out = tmp_path / ("o%d%d" % (breaks, stream))
-                s.imageSetStitchWithMutiple(str(proj), str(out) + os.sep, 1, s.calculateOffsetForFeatureSearchIncre, fileExtension="png", outputfileExtension="png")
+                out = tmp_path / ("o%d%d%s" % (breaks, stream, oext))
+                s.imageSetStitchWithMutiple(str(proj), str(out) + os.sep, 1, s.calculateOffsetForFeatureSearchIncre, fileExtension="png", outputfileExtension=oext)
                 names = sorted(n for n in os.listdir(str(out)) if not n.startswith("."))
-                outs[stream] = {n: np.asarray(Image.open(str(out / n))) for n in names if n.endswith(".png")}
+                outs[stream] = {n: np.asarray(Image.open(str(out / n))) for n in names if n.endswith("." + oext)}
                 assert not [n for n in os.listdir(str(out)) if n.startswith(".stitching_part")] and not eng.live
             assert sorted(outs[False]) == sorted(outs[True]) and len(outs[True]) == (2 if breaks else 1), (breaks, sorted(outs[True]))
             for n in outs[False]:
