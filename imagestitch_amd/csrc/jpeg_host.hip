@@ -99,7 +99,7 @@ struct JpegApi {
 };
 struct Guard { jmp_buf jb; int code; int parm0, parm1; char text[200]; };
 
-void on_error(void *cinfo)
+void on_error(void *cinfo)                 // (compressor or decompressor: err and client_data are jpeg_common_fields of both)
 {
     jdec_head_abi *c = (jdec_head_abi *)cinfo;
     Guard *g = (Guard *)c->client_data;
@@ -128,7 +128,7 @@ const JpegApi &api()
         // the struct size, from the library: a create call with a size no struct has fails with JERR_BAD_STRUCT_SIZE(library's, caller's)
         alignas(16) unsigned char cinfo[JPEG_CINFO_BYTES]; memset(cinfo, 0, sizeof(cinfo));
         jerr_abi err; memset(&err, 0, sizeof(err));
-        Guard g; memset(&g.code, 0, sizeof(g) - sizeof(g.jb));
+        Guard g; memset(&g.code, 0, sizeof(g) - offsetof(Guard, code));
         jdec_head_abi *c = (jdec_head_abi *)cinfo;
         c->err = a.std_error(&err);
         err.error_exit = on_error; err.output_message = on_message;
@@ -146,7 +146,7 @@ const JpegApi &api()
         a.c_finish = (void (*)(void *))dlsym(h, "jpeg_finish_compress");
         a.c_destroy = (void (*)(void *))dlsym(h, "jpeg_destroy_compress");
         if (!a.c_create || !a.c_mem_dest || !a.c_defaults || !a.c_quality || !a.c_start || !a.c_write || !a.c_finish || !a.c_destroy) return a;
-        memset(cinfo, 0, sizeof(cinfo)); memset(&err, 0, sizeof(err)); memset(&g.code, 0, sizeof(g) - sizeof(g.jb));
+        memset(cinfo, 0, sizeof(cinfo)); memset(&err, 0, sizeof(err)); memset(&g.code, 0, sizeof(g) - offsetof(Guard, code));
         c->err = a.std_error(&err);
         err.error_exit = on_error; err.output_message = on_message;
         c->client_data = &g;
@@ -192,7 +192,7 @@ int jpeg_decode_host(const unsigned char *jpeg, size_t nbytes, int want_planes, 
     if (!jpeg || !sof_size(jpeg, nbytes, &sh, &sw, &snc) || (snc != 1 && snc != 3)) { vfsms_set_error("jpeg: not a 1- or 3-component JPEG"); return VFSMS_ERR_UNSUPPORTED; }
     alignas(16) unsigned char cinfo[JPEG_CINFO_BYTES]; memset(cinfo, 0, sizeof(cinfo));
     jerr_abi err; memset(&err, 0, sizeof(err));
-    Guard g; memset(&g.code, 0, sizeof(g) - sizeof(g.jb));
+    Guard g; memset(&g.code, 0, sizeof(g) - offsetof(Guard, code));
     jdec_head_abi *c = (jdec_head_abi *)cinfo;
     volatile bool created = false;
     if (setjmp(g.jb)) {
@@ -289,7 +289,7 @@ int encode_impl(const uint8_t *rows, int n_rows, int cols, int channels, int str
     const JpegApi &A = api();
     alignas(16) unsigned char cinfo[JPEG_CINFO_BYTES]; memset(cinfo, 0, sizeof(cinfo));
     jerr_abi err; memset(&err, 0, sizeof(err));
-    Guard g; memset(&g.code, 0, sizeof(g) - sizeof(g.jb));
+    Guard g; memset(&g.code, 0, sizeof(g) - offsetof(Guard, code));
     jcomp_head_abi *c = (jcomp_head_abi *)cinfo;
     unsigned char *volatile swap = nullptr;
     volatile bool created = false;

@@ -9,6 +9,7 @@ in HBM; see imagestitch_amd/csrc.
 """
 import copy
 import os
+import threading
 import time
 
 import numpy as np
@@ -690,13 +691,15 @@ class Stitcher(Utility.Method):
                 block_alloc.__enter__()
 
                 istats = self._ingestStats = dict(tiles=0, decode_s=0.0, fill_s=0.0, threads=nthreads)   # summed over the decoder threads
+                istats_mu = threading.Lock()
 
                 def ingest(k):
                     hc = chandles[k] if color else 0
                     try:
                         t0 = time.perf_counter()
                         if _fill_from_jpeg(eng, fileList[k], handles[k], hc):
-                            istats["tiles"] += 1; istats["native"] = istats.get("native", 0) + 1; istats["decode_s"] += time.perf_counter() - t0
+                            with istats_mu:
+                                istats["tiles"] += 1; istats["native"] = istats.get("native", 0) + 1; istats["decode_s"] += time.perf_counter() - t0
                             return
                         owner, shape, parts = _decode_once(fileList[k], color)
                         t1 = time.perf_counter()
@@ -712,7 +715,8 @@ class Stitcher(Utility.Method):
                             if hc:
                                 eng.tile_fill(hc, parts[2])
                         del owner
-                        istats["tiles"] += 1; istats["decode_s"] += t1 - t0; istats["fill_s"] += time.perf_counter() - t1
+                        with istats_mu:
+                            istats["tiles"] += 1; istats["decode_s"] += t1 - t0; istats["fill_s"] += time.perf_counter() - t1
                     except BaseException:
                         for h in (handles[k], hc):            # the batch waiting for this tile fails instead of hanging
                             if h:
