@@ -690,10 +690,25 @@ class Engine:
         self._check(self.lib.vfsms_canvas_download_rows(self.ctx, C.c_int64(handle), int(row0), int(nrows), _ptr(out)))
         return out
 
-    def canvas_download_bands(self, handle, rows, cols, ch, band_rows=4096):
-        """Generator of (row0, band) over the whole mosaic, `band_rows` rows at a time (streamed write-out of large mosaics)."""
-        for r0 in range(0, rows, band_rows):
-            yield r0, self.canvas_download_rows(handle, r0, min(band_rows, rows - r0), cols, ch)
+    BAND_RING = 3
+
+    def canvas_download_bands(self, handle, rows, cols, ch, band_rows=4096, transient=False):
+        """Generator of (row0, band) over the whole mosaic, `band_rows` rows at a time (streamed write-out of large mosaics).  With
+        `transient` the bands are views of a ring of BAND_RING pinned buffers kept by the engine (the copy is a DMA at link speed, no
+        page faults of a fresh array per band): a band is valid until BAND_RING - 1 further bands have been requested -- for consumers
+        that are done with a band by then (JpegBandWriter declares it: `transient_bands`)."""
+        if not transient:
+            for r0 in range(0, rows, band_rows):
+                yield r0, self.canvas_download_rows(handle, r0, min(band_rows, rows - r0), cols, ch)
+            return
+        need = min(band_rows, rows) * cols * ch
+        ring = self.__dict__.get("_band_ring")
+        if ring is None or ring[0].size < need:
+            ring = self.__dict__["_band_ring"] = [self.pinned_empty((need,)) for _ in range(self.BAND_RING)]      # (an outgrown ring is freed with the engine)
+        for k, r0 in enumerate(range(0, rows, band_rows)):
+            n = min(band_rows, rows - r0)
+            out = ring[k % self.BAND_RING][:n * cols * ch].reshape((n, cols, ch) if ch > 1 else (n, cols))
+            yield r0, self.canvas_download_rows(handle, r0, n, cols, ch, out=out)
 
 
 _default_engine = None

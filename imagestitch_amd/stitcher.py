@@ -272,6 +272,8 @@ class NpyBandWriter:
     """A `Stitcher.mosaicSink`: writes the bands of a mosaic into one .npy file through a memory map, so a mosaic larger than host
     memory can be assembled (set `stitcher.mosaicSink = NpyBandWriter(path)`; getStitchByOffset then returns None)."""
 
+    transient_bands = True      # done with a band when the call returns
+
     def __init__(self, path):
         self.path, self._mm = path, None
 
@@ -291,6 +293,8 @@ class PngBandWriter:
     """A `Stitcher.mosaicSink` that encodes the bands into ONE PNG as they leave the device (cv2.imwrite's job at Stitcher.py:174-179,
     without the whole mosaic in host memory): IHDR, then every band deflated into IDAT chunks by a streaming zlib compressor (filter 0
     on every row), IEND.  Bands are B G R like the canvas; the file is R G B."""
+
+    transient_bands = True      # done with a band when the call returns
 
     def __init__(self, path, level=1):
         self.path, self.level, self._f, self._z = path, level, None, None
@@ -362,8 +366,10 @@ class JpegBandWriter:
         self.stripe_rows = stripe_rows
         self._reset()
 
+    transient_bands = True      # done with a band's memory once the band after the next one has been handed over (Engine.canvas_download_bands)
+
     def _reset(self):
-        self._futures, self._carry, self._rows_in, self._stripe, self._shape = [], None, 0, None, None
+        self._futures, self._carry, self._rows_in, self._stripe, self._shape, self._band_end = [], None, 0, None, None, []
 
     def _encode(self, rows):
         from . import _lib
@@ -404,6 +410,10 @@ class JpegBandWriter:
                 self._submit(band[r:min(r + S, full)])
             if full < n:
                 self._carry = band[full:].copy()
+            self._band_end.append(len(self._futures))
+            if len(self._band_end) >= 2:                       # the band before this one may be overwritten after the next call: its stripes are done
+                for f in self._futures[(self._band_end[-3] if len(self._band_end) >= 3 else 0):self._band_end[-2]]:
+                    f.result()
             if not last:
                 return
             from . import _lib
@@ -430,6 +440,8 @@ class JpegBandWriter:
 class TiffBandWriter:
     """A `Stitcher.mosaicSink` for uncompressed baseline TIFF (BigTIFF beyond 4 GB): one strip per band, the directory written behind the
     last band.  R G B (or gray) 8-bit samples."""
+
+    transient_bands = True      # done with a band when the call returns
 
     def __init__(self, path):
         self.path, self._f, self._strips = path, None, []
@@ -604,6 +616,7 @@ class Stitcher(Utility.Method):
             state["w"](row0, band, full_shape)
             if row0 + band.shape[0] >= full_shape[0]:
                 state["w"] = None
+        sink.transient_bands = bool(getattr(band_writer_for(probe), "transient_bands", False))
         self.mosaicSink = sink
         return sink
 
@@ -1347,7 +1360,11 @@ class Stitcher(Utility.Method):
                 sink = getattr(self, "mosaicSink", None)
                 if sink is not None and hasattr(eng, "canvas_download_bands"):
                     # streamed write-out: the mosaic leaves the device band by band and is never whole in host memory
-                    for r0, band in eng.canvas_download_bands(canvas, resultRow, resultCol, ch, int(getattr(self, "mosaicBandRows", 4096))):
+                    # (a sink that is done with a band two bands later -- `transient_bands`: JpegBandWriter -- gets views of the engine's
+                    #  pinned band ring instead of a fresh array per band; VFSMS_PINNED_BANDS=1 turns it on)
+                    transient = bool(getattr(sink, "transient_bands", False)) and os.environ.get("VFSMS_PINNED_BANDS", "0") == "1"
+                    kw = {"transient": True} if transient else {}
+                    for r0, band in eng.canvas_download_bands(canvas, resultRow, resultCol, ch, int(getattr(self, "mosaicBandRows", 4096)), **kw):
                         sink(r0, band, (resultRow, resultCol, ch) if ch > 1 else (resultRow, resultCol))
                     return None
                 return eng.canvas_download(canvas, resultRow, resultCol, ch)

@@ -222,10 +222,22 @@ class IngestOracleEngine(OracleEngine):
     def canvas_fuse_tile_resident(self, h, tile_handle, y0, x0, roi, dx, dy, want_info=False, method=0):
         self.canvas_fuse_tile(h, self._tile(tile_handle), y0, x0, roi, dx, dy, method=method)
 
-    def canvas_download_bands(self, h, rows, cols, ch, band_rows=4096):
+    def canvas_download_bands(self, h, rows, cols, ch, band_rows=4096, transient=False):
+        """`transient`: like the engine's pinned band ring -- three buffers, a band is OVERWRITTEN (here: scribbled over first) when the
+        third band after it is requested"""
         img = self.canvas_download(h, rows, cols, ch)
-        for r0 in range(0, rows, band_rows):
-            yield r0, img[r0:r0 + band_rows]
+        ring = [np.empty((min(band_rows, rows),) + img.shape[1:], np.uint8) for _ in range(3)] if transient else None
+        self.transient_bands_served = getattr(self, "transient_bands_served", 0)
+        for k, r0 in enumerate(range(0, rows, band_rows)):
+            if not transient:
+                yield r0, img[r0:r0 + band_rows]
+                continue
+            buf = ring[k % 3]
+            buf[:] = 0x5A
+            n = min(band_rows, rows - r0)
+            buf[:n] = img[r0:r0 + n]
+            self.transient_bands_served += 1
+            yield r0, buf[:n]
 
 
 class NativeJpegEngine(IngestOracleEngine):

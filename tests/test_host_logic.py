@@ -716,6 +716,27 @@ def test_jpeg_band_writer_writes_what_cv2_imwrite_writes(tmp_path):
             got = _lib.jpeg_decode(data, True)                             # and through the library's own decoder: the planes of the one-thread file
             assert got is not None and np.array_equal(got, _lib.jpeg_decode(ref.getvalue(), True))
     assert isinstance(isa.band_writer_for("x.jpg"), isa.JpegBandWriter)
+    # bands that live in a ring of three reused buffers (Engine.canvas_download_bands(transient=True): pinned memory): the writer is done
+    # with a band before the band after the next one overwrites it, also with slow encoders
+    import time
+    shape = (1500, 300, 3)
+    img = np.asarray(Image.fromarray(rng.integers(0, 256, (100, 20, 3), dtype=np.uint8)).resize((300, 1500), Image.BICUBIC))
+    bgr = np.ascontiguousarray(img[:, :, ::-1])
+    ref = io.BytesIO(); Image.fromarray(img).save(ref, "JPEG", quality=95)
+    for band in (128, 100):
+        path = os.path.join(str(tmp_path), "ring_%d.jpg" % band)
+        sink = isa.JpegBandWriter(path, stripe_rows=32, threads=2)
+        assert sink.transient_bands
+        real = sink._encode
+        sink._encode = lambda rows, real=real: (time.sleep(0.002), real(rows))[1]
+        ring = [np.empty((band,) + shape[1:], np.uint8) for _ in range(3)]
+        for k, r0 in enumerate(range(0, shape[0], band)):
+            buf = ring[k % 3]
+            buf[:] = 255 - buf                                              # whatever was there is gone now
+            n = min(band, shape[0] - r0)
+            buf[:n] = bgr[r0:r0 + n]
+            sink(r0, buf[:n], shape)
+        assert np.array_equal(np.asarray(Image.open(path)), np.asarray(Image.open(io.BytesIO(ref.getvalue())))), band
     # a stripe that is not a whole number of MCU rows cannot be a restart interval; neither can streams of different images
     a, b = _lib.jpeg_encode(bgr[:24]), _lib.jpeg_encode(bgr[24:48])
     with pytest.raises(Exception):
@@ -773,15 +794,18 @@ def test_streamed_output_names_and_bytes_equal_the_whole_image_write(oracle, tmp
                 eng = IngestOracleEngine(oracle, scripted=(lambda A, B, job: [1, 96, 0, 9, 10, 10, 9, 0]) if not breaks else _break_at_second_pair())
                 s = isa.Stitcher(); s._engine = eng; s.isPrintLog = False; s.direction = 2; isa.Stitcher.direction = 2
                 s.streamOutput = stream; s.mosaicBandRows = 50
+                os.environ["VFSMS_PINNED_BANDS"] = "1" if (stream and breaks) else "0"      # the engine's ring of reused band buffers
                 out = tmp_path / ("o%d%d%s" % (breaks, stream, oext))
                 s.imageSetStitchWithMutiple(str(proj), str(out) + os.sep, 1, s.calculateOffsetForFeatureSearchIncre, fileExtension="png", outputfileExtension=oext)
                 names = sorted(n for n in os.listdir(str(out)) if not n.startswith("."))
                 outs[stream] = {n: np.asarray(Image.open(str(out / n))) for n in names if n.endswith("." + oext)}
                 assert not [n for n in os.listdir(str(out)) if n.startswith(".stitching_part")] and not eng.live
+                assert (getattr(eng, "transient_bands_served", 0) > 0) == (stream and breaks)
             assert sorted(outs[False]) == sorted(outs[True]) and len(outs[True]) == (2 if breaks else 1), (breaks, sorted(outs[True]))
             for n in outs[False]:
                 assert np.array_equal(outs[False][n], outs[True][n]), n
     finally:
+        os.environ.pop("VFSMS_PINNED_BANDS", None)
         isa.Stitcher.direction, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod = old
 
 

@@ -28,15 +28,38 @@ def main(engine=None):
         s = isa.Stitcher(); s.isPrintLog = False
         if engine is not None:                                 # (dry runs of this script on a machine without a GPU: tests/fakes.py)
             s._engine = engine
+        # where the time goes (main-thread wall clock inside the named calls; the decoder and encoder pools run beside them)
+        from imagestitch_amd import stitcher as ST
+        phase = {}
+
+        def timed(obj, attr, key):
+            fn = getattr(obj, attr)
+
+            def wrapper(*a, **k):
+                t0 = time.perf_counter()
+                try:
+                    return fn(*a, **k)
+                finally:
+                    phase[key] = phase.get(key, 0.0) + time.perf_counter() - t0
+            setattr(obj, attr, wrapper)
+        timed(s, "_registerBatched", "ingest_and_registration")
+        timed(s, "getStitchByOffset", "mosaic_assembly_and_download")
+        timed(ST, "_imwrite", "imwrite")
+        eng = s.engine
+        for attr in ("canvas_download", "canvas_download_rows"):
+            if hasattr(eng, attr):
+                timed(eng, attr, "of_which_download")
         sys.stdout = open(os.devnull, "w")                     # (the reference prints a line per dataset)
         try:
-            for name, env, stream, reps in (("native", "1", False, 4), ("native_streamed", "1", True, 3), ("pillow_codecs", "0", False, 1)):
-                os.environ["VFSMS_NATIVE_JPEG"] = env
+            for name, env, stream, pinned, reps in (("native", "1", False, "0", 4), ("native_streamed", "1", True, "0", 3),
+                                                    ("native_streamed_pinned_bands", "1", True, "1", 3), ("pillow_codecs", "0", False, "0", 1)):
+                os.environ["VFSMS_NATIVE_JPEG"], os.environ["VFSMS_PINNED_BANDS"] = env, pinned
                 s.streamOutput = stream
                 times = []
                 for r in range(reps):
                     isa.Stitcher.direction = 1; s.direction = 1
                     o = os.path.join(d, "out_%s_%d" % (name, r)) + os.sep
+                    phase.clear()
                     t0 = time.perf_counter()
                     s.imageSetStitchWithMutiple(proj, o, 1, s.calculateOffsetForFeatureSearchIncre, startNum=1, fileExtension="jpg", outputfileExtension="jpg")
                     times.append(time.perf_counter() - t0)
@@ -44,7 +67,8 @@ def main(engine=None):
                 with Image.open(res) as im:
                     size = im.size
                 out[name] = {"seconds": [round(t, 3) for t in times], "best_s": round(min(times), 3), "result_px": [size[1], size[0]],
-                             "result_MB": round(os.path.getsize(res) / 1e6, 1), "pairs_per_s_whole_job": round(g.n_pairs / min(times), 1)}
+                             "result_MB": round(os.path.getsize(res) / 1e6, 1), "pairs_per_s_whole_job": round(g.n_pairs / min(times), 1),
+                             "last_run_phases_s": {k: round(v, 3) for k, v in phase.items()}}
         finally:
             sys.stdout = sys.__stdout__
     print(json.dumps(out))
