@@ -403,9 +403,18 @@ class GridRegistrar:
     def _bounds(self, P, world, weights, hint, direction):
         """the work split of the sharded form: by the caller's weights, else -- with a hint -- by the attempts the hint predicts (a hinted
         start costs nothing extra), else by pair count"""
+        # (the same split is asked for twice per registered path -- payload and assembly -- and path after path: the bisection is 60 greedy
+        #  passes over the pairs, half a millisecond of interpreter time that a rank's 6-ms step does not have)
+        key = (P, world, None if weights is None else tuple(weights), None if hint is None else tuple(int(v) for v in hint), int(direction), self.directIncre)
+        cached = self.__dict__.get("_bounds_cache")
+        if cached is not None and cached[0] == key:
+            return cached[1]
         if weights is None and hint is not None and len(hint) == P and world > 1:
-            return self.chunk_bounds(P, world, self.path_weights(hint, direction), blind_cost=0.0)
-        return self.chunk_bounds(P, world, weights)
+            out = self.chunk_bounds(P, world, self.path_weights(hint, direction), blind_cost=0.0)
+        else:
+            out = self.chunk_bounds(P, world, weights)
+        self._bounds_cache = (key, out)
+        return out
 
     def shard_payload(self, handles, shapes, direction, rank, world, weights=None, hint=None, blind=False):
         """This rank's offset table: int32[4 * per * 6 + 4] = results for each possible incoming direction
