@@ -553,6 +553,8 @@ def main():
     ap.add_argument("--from-files", action="store_true", help="N = 1: JPEG tiles on disk through Stitcher's ingest pipeline (decode inclusive)")
     ap.add_argument("--decode-threads", type=int, default=0, help="decoder threads of --from-files (0 = the Stitcher's default: one per host core, at most 32; 16 with VFSMS_NATIVE_JPEG=0)")
     ap.add_argument("--color", action="store_true", help="--from-files with colour JPEGs and isColorMode = True (Main.py:14's default)")
+    ap.add_argument("--force-dist", action="store_true", help="N = 1: initialise the process group (nccl = RCCL) and run the step's all_gather through it "
+                    "anyway -- the line then carries a non-null `collective` (RCCL start-up and the device-tensor all_gather exercised on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -565,13 +567,17 @@ def main():
     backend = os.environ.get("VFSMS_DIST_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        if world == 1:                                       # --force-dist without a launcher: a group of one, rendezvous on the loopback
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+        kw = dict(rank=rank, world_size=world)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
     coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     assert world == args.gpus, "launch with --nproc-per-node == --gpus"
     if dist is not None:
@@ -630,7 +636,7 @@ def main():
         # PROFILING AID (tools/profile_round.sh, PMC passes of one step): start with the scan pattern already learned, so that every launch
         # of the short run is a steady-state launch.  Never set for a measured line.
         reg.path_memory = [int(d) for d in grid.true_directions()]
-    gather = make_all_gather(coll_device) if world > 1 else single_process_all_gather
+    gather = make_all_gather(coll_device) if dist is not None else single_process_all_gather
 
     def step(hs=handles):
         return reg.register_sharded(hs, shapes, 1, rank, world, gather)

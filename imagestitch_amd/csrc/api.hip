@@ -352,7 +352,11 @@ int tile_is_filled(vfsms_ctx *ctx, int64_t handle)
     // an asynchronous upload that has not landed yet (vfsms_tile_upload_async: ninety tiles queued on the copy stream in front of a path): the
     // speculative part of a batch takes what is there, like with tiles a decoder still owes -- the first batch does not wait for a whole
     // window of copies
-    if (it->second.pending && it->second.ready && hipEventQuery(it->second.ready) != hipSuccess) return 0;
+    if (it->second.pending && it->second.ready) {
+        const hipError_t e = hipEventQuery(it->second.ready);
+        if (e == hipErrorNotReady) return 0;
+        if (e != hipSuccess) { (void)hipGetLastError(); return 0; }      // (not left behind as the "last error" of an unrelated launch check)
+    }
     return 1;
 }
 extern "C" int vfsms_tile_upload(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int stride, int64_t *handle)
@@ -384,7 +388,15 @@ static int stage_pinned_get(vfsms_ctx *ctx, size_t need, StageBuf *out)
             if (ctx->pin_pool[k].bytes >= need) { *out = ctx->pin_pool[k]; ctx->pin_pool.erase(ctx->pin_pool.begin() + k); return VFSMS_OK; }
     }
     out->ptr = nullptr; out->bytes = need;
-    HIP_TRY(hipHostMalloc((void **)&out->ptr, need, hipHostMallocDefault));
+    const hipError_t e = hipHostMalloc((void **)&out->ptr, need, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        // the caller falls back to the pageable hand-over: the runtime's sticky "last error" must not outlive this call, or the launch
+        // check of that very fallback (hipGetLastError behind k_ingest_split) would report THIS failure and give the tile up
+        (void)hipGetLastError();
+        out->ptr = nullptr;
+        vfsms_set_error("%s:%d hipHostMalloc(%zu) -> %s", __FILE__, __LINE__, need, hipGetErrorString(e));
+        return VFSMS_ERR_HIP;
+    }
     return VFSMS_OK;
 }
 static void stage_pinned_put(vfsms_ctx *ctx, StageBuf b)
@@ -546,7 +558,7 @@ extern "C" int vfsms_tile_fill_pair(vfsms_ctx *ctx, int64_t gray, int64_t color,
     return rc;
 }
 
-// A JPEG file's bytes -> the reserved gray tile and / or the reserved B G R tile, ONE decode (csrc/jpeg_host.hip: the system's libjpeg-turbo,
+// A JPEG file's bytes -> the reserved gray tile and / or the reserved B G R tile, ONE decode (csrc/jpeg_host.cpp: the system's libjpeg-turbo,
 // straight into a pinned staging buffer that is reused from call to call; Y only when no colour tile is asked for, the Y Cb Cr planes
 // otherwise, colour conversion on the device).  Any thread; blocks until the tiles are complete.  When the decode cannot be done here
 // (VFSMS_ERR_UNSUPPORTED: no libjpeg.so.8 on the host, not a 1- / 3-component JPEG; VFSMS_ERR_BAD_ARG: a damaged file, or a file whose size
@@ -1172,6 +1184,10 @@ extern "C" int vfsms_features_free(vfsms_ctx *ctx, int64_t feat);
 extern "C" int vfsms_features_surf_batch(vfsms_ctx *ctx, const int64_t *tiles, int n, const vfsms_surf_params *params,
                                          int enhance_mode, double clip_limit, int tile_grid, int64_t *feats, int *counts)
 {
+    // the output array is cleared BEFORE anything can fail: the clean-up below frees every live handle it finds in it, and a caller's array
+    // may still hold handles of an earlier call (they are the caller's; an early error -- bad arguments, unsupported parameters -- must not
+    // release them)
+    if (feats && n > 0) for (int k = 0; k < n; k++) feats[k] = 0;
     const int rc = features_surf_batch_impl(ctx, tiles, n, params, enhance_mode, clip_limit, tile_grid, feats, counts);
     if (rc != VFSMS_OK && ctx && feats && n > 0) {
         // an error in chunk 2 or later (e.g. VFSMS_ERR_CAPACITY): the sets of the earlier chunks never reach the caller -- release them

@@ -1,4 +1,4 @@
-// jpeg_host.hip -- host-side JPEG decode straight into pinned staging, for the ingest pipeline (scope row f-1: "host libjpeg-turbo + pinned
+// jpeg_host.cpp -- host-side JPEG decode straight into pinned staging, for the ingest pipeline (scope row f-1: "host libjpeg-turbo + pinned
 // upload").  No kernels here.
 //
 // The decoder pool of the Python host (Pillow) stops scaling at ~16 threads on the 256-thread host of the MI355X box: every decode maps

@@ -60,464 +60,10 @@ class ResidentFeatures:
             self.handle = None
 
 
-def _imread(path, color):
-    """cv2.imdecode(np.fromfile(path), IMREAD_COLOR | IMREAD_GRAYSCALE) stand-in (Stitcher.py:68-69,382-384).
-    Grayscale asks libjpeg for the luma plane directly like OpenCV does; colour is BGR."""
-    from PIL import Image
-    im = Image.open(path)
-    if not color:
-        im.draft("L", im.size)
-        return np.asarray(im.convert("L"))
-    return np.ascontiguousarray(np.asarray(im.convert("RGB"))[:, :, ::-1])
-
-
-def _imread_gray_pointer(path):
-    """_imread(path, False) without the copy that holds the GIL: (owner, address, (rows, cols)) of the decoded luma plane.  Pillow decodes
-    with the GIL released; its Arrow export (Pillow >= 11.2 with pyarrow) hands out the pixel block itself, so a pool of decoder threads
-    scales until the cores run out instead of serialising on np.asarray's 4 MB copy (measured on the 256-thread host of the MI355X box:
-    1.9 k tiles/s against 1.1 k).  Falls back to the numpy array."""
-    from PIL import Image
-    im = Image.open(path)
-    im.draft("L", im.size)
-    im.decodermaxblock = max(im.decodermaxblock, 1 << 24)    # the whole file in one read + decode call: fewer trips through the interpreter lock per tile
-    im.load()
-    if im.mode == "L" and hasattr(im, "__arrow_c_array__"):
-        try:
-            import pyarrow as pa
-            arr = pa.array(im)
-            buf = arr.buffers()[1]
-            if buf is not None and buf.size == im.size[0] * im.size[1]:
-                return (arr, im), buf.address, (im.size[1], im.size[0])
-        except Exception:                                    # no pyarrow / not exportable: the copying path below
-            pass
-    a = np.ascontiguousarray(np.asarray(im.convert("L")))
-    return a, a.ctypes.data, a.shape
-
-
-class _PillowBlocks:
-    """Pillow keeps 3-band images in 4-byte pixels: a 2048 x 2048 tile is 16.7 MB, more than one 16 MB storage block, and only an image in ONE
-    block can be handed to the engine without a copy (_decode_once).  While the decoder pool runs, colour images are allocated as single
-    blocks (process-wide switch, restored on exit).  (Measured and rejected: a cache of freed 32 MB blocks for the pool -- Image.core.
-    set_blocks_max -- made the per-tile decode 20 % slower on the 256-thread host, gray and colour alike.)"""
-
-    def __init__(self, color):
-        self.color, self.saved = color, None
-
-    def __enter__(self):
-        if self.color:
-            try:
-                from PIL import Image
-                self.saved = Image.core.get_use_block_allocator()
-                Image.core.set_use_block_allocator(1)
-            except Exception:                                # an older Pillow: the copying hand-over still works
-                self.saved = None
-        return self
-
-    def __exit__(self, *exc):
-        if self.saved is not None:
-            try:
-                from PIL import Image
-                Image.core.set_use_block_allocator(self.saved)
-            except Exception:
-                pass
-        return False
-
-
-_POOLS = {}
-
-
-def _decoder_pool(nthreads):
-    """the decoder threads are kept between calls (a dataset after the other: starting sixteen threads costs a millisecond or two each time)"""
-    from concurrent.futures import ThreadPoolExecutor
-    pool = _POOLS.get(nthreads)
-    if pool is None:
-        pool = _POOLS[nthreads] = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="vfsms-decode")
-    return pool
-
-
-def _decode_once(path, want_color):
-    """ONE decode of a file for both uses the reference makes of it (cv2.imdecode(..., 0) at Stitcher.py:68-69 for registration and, with
-    isColorMode, cv2.imdecode(..., IMREAD_COLOR) at Stitcher.py:382-403 for the mosaic) -> (owner, (rows, cols), parts) with
-    parts = ("src", address, stride_bytes, fmt): what vfsms_tile_fill_pair takes -- fmt 0 a gray plane, 1 / 2 the JPEG's own Y Cb Cr planes
-          interleaved (libjpeg out_color_space = JCS_YCbCr: the colour conversion happens on the GPU, the Y plane IS the grayscale decode),
-          or ("arrays", gray (h, w), bgr (h, w, 3) | None): other formats / colour spaces, both planes from the one loaded image."""
-    from PIL import Image
-    if not want_color:
-        keep, addr, shape = _imread_gray_pointer(path)
-        return keep, shape, ("src", addr, shape[1], 0)
-    im = Image.open(path)
-    im.decodermaxblock = max(im.decodermaxblock, 1 << 24)
-    if im.format == "JPEG" and im.mode == "RGB":
-        try:
-            im.draft("YCbCr", im.size)
-            im.load()
-        except Exception:                                    # e.g. an Adobe RGB JPEG (no YCbCr planes): decode as it is
-            im = Image.open(path)
-    else:
-        im.draft("L", im.size)
-    im.load()
-    shape = (im.size[1], im.size[0])
-    if im.mode in ("L", "YCbCr"):
-        spx = 1 if im.mode == "L" else 4                     # Pillow stores 3-band pixels in 4 bytes
-        if hasattr(im, "__arrow_c_array__"):
-            try:
-                import pyarrow as pa
-                arr = pa.array(im)
-                buf = (arr.buffers()[1] if spx == 1 else arr.values.buffers()[1])
-                if buf is not None and buf.size == shape[0] * shape[1] * spx:
-                    return (arr, im), shape, ("src", buf.address, shape[1] * spx, 0 if spx == 1 else 2)
-            except Exception:                                # no pyarrow / image in several blocks: the copying path below
-                pass
-        a = np.ascontiguousarray(np.asarray(im))
-        return a, shape, ("src", a.ctypes.data, a.strides[0], 0 if spx == 1 else 1)
-    gray = np.ascontiguousarray(np.asarray(im.convert("L")))
-    bgr = np.ascontiguousarray(np.asarray(im.convert("RGB"))[:, :, ::-1])
-    return None, shape, ("arrays", gray, bgr)
-
-
-def _fill_from_jpeg(eng, path, gray_handle, color_handle):
-    """JPEG files are decoded by the library itself when it can (vfsms_tile_fill_jpeg: the system's libjpeg-turbo writes into pinned staging
-    memory that is reused from tile to tile, outside the interpreter lock; one decode, colour conversion on the GPU) -> True, both tiles
-    filled.  False: not a JPEG, an engine without the entry point, a file this decoder does not take (CMYK, RGB-coded, damaged, ...), or
-    VFSMS_NATIVE_JPEG=0 -- the tiles are still reserved and `_decode_once` (Pillow) decodes the file."""
-    fill = getattr(eng, "tile_fill_jpeg", None)
-    if fill is None or os.environ.get("VFSMS_NATIVE_JPEG", "1") == "0":
-        return False
-    with open(path, "rb") as f:
-        data = f.read()
-    if data[:2] != b"\xff\xd8":
-        return False
-    return bool(fill(gray_handle, color_handle, data))
-
-
-def _ycc_to_bgr(ycc):
-    """libjpeg's YCbCr -> RGB (jdcolor.c: 16-bit fixed-point tables), stored B G R: what cv2.imdecode(IMREAD_COLOR) yields from the planes
-    `_decode_once` hands to the GPU.  Host-side twin of csrc/ingest_kernels.hip for the tiles that are not resident (lone tiles)."""
-    y = ycc[..., 0].astype(np.int32); cb = ycc[..., 1].astype(np.int32) - 128; cr = ycc[..., 2].astype(np.int32) - 128
-    r = y + ((91881 * cr + 32768) >> 16)
-    g = y + ((-22554 * cb + 32768 - 46802 * cr) >> 16)
-    b = y + ((116130 * cb + 32768) >> 16)
-    return np.clip(np.stack([b, g, r], -1), 0, 255).astype(np.uint8)
-
-
-def _imshape(path):
-    """(rows, cols) of an image file from its header (no decode).  JPEG and PNG headers are read directly -- the batched path asks for the
-    size of every file before the first decode starts, and ninety `Image.open` calls were 10-20 ms of interpreter time in front of the
-    whole pipeline; anything else (or anything unexpected) goes through Pillow."""
-    try:
-        with open(path, "rb") as f:
-            head = f.read(2048)
-            if head[:2] == b"\xff\xd8" and b"\xff\xc0" not in head and b"\xff\xc2" not in head:
-                head += f.read((1 << 18) - 2048)               # a long EXIF / ICC block in front of the frame header
-        if head[:8] == b"\x89PNG\r\n\x1a\n" and head[12:16] == b"IHDR":
-            return (int.from_bytes(head[20:24], "big"), int.from_bytes(head[16:20], "big"))
-        if head[:2] == b"\xff\xd8":
-            p, n = 2, len(head)
-            while p + 9 < n:
-                if head[p] != 0xFF:
-                    break
-                m = head[p + 1]
-                if m == 0xFF:                                  # fill byte
-                    p += 1
-                    continue
-                if 0xD0 <= m <= 0xD9 or m == 0x01:             # markers without a length
-                    p += 2
-                    continue
-                seg = int.from_bytes(head[p + 2:p + 4], "big")
-                if 0xC0 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC):      # SOFn: precision, height, width
-                    h, w = int.from_bytes(head[p + 5:p + 7], "big"), int.from_bytes(head[p + 7:p + 9], "big")
-                    if h > 0 and w > 0:
-                        return (h, w)
-                    break
-                p += 2 + seg
-    except OSError:
-        pass
-    from PIL import Image
-    with Image.open(path) as im:
-        return (im.size[1], im.size[0])
-
-
-def _imwrite(path, img):
-    if img is None:                                          # streamed to Stitcher.mosaicSink instead
-        return
-    from PIL import Image
-    img = np.asarray(img)
-    d = os.path.dirname(path)
-    if d and not os.path.exists(d):
-        os.makedirs(d)
-    if path.lower().endswith((".jpg", ".jpeg")) and _imwrite_jpeg_stripes(path, img):
-        return
-    if img.ndim == 3:
-        img = img[:, :, ::-1]
-    kw = {"quality": 95} if path.lower().endswith((".jpg", ".jpeg")) else {}     # cv2.imwrite's JPEG default (Pillow's is 75)
-    Image.fromarray(np.ascontiguousarray(img)).save(path, **kw)
-
-
-def _imwrite_jpeg_stripes(path, img):
-    """a .jpg result through the library's encoder (JpegBandWriter: the stripes of the image on all cores) -> True; False = not written
-    (no libjpeg.so.8, VFSMS_NATIVE_JPEG=0, an image libjpeg cannot hold): Pillow writes it."""
-    if os.environ.get("VFSMS_NATIVE_JPEG", "1") == "0" or img.dtype != np.uint8 or img.ndim not in (2, 3) or (img.ndim == 3 and img.shape[2] != 3):
-        return False
-    if max(img.shape[:2]) > 65500 or min(img.shape[:2]) < 1:
-        return False
-    w = JpegBandWriter(path)
-    try:
-        w(0, img, img.shape)
-    except _NoNativeJpeg:
-        return False
-    return True
-
-
-class NpyBandWriter:
-    """A `Stitcher.mosaicSink`: writes the bands of a mosaic into one .npy file through a memory map, so a mosaic larger than host
-    memory can be assembled (set `stitcher.mosaicSink = NpyBandWriter(path)`; getStitchByOffset then returns None)."""
-
-    transient_bands = True      # done with a band when the call returns
-
-    def __init__(self, path):
-        self.path, self._mm = path, None
-
-    def __call__(self, row0, band, full_shape):
-        if self._mm is None:
-            d = os.path.dirname(self.path)
-            if d and not os.path.exists(d):
-                os.makedirs(d)
-            self._mm = np.lib.format.open_memmap(self.path, mode="w+", dtype=np.uint8, shape=tuple(full_shape))
-        self._mm[row0:row0 + band.shape[0]] = band
-        if row0 + band.shape[0] >= full_shape[0]:
-            self._mm.flush()
-            self._mm = None
-
-
-class PngBandWriter:
-    """A `Stitcher.mosaicSink` that encodes the bands into ONE PNG as they leave the device (cv2.imwrite's job at Stitcher.py:174-179,
-    without the whole mosaic in host memory): IHDR, then every band deflated into IDAT chunks by a streaming zlib compressor (filter 0
-    on every row), IEND.  Bands are B G R like the canvas; the file is R G B."""
-
-    transient_bands = True      # done with a band when the call returns
-
-    def __init__(self, path, level=1):
-        self.path, self.level, self._f, self._z = path, level, None, None
-
-    @staticmethod
-    def _chunk(f, tag, data):
-        import struct
-        import zlib
-        f.write(struct.pack(">I", len(data))); f.write(tag); f.write(data)
-        f.write(struct.pack(">I", zlib.crc32(data, zlib.crc32(tag)) & 0xffffffff))
-
-    def __call__(self, row0, band, full_shape):
-        import struct
-        import zlib
-        if self._f is None:
-            d = os.path.dirname(self.path)
-            if d and not os.path.exists(d):
-                os.makedirs(d)
-            self._f = open(self.path, "wb")
-            self._f.write(b"\x89PNG\r\n\x1a\n")
-            ch = full_shape[2] if len(full_shape) == 3 else 1
-            self._chunk(self._f, b"IHDR", struct.pack(">IIBBBBB", full_shape[1], full_shape[0], 8, 2 if ch == 3 else 0, 0, 0, 0))
-            self._z = zlib.compressobj(self.level)
-        band = np.asarray(band)
-        if band.ndim == 3:
-            band = band[:, :, ::-1]
-        rows = np.empty((band.shape[0], 1 + band.shape[1] * (band.shape[2] if band.ndim == 3 else 1)), np.uint8)
-        rows[:, 0] = 0                                           # filter type None
-        rows[:, 1:] = band.reshape(band.shape[0], -1)
-        data = self._z.compress(rows.tobytes())
-        if data:
-            self._chunk(self._f, b"IDAT", data)
-        if row0 + band.shape[0] >= full_shape[0]:
-            data = self._z.flush()
-            if data:
-                self._chunk(self._f, b"IDAT", data)
-            self._chunk(self._f, b"IEND", b"")
-            self._f.close()
-            self._f = self._z = None
-
-
-class _NoNativeJpeg(Exception):
-    pass
-
-
-_ENCODER_POOL = {}
-
-
-def _encoder_pool(nthreads):
-    from concurrent.futures import ThreadPoolExecutor
-    pool = _ENCODER_POOL.get(nthreads)
-    if pool is None:
-        pool = _ENCODER_POOL[nthreads] = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="vfsms-encode")
-    return pool
-
-
-class JpegBandWriter:
-    """A `Stitcher.mosaicSink` for the reference's own output format (Main.py:21-51 writes every result as .jpg; cv2.imwrite at
-    Stitcher.py:149, 175-179): the bands are cut into STRIPES whose height is a multiple of the MCU height, every stripe is encoded on a pool
-    of threads by the library (vfsms_jpeg_encode: the system's libjpeg-turbo with cv2.imwrite's settings, quality 95, no interpreter lock)
-    while the next band is still leaving the device, and the stripes are joined into ONE baseline JPEG as restart intervals
-    (vfsms_jpeg_join).  The DCT coefficients -- hence the decoded pixels -- are those of cv2.imwrite's / Pillow's one-thread encode of the
-    whole mosaic; the file is a few bytes per stripe longer (RSTn markers + one DRI segment).  Only the compressed stripes are kept in
-    host memory.  Bands are B G R like the canvas."""
-
-    def __init__(self, path, quality=95, threads=None, stripe_rows=None):
-        self.path, self.quality = path, int(quality)
-        self.threads = int(threads or min(os.cpu_count() or 4, 32))
-        self.stripe_rows = stripe_rows
-        self._reset()
-
-    transient_bands = True      # done with a band's memory once the band after the next one has been handed over (Engine.canvas_download_bands)
-
-    def _reset(self):
-        self._futures, self._carry, self._rows_in, self._stripe, self._shape, self._band_end = [], None, 0, None, None, []
-
-    def _encode(self, rows):
-        from . import _lib
-        out = _lib.jpeg_encode(rows, bgr=True, quality=self.quality)
-        if out is None:
-            raise _NoNativeJpeg("no libjpeg.so.8 on this host")
-        return out
-
-    def _submit(self, rows):
-        if len(self._futures) >= 4 * self.threads:             # encoders far behind the band stream: do not pile the bands up in host memory
-            self._futures[len(self._futures) - 4 * self.threads].result()
-        self._futures.append(_encoder_pool(self.threads).submit(self._encode, rows))
-
-    def __call__(self, row0, band, full_shape):
-        band = np.asarray(band)
-        if self._shape is None:
-            rows, cols = int(full_shape[0]), int(full_shape[1])
-            ch = int(full_shape[2]) if len(full_shape) == 3 else 1
-            if ch not in (1, 3) or max(rows, cols) > 65500:
-                raise ValueError("JPEG holds 1- or 3-channel images of at most 65500 pixels a side (this one: %s)" % (tuple(full_shape),))
-            mcu = 16 if ch == 3 else 8
-            per_row = (cols + mcu - 1) // mcu
-            k = max(1, min((int(self.stripe_rows) if self.stripe_rows else 256) // mcu, 65535 // per_row))    # a stripe is one restart interval: <= 65535 MCUs
-            self._stripe, self._shape = k * mcu, (rows, cols, ch)
-        rows, cols, ch = self._shape
-        assert row0 == self._rows_in and band.shape[1] == cols, "bands arrive in order"
-        self._rows_in += band.shape[0]
-        last = self._rows_in >= rows
-        try:
-            if self._carry is not None:
-                band = np.concatenate([self._carry, band], 0)
-                self._carry = None
-            if not band.flags.c_contiguous:
-                band = np.ascontiguousarray(band)
-            S, n = self._stripe, band.shape[0]
-            full = n if last else (n // S) * S
-            for r in range(0, full, S):
-                self._submit(band[r:min(r + S, full)])
-            if full < n:
-                self._carry = band[full:].copy()
-            self._band_end.append(len(self._futures))
-            if len(self._band_end) >= 2:                       # the band before this one may be overwritten after the next call: its stripes are done
-                for f in self._futures[(self._band_end[-3] if len(self._band_end) >= 3 else 0):self._band_end[-2]]:
-                    f.result()
-            if not last:
-                return
-            from . import _lib
-            parts = [f.result() for f in self._futures]
-            data = _lib.jpeg_join(parts, S, rows)
-            d = os.path.dirname(self.path)
-            if d and not os.path.exists(d):
-                os.makedirs(d)
-            with open(self.path, "wb") as f:
-                f.write(memoryview(data))
-            self._reset()
-        except BaseException:
-            for f in self._futures:
-                f.cancel()
-            for f in self._futures:
-                try:
-                    f.result()
-                except BaseException:                          # noqa: PERF203
-                    pass
-            self._reset()
-            raise
-
-
-class TiffBandWriter:
-    """A `Stitcher.mosaicSink` for uncompressed baseline TIFF (BigTIFF beyond 4 GB): one strip per band, the directory written behind the
-    last band.  R G B (or gray) 8-bit samples."""
-
-    transient_bands = True      # done with a band when the call returns
-
-    def __init__(self, path):
-        self.path, self._f, self._strips = path, None, []
-
-    def __call__(self, row0, band, full_shape):
-        import struct
-        rows, cols = full_shape[0], full_shape[1]
-        ch = full_shape[2] if len(full_shape) == 3 else 1
-        big = rows * cols * ch + (1 << 20) >= (1 << 32)
-        if self._f is None:
-            d = os.path.dirname(self.path)
-            if d and not os.path.exists(d):
-                os.makedirs(d)
-            self._f = open(self.path, "wb")
-            self._f.write(struct.pack("<2sHHHQ", b"II", 43, 8, 0, 0) if big else struct.pack("<2sHI", b"II", 42, 0))
-            self._strips, self._band_rows = [], band.shape[0]
-        band = np.asarray(band)
-        if band.ndim == 3:
-            band = band[:, :, ::-1]
-        self._strips.append((self._f.tell(), band.size))
-        self._f.write(np.ascontiguousarray(band).tobytes())
-        if row0 + band.shape[0] < rows:
-            return
-        f, n = self._f, len(self._strips)
-        if f.tell() & 1:
-            f.write(b"\0")
-        fmt_off = "<%dQ" % n if big else "<%dI" % n
-        off_pos = f.tell(); f.write(struct.pack(fmt_off, *[o for o, _c in self._strips]))
-        cnt_pos = f.tell(); f.write(struct.pack(fmt_off, *[c for _o, c in self._strips]))
-        bps_pos = f.tell(); f.write(struct.pack("<3H", 8, 8, 8)); f.write(b"\0\0")
-        ifd = f.tell()
-        ltype = 16 if big else 4                                 # LONG8 / LONG
-        tags = [(256, ltype, 1, cols), (257, ltype, 1, rows), (258, 3, ch, bps_pos if ch == 3 else 8), (259, 3, 1, 1),
-                (262, 3, 1, 2 if ch == 3 else 1), (273, ltype, n, off_pos if n > 1 else self._strips[0][0]), (277, 3, 1, ch),
-                (278, ltype, 1, self._band_rows), (279, ltype, n, cnt_pos if n > 1 else self._strips[0][1])]
-        if big:
-            f.write(struct.pack("<Q", len(tags)))
-            for t, ty, c, v in tags:
-                f.write(struct.pack("<HHQQ", t, ty, c, v))
-            f.write(struct.pack("<Q", 0))
-            f.seek(8); f.write(struct.pack("<Q", ifd))
-        else:
-            f.write(struct.pack("<H", len(tags)))
-            for t, ty, c, v in tags:
-                f.write(struct.pack("<HHII", t, ty, c, v))
-            f.write(struct.pack("<I", 0))
-            f.seek(4); f.write(struct.pack("<I", ifd))
-        f.close()
-        self._f = None
-
-
-def _native_jpeg_encoder():
-    """does the library encode JPEG on this host (libjpeg.so.8 present, not switched off)?"""
-    if os.environ.get("VFSMS_NATIVE_JPEG", "1") == "0":
-        return False
-    try:
-        from . import _lib
-        return _lib.jpeg_encode(np.zeros((8, 8), np.uint8)) is not None
-    except Exception:
-        return False
-
-
-def band_writer_for(path):
-    """the streaming encoder for an output file name, or None when its format has none here (JPEG without libjpeg.so.8 on the host: written
-    whole through Pillow)"""
-    ext = os.path.splitext(path)[1].lower()
-    if ext in (".jpg", ".jpeg"):
-        return JpegBandWriter(path) if _native_jpeg_encoder() else None
-    return PngBandWriter(path) if ext == ".png" else TiffBandWriter(path) if ext in (".tif", ".tiff") else NpyBandWriter(path) if ext == ".npy" else None
-
-
-def _list_images(folder, extension):
-    """glob(folder/*.ext): the reference relies on Windows semantics (case-insensitive, name order)."""
-    ext = "." + extension.lower()
-    names = [n for n in os.listdir(folder) if n.lower().endswith(ext)] if os.path.isdir(folder) else []
-    return [os.path.join(folder, n) for n in sorted(names)]
+from .ingest import (_imread, _imread_gray_pointer, _PillowBlocks, _decoder_pool, _decode_once, _fill_from_jpeg, _ycc_to_bgr, _imshape,  # noqa: F401
+                     _list_images)
+from .io import (_imwrite, _imwrite_jpeg_stripes, NpyBandWriter, PngBandWriter, JpegBandWriter, TiffBandWriter, _NoNativeJpeg,  # noqa: F401
+                 _native_jpeg_encoder, band_writer_for)
 
 
 def _join(base, *parts):
@@ -758,7 +304,18 @@ class Stitcher(Utility.Method):
             # flowStitch discards everything behind a break (Stitcher.py:74-76) and the reference never opens those files: decodes that have
             # not started are cancelled (their handles are given up so that they can be freed), and a file behind the last registered pair
             # that fails to decode is not an error of this call
-            needed = len(fileList) if (failed or table is None) else min(len(table) + 1, len(fileList))
+            # tiles of this segment: 0 .. (leading registered pairs); the rest lies behind the break
+            n_used = len(fileList)
+            if table is not None and not failed:
+                n_used = 1
+                for row in table:
+                    if not row[0]:
+                        break
+                    n_used += 1
+                n_used = min(n_used, len(fileList))
+            # (the incremental registrars return a FULL-length table with zero rows behind the break, so len(table) says nothing: what the
+            #  registration looked at are the tiles of the leading registered pairs plus the B tile of the pair that failed)
+            needed = len(fileList) if (failed or table is None) else min(n_used + 1, len(fileList))
             err, unfilled = None, set()
             for k, fu in zip(todo, futures):
                 if fu.cancel():
@@ -779,15 +336,6 @@ class Stitcher(Utility.Method):
                         err = err or e
             if block_alloc is not None:
                 block_alloc.__exit__(None, None, None)
-            # tiles of this segment: 0 .. (leading registered pairs); the rest lies behind the break
-            n_used = len(fileList)
-            if table is not None and not failed:
-                n_used = 1
-                for row in table:
-                    if not row[0]:
-                        break
-                    n_used += 1
-                n_used = min(n_used, len(fileList))
             stash = self.__dict__.get("_ingestCache") if (not failed and err is None) else None
             mine = list(range(len(handles)))
 

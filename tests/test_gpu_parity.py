@@ -1421,3 +1421,26 @@ def test_driver_with_registration_breaks_decodes_once_and_matches_the_pair_loop(
     finally:
         (isa.Stitcher.direction, isa.Stitcher.directIncre, isa.Stitcher.roiRatio, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod,
          isa.Stitcher.fuseMethod, isa.Stitcher.offsetEvaluate) = old
+
+
+@pytest.mark.gpu
+def test_rccl_all_gather_at_world_size_1(tmp_path):
+    """Row e on hardware: the pair-sharded registration with the REAL collective -- torch.distributed "nccl" (= RCCL), device tensors on
+    cuda:0, imagestitch_amd.distributed.make_all_gather -- at world size 1, in a process of its own (tests/rccl_worker.py; the same worker runs
+    under torchrun at N = 8).  The sharded table (cold and with a primed path memory) equals GridRegistrar.register's and the ground truth
+    within 1 px: RCCL start-up, the device / host tensor hand-over and the one all_gather of the path have run on an MI355X before the first
+    8-GPU job does."""
+    import json
+    import subprocess
+    import sys
+    out = tmp_path / "rccl.json"
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_worker.py")
+    p = subprocess.run([sys.executable, worker, str(out)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    r = json.load(open(out))
+    assert r["backend"] == "nccl" and r["world"] == 1 and r["device"] == "cuda:0" and r["gathered_shape"] == [1, 7]
+    assert r["rows"] == r["rows_register"] == r["rows_single"] == r["rows_primed"]
+    assert len(set(r["direction"])) == 1 and r["repairs"] == 0
+    for row, t in zip(r["rows"], r["truth"]):
+        assert row[0] == 1 and abs(row[1] - t[0]) <= 1 and abs(row[2] - t[1]) <= 1, (row, t)

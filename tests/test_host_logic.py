@@ -473,7 +473,7 @@ def test_colour_mosaic_decodes_every_file_exactly_once(oracle, tmp_path):
 
 
 def test_library_jpeg_decoder_equals_pillow_and_refuses_what_it_does_not_take(tmp_path):
-    """vfsms_jpeg_decode (csrc/jpeg_host.hip: the system's libjpeg-turbo behind a self-declared ABI) against Pillow's decode of the same
+    """vfsms_jpeg_decode (csrc/jpeg_host.cpp: the system's libjpeg-turbo behind a self-declared ABI) against Pillow's decode of the same
     bytes -- the grayscale decode and the Y Cb Cr planes, for the chroma subsamplings, progressive files and a grayscale file -- byte for
     byte; files it must hand back to the caller (truncated, CMYK, not a JPEG) come back as None, never as a wrong image."""
     import io
@@ -642,6 +642,14 @@ def test_ingest_error_paths_free_every_handle(oracle, tmp_path):
             s = isa.Stitcher(); s._engine = eng; s.isPrintLog = False; s.direction = 1; s.decodeThreads = 1
             (status, mosaic) = s.flowStitch([files[0], files[1], files[3], bad[2]], s.calculateOffsetForFeatureSearchIncre)
             assert status == (False, 0) and mosaic.shape[:2] == (128, 128) and not eng.live
+            # ... and when its decode had already STARTED (one decoder thread per file, the refused attempt takes its time): the incremental
+            # registrar's table is full length with zero rows behind the break -- what counts is the leading registered pairs
+            import time as _time
+            slow_refuse = lambda A, B, job: (_time.sleep(0.3), [0, 0, 0, 0, 10, 10, 0, 0])[1]
+            eng = IngestOracleEngine(oracle, scripted=slow_refuse)
+            s = isa.Stitcher(); s._engine = eng; s.isPrintLog = False; s.direction = 1; s.decodeThreads = 4
+            (status, mosaic) = s.flowStitch([files[0], files[1], files[3], bad[2]], s.calculateOffsetForFeatureSearchIncre)
+            assert status == (False, 0) and mosaic.shape[:2] == (128, 128) and not eng.live
     finally:
         isa.Stitcher.direction, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod = old
 
@@ -662,6 +670,25 @@ def test_png_and_tiff_band_writers_round_trip(tmp_path):
                 back = np.asarray(Image.open(path))
                 want = img[:, :, ::-1] if img.ndim == 3 else img
                 assert back.shape == want.shape and np.array_equal(back, want), (shape, ext, band)
+
+
+def test_bigtiff_layout_is_readable_for_gray_and_colour(tmp_path):
+    """The BigTIFF branch of TiffBandWriter (mosaics >= 4 GB: configs[4]'s 32 x 32 grid of 4096^2 colour tiles is 40 GB) forced on a small
+    image: 8-byte offsets, LONG8 directory, and BitsPerSample 8, 8, 8 INLINE in the 8-byte value field (three SHORTs fit it; an offset there
+    is read as the values and the file is unreadable).  Pillow reads the same pixels back, gray and colour, one strip and several."""
+    from PIL import Image
+    rng = np.random.default_rng(23)
+    for shape in ((61, 47), (53, 38, 3)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        for band in (16, 200):
+            path = os.path.join(str(tmp_path), "big%d_%d.tif" % (len(shape), band))
+            sink = isa.TiffBandWriter(path, force_big=True)
+            for r0 in range(0, shape[0], band):
+                sink(r0, img[r0:r0 + band], shape)
+            assert open(path, "rb").read(4) == b"II\x2b\x00"                      # BigTIFF magic 43
+            back = np.asarray(Image.open(path))
+            want = img[:, :, ::-1] if img.ndim == 3 else img
+            assert back.shape == want.shape and np.array_equal(back, want), (shape, band)
 
 
 def _restart_layout(data):
