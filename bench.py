@@ -77,6 +77,27 @@ def pmc_value(kernel, key):
     return None, None
 
 
+def pmc_build():
+    """(what the newest PMC summary was taken of, what this run loaded, stale?)  tools/profile_round.sh stamps the summary with the content
+    hash of the kernel sources, the hash of the library and the commit (tools/build_id.py); the same hashes of THIS tree are formed here.
+    stale = the kernel sources changed behind the profile (or the summary predates the stamp): the PMC-derived fields of the line
+    (traffic, valu_busy_frac_pmc, ta_busy_frac_pmc, valu_issued_over_lower_bound, effective_clock_ghz) then describe an OLDER build and
+    the line says so -- `pmc_stale: true` -- instead of passing them off as this run's."""
+    import glob
+    from tools.build_id import build_id
+    mine = build_id(os.environ.get("VFSMS_LIB") or None)
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.txt")), reverse=True)
+    theirs, src = {}, None
+    if paths:
+        src = os.path.relpath(paths[0], ROOT)
+        for line in open(paths[0]):
+            if line.startswith("# build:"):
+                theirs = dict(tok.split("=", 1) for tok in line[len("# build:"):].split() if "=" in tok)
+                break
+    stale = theirs.get("src_sha256") != mine["src_sha256"]
+    return dict(pmc_summary=src, pmc_build=theirs or None, this_build=mine, pmc_stale=bool(stale))
+
+
 def pmc_total(kernel, key):
     """per-launch figure x launches of `kernel` in the newest PMC summary -> (total, launches)"""
     import glob
@@ -116,6 +137,17 @@ def valu_over_bound(spk_live):
     if not (a and kp):
         return None
     return round((a + (b or 0.0)) / (kp * (sp or spk_live) * DESC_OPS_LOWER_BOUND / 64.0), 3)
+
+
+def clock_fields(achieved_tlaneops):
+    """The VALU roof at the clock the kernel RUNS at: SQ_BUSY_CYCLES / 32 over the traced duration of k_describe in the PMC pass
+    (eff_clock_ghz in the summary; ~2.0-2.1 GHz under this load against the 2.4 GHz of the peak constant)."""
+    eff, _src = pmc_value("k_describe", "eff_clock_ghz")
+    if not eff:
+        return dict(effective_clock_ghz=None, peak_at_effective_clock=None, frac_at_effective_clock=None)
+    peak = 256 * 4 * 16 * eff * 1e9 / 1e12
+    return dict(effective_clock_ghz=round(eff, 3), peak_at_effective_clock=round(peak, 2), frac_at_effective_clock=round(achieved_tlaneops / peak, 4),
+                peak_clock_note="peak / frac assume 2.4 GHz; *_at_effective_clock use the shader clock measured under this kernel in the PMC pass")
 
 
 def sum_or_none(vals):
@@ -548,6 +580,10 @@ def main():
     ap.add_argument("--no-cold-leg", action="store_true", help="N = 1: skip the extra K steps without path memory (value_cold_path)")
     ap.add_argument("--no-path-memory", action="store_true", help="do not let the registrar use the scan pattern it learned from the previous step "
                     "(every step cold: history-driven speculation, blind chunk starts and chunks by pair count at N > 1)")
+    ap.add_argument("--prior", default="other", choices=["other", "same"],
+                    help="where the path memory of the timed steps is learned: other = a DIFFERENT instance of the scan pattern (same rows x cols x tile, "
+                         "seed + 1: other texture, jitter and offsets -- the previous dataset of a session), registered once before the warm-up; "
+                         "same = only the warm-up steps of the timed grid itself (round 4's headline)")
     ap.add_argument("--workload", default="grid", choices=["grid", "dendritic25"],
                     help="grid = the synthetic serpentine grid (BASELINE metric); dendritic25 = the 25 committed real pairs (N = 1, surf)")
     ap.add_argument("--from-files", action="store_true", help="N = 1: JPEG tiles on disk through Stitcher's ingest pipeline (decode inclusive)")
@@ -615,10 +651,14 @@ def main():
     need = list(range(grid.n_tiles)) if world > 1 else (list(range(lo, hi + 1)) if hi > lo else [])
     # tiles live in pinned host memory (what a decoder feeding this engine would write into): uploads from it are asynchronous DMA
     tiles = {}
-    for k, t in zip(need, grid.tiles(need, threads=min(8 if grid.n_tiles <= 128 else 48, os.cpu_count() or 1))):
+    # (grids beyond 128 tiles -- configs[4]: 1024 tiles of 4096^2, two core-hours of texture synthesis -- are generated by worker processes)
+    gen_procs = 0 if grid.n_tiles <= 128 else max(2, min(96, (os.cpu_count() or 4) // (2 * world)))
+    t_gen = time.perf_counter()
+    for k, t in zip(need, grid.tiles(need, threads=min(8, os.cpu_count() or 1), processes=gen_procs)):
         buf = eng.pinned_empty(t.shape)
         buf[...] = t
         tiles[k] = buf
+    t_gen = time.perf_counter() - t_gen
     shapes = [(grid.th, grid.tw)] * grid.n_tiles
     handles = [None] * grid.n_tiles
     t_up = time.perf_counter()
@@ -640,6 +680,26 @@ def main():
 
     def step(hs=handles):
         return reg.register_sharded(hs, shapes, 1, rank, world, gather)
+
+    # The prior of the timed steps comes from ANOTHER dataset of the same scan pattern (what a session has: Main.py runs dataset after
+    # dataset through one Stitcher): a second instance of the grid -- seed + 1: different texture, jitter, ground-truth offsets -- is
+    # registered once, cold, and teaches the registrar the pattern; its tiles are released before the warm-up.  (--prior same: only the
+    # warm-up steps of the timed grid teach it.)
+    prior_note = "the warm-up steps of the timed grid itself (--prior same)"
+    if args.prior == "other" and not args.no_path_memory and args.method in ("surf", "orb", "phase") and need:
+        g2 = SyntheticGrid(args.rows, args.cols, args.tile, overlap=args.overlap, seed=grid.seed + 1)
+        hs2 = [None] * grid.n_tiles
+        for k, t in zip(need, g2.tiles(need, threads=min(8, os.cpu_count() or 1), processes=gen_procs)):
+            hs2[k] = eng.tile_upload(t)
+        res2, _d2 = step(hs2)
+        if args.method == "surf":
+            t2 = np.array(g2.true_offsets(), np.int64)
+            assert (res2[:, 0] == 1).all() and int(np.abs(res2[:, 1:3].astype(np.int64) - t2).max()) <= 1, "prior instance not registered"
+        for k in need:
+            eng.tile_free(hs2[k])
+        assert reg.path_memory is not None and len(reg.path_memory) == P
+        prior_note = ("a DIFFERENT instance of the scan pattern (same %d x %d x %d geometry, seed + 1: other texture, jitter and offsets), registered "
+                      "once cold before the warm-up -- the previous dataset of a session" % (args.rows, args.cols, args.tile))
 
     def my_tiles():
         a, b = reg._bounds(P, world, None, reg._prediction(P, None), 1)[rank]
@@ -776,6 +836,7 @@ def main():
                         valu_insts_per_launch_pmc=valu_insts, valu_busy_frac_pmc=valu_busy, ta_busy_frac_pmc=pmc_value("k_describe", "ta_busy_frac")[0],
                         valu_peak_source="profiles/r04_valu_peak.txt (tools/valu_peak.hip on the MI355X box: 4-cycle class instructions 33-38 T lane-ops/s)",
                         ops_per_sample_lower_bound=DESC_OPS_LOWER_BOUND,
+                        **clock_fields(laneops / dur / 1e12),
                         valu_insts_lower_bound_per_launch=round(kps * spk * DESC_OPS_LOWER_BOUND / 64.0),
                         valu_issued_over_lower_bound=valu_over_bound(spk),
                         per_launch_pmc_note="PMC figures are per launch OF THE PMC RUN (its launches need not have this run's size); the ratio "
@@ -848,6 +909,9 @@ def main():
         cpu = cpu_baseline_surf(args, grid, tiles, isa)
 
     if rank == 0:
+        pmc_info = pmc_build()
+        if roofline is not None:
+            roofline["pmc_stale"] = pmc_info["pmc_stale"]
         out = {
             "metric": "image-pairs/sec (2048x2048 grayscale, SURF+BF)" if args.method == "surf" else "image-pairs/sec (%s)" % args.method,
             "value": round(P * args.steps / elapsed, 3),
@@ -865,8 +929,8 @@ def main():
                                        "phase": "FFT phase correlation of the ROI strips"}[args.method], args.offset_evaluate),
                        "pairs": P, "parallelism": "pairs%d" % world, "speculation_window": args.window,
                        "path_prediction": ("none (--no-path-memory): every step registers the path cold" if args.no_path_memory else
-                                           "path memory: the accepted directions of the previous registration of this scan pattern (the warm-up step) drive the "
-                                           "speculation plan of the timed steps; nothing from the ground truth, every attempt evaluated")},
+                                           "path memory: the accepted directions of the previous registration of this scan pattern drive the speculation plan "
+                                           "of the timed steps; nothing from the ground truth, every attempt evaluated; first learned from " + prior_note)},
             "max_abs_offset_error_px": max_err, "pairs_failed": n_failed,
             "path_memory_primed_for_profiling": os.environ.get("VFSMS_BENCH_PRIME", "0") not in ("", "0"),
             "value_cold_path": round(P * args.steps / elapsed_cold, 3) if elapsed_cold else None,
@@ -876,11 +940,12 @@ def main():
                                     "rounds 1-3's headline configuration") if elapsed_cold else None),
             "value_host_resident_tiles": round(P * args.steps / elapsed_host, 3) if elapsed_host else None,
             "ms_per_step_host_resident_tiles": round(elapsed_host / args.steps * 1e3, 3) if elapsed_host else None,
-            "h2d_ms_rank0_blocking": round(t_up * 1e3, 2),
+            "h2d_ms_rank0_blocking": round(t_up * 1e3, 2), "tile_synthesis_s": round(t_gen, 1),
             "attempts_per_step": st["attempts"] / max(args.steps, 1), "batches_per_step": st["batches"] / max(args.steps, 1),
             "keypoints_per_roi": round(st["sum_nq_plus_nt"] / max(2 * st["attempts"], 1), 1) if args.method == "surf" else None,
             "capacity_retries": getattr(reg, "capacity_retries", 0),
             "roofline": roofline,
+            "pmc": pmc_info,
             "cpu_baseline": cpu,
             "stages": stages,
             "per_rank": per_rank,

@@ -51,6 +51,10 @@ class GridRegistrar:
         # attempt is still evaluated, results never depend on it (tests/test_grid_registrar.py).
         self.remember = True
         self.path_memory = None
+        # A memory that mispredicts is not kept on trust (_learn): `path_suspect` marks a memory adopted from a path the previous memory had
+        # mispredicted; a second misprediction in a row drops the memory and the next path is registered cold.
+        self.path_suspect = False
+        self.mispredictions = 0
 
     # -- candidate order of Stitcher.py:319-351 --------------------------------------------------------------
     def maxI(self):
@@ -324,15 +328,50 @@ class GridRegistrar:
         m = self.path_memory
         return m if (self.remember and m is not None and len(m) == P) else None
 
-    def _learn(self, table):
-        if self.remember and len(table):
-            self.path_memory = [int(r[3]) if 1 <= int(r[3]) <= 4 else 1 for r in table]
+    MISPREDICT_EXTRA = 0.25     # a prediction is "wrong" when it cost more than this fraction of the attempts it had promised
+
+    def _learn(self, table, predicted=None):
+        """The path just registered becomes the prediction of the next one of its length -- unless the prediction it was registered WITH
+        (`predicted`: the memory, never a caller's hint) turned out wrong.  Wrong = the extra attempts it caused, estimated from the table
+        every rank holds (per pair whose accepted direction differs from the predicted one: the rotation steps between the two, at least
+        one), exceed MISPREDICT_EXTRA of the attempts it predicted (path_weights).  One misprediction: the new pattern is adopted on
+        probation (a session that moves on to another scan pattern is primed again from the second path on).  Two in a row (paths that do not
+        repeat): the memory is dropped, the next path runs cold -- a stale prior costs attempts (75 against 43 on the
+        dendriticCrystal neighbourhoods), a cold path only costs batches.  Decided from the table alone, so every rank of the sharded form
+        takes the same decision."""
+        if not (self.remember and len(table)):
+            return
+        new = [int(r[3]) if 1 <= int(r[3]) <= 4 else 1 for r in table]
+        if predicted is not None and len(predicted) == len(new):
+            extra = 0
+            for r, h, a in zip(table, predicted, new):
+                if int(r[0]) == 1 and int(h) != a:
+                    steps, c = 0, int(h)
+                    while c != a and steps < 4 and self.directIncre != 0:
+                        c = _rotate(c, self.directIncre); steps += 1
+                    extra += max(steps, 1)
+            promised = sum(self.path_weights(predicted, int(predicted[0])))
+            if extra > self.MISPREDICT_EXTRA * promised:
+                self.mispredictions += 1
+                if self.path_suspect:
+                    self.path_memory, self.path_suspect = None, False
+                    return
+                self.path_suspect = True
+            else:
+                self.path_suspect = False
+        self.path_memory = new
+
+    def _memory_prediction(self, P, hint):
+        """the memory, when it is what _prediction(P, hint) hands out (None for a caller's hint: only the memory is put on trial)"""
+        m = self.path_memory
+        return m if (hint is None and self.remember and m is not None and len(m) == P) else None
 
     def register(self, handles, shapes, direction=1, stop_on_fail=False, hint=None):
         """All P = len(handles)-1 consecutive pairs on this GPU.  -> (int32[P, 6], final direction).
         stop_on_fail: stop behind the first pair that cannot be registered (rows after it stay zero).
         hint: predicted accepted directions (default: the path memory)."""
         P = len(handles) - 1
+        mem = self._memory_prediction(P, hint)
         hint = self._prediction(P, hint)
         if self.native and hasattr(self.eng, "pairs_offsets"):
             out, d, st = self.eng.pairs_offsets(handles, shapes, self._grid_params(hint), 0, P, direction, False, stop_on_fail)
@@ -340,7 +379,7 @@ class GridRegistrar:
         else:
             out, d = self.chain(handles, shapes, 0, P, direction, stop_on_fail=stop_on_fail, hint=hint)
         if not stop_on_fail or bool(np.all(out[:, 0] == 1)):
-            self._learn(out)
+            self._learn(out, mem)
         return out, d
 
     # -- pair-sharded ---------------------------------------------------------------------------------------------------
@@ -486,6 +525,7 @@ class GridRegistrar:
         gathered a second time -- every rank sees the same tables, so all of them take the same decision.
         Returns the same (int32[P, 6], final direction) on every rank."""
         P = len(shapes) - 1
+        mem = self._memory_prediction(P, hint)
         hint = self._prediction(P, hint)
         payload = self.shard_payload(handles, shapes, direction, rank, world, weights, hint)
         gathered = all_gather(payload)
@@ -493,12 +533,12 @@ class GridRegistrar:
             raise RuntimeError("all_gather returned %d payloads for a world of %d ranks" % (len(gathered), world))
         if hint is None:
             full, d = self.assemble(gathered, P, world, direction, weights)
-            self._learn(full)
+            self._learn(full, mem)
             return full, d
         missing = []
         full, d = self.assemble(gathered, P, world, direction, weights, missing, hint)
         if not missing:
-            self._learn(full)
+            self._learn(full, mem)
             return full, d
         # repair: every rank that followed a single hinted chain is a suspect (a wrong direction upstream changes what enters the ranks
         # behind it); those whose assumption is not confirmed by the first walk redo their chunk blind.  One extra collective.
@@ -511,7 +551,7 @@ class GridRegistrar:
             mine = self.shard_payload(handles, shapes, direction, rank, world, weights, hint, blind=True)
         gathered = all_gather(mine)
         full, d = self.assemble(gathered, P, world, direction, weights, None, hint)
-        self._learn(full)
+        self._learn(full, mem)
         return full, d
 
 

@@ -208,6 +208,7 @@ class Stitcher(Utility.Method):
         # the scan pattern the previous dataset taught this stitcher (accepted directions, same number of tiles): the speculation prior of
         # this one (GridRegistrar.path_memory; Main.py runs its datasets through ONE Stitcher with one setting)
         reg.path_memory = self.__dict__.get("_pathMemory")
+        reg.path_suspect = bool(self.__dict__.get("_pathSuspect", False))
         if reg.path_memory is None and self.pathHint is not None and len(self.pathHint) == len(fileList) - 1:
             reg.path_memory = [int(d) for d in self.pathHint]
         device_fuse = (self.fuseMethod in ("notFuse", "fadeInAndFadeOut", "trigonometric") and hasattr(eng, "canvas_fuse_tile_resident")) or \
@@ -295,8 +296,8 @@ class Stitcher(Utility.Method):
                 table = self._fullImageTableOrb(handles, shapes)
             else:
                 table, _d = reg.register(handles, shapes, self.direction, stop_on_fail=True)
-                if reg.path_memory is not None:
-                    self._pathMemory = reg.path_memory
+                # (what this path taught, incl. "nothing": a memory that mispredicted twice in a row is dropped, GridRegistrar._learn)
+                self._pathMemory, self._pathSuspect = reg.path_memory, reg.path_suspect
         except BaseException:
             keep, failed = False, True
             raise

@@ -167,13 +167,46 @@ class SyntheticGrid:
         img = 128.0 + 45.0 * gain * t + rng.normal(0.0, 2.0, t.shape).astype(np.float32)
         return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
-    def tiles(self, ks=None, threads=8):
+    def tiles(self, ks=None, threads=8, processes=0):
+        """tiles ks (default: all) in order.  threads: a thread pool (the noise octaves release the interpreter lock, the blob layer's stamping
+        loop does not: ~2x at best).  processes > 1: worker PROCESSES instead (spawned, so that a parent that holds a GPU context is not
+        forked) -- the 1024 tiles of 4096 x 4096 of BASELINE configs[4] are 100 core-minutes of stamping; an iterator in this case (a tile is
+        handed over and dropped: 17 GB never sit in one list)."""
         ks = list(range(self.n_tiles)) if ks is None else list(ks)
+        if processes and processes > 1 and len(ks) > 1:
+            return self._tiles_by_processes(ks, processes)
         if threads <= 1 or len(ks) < 2:
             return [self.tile(k) for k in ks]
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(threads) as ex:
             return list(ex.map(self.tile, ks))
+
+    def _tiles_by_processes(self, ks, processes):
+        import multiprocessing as mp
+        ctx = mp.get_context("spawn")
+        args = (self.rows, self.cols, self.th, self.tw, self.seed, self.blobs, self.origins)
+        with ctx.Pool(min(processes, len(ks)), initializer=_worker_init, initargs=(args,)) as pool:
+            for t in pool.imap(_worker_tile, ks, chunksize=1):
+                yield t
+
+
+_WORKER_GRID = None
+
+
+def _worker_init(args):
+    global _WORKER_GRID
+    rows, cols, th, tw, seed, blobs, origins = args
+    g = SyntheticGrid.__new__(SyntheticGrid)
+    g.rows, g.cols, g.th, g.tw, g.seed, g.blobs, g.origins = rows, cols, th, tw, seed, blobs, origins
+    g.path = []
+    for c in range(cols):
+        g.path += [(r, c) for r in (range(rows) if c % 2 == 0 else range(rows - 1, -1, -1))]
+    g.n_tiles = len(g.path); g.n_pairs = g.n_tiles - 1
+    _WORKER_GRID = g
+
+
+def _worker_tile(k):
+    return _WORKER_GRID.tile(k)
 
 
 def line_scan(n=4, h=1024, w=1280, bar=48):

@@ -443,6 +443,13 @@ def test_dll_mode_parameter_set(engine, oracle, strips):
     assert np.array_equal(pairs, oracle.bf_l2_ratio_matches(da, db, 0.75))
     st, off, votes = engine.mode_offset(ka, kb, pairs, 3)
     assert row[:7].tolist() == [int(st), off[0], off[1], votes, len(ka), len(kb), len(pairs)], (row, st, off, votes)
+    # ... and the ORACLE's row for the same parameter set (surfIsExtended = True, ImageUtility.py:22-28): 128-d descriptors bit for bit,
+    # the match list and the vote of the whole chain on the CPU
+    oka, oda = oracle.surf_detect_describe(A, extended=True); okb, odb = oracle.surf_detect_describe(B, extended=True)
+    assert oda.shape[1] == 128 and np.array_equal(da, oda) and np.array_equal(db, odb)
+    opairs = oracle.bf_l2_ratio_matches(oda, odb, 0.75)
+    ost, ooff, ovotes = oracle.mode_offset(np.stack([oka["x"], oka["y"]], 1), np.stack([okb["x"], okb["y"]], 1), opairs, 3)
+    assert row[:7].tolist() == [int(ost), ooff[0], ooff[1], ovotes, len(oka), len(okb), len(opairs)], (row, ost, ooff, ovotes)
     # ORB with the distance threshold of the DLL path
     g2 = SyntheticGrid(2, 1, 1024, overlap=0.15)
     t2 = g2.tiles(threads=1)
@@ -1444,3 +1451,38 @@ def test_rccl_all_gather_at_world_size_1(tmp_path):
     assert len(set(r["direction"])) == 1 and r["repairs"] == 0
     for row, t in zip(r["rows"], r["truth"]):
         assert row[0] == 1 and abs(row[1] - t[0]) <= 1 and abs(row[2] - t[1]) <= 1, (row, t)
+
+
+@pytest.mark.gpu
+def test_full_width_dendritic_strips_surf_and_orb_equal_the_oracle_rows(engine, golden_dir):
+    """configs[1] at its real load (tests/golden/real_full_strips.*, tools/capture_golden.py realfull): the UNCROPPED ROI strips of two
+    dendriticCrystal pairs -- 004-005, a column pair (387 x 2584, 13.3 k / 13.5 k SURF keypoints), and 015-016, a serpentine turn
+    (1936 x 516) -- through vfsms_attempt_surf_batch and vfsms_attempt_orb_batch, both shapes in ONE batch.  Every row equals the
+    oracle's attempt row of dendritic_path_oracle*.json ([status, raw dx, raw dy, votes, nA, nB, matches]) and, with the axis
+    correction, lands within 1 px of Stitcher.py:87.  (The 25 neighbourhood pairs are 640-px crops with 2.6 k keypoints per strip.)"""
+    import json
+    meta = json.load(open(os.path.join(golden_dir, "real_full_strips.json")))["pairs"]
+    z = np.load(os.path.join(golden_dir, "real_full_strips.npz"))
+    hs, jobs = [], []
+    for m in meta:
+        a, b = z["p%d_a" % m["a"]], z["p%d_b" % m["a"]]
+        assert a.shape == b.shape == tuple(m["roi_first"][2:])
+        ha, hb = engine.tile_upload(a), engine.tile_upload(b)
+        hs += [ha, hb]
+        jobs.append((ha, hb, 0, 0, 0, 0, a.shape[0], a.shape[1]))
+    engine.set_keypoint_capacity(0)                     # the default: h w / 24 + 4096 candidates per ROI (45 k for these strips)
+    srows = engine.attempt_surf_batch(jobs)
+    orows = engine.attempt_orb_batch(jobs)
+    for m, sr, orr in zip(meta, srows, orows):
+        assert sr[:7].tolist() == m["expected_surf"], (m["a"], sr[:7].tolist(), m["expected_surf"])
+        assert orr[:7].tolist() == m["expected_orb"], (m["a"], orr[:7].tolist(), m["expected_orb"])
+        H, W = m["tile_shape"]
+        for row in (sr, orr):
+            off = [int(row[1]), int(row[2])]
+            if m["direction"] == 1:
+                off[0] += H - int(0.2 * H)
+            elif m["direction"] == 2:
+                off[1] += W - int(0.2 * W)
+            assert abs(off[0] - m["gold"][0]) <= 1 and abs(off[1] - m["gold"][1]) <= 1, (m["a"], off, m["gold"])
+    for h in hs:
+        engine.tile_free(h)

@@ -387,3 +387,63 @@ def test_path_memory_is_a_prior_never_a_result():
         assert [list(r[:4]) for r in res3.tolist()] == seq_o and d3 == d_o
         reg.remember = False
         reg.register(list(range(P + 1)), [SHAPE] * (P + 1), 1)
+
+
+def _serpentine_accept(rows, cols, first=1, across=2):
+    """scripted truth of a column serpentine: rows - 1 pairs along `first`, one `across`, rows - 1 back, ..."""
+    back = {1: 3, 3: 1, 2: 4, 4: 2}[first]
+    accept = []
+    for c in range(cols):
+        d_col = first if c % 2 == 0 else back
+        accept += [{(d_col, i): (3, 4) for i in range(1, 4)} for _ in range(rows - 1)]
+        if c < cols - 1:
+            accept.append({(across, i): (3, 4) for i in range(1, 4)})
+    return accept
+
+
+def test_a_path_memory_that_mispredicts_is_not_kept_on_trust():
+    """GridRegistrar._learn: a memory is a prior on probation.  Scan patterns A (10 x 9 column serpentine) and B (the 9 x 10 one: the SAME
+    number of pairs, turns elsewhere).  A, A: primed.  Then B: the stale memory costs attempts (a misprediction) -- B's pattern is adopted,
+    marked suspect, and a second B is primed again (the session moved on to another pattern).  A, B, A, B on the other hand: two
+    mispredictions in a row drop the memory and the next path is registered COLD, attempt for attempt and batch for batch what a fresh
+    registrar does -- paths that do not repeat stop paying for each other's patterns.  Offsets always equal the sequential search."""
+    A, B = _serpentine_accept(10, 9), _serpentine_accept(9, 10)
+    P = len(A)
+    assert len(B) == P
+    seqs = {id(A): sequential(A, 0.2, 1, 1), id(B): sequential(B, 0.2, 1, 1)}
+
+    def run(reg, eng, acc):
+        eng.accept = acc
+        before = dict(reg.stats)
+        res, d = reg.register(list(range(P + 1)), [SHAPE] * (P + 1), 1)
+        seq, d_end, _n = seqs[id(acc)]
+        assert [list(r[:4]) for r in res.tolist()] == seq and d == d_end
+        return {k: reg.stats[k] - before[k] for k in before}
+
+    def cold_cost(acc):
+        eng = ScriptedAttemptEngine(SHAPE, 0.2, acc)
+        reg = GridRegistrar(eng, roiRatio=0.2, directIncre=1, window=48)
+        return run(reg, eng, acc)
+    for native in (False, True):
+        eng = ScriptedAttemptEngine(SHAPE, 0.2, A)
+        reg = GridRegistrar(eng, roiRatio=0.2, directIncre=1, window=48)
+        reg.native = native and hasattr(eng, "pairs_offsets")
+        run(reg, eng, A)
+        hot = run(reg, eng, A)
+        assert hot["batches"] <= 4 and not reg.path_suspect and reg.mispredictions == 0
+        stale = run(reg, eng, B)                             # A's pattern predicts B badly
+        assert reg.mispredictions == 1 and reg.path_suspect and reg.path_memory is not None
+        assert stale["attempts"] > seqs[id(B)][2]
+        again = run(reg, eng, B)                             # ... but B was learned: primed, the probation ends
+        assert again["attempts"] == seqs[id(B)][2] and again["batches"] <= 4 and not reg.path_suspect and reg.mispredictions == 1
+        run(reg, eng, A)                                     # B's pattern predicts A badly: suspect
+        assert reg.mispredictions == 2 and reg.path_suspect
+        run(reg, eng, B)                                     # second misprediction in a row: dropped
+        assert reg.mispredictions == 3 and reg.path_memory is None and not reg.path_suspect
+        c = run(reg, eng, A)                                 # cold, like a fresh registrar
+        c0 = cold_cost(A)
+        assert (c["attempts"], c["batches"]) == (c0["attempts"], c0["batches"]), (c, c0)
+        assert reg.path_memory is not None and not reg.path_suspect and reg.mispredictions == 3
+        # a caller's hint is never put on trial (it is the caller's to correct)
+        reg.register(list(range(P + 1)), [SHAPE] * (P + 1), 1, hint=[1] * P)
+        assert reg.mispredictions == 3

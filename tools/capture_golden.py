@@ -583,6 +583,55 @@ def cap_real_path_orb():
     json.dump(meta, open(os.path.join(OUT, "real_path_strips.json"), "w"))
 
 
+def cap_real_full_strips():
+    """real_full_strips.npz / .json -- configs[1] at its REAL load: the full-width ROI strips of two dendriticCrystal pairs, uncropped.  Pair
+    4 -> 5 (a column pair: direction 1, 387 x 2584 strips, 13.3 k / 13.5 k SURF keypoints) and pair 15 -> 16 (a serpentine turn: direction 2,
+    1936 x 516 strips, 13.5 k / 12.8 k).  Expected = the attempt rows of the oracle's path runs (dendritic_path_oracle.json /
+    dendritic_path_oracle_orb.json: [status, raw dx, raw dy, votes, nA, nB, matches] of the accepted attempt), re-derived here from the
+    strips alone and asserted equal; gold = Stitcher.py:87.  The 640-px crops of real_path_strips carry 2.6 k keypoints per strip: the
+    BF / describe load of the real dataset goes through the HIP path only with these."""
+    from PIL import Image
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    from imagestitch_amd.utility import roi_rect
+    O.build()
+    d = os.path.join(refshim.REF, "demoImages", "dendriticCrystal", "1")
+
+    def load(t):
+        im = Image.open(os.path.join(d, "1-%03d.jpg" % t)); im.draft("L", im.size)
+        return np.asarray(im.convert("L"))
+    surf_rows = {r["a"]: r for r in json.load(open(os.path.join(OUT, "dendritic_path_oracle.json")))["rows"]}
+    orb_rows = {r["a"]: r for r in json.load(open(os.path.join(OUT, "dendritic_path_oracle_orb.json")))["rows"]}
+    store, meta = {}, []
+    for a, dd in ((4, 1), (15, 2)):
+        A, B = load(a), load(a + 1)
+        ra = roi_rect(A.shape, dd, "first", 0.2); rb = roi_rect(B.shape, dd, "second", 0.2)
+        sa = np.ascontiguousarray(A[ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]]); sb = np.ascontiguousarray(B[rb[0]:rb[0] + rb[2], rb[1]:rb[1] + rb[3]])
+        store["p%d_a" % a] = sa; store["p%d_b" % a] = sb
+        exp = {}
+        for method, rows in (("surf", surf_rows), ("orb", orb_rows)):
+            want = [att for att in rows[a]["attempts"] if att[0] == dd and att[1] == 1][0]
+            if method == "orb":
+                ka, da = O.orb_detect_describe(sa); kb, db = O.orb_detect_describe(sb)
+                pairs = O.bf_hamming_matches(da, db)[0]
+            else:
+                ka, da = O.surf_detect_describe(sa); kb, db = O.surf_detect_describe(sb)
+                pairs = O.bf_l2_ratio_matches(da, db, 0.75)
+            st, off, votes = O.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pairs, 3)
+            row = [int(st), int(off[0]), int(off[1]), int(votes), len(ka), len(kb), len(pairs)]
+            assert row == want[2:], (a, method, row, want)
+            exp[method] = row
+            print("full strips", a, dd, method, row, flush=True)
+        meta.append(dict(a=a, b=a + 1, direction=dd, i=1, tile_shape=list(A.shape), roi_first=list(map(int, ra)), roi_second=list(map(int, rb)),
+                         gold=surf_rows[a]["gold"], expected_surf=exp["surf"], expected_orb=exp["orb"]))
+    np.savez_compressed(os.path.join(OUT, "real_full_strips.npz"), **store)
+    json.dump(dict(source="full-width ROI strips (roiRatio 0.2, accepted direction) of demoImages/dendriticCrystal/1 pairs 004-005 and 015-016, Pillow "
+                          "draft-L decode; expected_* = [status, raw dx, raw dy, votes, nA, nB, matches] of the oracle on these strips == the rows of "
+                          "dendritic_path_oracle*.json; gold = Stitcher.py:87 (full offset incl. the axis correction)", pairs=meta),
+              open(os.path.join(OUT, "real_full_strips.json"), "w"), indent=1)
+    print("real full strips", os.path.getsize(os.path.join(OUT, "real_full_strips.npz")) // 1024, "KiB")
+
+
 def cap_demo_strips():
     """BASELINE configs[0] / configs[3]: ROI strips of the iron pair (direction 1) and of the first zirconCL pairs (direction 4)
     at roiRatio 0.2.  cv2 is not installable here, so the expected offsets are produced by the oracle (oracle/): these
@@ -773,6 +822,6 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["roi", "mode", "sm", "cache", "fuse", "stitch", "flow", "real", "realpath", "demo"]
     fns = dict(roi=cap_roi, mode=cap_mode, sm=cap_state_machine, cache=cap_feature_search_cache,
                fuse=cap_fuse, stitch=cap_stitch, flow=cap_flow, real=cap_real, realpath=cap_real_path, realpath_orb=cap_real_path_orb,
-               demo=cap_demo_strips, phase2=cap_phase_independent, phase87=cap_phase87)
+               demo=cap_demo_strips, phase2=cap_phase_independent, phase87=cap_phase87, realfull=cap_real_full_strips)
     for w in which:
         fns[w]()

@@ -30,23 +30,37 @@ timeout 500 rocprofv3 --kernel-trace --pmc TA_TA_BUSY TA_FLAT_READ_WAVEFRONTS_su
 timeout 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $OUT/pmc_mfma -o pmc --output-format csv -- $PCMD > $OUT/pmc_mfma_bench.json 2> $OUT/pmc_mfma.err
 python - <<PY
 import csv, glob, collections
+dur=collections.defaultdict(float)          # kernel -> summed (End - Start) ns over the dispatches of the pass agg() read last
 def agg(pat):
     a=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter(); seen=set()
     f=glob.glob(pat, recursive=True)
+    dur.clear()
     if not f: return a, n
     for row in csv.DictReader(open(f[0])):
         k=row['Kernel_Name'].split('(')[0]
         a[k][row['Counter_Name']]+=float(row['Counter_Value'])
         key=(row.get('Dispatch_Id'),k)
-        if key not in seen: seen.add(key); n[k]+=1
+        if key not in seen:
+            seen.add(key); n[k]+=1
+            try: dur[k]+=float(row['End_Timestamp'])-float(row['Start_Timestamp'])
+            except (KeyError, ValueError): pass
     return a, n
 out=open('$OUT/pmc_summary.txt','w')
+# what was profiled: bench.py compares this with the library it loads and reports "pmc_stale" when the kernels changed behind the profile
+import sys
+sys.path.insert(0, '.')
+from tools.build_id import build_id
+out.write('# build: ' + ' '.join('%s=%s' % kv for kv in sorted(build_id().items())) + '\n')
 sq,nsq=agg('$OUT/pmc_sq/**/*counter_collection.csv')
+sqdur=dict(dur)
 out.write('# SQ counters per launch (rocprofv3 --pmc, one step of the default bench workload, kernels serialised); quad-cycle units for\\n# WAVE_CYCLES / WAIT_ANY / ACTIVE_INST_ANY; INSTS_* = wave-instructions (one VALU wave-instruction occupies its SIMD for 4 cycles)\\n')
 for k,v in sorted(sq.items(), key=lambda kv:-kv[1].get('SQ_WAVE_CYCLES',0)):
     if 'k_' in k:
         n=max(nsq[k],1)
-        out.write('%-28s launches=%d '%(k[:28],n)+' '.join('%s=%.4g'%(c.replace('SQ_',''),x/n) for c,x in sorted(v.items()))+'\\n')
+        # eff_clock_ghz: SQ_BUSY_CYCLES (summed over the 32 shader engines) / 32 = cycles the launch lasted, over its traced duration in
+        # the same pass: the shader clock the kernel actually ran at (the roofline's peak constant assumes 2.4 GHz)
+        clk=(v.get('SQ_BUSY_CYCLES',0)/32.0)/sqdur[k] if sqdur.get(k) else 0.0
+        out.write('%-28s launches=%d '%(k[:28],n)+' '.join('%s=%.4g'%(c.replace('SQ_',''),x/n) for c,x in sorted(v.items()))+(' eff_clock_ghz=%.3f dur_ms=%.4g'%(clk,sqdur[k]/n/1e6) if clk else '')+'\\n')
 f,nf=agg('$OUT/pmc_fetch/**/*counter_collection.csv'); w,nw=agg('$OUT/pmc_write/**/*counter_collection.csv')
 out.write('\\n# HBM traffic per launch (MI355X_MICROARCH.md HBM section): bytes = FETCH_SIZE*1024*2 (gfx950 reports half of a wide\\n# coalesced read stream; scattered/narrow accesses uncalibrated) + WRITE_SIZE*1024; separate --pmc passes\\n')
 for k in sorted(f):
