@@ -652,6 +652,7 @@ def main():
     # tiles live in pinned host memory (what a decoder feeding this engine would write into): uploads from it are asynchronous DMA
     tiles = {}
     # (grids beyond 128 tiles -- configs[4]: 1024 tiles of 4096^2, two core-hours of texture synthesis -- are generated by worker processes)
+    t_start = time.perf_counter()
     gen_procs = 0 if grid.n_tiles <= 128 else max(2, min(96, (os.cpu_count() or 4) // (2 * world)))
     t_gen = time.perf_counter()
     for k, t in zip(need, grid.tiles(need, threads=min(8, os.cpu_count() or 1), processes=gen_procs)):
@@ -659,6 +660,12 @@ def main():
         buf[...] = t
         tiles[k] = buf
     t_gen = time.perf_counter() - t_gen
+    big = grid.n_tiles > 128
+
+    def progress(msg):
+        if big and rank == 0:
+            print("[bench %7.1f s] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+    progress("%d tiles synthesised in %.1f s (%d worker processes)" % (len(need), t_gen, gen_procs))
     shapes = [(grid.th, grid.tw)] * grid.n_tiles
     handles = [None] * grid.n_tiles
     t_up = time.perf_counter()
@@ -723,8 +730,10 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
+    progress("tiles resident (%.1f s of uploads); first step ..." % t_up)
     for _ in range(args.warmup):
         res, _d = step()
+        progress("warm-up step done: %d attempts in %d batches so far, %d capacity retries" % (reg.stats["attempts"], reg.stats["batches"], getattr(reg, "capacity_retries", 0)))
     if args.warmup == 0:
         res, _d = step()
     t_w = time.perf_counter()                               # the clock of the steady-state warm-up starts AFTER the first (slow) steps
@@ -758,6 +767,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    progress("%d timed steps: %.1f ms per step" % (args.steps, elapsed / args.steps * 1e3))
     prof = eng.profile_read(reset=True)
     eng.profile_enable(False)
     st = dict(reg.stats)

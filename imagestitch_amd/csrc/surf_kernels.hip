@@ -974,10 +974,209 @@ __device__ __forceinline__ float bilinear_pk(uint32_t top, float a, float b)
 #ifndef STAGE_ILP
 #define STAGE_ILP 4
 #endif
-#define UNIT_W (8 * STAGE_ILP)    // columns of a work unit
+#define UNIT_W (8 * STAGE_ILP)    // columns of a work unit (round-4 form; the balanced form below cuts its own blocks)
 #ifndef BORDER_ILP
 #define BORDER_ILP 2            // strips that cross the image border: shorter trips keep the register budget of the hot path
 #endif
+#if !(VFSMS_EXP & 4)
+// ---- interior rounds of the balanced form -----------------------------------------------------------------------------------------
+// N samples of one lane, 8 columns apart, starting at column j0 + lj of the lane's row: positions px0 + 8 u c (8 c, 16 c, 24 c are exact
+// doubles, so the sum rounds like start + j * step whenever that is exact), N gathers issued back to back, then the arithmetic; the LDS
+// bytes go to wrow + 8 u -- immediate offsets of ds_write_b8, no address arithmetic per sample.
+template <int N>
+__device__ __forceinline__ void stage_round(g_cu8 ubase, const uint32_t pw, const double c, const double sn, const double sxc, const double syc,
+                                            const int jlane, uint8_t *wrow)
+{
+    uint32_t top[N];
+    double px[N], py[N];
+    const double jd = (double)jlane;
+    px[0] = __builtin_fma(jd, c, sxc); py[0] = __builtin_fma(jd, -sn, syc);     // start + j * step: the product is exact in double
+#pragma unroll
+    for (int u = 1; u < N; u++) { px[u] = px[0] + (double)(8 * u) * c; py[u] = py[0] - (double)(8 * u) * sn; }
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        const uint32_t off = ((uint32_t)__umul24((uint32_t)(int)py[u], pw) + (uint32_t)(int)px[u]) << 1;
+        top[u] = *(GAS const uint32_t *)(ubase + off);              // 2-byte-aligned dword gather, uniform base + 32-bit offset
+    }
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
+        wrow[8 * u] = round_u8_pos(bilinear_pk(top[u], a, b));
+    }
+}
+
+// Balanced form (round 5).  A work unit is (strip of 8 rows) x (a run of 8-column GROUPS): the G8 = ceil(win / 8) groups of a row are cut
+// into nb runs of floor / ceil(G8 / nb) groups -- at most 8 (64 columns) --, so that no unit is padded: the round-4 form cut 32-column
+// blocks from the left, and a 140-px window cost five of them (160 columns), a 42-px one two (64).  A unit samples its groups in rounds of
+// four (then 3, 2 or 1: a round is code of its own, stage_round<N>), its bookkeeping -- row origins, interior flag, LDS row, first column
+// as a double -- is paid once per up to 8 samples of a lane instead of once per 4, and the group that hangs over the window's last column
+// (win % 8 != 0) is a clamped round of its own, done by the unit that holds the row's last run.
+template <int NW>                                              // NW waves share the strips (4: the workgroup; 1: one wave on its own)
+__device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row, const float *sy_row,
+                                           int r0, int nrows, uint8_t *dst, uint8_t *strip_in)
+{
+    // everything that is the same for the whole wave is pinned to SGPRs (the compiler cannot know that a keypoint read through a
+    // ticket index, or threadIdx.x >> 6, is wave-uniform): the unit bookkeeping below then runs on the scalar unit, not on the VALU
+    // that bounds this kernel
+    const int win = __builtin_amdgcn_readfirstlane(G.win);
+    r0 = __builtin_amdgcn_readfirstlane(r0); nrows = __builtin_amdgcn_readfirstlane(nrows);
+    const int lane = threadIdx.x & 63, wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int li = lane >> 3, lj = lane & 7;
+    const int strips = (nrows + 7) >> 3;
+    const double c = (double)G.cos_dir, sn = (double)G.sin_dir;
+    const int ncols1 = __builtin_amdgcn_readfirstlane(G.w) - 1, nrows1 = __builtin_amdgcn_readfirstlane(G.h) - 1;
+    // Samples read the ROW-PAIR image (k_pair_rows): element (y, x) = pixel (y, x) | pixel (y + 1, x) << 8, so the four taps of a
+    // bilinear sample are ONE dword at element (iy, ix) -- bytes t00, t10, t01, t11.  Its base is the same for the whole workgroup:
+    // pinned to SGPRs so gathers use scalar-base + 32-bit-offset addressing.
+    const uint64_t bp = (uint64_t)G.pair;
+    // (readfirstlane returns int: widen through uint32_t, or a low half with bit 31 set sign-extends into the high half)
+    g_cu8 ubase = (g_cu8)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32)) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)bp));
+    const uint32_t pw = (uint32_t)(ncols1 + 1);                  // pitch of the pair image in elements
+    // the cut of a row into runs of groups: full groups only (the partial last group is the tail round of the last run)
+    const int gfull = win >> 3, tailc = win & 7;                 // win >= 21: gfull >= 2
+    int nb = (gfull + 7) >> 3;                                   // runs of at most 8 groups
+#if VFSMS_EXP & 16
+    nb = (gfull + 3) >> 2;                                       // (experiment: runs of at most 4 groups, the round-4 unit size without its padding)
+#endif
+    if (NW > 1 && !(VFSMS_EXP & (8 | 16))) {
+        // more, shorter runs when the waves would otherwise end unevenly: cost = (units of the busiest wave) x (bookkeeping + samples of a unit)
+        int best = 0x7fffffff, best_nb = nb;
+        for (int t = nb; t <= ((gfull + 3) >> 2); t++) {
+            const int per = (gfull + t - 1) / t;
+            const int cost = ((strips * t + NW - 1) / NW) * (6 + 7 * per);
+            if (cost < best) { best = cost; best_nb = t; }
+        }
+        nb = best_nb;
+    }
+    const int gbase = gfull / nb, grem = gfull - gbase * nb;     // run b holds gbase + (b < grem) groups and starts at b gbase + min(b, grem)
+    const int total = strips * nb;
+    // Which strips lie inside the image as a whole (all `win` columns)?  One lane per strip answers once for everybody (separable
+    // extremes: row-origin extreme + column-step extreme, over the full width); units of such strips skip their own test.
+    if (!G.upright) {
+        const int tid = NW == 1 ? lane : (int)threadIdx.x;
+        if (tid < strips) {
+            const int ia = min(r0 + tid * 8, VFSMS_MAX_WIN - 1), ib = min(min(r0 + tid * 8 + 7, r0 + nrows - 1), VFSMS_MAX_WIN - 1);
+            const double xa = (double)sx_row[ia], xb = (double)sx_row[ib], ya = (double)sy_row[ia], yb = (double)sy_row[ib];
+            const double jb = (double)(win - 1);
+            const double jxb = jb * c, jyb = -(jb * sn);
+            const double xmin = fmin(xa, xb) + fmin(0.0, jxb), xmax = fmax(xa, xb) + fmax(0.0, jxb);
+            const double ymin = fmin(ya, yb) + fmin(0.0, jyb), ymax = fmax(ya, yb) + fmax(0.0, jyb);
+            strip_in[tid] = xmin >= 0.0 && ymin >= 0.0 && xmax < (double)(ncols1 - 2) && ymax < (double)nrows1;
+        }
+        if (NW == 1) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    }
+    int ty = 0, cbi = wv;                                        // (strip, run) of the wave's current unit; stepped, not divided
+    while (cbi >= nb) { cbi -= nb; ty++; }
+#ifdef VFSMS_DESC_TIMING
+    unsigned long long _s0 = clock64(), _uacc[2] = {0, 0}, _ucnt[2] = {0, 0};
+#endif
+    const int last_row = r0 + nrows - 1;                         // (<= win - 1 < VFSMS_MAX_WIN)
+    const int liw = li * win;                                    // the lane's row inside a strip, as an LDS offset
+    const int last_off = (nrows - 1) * win;
+    // The row origins and the strip flag of a unit sit at the head of its dependency chain (LDS read -> f64 position -> address ->
+    // gather): they are fetched ONE UNIT AHEAD, so the chain of a unit starts with values that are already in registers.
+    float nsx = 0.f, nsy = 0.f; int nflag = 0;
+    if (wv < total) {
+        const int ic0 = min(r0 + ty * 8 + li, last_row);
+        nsx = sx_row[ic0]; nsy = sy_row[ic0]; nflag = strip_in[ty];
+    }
+    for (int unit = wv; unit < total; unit += NW) {
+        DT_UNIT_BEGIN;
+        const int g0 = cbi * gbase + min(cbi, grem), gn = gbase + (cbi < grem ? 1 : 0);
+        const bool last_run = cbi == nb - 1;
+        const int cb0 = g0 * 8;
+        const int cb1 = last_run ? win : cb0 + gn * 8;
+        // a lane past the strip's last row repeats that row: same position, same value, same LDS byte
+        const double sxc = (double)nsx, syc = (double)nsy;
+        const int flag_cur = nflag;
+        const int ty_cur = ty;
+        uint8_t *drc = dst + min(ty * 8 * win + liw, last_off);
+        cbi += NW;
+        while (cbi >= nb) { cbi -= nb; ty++; }
+        if (unit + NW < total) {
+            const int icn = min(r0 + ty * 8 + li, last_row);
+            nsx = sx_row[icn]; nsy = sy_row[icn]; nflag = strip_in[ty];
+        }
+        if (G.upright) {
+            for (int j = cb0 + lj; j < cb1; j += 8) drc[j] = (uint8_t)win_sample_upright(G, min(r0 + ty_cur * 8 + li, last_row), j);
+            continue;
+        }
+        // Unit-level interior test: x = origin(row) + j * c is separable, rows are monotone, so the extremes of the unit's samples are
+        // (extreme row origin) + (extreme of j * c).  A unit inside the image (with the 2 px of slack the dword taps need) runs
+        // without any per-sample bounds logic.
+        bool unit_in = __builtin_amdgcn_readfirstlane(flag_cur) != 0;
+        if (!unit_in) {
+            const int ia = min(r0 + ty_cur * 8, VFSMS_MAX_WIN - 1), ib = min(min(r0 + ty_cur * 8 + 7, last_row), VFSMS_MAX_WIN - 1);
+            const double xa = (double)sx_row[ia], xb = (double)sx_row[ib], ya = (double)sy_row[ia], yb = (double)sy_row[ib];
+            const double ja = (double)cb0, jb = (double)(cb1 - 1);
+            const double jxa = ja * c, jxb = jb * c, jya = -(ja * sn), jyb = -(jb * sn);
+            const double xmin = fmin(xa, xb) + fmin(jxa, jxb), xmax = fmax(xa, xb) + fmax(jxa, jxb);
+            const double ymin = fmin(ya, yb) + fmin(jya, jyb), ymax = fmax(ya, yb) + fmax(jya, jyb);
+            unit_in = xmin >= 0.0 && ymin >= 0.0 && xmax < (double)(ncols1 - 2) && ymax < (double)nrows1;
+        }
+        if (unit_in) {
+            // No predicates here: every lane gathers from inside the tested unit, the loads keep the scalar-base form and there is no
+            // exec-mask bookkeeping around them.
+            DT_TRIP(0);
+            uint8_t *wrow = drc + cb0 + lj;
+            int jl = cb0 + lj, left = gn;
+            while (left >= 4) { stage_round<4>(ubase, pw, c, sn, sxc, syc, jl, wrow); jl += 32; wrow += 32; left -= 4; }
+            if (left == 3) stage_round<3>(ubase, pw, c, sn, sxc, syc, jl, wrow);
+            else if (left == 2) stage_round<2>(ubase, pw, c, sn, sxc, syc, jl, wrow);
+            else if (left == 1) stage_round<1>(ubase, pw, c, sn, sxc, syc, jl, wrow);
+            if (last_run && tailc) {
+                // the group that hangs over the last column: lanes past it repeat that column (same position, same byte)
+                const int jc = min(gfull * 8 + lj, win - 1);
+                stage_round<1>(ubase, pw, c, sn, sxc, syc, jc, drc + jc);
+            }
+            DT_UNIT_END(0);
+            continue;
+        }
+        // The unit crosses the image border.  No branch per sample: every lane gathers at clamped coordinates -- the bilinear taps
+        // when (ix, iy) is interior, the nearest pixel clamp(cvRound(px), cvRound(py)) otherwise -- and selects at the end.
+        DT_TRIP(2);
+        for (int jb = cb0; jb < cb1; jb += 8 * BORDER_ILP) {
+            double px[BORDER_ILP], py[BORDER_ILP];
+            int jc[BORDER_ILP];
+            uint32_t q0[BORDER_ILP], q1[BORDER_ILP];          // pair elements (cy, cx) and (cy, cx1): two 16-bit gathers, not four bytes
+            bool inside[BORDER_ILP];
+#pragma unroll
+            for (int u = 0; u < BORDER_ILP; u++) {
+                jc[u] = min(jb + u * 8 + lj, cb1 - 1);
+                px[u] = sxc + (double)jc[u] * c;
+                py[u] = syc - (double)jc[u] * sn;
+                const int ix = (int)px[u], iy = (int)py[u];                       // trunc == floor wherever `inside` holds
+                inside[u] = px[u] >= 0.0 && py[u] >= 0.0 && ix < ncols1 && iy < nrows1;
+                const int rx = min(max(cv_round_d(px[u]), 0), ncols1), ry = min(max(cv_round_d(py[u]), 0), nrows1);
+                const int cx = inside[u] ? ix : rx, cy = inside[u] ? iy : ry;
+                const int cx1 = min(cx + 1, ncols1);
+                const uint32_t o0 = (uint32_t)__umul24((uint32_t)cy, pw);
+                q0[u] = *(GAS const uint16_t *)(ubase + ((o0 + (uint32_t)cx) << 1));
+                q1[u] = *(GAS const uint16_t *)(ubase + ((o0 + (uint32_t)cx1) << 1));
+            }
+#pragma unroll
+            for (int u = 0; u < BORDER_ILP; u++) {
+                const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
+                // the high bytes are row min(cy + 1, h - 1): the clamped lower taps
+                const float v = (uint8_t)(q0[u] & 0xff) * (1.f - a) * (1.f - b) + (uint8_t)(q1[u] & 0xff) * a * (1.f - b) +
+                                (uint8_t)(q0[u] >> 8) * (1.f - a) * b + (uint8_t)(q1[u] >> 8) * a * b;
+                drc[jc[u]] = inside[u] ? (uint8_t)cv_round_f(v) : (uint8_t)(q0[u] & 0xff);
+            }
+        }
+        DT_UNIT_END(1);
+    }
+#ifdef VFSMS_DESC_TIMING
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_desc_unit_cycles[2], clock64() - _s0);
+        atomicAdd(&g_desc_unit_cycles[0], _uacc[0]); atomicAdd(&g_desc_unit_cycles[1], _uacc[1]);
+        atomicAdd(&g_desc_trips[0], _ucnt[0]); atomicAdd(&g_desc_trips[2], _ucnt[1]);
+    }
+#endif
+}
+#else
+// ---- round-4 form (VFSMS_EXP & 4: kept for A/B timing against the balanced form) ------------------------------------------------
 template <int NW>                                              // NW waves share the strips (4: the workgroup; 1: one wave on its own)
 __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row, const float *sy_row,
                                            int r0, int nrows, uint8_t *dst, uint8_t *strip_in)
@@ -1153,6 +1352,8 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
     }
 #endif
 }
+
+#endif
 
 __device__ __forceinline__ uint8_t sat_u8(float v)
 {

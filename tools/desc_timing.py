@@ -3,7 +3,7 @@ import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from imagestitch_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvfsms_timing.so")
+_lib.LIB_PATH = os.path.abspath(os.environ.get("VFSMS_TIMING_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvfsms_timing.so"))
 import imagestitch_amd as isa
 from imagestitch_amd.synthetic import SyntheticGrid
 eng = isa.Engine(0)
