@@ -813,7 +813,15 @@ def main():
     roofline = None
     extra = {}
     roi_h, roi_w = isa.roi_rect((grid.th, grid.tw), 1, "first", 0.2)[2:]
-    de_ms, de_n = prof.get("describe", (0.0, 0))
+    # A "launch" of the rooflines below is one launch GROUP = one fused batch of the registrar.  Since round 5 a large batch is cut in two parts
+    # (the 2-NN search of part 0 runs on a second stream beside the detect stage of part 1, csrc/api.hip: attempt_surf_impl), so a stage may be
+    # enqueued twice per batch and the stages of the second stream carry "@s2": times are summed per stage, divided by the batches.
+    groups = int(st["batches"])
+
+    def stage(name):
+        a, b = prof.get(name, (0.0, 0)), prof.get(name + "@s2", (0.0, 0))
+        return (a[0] + b[0], groups if (a[1] + b[1]) else 0)
+    de_ms, de_n = stage("describe")
     if de_n and args.method == "surf":
         # dominant kernels: k_describe + k_describe_small (descriptor windows).  Until the row-pair image they were bound by the
         # texture-address path (TA busy 73 % of the launch: two gathers per sample); with one gather per sample the VALU is the
@@ -851,7 +859,7 @@ def main():
                         valu_issued_over_lower_bound=valu_over_bound(spk),
                         per_launch_pmc_note="PMC figures are per launch OF THE PMC RUN (its launches need not have this run's size); the ratio "
                                             "valu_issued_over_lower_bound is formed from counter TOTALS and the keypoints that run described (pmc_run line)")
-    bf_ms, bf_n = prof.get("bf_mfma", (0.0, 0))
+    bf_ms, bf_n = stage("bf_mfma")
     if bf_n:
         dur = bf_ms / bf_n * 1e-3
         flops = 2.0 * 64 * st["sum_nq_nt"] / bf_n                         # one 64-d dot product per (query, train)
@@ -872,13 +880,13 @@ def main():
                                         "; the exact distances are evaluated by k_bf_verify_d64 for the few surviving candidates")
         extra["bf_l2_hbm"] = dict(bound="hbm", achieved=round(bytes_ / dur / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                                   frac=round(bytes_ / dur / 1e9 / HBM_PEAK_GBS, 5), bytes_per_launch=bytes_)
-    in_ms, in_n = prof.get("integral", (0.0, 0))
+    in_ms, in_n = stage("integral")
     if in_n:
         # algorithmic bytes of cv::integral per ROI: h*w (u8 in) + 4 (h+1)(w+1) (i32 out) ~ 5 B/px
         extra["integral_hbm"] = hbm_roofline("k_integral_final+k_integral_bandsum+k_integral_bandscan", st["roi_px"] / in_n * 5.0, in_ms / in_n, in_n)
         tr = [pmc_traffic_scaled(k, st["attempts"] / in_n)[0] for k in ("k_integral_final", "k_integral_bandsum", "k_integral_bandscan")]
         extra["integral_hbm"]["traffic"] = sum(tr) if all(v is not None for v in tr) else None
-    he_ms, he_n = prof.get("hessian", (0.0, 0))
+    he_ms, he_n = stage("hessian")
     if he_n:
         # reads S once per octave pass 4 (h+1)(w+1) x 4 + writes det + trace 8 x sum_o 5 (h/2^o)(w/2^o) = 69.1 B/px
         extra["hessian_hbm"] = hbm_roofline("k_hessian_lds<1,64>+k_hessian_lds<2,32>+k_hessian_coarse(octaves 2, 3)", st["roi_px"] / he_n * 69.1, he_ms / he_n, he_n)
@@ -958,6 +966,10 @@ def main():
             "pmc": pmc_info,
             "cpu_baseline": cpu,
             "stages": stages,
+            "stages_sum_ms_per_step": round(sum(v[0] for v in prof.values()) / max(args.steps, 1), 3),
+            "stages_second_stream_ms_per_step": round(sum(v[0] for k, v in prof.items() if k.endswith("@s2")) / max(args.steps, 1), 3),
+            "overlap_note": "stages named @s2 were enqueued on the second compute stream (2-NN search + vote of the first part of a batch beside the detect "
+                            "stage of the second part): ms_per_step < stages_sum_ms_per_step by what the two pipes hid of each other",
             "per_rank": per_rank,
             "collective": (dict(backend=dist.get_backend(), world_size=dist.get_world_size(), device=str(coll_device), rank_devices=devs,
                                 prediction_repair_rounds=getattr(reg, "hint_repairs", 0),

@@ -60,8 +60,12 @@ int prof_begin(vfsms_ctx *ctx, const char *name)
 {
     if (!ctx->prof_on) return -1;
     int id = -1;
-    for (size_t k = 0; k < ctx->prof_names.size(); k++) if (ctx->prof_names[k] == name) { id = (int)k; break; }
-    if (id < 0) { id = (int)ctx->prof_names.size(); ctx->prof_names.push_back(name); ctx->prof_ms.push_back(0.0); ctx->prof_calls.push_back(0); }
+    // stages enqueued on the second compute stream are booked under their own name ("bf_mfma@s2"): they run beside the first stream's stages,
+    // so the per-stage times of a step no longer add up to its wall clock -- the reader sees which ones overlapped
+    std::string key(name);
+    if (ctx->stream2 && ctx->stream == ctx->stream2) key += "@s2";
+    for (size_t k = 0; k < ctx->prof_names.size(); k++) if (ctx->prof_names[k] == key) { id = (int)k; break; }
+    if (id < 0) { id = (int)ctx->prof_names.size(); ctx->prof_names.push_back(key); ctx->prof_ms.push_back(0.0); ctx->prof_calls.push_back(0); }
     ProfRec r; r.id = id;
     for (hipEvent_t *e : {&r.a, &r.b}) {
         if (!ctx->prof_pool.empty()) { *e = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); }
@@ -239,6 +243,9 @@ extern "C" int vfsms_ctx_destroy(vfsms_ctx *ctx)
     for (auto &pb : ctx->pin_pool) hipHostFree(pb.ptr);
     for (hipEvent_t ev : ctx->event_pool) hipEventDestroy(ev);
     hipStreamDestroy(ctx->copy_stream);
+    if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); }
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     for (auto &kv : ctx->canvases) { hipFree(kv.second.pix); hipFree(kv.second.mask); hipFree(kv.second.d_err); hipFree(kv.second.scratch); }
     for (auto &kv : ctx->feats) if (!kv.second.block) { if (kv.second.kps_xy) hipFree(kv.second.kps_xy); if (kv.second.desc) hipFree(kv.second.desc); }
     for (auto &kv : ctx->feat_blocks) hipFree(kv.second.base);
@@ -1004,6 +1011,22 @@ extern "C" int vfsms_attempt_phase_batch(vfsms_ctx *ctx, const vfsms_roi_pair *j
 }
 
 // ---- fused SURF + BF + ratio + mode attempts --------------------------------------------------------------------------------
+// the second compute stream and its fork / join events (created on first use)
+static int ctx_second_stream(vfsms_ctx *ctx)
+{
+    if (ctx->stream2) return VFSMS_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    return VFSMS_OK;
+}
+// ctx->stream is what every launcher enqueues on: swapped for a scope, restored on every way out of it
+struct StreamSwap {
+    vfsms_ctx *c; hipStream_t saved;
+    StreamSwap(vfsms_ctx *ctx, hipStream_t s) : c(ctx), saved(ctx->stream) { ctx->stream = s; }
+    ~StreamSwap() { c->stream = saved; }
+};
+
 static int attempt_surf_impl(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, const vfsms_surf_params *params, double ratio,
                              int offset_evaluate, int enh_mode, double clip_limit, int tile_grid, int32_t *out)
 {
@@ -1071,11 +1094,37 @@ static int attempt_surf_impl(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, 
         TRY(launch_enhance(ctx, dE, E.data(), 2 * n, enh_mode, clip_limit, tile_grid));
     }
     HIP_TRY(hipMemsetAsync(cblock, 0, sizeof(int) * 16 * 2 * n, ctx->stream));
-    TRY(launch_surf_detect(ctx, dR, R.data(), 2 * n, params));
-    TRY(launch_surf_describe(ctx, dR, R.data(), 2 * n, params));
-    if (filtered) { TRY(launch_bf_l2_filtered(ctx, dM, n, maxcap, maxcap, cns)); }
-    else { TRY(launch_bf_l2(ctx, dM, n, maxcap, ns, dim)); }
-    TRY(launch_ratio_mode(ctx, dM, n, maxcap, ratio, offset_evaluate));
+    // Two pipes at once.  The 2-NN search lives on the matrix cores (k_bf_mfma16_d64: MFMA pipe 55-65 % busy, VALU idle), detection on the
+    // VALU and the texture-address path (Hessian 97 % VALU, coarse octaves TA 0.95).  A large batch is therefore cut in two parts of slots:
+    // part 0 (~70 %) is detected and described, then its search + ratio + vote are handed to the second stream and run BESIDE the detect
+    // stage of part 1 on the first (the persistent descriptor kernel takes every CU's LDS: what overlaps is integral / Hessian / NMS /
+    // sort / orientation of part 1); part 1's own search follows its descriptors on the first stream.  Every attempt is independent
+    // (Stitcher.py:64-79), every buffer belongs to one slot: same kernels, same results.  VFSMS_OVERLAP=0 keeps the single stream.
+    static const bool overlap_on = !(getenv("VFSMS_OVERLAP") && atoi(getenv("VFSMS_OVERLAP")) == 0);
+    static const int overlap_pct = getenv("VFSMS_OVERLAP_PCT") ? atoi(getenv("VFSMS_OVERLAP_PCT")) : 70;
+    const int n0 = (overlap_on && filtered && n >= 12) ? std::min(n - 2, std::max(2, n * overlap_pct / 100)) : n;
+    if (n0 < n) TRY(ctx_second_stream(ctx));
+    TRY(launch_surf_detect(ctx, dR, R.data(), 2 * n0, params));
+    TRY(launch_surf_describe(ctx, dR, R.data(), 2 * n0, params));
+    if (n0 < n) {
+        HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        {
+            StreamSwap on_second(ctx, ctx->stream2);              // the launchers enqueue on ctx->stream (their profiling events too)
+            TRY(launch_bf_l2_filtered(ctx, dM, n0, maxcap, maxcap, cns));
+            TRY(launch_ratio_mode(ctx, dM, n0, maxcap, ratio, offset_evaluate));
+            HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
+        }
+        TRY(launch_surf_detect(ctx, dR + 2 * n0, R.data() + 2 * n0, 2 * (n - n0), params));
+        TRY(launch_surf_describe(ctx, dR + 2 * n0, R.data() + 2 * n0, 2 * (n - n0), params));
+        TRY(launch_bf_l2_filtered(ctx, dM + n0, n - n0, maxcap, maxcap, cns));
+        TRY(launch_ratio_mode(ctx, dM + n0, n - n0, maxcap, ratio, offset_evaluate));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    } else {
+        if (filtered) { TRY(launch_bf_l2_filtered(ctx, dM, n, maxcap, maxcap, cns)); }
+        else { TRY(launch_bf_l2(ctx, dM, n, maxcap, ns, dim)); }
+        TRY(launch_ratio_mode(ctx, dM, n, maxcap, ratio, offset_evaluate));
+    }
     std::vector<int> counters((size_t)16 * 2 * n);
     HIP_TRY(hipMemcpyAsync(counters.data(), cblock, sizeof(int) * 16 * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(out, rblock, sizeof(int32_t) * VFSMS_ATTEMPT_INTS * n, hipMemcpyDeviceToHost, ctx->stream));

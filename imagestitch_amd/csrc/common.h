@@ -165,6 +165,9 @@ struct vfsms_ctx {
     std::mutex stage_mu; std::vector<StageBuf> stage_pool;   // device staging buffers of the decoder threads (vfsms_tile_fill_pair), the pools they share
     std::vector<StageBuf> pin_pool;                          // pinned host staging of the same threads (also under stage_mu)
     hipStream_t copy_stream;                                  // H2D uploads of tiles, overlapped with compute (vfsms_tile_upload_async)
+    // second compute stream: the MFMA-bound 2-NN search of the first part of a batch runs on it beside the VALU / TA-bound detect stage of
+    // the second part (attempt_surf_impl); created on first use, always joined back into `stream` before a call returns
+    hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<PoolEnt> tile_pool;      // freed tile buffers, reused by allocation size (no hipMalloc / hipFree per step)
     size_t tile_pool_bytes = 0;
     std::vector<hipEvent_t> event_pool;

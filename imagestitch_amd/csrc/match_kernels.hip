@@ -775,9 +775,9 @@ __global__ __launch_bounds__(256) void k_votes_from_pairs(const MatchDev *jobs, 
 // the most frequent tuple, ties to the first inserted -- Method.getOffsetByMode's dict order + stable sort (ImageUtility.py:165-168) --
 // in O(M) instead of the O(M^2) equality count (100 us per launch on SURF batches, 230 us on ORB's 5000 unconditional votes).
 #define MODE_SLOTS 8192
-#define MODE_HASH_MAX 5600
+#define MODE_HASH_MAX 5600         // votes per pass of the table (ORB votes 5000 times: one pass); more are dealt to several passes
 // three uint32[8192] tables = 96 KB of static LDS: this kernel needs gfx950's 160 KB per CU (the library is gfx950-only: README, Makefile);
-// a 64 KB-LDS target would have to shrink MODE_SLOTS and send more votes through the O(M^2) fallback above MODE_HASH_MAX
+// a 64 KB-LDS target would have to shrink MODE_SLOTS and run more passes (MODE_HASH_MAX)
 static_assert(3 * MODE_SLOTS * sizeof(uint32_t) <= 160 * 1024 - 16 * 1024, "k_scan_mode's hash tables are sized for the 160 KB LDS of gfx950");
 __global__ __launch_bounds__(1024) void k_scan_mode(const MatchDev *jobs, int offset_evaluate)
 {
@@ -818,37 +818,38 @@ __global__ __launch_bounds__(1024) void k_scan_mode(const MatchDev *jobs, int of
     if (threadIdx.x == 0) { J.mcount[0] = nm; J.mcount[1] = nv; J.mcount[2] = 0; J.mcount[3] = 0; }
     __threadfence_block();
     __syncthreads();
-    if (nv > MODE_HASH_MAX) {
-        // more votes than the table takes (never seen: SURF's ratio test keeps 1-2 k matches, ORB votes at most 5000 times): every vote
-        // counts its equals and the first occurrence of each tuple bids, the O(M^2) form of k_mode_count inside this workgroup
-        const long long *V = reinterpret_cast<const long long *>(J.votes);
+    // insert: key = (dx + 32768) << 16 | (dy + 32768); offsets beyond +-32767 px cannot occur (tiles are <= 8192 px).
+    // More votes than one table takes (configs[4]: 37 k keypoints per 819 x 4096 strip leave 6-9 k matches; round 4 sent those
+    // through an O(M^2) equality count, 25 ms per launch): the votes are dealt to P passes by a second hash of the key -- equal tuples meet in
+    // one pass, every pass fills a cleared table and bids (count, -first index) into `best`, so the winner is still the most frequent tuple,
+    // ties to the first inserted (ImageUtility.py:165-168).
+    const int P = (nv + MODE_HASH_MAX - 1) / MODE_HASH_MAX;
+    for (int pass = 0; pass < P; pass++) {
+        if (pass > 0) {
+            __syncthreads();
+            for (int s = threadIdx.x; s < MODE_SLOTS; s += 1024) { hkey[s] = 0u; hcnt[s] = 0u; hfirst[s] = 0xFFFFFFFFu; }
+            __syncthreads();
+        }
         for (int i = threadIdx.x; i < nv; i += 1024) {
-            const long long me = V[i];
-            unsigned cnt = 0; bool first = true;
-            for (int k = 0; k < nv; k++) { const bool eq = V[k] == me; cnt += eq ? 1u : 0u; if (eq && k < i) first = false; }
-            if (first) atomicMax(&best, ((unsigned long long)cnt << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i));
+            const int dx = J.votes[2 * (size_t)i], dy = J.votes[2 * (size_t)i + 1];
+            const uint32_t key = ((uint32_t)(dx + 32768) << 16) | ((uint32_t)(dy + 32768) & 0xffffu);
+            if (P > 1 && (int)(((key ^ (key >> 15)) * 0x9E3779B1u >> 8) % (uint32_t)P) != pass) continue;
+            uint32_t h = (key * 2654435761u) >> 19;             // 13 bits
+            for (;;) {
+                const uint32_t old = atomicCAS(&hkey[h], 0u, key);
+                if (old == 0u || old == key) { atomicAdd(&hcnt[h], 1u); atomicMin(&hfirst[h], (uint32_t)i); break; }
+                h = (h + 1) & (MODE_SLOTS - 1);
+            }
         }
-    } else {
-    // insert: key = (dx + 32768) << 16 | (dy + 32768); offsets beyond +-32767 px cannot occur (tiles are <= 8192 px)
-    for (int i = threadIdx.x; i < nv; i += 1024) {
-        const int dx = J.votes[2 * (size_t)i], dy = J.votes[2 * (size_t)i + 1];
-        const uint32_t key = ((uint32_t)(dx + 32768) << 16) | ((uint32_t)(dy + 32768) & 0xffffu);
-        uint32_t h = (key * 2654435761u) >> 19;             // 13 bits
-        for (;;) {
-            const uint32_t old = atomicCAS(&hkey[h], 0u, key);
-            if (old == 0u || old == key) { atomicAdd(&hcnt[h], 1u); atomicMin(&hfirst[h], (uint32_t)i); break; }
-            h = (h + 1) & (MODE_SLOTS - 1);
-        }
-    }
-    __syncthreads();
-    unsigned long long mine = 0ull;
-    for (int s = threadIdx.x; s < MODE_SLOTS; s += 1024)
-        if (hcnt[s]) {
-            const unsigned long long bid = ((unsigned long long)hcnt[s] << 32) | (unsigned long long)(0xFFFFFFFFu - hfirst[s]);
-            mine = bid > mine ? bid : mine;
-        }
-    for (int d = 32; d > 0; d >>= 1) { const unsigned long long o = __shfl_down(mine, d, 64); mine = o > mine ? o : mine; }
-    if (lane == 0 && mine) atomicMax(&best, mine);
+        __syncthreads();
+        unsigned long long mine = 0ull;
+        for (int s = threadIdx.x; s < MODE_SLOTS; s += 1024)
+            if (hcnt[s]) {
+                const unsigned long long bid = ((unsigned long long)hcnt[s] << 32) | (unsigned long long)(0xFFFFFFFFu - hfirst[s]);
+                mine = bid > mine ? bid : mine;
+            }
+        for (int d = 32; d > 0; d >>= 1) { const unsigned long long o = __shfl_down(mine, d, 64); mine = o > mine ? o : mine; }
+        if (lane == 0 && mine) atomicMax(&best, mine);
     }
     __syncthreads();
     if (threadIdx.x == 0) {

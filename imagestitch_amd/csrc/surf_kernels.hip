@@ -1035,20 +1035,13 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
     const uint32_t pw = (uint32_t)(ncols1 + 1);                  // pitch of the pair image in elements
     // the cut of a row into runs of groups: full groups only (the partial last group is the tail round of the last run)
     const int gfull = win >> 3, tailc = win & 7;                 // win >= 21: gfull >= 2
-    int nb = (gfull + 7) >> 3;                                   // runs of at most 8 groups
+    // runs of at most 8 groups.  (Measured, fixed 16-pair batch: shorter runs -- at most 4 groups, the round-4 unit size without its padding --
+    // +2.5 %; a per-call choice of the run count by a cost model of the busiest wave +4 %: its scalar divisions cost more than the even
+    // finish buys.)
+    int nb = (gfull + 7) >> 3;
 #if VFSMS_EXP & 16
-    nb = (gfull + 3) >> 2;                                       // (experiment: runs of at most 4 groups, the round-4 unit size without its padding)
+    nb = (gfull + 3) >> 2;
 #endif
-    if (NW > 1 && !(VFSMS_EXP & (8 | 16))) {
-        // more, shorter runs when the waves would otherwise end unevenly: cost = (units of the busiest wave) x (bookkeeping + samples of a unit)
-        int best = 0x7fffffff, best_nb = nb;
-        for (int t = nb; t <= ((gfull + 3) >> 2); t++) {
-            const int per = (gfull + t - 1) / t;
-            const int cost = ((strips * t + NW - 1) / NW) * (6 + 7 * per);
-            if (cost < best) { best = cost; best_nb = t; }
-        }
-        nb = best_nb;
-    }
     const int gbase = gfull / nb, grem = gfull - gbase * nb;     // run b holds gbase + (b < grem) groups and starts at b gbase + min(b, grem)
     const int total = strips * nb;
     // Which strips lie inside the image as a whole (all `win` columns)?  One lane per strip answers once for everybody (separable

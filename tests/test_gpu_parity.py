@@ -1486,3 +1486,35 @@ def test_full_width_dendritic_strips_surf_and_orb_equal_the_oracle_rows(engine, 
             assert abs(off[0] - m["gold"][0]) <= 1 and abs(off[1] - m["gold"][1]) <= 1, (m["a"], off, m["gold"])
     for h in hs:
         engine.tile_free(h)
+
+
+@pytest.mark.gpu
+def test_mode_vote_beyond_one_hash_table_equals_the_oracle(engine, oracle):
+    """Method.getOffsetByMode (ImageUtility.py:150-170) with MORE votes than one pass of k_scan_mode's LDS table takes (> 5600: configs[4]'s
+    819 x 4096 strips leave 6-9 k ratio-test survivors): the votes go through several passes of the table, dealt by a hash of the tuple.  The
+    most frequent (dx, dy), ties to the tuple that occurs FIRST in match order, and its count equal the oracle's for planted ties (two
+    tuples with the same count in both orders), a dominant mode, all-distinct tuples and zero votes."""
+    rng = np.random.default_rng(321)
+
+    def case(n, tuples, counts, shuffle_seed):
+        """n matches; tuple t is voted counts[t] times, the rest are distinct tuples"""
+        offs = []
+        for t, c in zip(tuples, counts):
+            offs += [t] * c
+        k = 0
+        while len(offs) < n:
+            offs.append((1000 + k % 4000, -3000 + k // 4000)); k += 1
+        offs = np.array(offs, np.int64)
+        np.random.default_rng(shuffle_seed).shuffle(offs)
+        kb = rng.integers(5000, 9000, (n, 2)).astype(np.float32)
+        ka = kb + offs[:, ::-1].astype(np.float32)            # vote = (int(yA - yB), int(xA - xB)): dx = rows, dy = columns
+        pairs = np.stack([np.arange(n), np.arange(n)], 1).astype(np.int32)
+        return ka, kb, pairs
+    cases = [case(9000, [(7, -3), (-12, 40)], [50, 50], 1), case(9000, [(7, -3), (-12, 40)], [50, 50], 2),
+             case(20000, [(3, 4)], [6000], 3), case(12000, [], [], 4), case(5601, [(1, 1), (2, 2), (0, 5)], [3, 3, 2], 5),
+             case(30000, [(9, 9), (8, 8)], [2, 3], 6)]
+    for ci, (ka, kb, pairs) in enumerate(cases):
+        for ev in (3, 10):
+            got = engine.mode_offset(ka, kb, pairs, ev)
+            want = oracle.mode_offset(ka, kb, pairs, ev)
+            assert (bool(got[0]), list(got[1]), int(got[2])) == (bool(want[0]), [int(want[1][0]), int(want[1][1])], int(want[2])), (ci, ev, got, want)
