@@ -1094,13 +1094,16 @@ static int attempt_surf_impl(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, 
         TRY(launch_enhance(ctx, dE, E.data(), 2 * n, enh_mode, clip_limit, tile_grid));
     }
     HIP_TRY(hipMemsetAsync(cblock, 0, sizeof(int) * 16 * 2 * n, ctx->stream));
-    // Two pipes at once.  The 2-NN search lives on the matrix cores (k_bf_mfma16_d64: MFMA pipe 55-65 % busy, VALU idle), detection on the
-    // VALU and the texture-address path (Hessian 97 % VALU, coarse octaves TA 0.95).  A large batch is therefore cut in two parts of slots:
-    // part 0 (~70 %) is detected and described, then its search + ratio + vote are handed to the second stream and run BESIDE the detect
-    // stage of part 1 on the first (the persistent descriptor kernel takes every CU's LDS: what overlaps is integral / Hessian / NMS /
-    // sort / orientation of part 1); part 1's own search follows its descriptors on the first stream.  Every attempt is independent
-    // (Stitcher.py:64-79), every buffer belongs to one slot: same kernels, same results.  VFSMS_OVERLAP=0 keeps the single stream.
-    static const bool overlap_on = !(getenv("VFSMS_OVERLAP") && atoi(getenv("VFSMS_OVERLAP")) == 0);
+    // Two pipes at once -- built, measured, OFF by default.  The 2-NN search lives on the matrix cores (k_bf_mfma16_d64: MFMA pipe 55-65 %
+    // busy, VALU idle), detection on the VALU and the texture-address path.  With VFSMS_OVERLAP=1 a large batch is cut in two parts of
+    // slots: part 0 (VFSMS_OVERLAP_PCT, default 70 %) is detected and described, then its search + ratio + vote run on the second stream
+    // BESIDE the detect stage of part 1 (the persistent descriptor kernel takes every CU's LDS, so what can overlap is integral / Hessian /
+    // NMS / sort / orientation of part 1).  Same kernels, same results (the GPU suite passes either way).  On the bench (A B A B, one call,
+    // profiles/r05_ab_overlap.txt): 52.03 ms per step on one stream, 52.85 with the overlap -- the second stream's 5.5 ms of stages do run
+    // concurrently (stage sum 57.4 ms against 52.8 ms of wall clock), but Hessian and integral slow down by what the search takes from
+    // them (8.95 vs 6.85 ms, 1.25 vs 0.38 ms) and the halved launches add their tails: these kernels fill the chip on their own, a second
+    // queue only re-divides it.  (Rounds 2-3 found the same for two half batches of the same mix.)
+    static const bool overlap_on = getenv("VFSMS_OVERLAP") && atoi(getenv("VFSMS_OVERLAP")) != 0;
     static const int overlap_pct = getenv("VFSMS_OVERLAP_PCT") ? atoi(getenv("VFSMS_OVERLAP_PCT")) : 70;
     const int n0 = (overlap_on && filtered && n >= 12) ? std::min(n - 2, std::max(2, n * overlap_pct / 100)) : n;
     if (n0 < n) TRY(ctx_second_stream(ctx));

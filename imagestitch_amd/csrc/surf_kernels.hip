@@ -1005,6 +1005,186 @@ __device__ __forceinline__ void stage_round(g_cu8 ubase, const uint32_t pw, cons
     }
 }
 
+#if VFSMS_EXP & 64
+// ---- software-pipelined form (VFSMS_EXP & 64) ------------------------------------------------------------------------------------------
+// The gathers of round n + 1 are issued BEFORE the arithmetic of round n: a wave always has four gathers in flight while it computes, instead
+// of issuing four, waiting for them and only then computing (the compiler orders a round as written; it does not rotate loops).  A round is
+// always four samples of a lane (8 columns apart); rounds are drawn from the wave's units one after the other -- across unit and strip
+// boundaries -- into two register sets used in turn.  The last round of a row clamps its columns to the window (lanes past it repeat the
+// last column: same position, same byte).
+struct StageRound { uint32_t top[4]; float a[4], b[4]; uint8_t *drc; int jl; };
+
+template <bool CLAMP>
+__device__ __forceinline__ void round_issue(StageRound &S, g_cu8 ubase, const uint32_t pw, const double c, const double sn, const double sxc,
+                                            const double syc, const int jl, uint8_t *drc, const int win)
+{
+    S.drc = drc; S.jl = jl;
+    double px[4], py[4];
+    if (!CLAMP) {
+        const double jd = (double)jl;
+        px[0] = __builtin_fma(jd, c, sxc); py[0] = __builtin_fma(jd, -sn, syc);
+#pragma unroll
+        for (int u = 1; u < 4; u++) { px[u] = px[0] + (double)(8 * u) * c; py[u] = py[0] - (double)(8 * u) * sn; }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const double jd = (double)min(jl + 8 * u, win - 1);
+            px[u] = __builtin_fma(jd, c, sxc); py[u] = __builtin_fma(jd, -sn, syc);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t off = ((uint32_t)__umul24((uint32_t)(int)py[u], pw) + (uint32_t)(int)px[u]) << 1;
+        S.top[u] = *(GAS const uint32_t *)(ubase + off);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { S.a[u] = (float)__builtin_amdgcn_fract(px[u]); S.b[u] = (float)__builtin_amdgcn_fract(py[u]); }
+}
+template <bool CLAMP>
+__device__ __forceinline__ void round_finish(const StageRound &S, const int win)
+{
+    uint8_t *w = S.drc + S.jl;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint8_t v = round_u8_pos(bilinear_pk(S.top[u], S.a[u], S.b[u]));
+        if (!CLAMP) w[8 * u] = v; else S.drc[min(S.jl + 8 * u, win - 1)] = v;
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row, const float *sy_row,
+                                           int r0, int nrows, uint8_t *dst, uint8_t *strip_in)
+{
+    const int win = __builtin_amdgcn_readfirstlane(G.win);
+    r0 = __builtin_amdgcn_readfirstlane(r0); nrows = __builtin_amdgcn_readfirstlane(nrows);
+    const int lane = threadIdx.x & 63, wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int li = lane >> 3, lj = lane & 7;
+    const int strips = (nrows + 7) >> 3;
+    const double c = (double)G.cos_dir, sn = (double)G.sin_dir;
+    const int ncols1 = __builtin_amdgcn_readfirstlane(G.w) - 1, nrows1 = __builtin_amdgcn_readfirstlane(G.h) - 1;
+    const uint64_t bp = (uint64_t)G.pair;
+    g_cu8 ubase = (g_cu8)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32)) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)bp));
+    const uint32_t pw = (uint32_t)(ncols1 + 1);
+    const int rounds = (win + 31) >> 5;                          // rounds of 4 groups (32 columns) per row; the last one clamps if win % 32
+    const int nb = (rounds + 1) >> 1;                            // units of two rounds (64 columns)
+    const bool ragged = (win & 31) != 0;
+    const int total = strips * nb;
+    if (!G.upright) {
+        const int tid = NW == 1 ? lane : (int)threadIdx.x;
+        if (tid < strips) {
+            const int ia = min(r0 + tid * 8, VFSMS_MAX_WIN - 1), ib = min(min(r0 + tid * 8 + 7, r0 + nrows - 1), VFSMS_MAX_WIN - 1);
+            const double xa = (double)sx_row[ia], xb = (double)sx_row[ib], ya = (double)sy_row[ia], yb = (double)sy_row[ib];
+            const double jb = (double)(win - 1);
+            const double jxb = jb * c, jyb = -(jb * sn);
+            const double xmin = fmin(xa, xb) + fmin(0.0, jxb), xmax = fmax(xa, xb) + fmax(0.0, jxb);
+            const double ymin = fmin(ya, yb) + fmin(0.0, jyb), ymax = fmax(ya, yb) + fmax(0.0, jyb);
+            strip_in[tid] = xmin >= 0.0 && ymin >= 0.0 && xmax < (double)(ncols1 - 2) && ymax < (double)nrows1;
+        }
+        if (NW == 1) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    }
+    int ty = 0, cbi = wv;
+    while (cbi >= nb) { cbi -= nb; ty++; }
+    const int last_row = r0 + nrows - 1;
+    const int liw = li * win;
+    const int last_off = (nrows - 1) * win;
+    float nsx = 0.f, nsy = 0.f; int nflag = 0;
+    if (wv < total) {
+        const int ic0 = min(r0 + ty * 8 + li, last_row);
+        nsx = sx_row[ic0]; nsy = sy_row[ic0]; nflag = strip_in[ty];
+    }
+    // the round stream of this wave: (unit, round inside the unit)
+    int unit = wv;
+    int left = 0;                                                // rounds left in the current (interior) unit
+    int rnd = 0;                                                 // index of the next round in its row
+    double sxc = 0.0, syc = 0.0;
+    uint8_t *drc = dst;
+    StageRound A, B;
+    int pend = 0;                                                // 0: nothing in flight, 1: A, 2: B
+    bool clampA = false, clampB = false;
+    for (;;) {
+        if (left == 0) {
+            if (unit >= total) break;
+            // ---- next unit: bookkeeping, border / upright units are done here as a whole
+            const int r_lo = cbi * 2, r_hi = min(r_lo + 2, rounds);
+            const int cb0 = r_lo * 32, cb1 = min(r_hi * 32, win);
+            sxc = (double)nsx; syc = (double)nsy;
+            const int flag_cur = nflag;
+            const int ty_cur = ty;
+            drc = dst + min(ty * 8 * win + liw, last_off);
+            cbi += NW;
+            while (cbi >= nb) { cbi -= nb; ty++; }
+            unit += NW;
+            if (unit < total) {
+                const int icn = min(r0 + ty * 8 + li, last_row);
+                nsx = sx_row[icn]; nsy = sy_row[icn]; nflag = strip_in[ty];
+            }
+            if (G.upright) {
+                for (int j = cb0 + lj; j < cb1; j += 8) drc[j] = (uint8_t)win_sample_upright(G, min(r0 + ty_cur * 8 + li, last_row), j);
+                continue;
+            }
+            bool unit_in = __builtin_amdgcn_readfirstlane(flag_cur) != 0;
+            if (!unit_in) {
+                const int ia = min(r0 + ty_cur * 8, VFSMS_MAX_WIN - 1), ib = min(min(r0 + ty_cur * 8 + 7, last_row), VFSMS_MAX_WIN - 1);
+                const double xa = (double)sx_row[ia], xb = (double)sx_row[ib], ya = (double)sy_row[ia], yb = (double)sy_row[ib];
+                const double ja = (double)cb0, jb = (double)(cb1 - 1);
+                const double jxa = ja * c, jxb = jb * c, jya = -(ja * sn), jyb = -(jb * sn);
+                const double xmin = fmin(xa, xb) + fmin(jxa, jxb), xmax = fmax(xa, xb) + fmax(jxa, jxb);
+                const double ymin = fmin(ya, yb) + fmin(jya, jyb), ymax = fmax(ya, yb) + fmax(jya, jyb);
+                unit_in = xmin >= 0.0 && ymin >= 0.0 && xmax < (double)(ncols1 - 2) && ymax < (double)nrows1;
+            }
+            if (unit_in) { left = r_hi - r_lo; rnd = r_lo; continue; }
+            // the unit crosses the image border: clamped coordinates, select at the end (no branch per sample)
+            for (int jb = cb0; jb < cb1; jb += 8 * BORDER_ILP) {
+                double px[BORDER_ILP], py[BORDER_ILP];
+                int jc[BORDER_ILP];
+                uint32_t q0[BORDER_ILP], q1[BORDER_ILP];
+                bool inside[BORDER_ILP];
+#pragma unroll
+                for (int u = 0; u < BORDER_ILP; u++) {
+                    jc[u] = min(jb + u * 8 + lj, cb1 - 1);
+                    px[u] = sxc + (double)jc[u] * c;
+                    py[u] = syc - (double)jc[u] * sn;
+                    const int ix = (int)px[u], iy = (int)py[u];
+                    inside[u] = px[u] >= 0.0 && py[u] >= 0.0 && ix < ncols1 && iy < nrows1;
+                    const int rx = min(max(cv_round_d(px[u]), 0), ncols1), ry = min(max(cv_round_d(py[u]), 0), nrows1);
+                    const int cx = inside[u] ? ix : rx, cy = inside[u] ? iy : ry;
+                    const int cx1 = min(cx + 1, ncols1);
+                    const uint32_t o0 = (uint32_t)__umul24((uint32_t)cy, pw);
+                    q0[u] = *(GAS const uint16_t *)(ubase + ((o0 + (uint32_t)cx) << 1));
+                    q1[u] = *(GAS const uint16_t *)(ubase + ((o0 + (uint32_t)cx1) << 1));
+                }
+#pragma unroll
+                for (int u = 0; u < BORDER_ILP; u++) {
+                    const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
+                    const float v = (uint8_t)(q0[u] & 0xff) * (1.f - a) * (1.f - b) + (uint8_t)(q1[u] & 0xff) * a * (1.f - b) +
+                                    (uint8_t)(q0[u] >> 8) * (1.f - a) * b + (uint8_t)(q1[u] >> 8) * a * b;
+                    drc[jc[u]] = inside[u] ? (uint8_t)cv_round_f(v) : (uint8_t)(q0[u] & 0xff);
+                }
+            }
+            continue;
+        }
+        // ---- one round of the current unit: issue it, then finish the round issued before it
+        const int jl = rnd * 32 + lj;
+        const bool clamp = ragged && rnd == rounds - 1;
+        rnd++; left--;
+        if (pend != 1) {
+            if (clamp) round_issue<true>(A, ubase, pw, c, sn, sxc, syc, jl, drc, win); else round_issue<false>(A, ubase, pw, c, sn, sxc, syc, jl, drc, win);
+            clampA = clamp;
+            if (pend == 2) { if (clampB) round_finish<true>(B, win); else round_finish<false>(B, win); }
+            pend = 1;
+        } else {
+            if (clamp) round_issue<true>(B, ubase, pw, c, sn, sxc, syc, jl, drc, win); else round_issue<false>(B, ubase, pw, c, sn, sxc, syc, jl, drc, win);
+            clampB = clamp;
+            if (clampA) round_finish<true>(A, win); else round_finish<false>(A, win);
+            pend = 2;
+        }
+    }
+    if (pend == 1) { if (clampA) round_finish<true>(A, win); else round_finish<false>(A, win); }
+    else if (pend == 2) { if (clampB) round_finish<true>(B, win); else round_finish<false>(B, win); }
+}
+#else
 // Balanced form (round 5).  A work unit is (strip of 8 rows) x (a run of 8-column GROUPS): the G8 = ceil(win / 8) groups of a row are cut
 // into nb runs of floor / ceil(G8 / nb) groups -- at most 8 (64 columns) --, so that no unit is padded: the round-4 form cut 32-column
 // blocks from the left, and a 140-px window cost five of them (160 columns), a 42-px one two (64).  A unit samples its groups in rounds of
@@ -1168,6 +1348,7 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
     }
 #endif
 }
+#endif      // pipelined / balanced
 #else
 // ---- round-4 form (VFSMS_EXP & 4: kept for A/B timing against the balanced form) ------------------------------------------------
 template <int NW>                                              // NW waves share the strips (4: the workgroup; 1: one wave on its own)
@@ -1594,28 +1775,54 @@ __global__ __launch_bounds__(1024) void k_desc_order(const RoiDev *rois)
 }
 
 // The ticket counter is sharded 8 ways (one head per XCD, 256 B apart): a single device-scope word saturates near 90 returning
-// atomics per microsecond, which for the ~280 k keypoints of a 16-pair batch is 3 ms of a 7.7 ms kernel.  Head q serves the
-// tickets t = q, q + 8, q + 16, ... of the one class-major order, so every head carries the same mix of window classes, largest
-// first; a workgroup starts on the head of its XCD (blockIdx % 8) and moves on to the next head when one runs dry.
+// atomics per microsecond, which for the ~280 k keypoints of a 16-pair batch is 3 ms of a 7.7 ms kernel.
+// Round 5: the heads are XCD-AFFINE.  Head q owns the ROIs q, q + 8, q + 16, ... and serves them ONE AFTER THE OTHER (ROI-major; inside an
+// ROI class by class, largest windows first); a workgroup starts on the head of its XCD (blockIdx % 8: workgroups are dealt to the XCDs
+// round-robin) and moves on to the next head when its own runs dry.  The 160 workgroups of an XCD then sample one or two pair images at a
+// time -- 1.7 MB each, inside the XCD's 4 MB of L2 -- instead of all 80 of a launch: round 4's one class-major order over all ROIs had
+// every XCD draw tickets of every ROI, 21x the compulsory bytes from HBM (PMC) and an L2 miss behind most gathers of a kernel that
+// turned out to be latency-bound (profiles/r05_pmc_describe_staging_ab.txt).  (VFSMS_EXP & 32: round 4's order, for A/B timing.)
 #define DESC_HEADS 8
 #define DESC_HEAD_STRIDE 64          // ints between heads
-struct TicketState { int prefix[DESC_NCLS * VFSMS_MAX_ROIS + 1]; int ticket; int split; int head; };
+// segment e = rank * ncls + class over the ROIs in head order (rank: head 0's ROIs, then head 1's, ...); prefix[e] = tickets before it
+struct TicketState { int prefix[DESC_NCLS * VFSMS_MAX_ROIS + 1]; int head_rank[DESC_HEADS + 1]; int ticket; int split; int head; };
+
+__device__ __forceinline__ int ticket_rank_to_roi(const TicketState &S, int rank)
+{
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < DESC_HEADS; k++) q += rank >= S.head_rank[k] ? 1 : 0;
+    return q + DESC_HEADS * (rank - S.head_rank[q]);
+}
 
 __device__ __forceinline__ void ticket_init(const RoiDev *rois, int nrois, TicketState &S)
 {
-    for (int e = threadIdx.x; e < DESC_NCLS * nrois; e += blockDim.x) S.prefix[e + 1] = rois[e % nrois].counters[12 + e / nrois];
+    const int NC = 3;                                            // classes 0..2 are k_describe's; class 3 (windows <= 64 px) is k_describe_small's
+    if (threadIdx.x <= DESC_HEADS) {
+        int r = 0;
+        for (int q = 0; q < (int)threadIdx.x; q++) r += (nrois - q + DESC_HEADS - 1) / DESC_HEADS;      // ROIs of the heads before this one
+        S.head_rank[threadIdx.x] = r;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NC * nrois; e += blockDim.x) {
+        const int rank = e / NC, cls = e - rank * NC;
+#if VFSMS_EXP & 32
+        const int roi = rank;
+#else
+        const int roi = ticket_rank_to_roi(S, rank);
+#endif
+        S.prefix[e + 1] = rois[roi].counters[12 + cls];
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         // Small batches (fewer than ~48 keypoints per resident workgroup) are bounded by their few largest windows: those
         // (class 0, win > 256) are then drawn as 21 tickets each, one per output row of the patch.  Large batches keep one
         // ticket per keypoint (the split repeats the row-origin prologue 21 times).
         int total = 0;
-        for (int e = 0; e < DESC_NCLS * nrois; e++) total += S.prefix[e + 1];
+        for (int e = 0; e < NC * nrois; e++) total += S.prefix[e + 1];
         S.split = total < (int)gridDim.x * 48 ? 21 : 1;
         S.prefix[0] = 0;
-        // class 3 (windows <= 64 px) is k_describe_small's: no tickets for it here
-        for (int e = 0; e < DESC_NCLS * nrois; e++)
-            S.prefix[e + 1] = S.prefix[e] + (e >= 3 * nrois ? 0 : S.prefix[e + 1] * (e < nrois ? S.split : 1));
+        for (int e = 0; e < NC * nrois; e++) S.prefix[e + 1] = S.prefix[e] + S.prefix[e + 1] * (e % NC == 0 ? S.split : 1);
         S.head = 0;
     }
     __syncthreads();
@@ -1623,15 +1830,22 @@ __device__ __forceinline__ void ticket_init(const RoiDev *rois, int nrois, Ticke
 // returns false when the batch is exhausted; otherwise (roi, k).  Contains workgroup barriers.
 __device__ __forceinline__ bool ticket_next(const RoiDev *rois, int *counter, int nrois, TicketState &S, int &roi, int &k, int &band)
 {
+    const int NC = 3;
     __syncthreads();
-    const int ne = DESC_NCLS * nrois;
+    const int ne = NC * nrois;
     if (threadIdx.x == 0) {
         const int total = S.prefix[ne];
         int t = total;
         while (S.head < DESC_HEADS) {
             const int q = (blockIdx.x + S.head) & (DESC_HEADS - 1);
+#if VFSMS_EXP & 32
             t = atomicAdd(counter + q * DESC_HEAD_STRIDE, 1) * DESC_HEADS + q;
             if (t < total) break;
+#else
+            const int lo = S.prefix[NC * S.head_rank[q]], hi = S.prefix[NC * S.head_rank[q + 1]];      // this head's tickets
+            t = hi > lo ? lo + atomicAdd(counter + q * DESC_HEAD_STRIDE, 1) : hi;
+            if (t < hi) break;
+#endif
             S.head++;                                            // this head is exhausted (it stays exhausted): steal from the next
             t = total;
         }
@@ -1642,13 +1856,16 @@ __device__ __forceinline__ bool ticket_next(const RoiDev *rois, int *counter, in
     if (t >= S.prefix[ne]) return false;
     int lo = 0, hi = ne;                                      // prefix[lo] <= t < prefix[hi]
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (S.prefix[mid] <= t) lo = mid; else hi = mid; }
-    const int cls = lo / nrois;
-    roi = lo - cls * nrois;
-    int within = t - S.prefix[lo];                            // position inside (class, roi); the ROI's list is class-major
+    const int rank = lo / NC, cls = lo - rank * NC;
+#if VFSMS_EXP & 32
+    roi = rank;
+#else
+    roi = ticket_rank_to_roi(S, rank);
+#endif
+    int within = t - S.prefix[lo];                            // position inside (roi, class); the ROI's keypoint list is class-major
     band = -1;
     if (cls == 0) { if (S.split > 1) { band = within % S.split; within /= S.split; } }
-    else within += (S.prefix[roi + 1] - S.prefix[roi]) / S.split;
-    for (int c = 1; c < cls; c++) within += S.prefix[c * nrois + roi + 1] - S.prefix[c * nrois + roi];
+    for (int c = 0; c < cls; c++) within += rois[roi].counters[12 + c];
     k = rois[roi].order[within];
     return true;
 }
@@ -1738,13 +1955,33 @@ __device__ void describe_small(const RoiDev &R, const AreaRec *area_tab, const i
     wave_sync_lds();                                       // the next keypoint of this wave overwrites L
 }
 
+#ifndef DESC_SMALL_WGS
 #define DESC_SMALL_WGS 6
+#endif
 __global__ __launch_bounds__(256, DESC_SMALL_WGS) void k_describe_small(const RoiDev *rois, int nrois, int *counter, const AreaRec *area_tab, int upright)
 {
-    __shared__ int prefix[VFSMS_MAX_ROIS + 1];            // class-3 keypoints of the ROIs before each ROI
+    // tickets as in k_describe: head q (the workgroup's XCD first) serves the class-3 keypoints of the ROIs q, q + 8, ... one ROI after the other
+    __shared__ int prefix[VFSMS_MAX_ROIS + 1];            // class-3 keypoints of the ROIs before each ROI, in head order (rank)
+    __shared__ int head_rank[DESC_HEADS + 1];
     __shared__ SmallLds L[4];
     if (threadIdx.x < 4) L[threadIdx.x].rec_win = -1;
-    for (int e = threadIdx.x; e < nrois; e += 256) prefix[e + 1] = rois[e].counters[12 + 3];
+    if (threadIdx.x <= DESC_HEADS) {
+        int r = 0;
+        for (int q = 0; q < (int)threadIdx.x; q++) r += (nrois - q + DESC_HEADS - 1) / DESC_HEADS;
+        head_rank[threadIdx.x] = r;
+    }
+    __syncthreads();
+    auto rank_to_roi = [&](int rank) {
+#if VFSMS_EXP & 32
+        return rank;
+#else
+        int q = 0;
+#pragma unroll
+        for (int k = 1; k < DESC_HEADS; k++) q += rank >= head_rank[k] ? 1 : 0;
+        return q + DESC_HEADS * (rank - head_rank[q]);
+#endif
+    };
+    for (int e = threadIdx.x; e < nrois; e += 256) prefix[e + 1] = rois[rank_to_roi(e)].counters[12 + 3];
     __syncthreads();
     if (threadIdx.x == 0) { prefix[0] = 0; for (int e = 0; e < nrois; e++) prefix[e + 1] += prefix[e]; }
     __syncthreads();
@@ -1756,16 +1993,23 @@ __global__ __launch_bounds__(256, DESC_SMALL_WGS) void k_describe_small(const Ro
         if (lane == 0)
             while (head < DESC_HEADS) {
                 const int q = (blockIdx.x + head) & (DESC_HEADS - 1);
+#if VFSMS_EXP & 32
                 t = atomicAdd(counter + q * DESC_HEAD_STRIDE, 1) * DESC_HEADS + q;
                 if (t < total) break;
+#else
+                const int lo = prefix[head_rank[q]], hi = prefix[head_rank[q + 1]];
+                t = hi > lo ? lo + atomicAdd(counter + q * DESC_HEAD_STRIDE, 1) : hi;
+                if (t < hi) break;
+#endif
                 head++;                                      // this head is exhausted (it stays exhausted): steal from the next
                 t = total;
             }
         t = __builtin_amdgcn_readfirstlane(t);               // lane 0's ticket, as an SGPR: the ROI record and keypoint index below are scalar
+        head = __builtin_amdgcn_readfirstlane(head);
         if (t >= total) break;
         int lo = 0, hi = nrois;                               // prefix[lo] <= t < prefix[hi]
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= t) lo = mid; else hi = mid; }
-        const RoiDev &R = rois[lo];
+        const RoiDev &R = rois[__builtin_amdgcn_readfirstlane(rank_to_roi(lo))];
         const int within = t - prefix[lo] + R.counters[12] + R.counters[13] + R.counters[14];   // the ROI's list is class-major
         describe_small(R, area_tab, __builtin_amdgcn_readfirstlane(R.order[within]), upright, L[wave]);
     }

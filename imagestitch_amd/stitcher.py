@@ -140,7 +140,7 @@ class Stitcher(Utility.Method):
         return ((status, endfileIndex), stitchImage)
 
     pathHint = None              # optional PREDICTION of the accepted direction of every pair (a scan pattern the operator knows, e.g. from grid.serpentine_directions); the speculation prior of the FIRST dataset -- later ones use what the previous one taught (GridRegistrar.path_memory).  Results never depend on it.
-    streamOutput = False         # imageSetStitch*: encode PNG / TIFF / NPY results band by band as they leave the device (mosaics beyond host memory)
+    streamOutput = True          # imageSetStitch*: encode JPEG / PNG / TIFF / NPY results band by band as they leave the device -- the mosaic is never whole in host memory and the encoder works while later bands are still copied (default since round 5; False: download the whole mosaic, then write it)
     batchRegistration = True     # let flowStitch register a whole file list in fused device batches when the stock search is used
     decodeThreads = 0            # decoder threads of the ingest pipeline (0: one per host core, at most 32 with the library's own JPEG decoder, 16 with Pillow -- beyond that its Python-side work and the registrar's own host thread get in each other's way; _decoderThreads)
 
@@ -910,8 +910,9 @@ class Stitcher(Utility.Method):
                 if sink is not None and hasattr(eng, "canvas_download_bands"):
                     # streamed write-out: the mosaic leaves the device band by band and is never whole in host memory
                     # (a sink that is done with a band two bands later -- `transient_bands`: JpegBandWriter -- gets views of the engine's
-                    #  pinned band ring instead of a fresh array per band; VFSMS_PINNED_BANDS=1 turns it on)
-                    transient = bool(getattr(sink, "transient_bands", False)) and os.environ.get("VFSMS_PINNED_BANDS", "0") == "1"
+                    #  pinned band ring instead of a fresh array per band: a DMA at link speed, no page faults of a fresh 300 MB array per
+                    #  band; VFSMS_PINNED_BANDS=0 turns it off)
+                    transient = bool(getattr(sink, "transient_bands", False)) and os.environ.get("VFSMS_PINNED_BANDS", "1") == "1"
                     kw = {"transient": True} if transient else {}
                     for r0, band in eng.canvas_download_bands(canvas, resultRow, resultCol, ch, int(getattr(self, "mosaicBandRows", 4096)), **kw):
                         sink(r0, band, (resultRow, resultCol, ch) if ch > 1 else (resultRow, resultCol))

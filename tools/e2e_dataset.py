@@ -51,8 +51,10 @@ def main(engine=None):
                 timed(eng, attr, "of_which_download")
         sys.stdout = open(os.devnull, "w")                     # (the reference prints a line per dataset)
         try:
-            for name, env, stream, pinned, reps in (("native", "1", False, "0", 4), ("native_streamed", "1", True, "0", 3),
-                                                    ("native_streamed_pinned_bands", "1", True, "1", 3), ("pillow_codecs", "0", False, "0", 1)):
+            # "default" = the Stitcher as it comes since round 5: results streamed to the encoder through the pinned band ring
+            for name, env, stream, pinned, reps in (("default_streamed_pinned_bands", "1", True, "1", 4), ("whole_mosaic_download", "1", False, "0", 3),
+                                                    ("streamed_pageable_bands", "1", True, "0", 3), ("default_streamed_pinned_bands_again", "1", True, "1", 3),
+                                                    ("pillow_codecs", "0", False, "0", 1)):
                 os.environ["VFSMS_NATIVE_JPEG"], os.environ["VFSMS_PINNED_BANDS"] = env, pinned
                 s.streamOutput = stream
                 times = []
