@@ -87,6 +87,23 @@ struct RoiDev {
     vfsms_keypoint *kps_out;          // compacted
 };
 
+// ---- descriptor work list of a launch (round 5) -------------------------------------------------------------
+// One 32-byte record per surviving keypoint, written by k_desc_recs in the order the descriptor kernels draw them: everything a workgroup
+// needs to start on a keypoint in ONE scalar load -- before, a ticket led through counters -> order[] -> kps[] -> the trig values behind the
+// patch row, four dependent trips to memory with the workgroup's four waves waiting.
+struct DescRec { int roi, k, win, pad; float sin_dir, cos_dir, x, y; };      // win = (int)(21 * size * 1.2f / 9) unclamped
+// The plan of a launch (k_desc_plan, one workgroup): per ticket head q (= XCD) the slice of the record arrays it serves.  Head q owns the ROIs
+// q, q + 8, ...; its slice of the BIG array (windows > 64 px, k_describe) is [class 0 of its ROIs, ROI after ROI][class 1 + 2 of its first
+// ROI][of its second] ..., of the SMALL array (k_describe_small) [class 3 of its first ROI][of its second] ...
+#define DESC_PLAN_HEADS 8
+#define VFSMS_MAX_ROIS 256        // ROIs of one fused launch
+struct DescPlan {
+    int big_start[DESC_PLAN_HEADS], big_n0[DESC_PLAN_HEADS], big_tickets[DESC_PLAN_HEADS];     // records before the head's slice, its class-0 records, its tickets
+    int small_start[DESC_PLAN_HEADS], small_tickets[DESC_PLAN_HEADS];
+    int split;                        // 21: every class-0 keypoint is 21 tickets, one per output row of its patch (small batches); else 1
+    int seg_base[VFSMS_MAX_ROIS][4];  // record index of the first keypoint of (roi, class) in its array
+};
+
 // ---- ORB working set of one ROI --------------------------------------------------------------------------
 #define VFSMS_ORB_MAX_LEVELS 8
 struct OrbDev {

@@ -1563,24 +1563,21 @@ __device__ __forceinline__ uint8_t area_col_tab(const float *rb, const AreaRec &
     return sat_u8(sum);
 }
 
-// band >= 0: only row `band` of the 21 x 21 patch (tickets of the largest windows are split by output row, see ticket_next)
-__device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec *area_tab, const int k, int extended, int upright, const int band)
+// band >= 0: only row `band` of the 21 x 21 patch (tickets of the largest windows are split by output row, see k_desc_plan)
+__device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec *area_tab, const DescRec &rec, int extended, int upright, const int band)
 {
     DT_START;
-    vfsms_keypoint kp = R.kps[k];
-    if (!(kp.size > 0)) return;                            // deleted by the orientation stage
+    const int k = rec.k;
     __shared__ float sx_row[VFSMS_MAX_WIN], sy_row[VFSMS_MAX_WIN];
     __shared__ uint8_t PATCH[21][21 + 3];
-    __shared__ float trig_s[2];
     __shared__ AreaRec REC[AREA_RECS];                     // computeResizeAreaTab of this window size: same records for x and y
     __shared__ uint8_t WINBUF[DESC_WBUF];
     __shared__ float rowsum[40 * 21];                      // buf[dx] of up to 40 source rows
     __shared__ uint8_t STRIP_IN[VFSMS_MAX_WIN / 8 + 8];    // per 8-row strip of a staging call: inside the image as a whole?
-    const float s = kp.size * 1.2f / 9.0f;
     WinGeom G;
-    G.win = __builtin_amdgcn_readfirstlane(max(21, min((int)((20 + 1) * s), VFSMS_MAX_WIN)));     // wave-uniform: keep it (and what derives from it) scalar
+    G.win = max(21, min(rec.win, VFSMS_MAX_WIN));          // (the record is wave-uniform: scalar registers, and so is what derives from it)
     G.h = R.h; G.w = R.w; G.stride = R.stride; G.img = (g_cu8)R.img; G.pair = (g_cu8)R.pair;
-    G.upright = upright; G.usx = 0; G.usy = 0; G.sin_dir = 0.f; G.cos_dir = 0.f;
+    G.upright = upright; G.usx = 0; G.usy = 0; G.sin_dir = rec.sin_dir; G.cos_dir = rec.cos_dir;
     const int win = G.win;
     const int dsz = 21;
     if (threadIdx.x < AREA_RECS * 8) ((int *)REC)[threadIdx.x] = ((const int *)(area_tab + (size_t)win * AREA_RECS))[threadIdx.x];
@@ -1589,47 +1586,23 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
     const int mode = __builtin_amdgcn_readfirstlane(REC[21].mode);
     const float inv_area = REC[21].a0;
     if (!upright) {
-        // Row origins are running float sums in the reference (start_x += sin_dir per row): inherently sequential,
-        // so one lane of wave 0 walks x while one lane of wave 1 walks y.
-        // sin/cos of the orientation were evaluated one thread per keypoint by k_desc_trig and parked behind the keypoint's
-        // patch row (several workgroups may work on one large keypoint, so the patch bytes themselves cannot be borrowed).
-#if !(VFSMS_EXP & 1)
-        // (one lane of wave 0 walks x while one lane of wave 1 walks y; both chains in lanes 0 / 1 of ONE wave -- half the issue slots -- measured
-        //  0.7 % SLOWER on the fixed 16-pair batch: the prologue is latency, not issue, and the lane select lengthens the chain)
+        // Row origins are running float sums in the reference (start_x += sin_dir per row): inherently sequential, so one lane of wave 0
+        // walks x while one lane of wave 1 walks y (both chains in lanes 0 / 1 of ONE wave -- half the issue slots -- measured 0.7 %
+        // SLOWER: the prologue is latency, not issue).  sin / cos of the orientation come with the keypoint's record (k_desc_recs).
         if (threadIdx.x == 0 || threadIdx.x == 64) {
-            const float sin_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[0];
-            const float cos_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[1];
+            const float sin_dir = rec.sin_dir, cos_dir = rec.cos_dir;
             const float win_offset = -(float)(win - 1) / 2;
             // a band ticket only needs the origins up to the last source row of its band
             const int need = band >= 0 ? min(win, REC[band].j0 + REC[band].n) : win;
-            if (threadIdx.x == 0) {
-                trig_s[0] = sin_dir; trig_s[1] = cos_dir;
-                origin_chain(sx_row, kp.x + win_offset * cos_dir + win_offset * sin_dir, sin_dir, need);
-            } else {
-                origin_chain(sy_row, kp.y - win_offset * sin_dir + win_offset * cos_dir, cos_dir, need);
-            }
+            if (threadIdx.x == 0) origin_chain(sx_row, rec.x + win_offset * cos_dir + win_offset * sin_dir, sin_dir, need);
+            else origin_chain(sy_row, rec.y - win_offset * sin_dir + win_offset * cos_dir, cos_dir, need);
         }
-#else
-        // lanes 0 and 1 of ONE wave: a wave instruction costs its issue slot whether 1 or 64 lanes are active, and this kernel is bound by
-        // instruction issue -- two waves walking one chain each issued the loop twice
-        if (threadIdx.x < 2) {
-            const float sin_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[0];
-            const float cos_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[1];
-            const float win_offset = -(float)(win - 1) / 2;
-            // a band ticket only needs the origins up to the last source row of its band
-            const int need = band >= 0 ? min(win, REC[band].j0 + REC[band].n) : win;
-            if (threadIdx.x == 0) { trig_s[0] = sin_dir; trig_s[1] = cos_dir; }
-            const float sx0 = kp.x + win_offset * cos_dir + win_offset * sin_dir, sy0 = kp.y - win_offset * sin_dir + win_offset * cos_dir;
-            origin_chain(threadIdx.x == 0 ? sx_row : sy_row, threadIdx.x == 0 ? sx0 : sy0, threadIdx.x == 0 ? sin_dir : cos_dir, need);
-        }
-#endif
     } else {
         const float win_offset = -(float)(win - 1) / 2;
-        G.usx = cv_round_f(kp.x + win_offset);
-        G.usy = cv_round_f(kp.y - win_offset);
+        G.usx = cv_round_f(rec.x + win_offset);
+        G.usy = cv_round_f(rec.y - win_offset);
     }
     __syncthreads();
-    if (!upright) { G.sin_dir = trig_s[0]; G.cos_dir = trig_s[1]; }
     DT_MARK(0);
 
     // The rotated window is staged through LDS so that every bilinear sample is produced exactly once: the whole
@@ -1719,7 +1692,6 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
 // device-side counts, rebuilt per workgroup in LDS).  Window cost varies 100x between keypoints, so dynamic
 // tickets matter: static striding measured 45 % slower, 4-ticket chunks 20 % slower.
 // ---------------------------------------------------------------------------------------------------
-#define VFSMS_MAX_ROIS 256
 #define DESC_NCLS 4                  // window-size classes, largest first: win > 256, > 128, > 64, rest
 
 // Tickets are drawn class by class, largest descriptor windows first: one window of 700 px costs as much as 300 windows of 40 px,
@@ -1774,100 +1746,80 @@ __global__ __launch_bounds__(1024) void k_desc_order(const RoiDev *rois)
     }
 }
 
-// The ticket counter is sharded 8 ways (one head per XCD, 256 B apart): a single device-scope word saturates near 90 returning
-// atomics per microsecond, which for the ~280 k keypoints of a 16-pair batch is 3 ms of a 7.7 ms kernel.
-// Round 5: the heads are XCD-AFFINE.  Head q owns the ROIs q, q + 8, q + 16, ... and serves them ONE AFTER THE OTHER (ROI-major; inside an
-// ROI class by class, largest windows first); a workgroup starts on the head of its XCD (blockIdx % 8: workgroups are dealt to the XCDs
-// round-robin) and moves on to the next head when its own runs dry.  The 160 workgroups of an XCD then sample one or two pair images at a
-// time -- 1.7 MB each, inside the XCD's 4 MB of L2 -- instead of all 80 of a launch: round 4's one class-major order over all ROIs had
-// every XCD draw tickets of every ROI, 21x the compulsory bytes from HBM (PMC) and an L2 miss behind most gathers of a kernel that
-// turned out to be latency-bound (profiles/r05_pmc_describe_staging_ab.txt).  (VFSMS_EXP & 32: round 4's order, for A/B timing.)
-#define DESC_HEADS 8
+// ---------------------------------------------------------------------------------------------------
+// Work list of the descriptor kernels (round 5).  The ticket counter is sharded 8 ways (one head per XCD, 256 B apart: a single
+// device-scope word saturates near 90 returning atomics per microsecond) and the heads are XCD-AFFINE: head q owns the ROIs q, q + 8, ...
+// and serves them one after the other, so the 160 workgroups of an XCD sample one or two pair images at a time -- 1.7 MB each, inside the
+// XCD's 4 MB of L2 -- instead of all 80 of a launch (round 4's one class-major order over all ROIs: every XCD drew tickets of every ROI,
+// PMC FETCH_SIZE 0.94 GB per launch of 40 pairs for k_describe and 0.61 GB for k_describe_small, now 0.11 GB each).  A workgroup starts
+// on the head of its XCD (blockIdx % 8: workgroups are dealt to the XCDs round-robin) and moves on to the next head when its own runs dry.
+// What a ticket leads to is ONE 32-byte record (DescRec) at a position that follows from the ticket alone: k_desc_plan lays the heads'
+// slices out, k_desc_recs fills them.
+// ---------------------------------------------------------------------------------------------------
+#define DESC_HEADS DESC_PLAN_HEADS
 #define DESC_HEAD_STRIDE 64          // ints between heads
-// segment e = rank * ncls + class over the ROIs in head order (rank: head 0's ROIs, then head 1's, ...); prefix[e] = tickets before it
-struct TicketState { int prefix[DESC_NCLS * VFSMS_MAX_ROIS + 1]; int head_rank[DESC_HEADS + 1]; int ticket; int split; int head; };
 
-__device__ __forceinline__ int ticket_rank_to_roi(const TicketState &S, int rank)
+// one workgroup: the layout of the record arrays from the class counts of all ROIs (counters[12..15], k_desc_order)
+__global__ __launch_bounds__(256) void k_desc_plan(const RoiDev *rois, int nrois, DescPlan *plan, int big_grid)
 {
-    int q = 0;
-#pragma unroll
-    for (int k = 1; k < DESC_HEADS; k++) q += rank >= S.head_rank[k] ? 1 : 0;
-    return q + DESC_HEADS * (rank - S.head_rank[q]);
-}
-
-__device__ __forceinline__ void ticket_init(const RoiDev *rois, int nrois, TicketState &S)
-{
-    const int NC = 3;                                            // classes 0..2 are k_describe's; class 3 (windows <= 64 px) is k_describe_small's
-    if (threadIdx.x <= DESC_HEADS) {
-        int r = 0;
-        for (int q = 0; q < (int)threadIdx.x; q++) r += (nrois - q + DESC_HEADS - 1) / DESC_HEADS;      // ROIs of the heads before this one
-        S.head_rank[threadIdx.x] = r;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < NC * nrois; e += blockDim.x) {
-        const int rank = e / NC, cls = e - rank * NC;
-#if VFSMS_EXP & 32
-        const int roi = rank;
-#else
-        const int roi = ticket_rank_to_roi(S, rank);
-#endif
-        S.prefix[e + 1] = rois[roi].counters[12 + cls];
-    }
+    __shared__ int c[VFSMS_MAX_ROIS][4];
+    for (int e = threadIdx.x; e < nrois * 4; e += 256) c[e >> 2][e & 3] = rois[e >> 2].counters[12 + (e & 3)];
     __syncthreads();
     if (threadIdx.x == 0) {
-        // Small batches (fewer than ~48 keypoints per resident workgroup) are bounded by their few largest windows: those
-        // (class 0, win > 256) are then drawn as 21 tickets each, one per output row of the patch.  Large batches keep one
-        // ticket per keypoint (the split repeats the row-origin prologue 21 times).
-        int total = 0;
-        for (int e = 0; e < NC * nrois; e++) total += S.prefix[e + 1];
-        S.split = total < (int)gridDim.x * 48 ? 21 : 1;
-        S.prefix[0] = 0;
-        for (int e = 0; e < NC * nrois; e++) S.prefix[e + 1] = S.prefix[e] + S.prefix[e + 1] * (e % NC == 0 ? S.split : 1);
-        S.head = 0;
-    }
-    __syncthreads();
-}
-// returns false when the batch is exhausted; otherwise (roi, k).  Contains workgroup barriers.
-__device__ __forceinline__ bool ticket_next(const RoiDev *rois, int *counter, int nrois, TicketState &S, int &roi, int &k, int &band)
-{
-    const int NC = 3;
-    __syncthreads();
-    const int ne = NC * nrois;
-    if (threadIdx.x == 0) {
-        const int total = S.prefix[ne];
-        int t = total;
-        while (S.head < DESC_HEADS) {
-            const int q = (blockIdx.x + S.head) & (DESC_HEADS - 1);
-#if VFSMS_EXP & 32
-            t = atomicAdd(counter + q * DESC_HEAD_STRIDE, 1) * DESC_HEADS + q;
-            if (t < total) break;
-#else
-            const int lo = S.prefix[NC * S.head_rank[q]], hi = S.prefix[NC * S.head_rank[q + 1]];      // this head's tickets
-            t = hi > lo ? lo + atomicAdd(counter + q * DESC_HEAD_STRIDE, 1) : hi;
-            if (t < hi) break;
-#endif
-            S.head++;                                            // this head is exhausted (it stays exhausted): steal from the next
-            t = total;
+        int acc = 0, total = 0;
+        for (int q = 0; q < DESC_HEADS; q++) {
+            plan->big_start[q] = acc;
+            for (int r = q; r < nrois; r += DESC_HEADS) { plan->seg_base[r][0] = acc; acc += c[r][0]; }
+            plan->big_n0[q] = acc - plan->big_start[q];
+            for (int r = q; r < nrois; r += DESC_HEADS) {
+                plan->seg_base[r][1] = acc; acc += c[r][1];
+                plan->seg_base[r][2] = acc; acc += c[r][2];
+            }
+            plan->big_tickets[q] = acc - plan->big_start[q];
         }
-        S.ticket = t;
+        total = acc;
+        // Small batches (fewer than ~48 keypoints per resident workgroup) are bounded by their few largest windows: those (class 0,
+        // win > 256) are then drawn as 21 tickets each, one per output row of the patch.  Large batches keep one ticket per keypoint
+        // (the split repeats the row-origin prologue 21 times).
+        const int split = total < big_grid * 48 ? 21 : 1;
+        plan->split = split;
+        for (int q = 0; q < DESC_HEADS; q++) plan->big_tickets[q] += (split - 1) * plan->big_n0[q];
+        acc = 0;
+        for (int q = 0; q < DESC_HEADS; q++) {
+            plan->small_start[q] = acc;
+            for (int r = q; r < nrois; r += DESC_HEADS) { plan->seg_base[r][3] = acc; acc += c[r][3]; }
+            plan->small_tickets[q] = acc - plan->small_start[q];
+        }
     }
-    __syncthreads();
-    const int t = S.ticket;
-    if (t >= S.prefix[ne]) return false;
-    int lo = 0, hi = ne;                                      // prefix[lo] <= t < prefix[hi]
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (S.prefix[mid] <= t) lo = mid; else hi = mid; }
-    const int rank = lo / NC, cls = lo - rank * NC;
-#if VFSMS_EXP & 32
-    roi = rank;
-#else
-    roi = ticket_rank_to_roi(S, rank);
-#endif
-    int within = t - S.prefix[lo];                            // position inside (roi, class); the ROI's keypoint list is class-major
-    band = -1;
-    if (cls == 0) { if (S.split > 1) { band = within % S.split; within /= S.split; } }
-    for (int c = 0; c < cls; c++) within += rois[roi].counters[12 + c];
-    k = rois[roi].order[within];
-    return true;
+}
+
+// One thread per surviving keypoint (position p of the ROI's class-major order list): its record, with sin / cos of the descriptor window's
+// rotation (std::sin / std::cos on float in the reference).  det_sincos (detmath.h) is the explicit double-precision algorithm the oracle
+// evaluates too, so both sides round to the same float; it agrees with a correctly rounded sinf / cosf except within ~2^-29 ulp of a
+// rounding boundary.
+__global__ __launch_bounds__(256) void k_desc_recs(const RoiDev *rois, const DescPlan *plan, DescRec *big, DescRec *small, int upright)
+{
+    const int roi = blockIdx.y;
+    const RoiDev &R = rois[roi];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int c0 = R.counters[12], c1 = R.counters[13], c2 = R.counters[14], c3 = R.counters[15];
+    if (p >= c0 + c1 + c2 + c3) return;
+    const int cls = p < c0 ? 0 : p < c0 + c1 ? 1 : p < c0 + c1 + c2 ? 2 : 3;
+    const int idx = p - (cls > 0 ? c0 : 0) - (cls > 1 ? c1 : 0) - (cls > 2 ? c2 : 0);
+    const int k = R.order[p];
+    const vfsms_keypoint kp = R.kps[k];
+    DescRec rec;
+    rec.roi = roi; rec.k = k; rec.pad = 0; rec.x = kp.x; rec.y = kp.y;
+    rec.win = (int)((20 + 1) * (kp.size * 1.2f / 9.0f));
+    rec.sin_dir = 0.f; rec.cos_dir = 0.f;
+    if (!upright) {
+        const float dir = kp.angle * (float)(3.1415926535897932384626433832795 / 180);
+        double sd, cd;
+        det_sincos((double)dir, &sd, &cd);
+        rec.sin_dir = -(float)sd;
+        rec.cos_dir = (float)cd;
+    }
+    (cls < 3 ? big : small)[plan->seg_base[roi][cls] + idx] = rec;
 }
 
 __global__ __launch_bounds__(1024, 8) void k_orientation(const RoiDev *rois, const SurfTables *T, int upright)
@@ -1895,16 +1847,14 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ void describe_small(const RoiDev &R, const AreaRec *area_tab, const int k, int upright, SmallLds &L)
+__device__ void describe_small(const RoiDev &R, const AreaRec *area_tab, const DescRec &rec, int upright, SmallLds &L)
 {
     const int lane = threadIdx.x & 63;
-    const vfsms_keypoint kp = R.kps[k];
-    if (!(kp.size > 0)) return;                            // deleted by the orientation stage (wave-uniform)
-    const float s = kp.size * 1.2f / 9.0f;
+    const int k = rec.k;
     WinGeom G;
-    G.win = __builtin_amdgcn_readfirstlane(min((int)((20 + 1) * s), DESC_SMALL_WIN));      // (class 3 means <= 64 already)
+    G.win = min(rec.win, DESC_SMALL_WIN);                      // (class 3 means <= 64 already; wave-uniform, scalar)
     G.h = R.h; G.w = R.w; G.stride = R.stride; G.img = (g_cu8)R.img; G.pair = (g_cu8)R.pair;
-    G.upright = upright; G.usx = 0; G.usy = 0; G.sin_dir = 0.f; G.cos_dir = 0.f;
+    G.upright = upright; G.usx = 0; G.usy = 0; G.sin_dir = rec.sin_dir; G.cos_dir = rec.cos_dir;
     const int win = G.win;
     const int dsz = 21;
     // computeResizeAreaTab of this window size from the host-built table (kept while the wave's next keypoint has the same window)
@@ -1915,18 +1865,16 @@ __device__ void describe_small(const RoiDev &R, const AreaRec *area_tab, const i
         if (lane == 0) L.rec_win = win;
     }
     if (!upright) {
-        const float sin_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[0];
-        const float cos_dir = ((const float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG))[1];
-        G.sin_dir = sin_dir; G.cos_dir = cos_dir;
+        const float sin_dir = rec.sin_dir, cos_dir = rec.cos_dir;
         if (lane < 2) {                                    // running float sums of the reference: lane 0 walks x, lane 1 walks y, in ONE loop
             const float win_offset = -(float)(win - 1) / 2;
-            const float sx0 = kp.x + win_offset * cos_dir + win_offset * sin_dir, sy0 = kp.y - win_offset * sin_dir + win_offset * cos_dir;
+            const float sx0 = rec.x + win_offset * cos_dir + win_offset * sin_dir, sy0 = rec.y - win_offset * sin_dir + win_offset * cos_dir;
             origin_chain(lane == 0 ? L.sx : L.sy, lane == 0 ? sx0 : sy0, lane == 0 ? sin_dir : cos_dir, win);
         }
     } else {
         const float win_offset = -(float)(win - 1) / 2;
-        G.usx = cv_round_f(kp.x + win_offset);
-        G.usy = cv_round_f(kp.y - win_offset);
+        G.usx = cv_round_f(rec.x + win_offset);
+        G.usy = cv_round_f(rec.y - win_offset);
     }
     wave_sync_lds();
     stage_rows<1>(G, L.sx, L.sy, 0, win, L.win, L.strip_in);
@@ -1958,60 +1906,40 @@ __device__ void describe_small(const RoiDev &R, const AreaRec *area_tab, const i
 #ifndef DESC_SMALL_WGS
 #define DESC_SMALL_WGS 6
 #endif
-__global__ __launch_bounds__(256, DESC_SMALL_WGS) void k_describe_small(const RoiDev *rois, int nrois, int *counter, const AreaRec *area_tab, int upright)
+// a wave-uniform record through the scalar unit: one s_load_dwordx8
+__device__ __forceinline__ DescRec load_rec_uniform(const DescRec *p)
 {
-    // tickets as in k_describe: head q (the workgroup's XCD first) serves the class-3 keypoints of the ROIs q, q + 8, ... one ROI after the other
-    __shared__ int prefix[VFSMS_MAX_ROIS + 1];            // class-3 keypoints of the ROIs before each ROI, in head order (rank)
-    __shared__ int head_rank[DESC_HEADS + 1];
+    const int *q = (const int *)p;
+    DescRec r;
+    r.roi = __builtin_amdgcn_readfirstlane(q[0]); r.k = __builtin_amdgcn_readfirstlane(q[1]);
+    r.win = __builtin_amdgcn_readfirstlane(q[2]); r.pad = 0;
+    r.sin_dir = __int_as_float(__builtin_amdgcn_readfirstlane(q[4])); r.cos_dir = __int_as_float(__builtin_amdgcn_readfirstlane(q[5]));
+    r.x = __int_as_float(__builtin_amdgcn_readfirstlane(q[6])); r.y = __int_as_float(__builtin_amdgcn_readfirstlane(q[7]));
+    return r;
+}
+__global__ __launch_bounds__(256, DESC_SMALL_WGS) void k_describe_small(const RoiDev *rois, const DescPlan *plan, const DescRec *recs, int *counter,
+                                                                 const AreaRec *area_tab, int upright)
+{
     __shared__ SmallLds L[4];
     if (threadIdx.x < 4) L[threadIdx.x].rec_win = -1;
-    if (threadIdx.x <= DESC_HEADS) {
-        int r = 0;
-        for (int q = 0; q < (int)threadIdx.x; q++) r += (nrois - q + DESC_HEADS - 1) / DESC_HEADS;
-        head_rank[threadIdx.x] = r;
-    }
     __syncthreads();
-    auto rank_to_roi = [&](int rank) {
-#if VFSMS_EXP & 32
-        return rank;
-#else
-        int q = 0;
-#pragma unroll
-        for (int k = 1; k < DESC_HEADS; k++) q += rank >= head_rank[k] ? 1 : 0;
-        return q + DESC_HEADS * (rank - head_rank[q]);
-#endif
-    };
-    for (int e = threadIdx.x; e < nrois; e += 256) prefix[e + 1] = rois[rank_to_roi(e)].counters[12 + 3];
-    __syncthreads();
-    if (threadIdx.x == 0) { prefix[0] = 0; for (int e = 0; e < nrois; e++) prefix[e + 1] += prefix[e]; }
-    __syncthreads();
-    const int total = prefix[nrois];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int head = 0;
     for (;;) {
-        int t = total;
+        int slot = -1;                                       // record index, lane 0's
         if (lane == 0)
             while (head < DESC_HEADS) {
                 const int q = (blockIdx.x + head) & (DESC_HEADS - 1);
-#if VFSMS_EXP & 32
-                t = atomicAdd(counter + q * DESC_HEAD_STRIDE, 1) * DESC_HEADS + q;
-                if (t < total) break;
-#else
-                const int lo = prefix[head_rank[q]], hi = prefix[head_rank[q + 1]];
-                t = hi > lo ? lo + atomicAdd(counter + q * DESC_HEAD_STRIDE, 1) : hi;
-                if (t < hi) break;
-#endif
+                const int n = plan->small_tickets[q];
+                const int t = n > 0 ? atomicAdd(counter + q * DESC_HEAD_STRIDE, 1) : 0;
+                if (t < n) { slot = plan->small_start[q] + t; break; }
                 head++;                                      // this head is exhausted (it stays exhausted): steal from the next
-                t = total;
             }
-        t = __builtin_amdgcn_readfirstlane(t);               // lane 0's ticket, as an SGPR: the ROI record and keypoint index below are scalar
+        slot = __builtin_amdgcn_readfirstlane(slot);         // lane 0's ticket, as an SGPR: the records below are scalar loads
         head = __builtin_amdgcn_readfirstlane(head);
-        if (t >= total) break;
-        int lo = 0, hi = nrois;                               // prefix[lo] <= t < prefix[hi]
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= t) lo = mid; else hi = mid; }
-        const RoiDev &R = rois[__builtin_amdgcn_readfirstlane(rank_to_roi(lo))];
-        const int within = t - prefix[lo] + R.counters[12] + R.counters[13] + R.counters[14];   // the ROI's list is class-major
-        describe_small(R, area_tab, __builtin_amdgcn_readfirstlane(R.order[within]), upright, L[wave]);
+        if (slot < 0) break;
+        const DescRec rec = load_rec_uniform(recs + slot);
+        describe_small(rois[rec.roi], area_tab, rec, upright, L[wave]);
     }
 }
 
@@ -2036,26 +1964,47 @@ __global__ __launch_bounds__(256) void k_pair_rows(const RoiDev *rois)
 #ifndef DESC_WGS
 #define DESC_WGS 5
 #endif
-__global__ __launch_bounds__(256, DESC_WGS) void k_describe(const RoiDev *rois, int nrois, int *counter, const SurfTables *T,
+__global__ __launch_bounds__(256, DESC_WGS) void k_describe(const RoiDev *rois, const DescPlan *plan, const DescRec *recs, int *counter, const SurfTables *T,
                                                   const AreaRec *area_tab, int extended, int upright)
 {
-    __shared__ TicketState S;
-    ticket_init(rois, nrois, S);
-    int roi, k, band;
+    __shared__ int s_slot, s_band;
+    int head = 0;                                            // thread 0's
 #ifdef VFSMS_DESC_TIMING
     unsigned long long tq = clock64();
-    while (ticket_next(rois, counter, nrois, S, roi, k, band)) {
-        if (threadIdx.x == 0) atomicAdd(&g_desc_cycles[6], clock64() - tq);
-        describe_one(rois[roi], T, area_tab, k, extended, upright, band);
-        tq = clock64();
-    }
-#else
-    // (roi, k, band) come out of LDS, i.e. in VGPRs; they are the same for the whole workgroup: as SGPRs the ROI record and the
-    // keypoint are fetched by scalar loads and everything derived from them stays off the VALU
-    while (ticket_next(rois, counter, nrois, S, roi, k, band))
-        describe_one(rois[__builtin_amdgcn_readfirstlane(roi)], T, area_tab, __builtin_amdgcn_readfirstlane(k), extended, upright,
-                     __builtin_amdgcn_readfirstlane(band));
 #endif
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int slot = -1, band = -1;
+            const int split = plan->split;
+            while (head < DESC_HEADS) {
+                const int q = (blockIdx.x + head) & (DESC_HEADS - 1);
+                const int n = plan->big_tickets[q];
+                const int t = n > 0 ? atomicAdd(counter + q * DESC_HEAD_STRIDE, 1) : 0;
+                if (t < n) {
+                    // the head's class-0 records come first; with split > 1 each of them is `split` tickets, one per output row
+                    const int n0 = plan->big_n0[q];
+                    if (t < n0 * split) { slot = plan->big_start[q] + t / split; band = split > 1 ? t % split : -1; }
+                    else slot = plan->big_start[q] + n0 + (t - n0 * split);
+                    break;
+                }
+                head++;                                      // this head is exhausted (it stays exhausted): steal from the next
+            }
+            s_slot = slot; s_band = band;
+        }
+        __syncthreads();
+        const int slot = __builtin_amdgcn_readfirstlane(s_slot), band = __builtin_amdgcn_readfirstlane(s_band);
+        if (slot < 0) break;
+#ifdef VFSMS_DESC_TIMING
+        if (threadIdx.x == 0) atomicAdd(&g_desc_cycles[6], clock64() - tq);
+#endif
+        // the record and the ROI it names are the same for the whole workgroup: scalar loads, and everything derived from them stays off the VALU
+        const DescRec rec = load_rec_uniform(recs + slot);
+        describe_one(rois[rec.roi], T, area_tab, rec, extended, upright, band);
+#ifdef VFSMS_DESC_TIMING
+        tq = clock64();
+#endif
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2087,23 +2036,6 @@ __global__ __launch_bounds__(1024) void k_keep_scan(const RoiDev *rois)
     if (threadIdx.x == 0) R.counters[1] = carry;
 }
 
-// One thread per keypoint: sin/cos of the descriptor window's rotation (std::sin / std::cos on float in the reference).
-// det_sincos (detmath.h) is the explicit double-precision algorithm the oracle evaluates too, so both sides round to the
-// same float; it agrees with a correctly rounded sinf/cosf except within ~2^-29 ulp of a rounding boundary.
-__global__ __launch_bounds__(256) void k_desc_trig(const RoiDev *rois)
-{
-    const RoiDev &R = rois[blockIdx.y];
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= min(R.counters[0], R.cap)) return;
-    const vfsms_keypoint kp = R.kps[k];
-    if (!(kp.size > 0)) return;
-    const float dir = kp.angle * (float)(3.1415926535897932384626433832795 / 180);
-    float *row = (float *)(R.patch + (size_t)k * VFSMS_PATCH_ROW + VFSMS_PATCH_TRIG);
-    double sd, cd;
-    det_sincos((double)dir, &sd, &cd);
-    row[0] = -(float)sd;
-    row[1] = (float)cd;
-}
 
 // Descriptor tail, 16 keypoints per workgroup, 16 threads (one per 5 x 5 cell) per keypoint: Gaussian-weighted
 // gradients of the 21 x 21 patch, per-cell sums in raster order, L2 normalisation with the double accumulator of
@@ -2192,6 +2124,7 @@ size_t surf_roi_bytes(int h, int w, int cap, int nlayers_total, int noctaves, in
     }
     b += al(16 * sizeof(int)) + al(sizeof(Cand) * cap) + al(sizeof(vfsms_keypoint) * cap) + al((size_t)cap * VFSMS_PATCH_ROW);
     b += 2 * al(sizeof(int) * cap) + al(sizeof(float) * 2 * cap) + al(sizeof(float) * (size_t)cap * dim) + al(sizeof(vfsms_keypoint) * cap);
+    b += 2 * al(sizeof(DescRec) * (size_t)cap);               // this ROI's share of the launch's two record arrays (launch_surf_describe)
     return b + 4096;
 }
 
@@ -2375,17 +2308,24 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
     }
     {
         ProfScope ps(ctx, "describe");
-        // ticket heads: 8 counters, 256 B apart, out of the call's arena (callers reserve 64 KB of slack)
+        // ticket heads (8 counters per kernel, 256 B apart), the launch's plan and its two record arrays out of the call's arena (surf_roi_bytes
+        // counts the records of every ROI; callers reserve 64 KB of slack for the rest)
         int *tickets = (int *)ctx_arena_alloc(ctx, sizeof(int) * 2 * DESC_HEADS * DESC_HEAD_STRIDE);
-        if (!tickets) { vfsms_set_error("arena exhausted (descriptor tickets)"); return VFSMS_ERR_CAPACITY; }
+        DescPlan *plan = (DescPlan *)ctx_arena_alloc(ctx, sizeof(DescPlan));
+        size_t capsum = 0;
+        for (int r = 0; r < nrois; r++) capsum += (size_t)h_rois[r].cap;
+        DescRec *rec_big = (DescRec *)ctx_arena_alloc(ctx, sizeof(DescRec) * capsum);
+        DescRec *rec_small = (DescRec *)ctx_arena_alloc(ctx, sizeof(DescRec) * capsum);
+        if (!tickets || !plan || !rec_big || !rec_small) { vfsms_set_error("arena exhausted (descriptor work list)"); return VFSMS_ERR_CAPACITY; }
         HIP_TRY(hipMemsetAsync(tickets, 0, sizeof(int) * 2 * DESC_HEADS * DESC_HEAD_STRIDE, ctx->stream));
         for (const ShapeRun &q : shape_runs(h_rois, nrois))
             hipLaunchKernelGGL(k_pair_rows, dim3((q.w + 1023) / 1024, q.h, q.count), dim3(256), 0, ctx->stream, d_rois + q.first);
         hipLaunchKernelGGL(k_desc_order, dim3(nrois), dim3(1024), 0, ctx->stream, d_rois);
-        if (!p->upright) hipLaunchKernelGGL(k_desc_trig, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois);
-        hipLaunchKernelGGL(k_describe, dim3(256 * DESC_WGS), dim3(256), 0, ctx->stream, d_rois, nrois, tickets,
+        hipLaunchKernelGGL(k_desc_plan, dim3(1), dim3(256), 0, ctx->stream, d_rois, nrois, plan, 256 * DESC_WGS);
+        hipLaunchKernelGGL(k_desc_recs, dim3((maxcap + 255) / 256, nrois), dim3(256), 0, ctx->stream, d_rois, plan, rec_big, rec_small, p->upright);
+        hipLaunchKernelGGL(k_describe, dim3(256 * DESC_WGS), dim3(256), 0, ctx->stream, d_rois, plan, rec_big, tickets,
                            ctx->d_tables, (const AreaRec *)ctx->d_area_tab, p->extended, p->upright);
-        hipLaunchKernelGGL(k_describe_small, dim3(256 * DESC_SMALL_WGS), dim3(256), 0, ctx->stream, d_rois, nrois,
+        hipLaunchKernelGGL(k_describe_small, dim3(256 * DESC_SMALL_WGS), dim3(256), 0, ctx->stream, d_rois, plan, rec_small,
                            tickets + DESC_HEADS * DESC_HEAD_STRIDE, (const AreaRec *)ctx->d_area_tab, p->upright);
         hipLaunchKernelGGL(k_desc_tail, dim3((maxcap + 15) / 16, nrois), dim3(256), 0, ctx->stream, d_rois, ctx->d_tables, p->extended);
     }
