@@ -1564,10 +1564,71 @@ __device__ __forceinline__ uint8_t area_col_tab(const float *rb, const AreaRec &
 }
 
 // band >= 0: only row `band` of the 21 x 21 patch (tickets of the largest windows are split by output row, see k_desc_plan)
-__device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec *area_tab, const DescRec &rec, int extended, int upright, const int band)
+#define DESC_HEADS DESC_PLAN_HEADS
+#define DESC_HEAD_STRIDE 64          // ints between the ticket heads of a kernel
+// What thread 0 carries through a keypoint for the NEXT one (k_describe): the ticket it drew at the start -- an atomic whose return nobody
+// waits for --, then, once the window is staged, the record that ticket leads to.  Both trips to memory run beside the sampling; at the end
+// the record is handed to the workgroup through LDS.  (Before: atomic -> record, two dependent trips with four waves waiting, per keypoint.)
+struct DescNext {
+    int t, drawn;                 // the ticket (valid once the atomic has returned) / was one drawn?
+    int n, n0, start, split;      // the slice of the head it was drawn from (DescPlan)
+    int slot, band;               // resolved: record index (< 0: none yet) and output row of a split ticket
+    int r[8];                     // the record, in flight
+    int head, info_head;          // heads this workgroup has found exhausted / the head n, n0, start belong to
+};
+__device__ __forceinline__ void next_resolve(DescNext &N)
+{
+    // the head's class-0 records come first; with split > 1 each of them is `split` tickets, one per output row
+    N.band = -1;
+    if (N.t < N.n0 * N.split) { N.slot = N.start + N.t / N.split; N.band = N.split > 1 ? N.t % N.split : -1; }
+    else N.slot = N.start + N.n0 + (N.t - N.n0 * N.split);
+}
+__device__ __forceinline__ void next_draw(DescNext &N, const DescPlan *plan, int *counter)     // thread 0: issue the atomic of the next ticket
+{
+    N.drawn = 0; N.slot = -1; N.t = 0;
+    if (N.head < DESC_HEADS) {
+        const int q = (blockIdx.x + N.head) & (DESC_HEADS - 1);
+        if (N.info_head != N.head) {                         // the head's slice: read once per head, not once per keypoint (a trip to memory in front of the atomic)
+            N.n = plan->big_tickets[q]; N.n0 = plan->big_n0[q]; N.start = plan->big_start[q]; N.split = plan->split;
+            N.info_head = N.head;
+        }
+        if (N.n > 0) { N.t = atomicAdd(counter + q * DESC_HEAD_STRIDE, 1); N.drawn = 1; }
+    }
+}
+__device__ __forceinline__ void next_fetch(DescNext &N, const DescRec *recs)                    // thread 0: the ticket is back -- request its record
+{
+    if (N.drawn && N.t < N.n) {
+        next_resolve(N);
+        const int *q = (const int *)(recs + N.slot);
+#pragma unroll
+        for (int i = 0; i < 8; i++) N.r[i] = q[i];
+    }
+}
+// thread 0: hand the next keypoint to the workgroup (slot < 0: the launch is exhausted).  A ticket beyond its head's slice means that head
+// ran dry: the following heads are tried one after the other, this time waiting for every answer.
+__device__ __forceinline__ void next_publish(DescNext &N, const DescPlan *plan, const DescRec *recs, int *counter, int *s_next)
+{
+    if (N.slot < 0) {
+        if (N.drawn || (N.head < DESC_HEADS && N.n <= 0)) N.head++;
+        while (N.head < DESC_HEADS) {
+            next_draw(N, plan, counter);
+            if (N.drawn && N.t < N.n) { next_fetch(N, recs); break; }
+            N.head++;
+        }
+    }
+    s_next[0] = N.slot; s_next[1] = N.band;
+    if (N.slot >= 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) s_next[2 + i] = N.r[i];
+    }
+}
+
+__device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec *area_tab, const DescRec &rec, int extended, int upright, const int band,
+                             DescNext &N, const DescPlan *plan, const DescRec *recs, int *counter, int *s_next)
 {
     DT_START;
     const int k = rec.k;
+    if (threadIdx.x == 0) next_draw(N, plan, counter);     // the next keypoint's ticket: on its way while this one is worked on
     __shared__ float sx_row[VFSMS_MAX_WIN], sy_row[VFSMS_MAX_WIN];
     __shared__ uint8_t PATCH[21][21 + 3];
     __shared__ AreaRec REC[AREA_RECS];                     // computeResizeAreaTab of this window size: same records for x and y
@@ -1580,11 +1641,21 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
     G.upright = upright; G.usx = 0; G.usy = 0; G.sin_dir = rec.sin_dir; G.cos_dir = rec.cos_dir;
     const int win = G.win;
     const int dsz = 21;
-    if (threadIdx.x < AREA_RECS * 8) ((int *)REC)[threadIdx.x] = ((const int *)(area_tab + (size_t)win * AREA_RECS))[threadIdx.x];
-    __syncthreads();
-    const int nmin = __builtin_amdgcn_readfirstlane(REC[21].j0), nmax = __builtin_amdgcn_readfirstlane(REC[21].n);
-    const int mode = __builtin_amdgcn_readfirstlane(REC[21].mode);
-    const float inv_area = REC[21].a0;
+    // computeResizeAreaTab of this window size (host-built table): requested now.  A window that is staged whole (win <= 128, not a band
+    // ticket) needs it only for the reduction -- its words go to LDS behind the sampling, their trip to memory beside it; the band forms
+    // cut their staging calls from it and wait here.
+    const bool whole = win * win <= DESC_WBUF && band < 0;
+    int rec_word = 0;
+    if (threadIdx.x < AREA_RECS * 8) rec_word = ((const int *)(area_tab + (size_t)win * AREA_RECS))[threadIdx.x];
+    int nmin = 0, nmax = 0, mode = 0; float inv_area = 0.f;
+    auto rec_arrived = [&]() {
+        if (threadIdx.x < AREA_RECS * 8) ((int *)REC)[threadIdx.x] = rec_word;
+        __syncthreads();
+        nmin = __builtin_amdgcn_readfirstlane(REC[21].j0); nmax = __builtin_amdgcn_readfirstlane(REC[21].n);
+        mode = __builtin_amdgcn_readfirstlane(REC[21].mode);
+        inv_area = REC[21].a0;
+    };
+    if (!whole) rec_arrived();
     if (!upright) {
         // Row origins are running float sums in the reference (start_x += sin_dir per row): inherently sequential, so one lane of wave 0
         // walks x while one lane of wave 1 walks y (both chains in lanes 0 / 1 of ONE wave -- half the issue slots -- measured 0.7 %
@@ -1630,9 +1701,12 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
             dyA = dyB;
         }
     };
-    if (win * win <= DESC_WBUF) {
+    bool fetched = false;                                  // has thread 0 asked for the next keypoint's record?
+    if (whole) {
         stage_rows<4>(G, sx_row, sy_row, 0, win, WINBUF, STRIP_IN);
-        __syncthreads();
+        rec_arrived();                                     // (its barrier is the one behind the staging)
+        if (threadIdx.x == 0) next_fetch(N, recs);
+        fetched = true;
         DT_MARK(1);
         reduce_rows(0, 0, dsz);
         DT_MARK(2);
@@ -1650,6 +1724,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
                 const int end = REC[d_stop - 1].j0 + REC[d_stop - 1].n - 1;
                 stage_rows<4>(G, sx_row, sy_row, rlo, end - rlo + 1, WINBUF, STRIP_IN);
                 __syncthreads();
+                if (!fetched) { if (threadIdx.x == 0) next_fetch(N, recs); fetched = true; }
                 DT_MARK(3);
                 reduce_rows(rlo, dy, d_stop);
                 DT_MARK(4);
@@ -1660,6 +1735,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
                     const int cn = min(crows, nrows - c0);
                     stage_rows<4>(G, sx_row, sy_row, rlo + c0, cn, WINBUF, STRIP_IN);
                     __syncthreads();
+                    if (!fetched) { if (threadIdx.x == 0) next_fetch(N, recs); fetched = true; }
                     DT_MARK(3);
                     for (int e = threadIdx.x; e < cn * 21; e += 256) {
                         const int r = (int)(((uint32_t)e * 3121u) >> 16), dx = e - 21 * r;
@@ -1675,6 +1751,10 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
         }
     }
     __syncthreads();
+    if (threadIdx.x == 0) {
+        if (!fetched) next_fetch(N, recs);
+        next_publish(N, plan, recs, counter, s_next);
+    }
     // hand the 21 x 21 patch to k_desc_tail (gradients, cell sums, normalisation run there, 16 keypoints per workgroup)
     if (band >= 0) {
         if (threadIdx.x < 21) R.patch[(size_t)k * VFSMS_PATCH_ROW + band * 21 + threadIdx.x] = PATCH[band][threadIdx.x];
@@ -1756,8 +1836,6 @@ __global__ __launch_bounds__(1024) void k_desc_order(const RoiDev *rois)
 // What a ticket leads to is ONE 32-byte record (DescRec) at a position that follows from the ticket alone: k_desc_plan lays the heads'
 // slices out, k_desc_recs fills them.
 // ---------------------------------------------------------------------------------------------------
-#define DESC_HEADS DESC_PLAN_HEADS
-#define DESC_HEAD_STRIDE 64          // ints between heads
 
 // one workgroup: the layout of the record arrays from the class counts of all ROIs (counters[12..15], k_desc_order)
 __global__ __launch_bounds__(256) void k_desc_plan(const RoiDev *rois, int nrois, DescPlan *plan, int big_grid)
@@ -1967,40 +2045,29 @@ __global__ __launch_bounds__(256) void k_pair_rows(const RoiDev *rois)
 __global__ __launch_bounds__(256, DESC_WGS) void k_describe(const RoiDev *rois, const DescPlan *plan, const DescRec *recs, int *counter, const SurfTables *T,
                                                   const AreaRec *area_tab, int extended, int upright)
 {
-    __shared__ int s_slot, s_band;
-    int head = 0;                                            // thread 0's
+    __shared__ int s_next[2][10];                            // [slot, band, record] of the keypoint to do next, double-buffered (written while the current one is read)
+    DescNext N;
+    N.head = 0; N.info_head = -1; N.slot = -1; N.drawn = 0; N.n = 1; N.band = -1; N.t = 0; N.n0 = 0; N.start = 0; N.split = 1;
+    if (threadIdx.x == 0) next_publish(N, plan, recs, counter, s_next[0]);      // the first keypoint: drawn and fetched with the workgroup waiting
+    int cur = 0;
 #ifdef VFSMS_DESC_TIMING
     unsigned long long tq = clock64();
 #endif
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int slot = -1, band = -1;
-            const int split = plan->split;
-            while (head < DESC_HEADS) {
-                const int q = (blockIdx.x + head) & (DESC_HEADS - 1);
-                const int n = plan->big_tickets[q];
-                const int t = n > 0 ? atomicAdd(counter + q * DESC_HEAD_STRIDE, 1) : 0;
-                if (t < n) {
-                    // the head's class-0 records come first; with split > 1 each of them is `split` tickets, one per output row
-                    const int n0 = plan->big_n0[q];
-                    if (t < n0 * split) { slot = plan->big_start[q] + t / split; band = split > 1 ? t % split : -1; }
-                    else slot = plan->big_start[q] + n0 + (t - n0 * split);
-                    break;
-                }
-                head++;                                      // this head is exhausted (it stays exhausted): steal from the next
-            }
-            s_slot = slot; s_band = band;
-        }
-        __syncthreads();
-        const int slot = __builtin_amdgcn_readfirstlane(s_slot), band = __builtin_amdgcn_readfirstlane(s_band);
+        const int slot = __builtin_amdgcn_readfirstlane(s_next[cur][0]), band = __builtin_amdgcn_readfirstlane(s_next[cur][1]);
         if (slot < 0) break;
 #ifdef VFSMS_DESC_TIMING
         if (threadIdx.x == 0) atomicAdd(&g_desc_cycles[6], clock64() - tq);
 #endif
-        // the record and the ROI it names are the same for the whole workgroup: scalar loads, and everything derived from them stays off the VALU
-        const DescRec rec = load_rec_uniform(recs + slot);
-        describe_one(rois[rec.roi], T, area_tab, rec, extended, upright, band);
+        // the record and the ROI it names are the same for the whole workgroup: scalar registers, and everything derived from them stays off the VALU
+        DescRec rec;
+        rec.roi = __builtin_amdgcn_readfirstlane(s_next[cur][2]); rec.k = __builtin_amdgcn_readfirstlane(s_next[cur][3]);
+        rec.win = __builtin_amdgcn_readfirstlane(s_next[cur][4]); rec.pad = 0;
+        rec.sin_dir = __int_as_float(__builtin_amdgcn_readfirstlane(s_next[cur][6])); rec.cos_dir = __int_as_float(__builtin_amdgcn_readfirstlane(s_next[cur][7]));
+        rec.x = __int_as_float(__builtin_amdgcn_readfirstlane(s_next[cur][8])); rec.y = __int_as_float(__builtin_amdgcn_readfirstlane(s_next[cur][9]));
+        describe_one(rois[rec.roi], T, area_tab, rec, extended, upright, band, N, plan, recs, counter, s_next[cur ^ 1]);
+        cur ^= 1;
 #ifdef VFSMS_DESC_TIMING
         tq = clock64();
 #endif
