@@ -45,15 +45,16 @@ BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak of gfx950 (v_mfma_f32_32x3
 FP32_PEAK_TFLOPS = 157.3       # dense FP32 MFMA peak of gfx950 (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md
 # VALU issue peak in lane-operations: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T/s, i.e. one wave64 VALU instruction occupies its SIMD
 # for 4 cycles.  CALIBRATED on the box (tools/valu_peak.hip, every SIMD filled with 1-8 waves of independent chains,
-# profiles/r04_valu_peak.txt): v_fma_f32 38.3, v_fma_f64 33.2, v_add_f64 36.9, v_cvt_f32_ubyte0 37.8, v_cvt_i32_f64 37.5, v_cvt_f32_f64 36.8,
+# profiles/r05_valu_peak.txt): v_fma_f32 38.3, v_fma_f64 33.2, v_add_f64 36.9, v_cvt_f32_ubyte0 37.8, v_cvt_i32_f64 37.5, v_cvt_f32_f64 36.8,
 # v_pk_mul_f32 33.1 T lane-ops/s -- the 4-cycle rate (0.84-0.97 of 39.3) for every VOP3 / conversion / f64 / packed instruction the
 # descriptor kernels lean on; MI355X_MICROARCH.md's "SIMD-32, 2 cycles" (78.6 T/s) is NOT reached by them.  Only plain VOP2 operations run
 # faster: v_mul_f32 56.4, v_add_u32 60.7 T/s (~2.7 cycles).  157.3 TFLOP/s = 39.3 T x 2 flop per FMA x 2 for packed FP32.
 VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
-# VALU instructions per bilinear sample of k_describe's staging loop, counted in its gfx950 assembly (interior path: index + v_cvt_f64,
-# 2 v_fma_f64, 2 v_cvt_i32_f64, 2 address, 2 v_fract_f64, 2 v_cvt_f32_f64, 2 v_sub, 4 v_cvt_f32_ubyte, 4 v_pk_mul (+2 moves), 3 v_add,
-# v_rndne, v_cvt, LDS address) -- the ALGORITHMIC work of one sample as this kernel formulates it
-DESC_VALU_PER_SAMPLE = 30
+# VALU instructions per bilinear sample of k_describe's staging loop, counted in its gfx950 assembly (stage_round<4>: 99 per four samples of a
+# lane -- cvt_f64_i32 + 2 v_fma_f64 + 6 v_add_f64 for the positions, 8 v_cvt_i32_f64, 4 v_mul_u32_u24 + 4 v_add_lshl for the addresses, 8
+# v_fract_f64, 8 v_cvt_f32_f64, 8 v_sub, 16 v_cvt_f32_ubyte, 16 v_pk_mul, 16 v_add, 2 address / counter adds); reported beside the roofline.
+# The roofline itself counts the REFERENCE's 26 operations per sample (below): a number that does not move when the kernel is rewritten.
+DESC_VALU_PER_SAMPLE = 24.75
 # An op count that does not depend on how the kernel is written: the arithmetic the REFERENCE's expression needs per window sample
 # (SURFInvoker: pixel_x += cos, pixel_y -= sin (2), two floors (2), two (float)(p - i) (2), four u8 -> float (4), 1 - a, 1 - b (2),
 # eight products (8), three sums (3), cvRound (1)) = 24, + resize(INTER_AREA)'s multiply-add per window pixel (2) = 26 lane-ops.
@@ -846,7 +847,7 @@ def main():
         spk = float((win.astype(np.float64) ** 2).mean()) if len(win) else 0.0
         kps = st["sum_nq_plus_nt"] / de_n                                   # keypoints described per launch
         dur = de_ms / de_n * 1e-3
-        laneops = kps * spk * DESC_VALU_PER_SAMPLE
+        laneops = kps * spk * DESC_OPS_LOWER_BOUND
         traffic, traffic_src = pmc_traffic_scaled("k_describe", st["attempts"] / de_n)
         valu_insts, _src = pmc_value("k_describe", "INSTS_VALU")
         busy, _src2 = pmc_value("k_describe", "BUSY_CYCLES")            # summed over the 32 shader engines: / 32 = cycles of the launch
@@ -854,15 +855,17 @@ def main():
         roofline = dict(kernel="k_describe+k_describe_small", bound="valu", achieved=round(laneops / dur / 1e12, 3), peak=round(VALU_PEAK_TLANEOPS, 2),
                         unit="Tlane-op/s", frac=round(laneops / dur / 1e12 / VALU_PEAK_TLANEOPS, 4), traffic=traffic, traffic_source=traffic_src,
                         compulsory_bytes_per_launch=round(kps / max(len(kf), 1) * (2.0 * roi_h * roi_w) + kps * 441.0), avg_launch_ms=round(dur * 1e3, 4),
-                        lane_ops_per_launch=laneops, valu_ops_per_sample=DESC_VALU_PER_SAMPLE, keypoints_per_launch=kps,
+                        lane_ops_per_launch=laneops, kernel_valu_insts_per_sample_inner_loop=DESC_VALU_PER_SAMPLE, keypoints_per_launch=kps,
                         samples_per_keypoint=round(spk, 1), launches=de_n,
                         note="dominant stage by time (%.0f %% of the GPU time of a step; the timed scope also holds k_pair_rows, k_desc_order, "
-                             "k_desc_trig and k_desc_tail); achieved counts only the inner-loop instructions of the samples; all VALU "
-                             "instructions k_describe issues (PMC SQ_INSTS_VALU, profiles/) keep its SIMDs busy for valu_busy_frac_pmc of the "
-                             "launch (lane padding of 8 x 32-sample units, INTER_AREA reduction, row-origin chains, tickets)"
+                             "k_desc_plan, k_desc_recs and k_desc_tail); achieved = bilinear samples x the 26 lane-operations the REFERENCE's expression "
+                             "needs per sample (ops_per_sample_lower_bound: independent of how the kernel is written; rounds 1-4 counted the kernel's own "
+                             "30 instructions per sample) / the live HIP-event duration; all VALU instructions k_describe issues (PMC SQ_INSTS_VALU, "
+                             "profiles/) keep its SIMDs busy for valu_busy_frac_pmc of the launch (bookkeeping of the staging units, border units, "
+                             "INTER_AREA reduction, row-origin chains)"
                              % (100.0 * de_ms / max(sum(v[0] for v in prof.values()), 1e-9)),
                         valu_insts_per_launch_pmc=valu_insts, valu_busy_frac_pmc=valu_busy, ta_busy_frac_pmc=pmc_value("k_describe", "ta_busy_frac")[0],
-                        valu_peak_source="profiles/r04_valu_peak.txt (tools/valu_peak.hip on the MI355X box: 4-cycle class instructions 33-38 T lane-ops/s)",
+                        valu_peak_source="profiles/r05_valu_peak.txt (tools/valu_peak.hip on the MI355X box: 4-cycle class instructions 33-38 T lane-ops/s)",
                         ops_per_sample_lower_bound=DESC_OPS_LOWER_BOUND,
                         **clock_fields(laneops / dur / 1e12),
                         valu_insts_lower_bound_per_launch=round(kps * spk * DESC_OPS_LOWER_BOUND / 64.0),
@@ -898,16 +901,20 @@ def main():
         extra["integral_hbm"]["traffic"] = sum(tr) if all(v is not None for v in tr) else None
     he_ms, he_n = stage("hessian")
     if he_n:
-        # reads S once per octave pass 4 (h+1)(w+1) x 4 + writes det + trace 8 x sum_o 5 (h/2^o)(w/2^o) = 69.1 B/px
-        extra["hessian_hbm"] = hbm_roofline("k_hessian_lds<1,64>+k_hessian_lds<2,32>+k_hessian_coarse(octaves 2, 3)", st["roi_px"] / he_n * 69.1, he_ms / he_n, he_n)
+        # bytes the stage moves as it is built: the integral image read once per octave pass, 4 (h+1)(w+1) x 4 = 16 B/px, + the determinant
+        # layers written, 4 x sum_o 5 (h/2^o)(w/2^o) = 26.6 B/px -- 42.6 B/px.  (SURVEY 8d's 69.1 B/px also counts the trace layers, which
+        # have not been written since round 3: the sign of the Laplacian is recomputed for the few thousand candidates.)
+        HESS_BYTES_PER_PX = 16.0 + 4.0 * 5.0 * (1 + 1 / 4.0 + 1 / 16.0 + 1 / 64.0)
+        extra["hessian_hbm"] = hbm_roofline("k_hessian_lds<1,64>+k_hessian_lds<2,32>+k_hessian_coarse(octaves 2, 3)", st["roi_px"] / he_n * HESS_BYTES_PER_PX, he_ms / he_n, he_n)
+        extra["hessian_hbm"]["bytes_per_px"] = round(HESS_BYTES_PER_PX, 2)
         hv, _s = pmc_value("void k_hessian_lds<1, 64>", "INSTS_VALU"); hb, _s = pmc_value("void k_hessian_lds<1, 64>", "BUSY_CYCLES")
         extra["hessian_hbm"]["valu_insts_x4_over_simd_cycles_octave0"] = round(hv * 4.0 / (hb / 32.0 * 1024.0), 3) if hv and hb else None
         htr = [pmc_traffic_scaled(k, st["attempts"] / he_n)[0] for k in ("void k_hessian_lds<1, 64>", "void k_hessian_lds<2, 32>", "k_hessian_coarse")]
         extra["hessian_hbm"]["traffic"] = sum(htr) if all(v is not None for v in htr) else None
-        extra["hessian_hbm"]["note"] = ("bytes = SURVEY 8d's 69.1 B/px (it still counts the trace layers, no longer written); the fine octaves are bound by VALU "
+        extra["hessian_hbm"]["note"] = ("bytes = what the stage moves (42.6 B/px: no trace layers; SURVEY 8d's 69.1 B/px counted them); the fine octaves are bound by VALU "
                                         "issue + LDS taps, not by HBM: SQ_INSTS_VALU x 4 cycles EXCEEDS the SIMD cycles of octave 0's launches "
                                         "(valu_insts_x4_over_simd_cycles_octave0 > 1) -- part of its instructions are plain VOP2 integer adds, which issue in "
-                                        "~2.7 cycles (profiles/r04_valu_peak.txt): the kernel has no idle issue slots")
+                                        "~2.7 cycles (profiles/r05_valu_peak.txt): the kernel has no idle issue slots")
     if args.method == "phase":
         ph_ms, ph_n = prof.get("phase", (0.0, 0))
         if ph_n:

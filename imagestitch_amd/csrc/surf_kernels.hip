@@ -978,7 +978,6 @@ __device__ __forceinline__ float bilinear_pk(uint32_t top, float a, float b)
 #ifndef BORDER_ILP
 #define BORDER_ILP 2            // strips that cross the image border: shorter trips keep the register budget of the hot path
 #endif
-#if !(VFSMS_EXP & 4)
 // ---- interior rounds of the balanced form -----------------------------------------------------------------------------------------
 // N samples of one lane, 8 columns apart, starting at column j0 + lj of the lane's row: positions px0 + 8 u c (8 c, 16 c, 24 c are exact
 // doubles, so the sum rounds like start + j * step whenever that is exact), N gathers issued back to back, then the arithmetic; the LDS
@@ -1005,186 +1004,6 @@ __device__ __forceinline__ void stage_round(g_cu8 ubase, const uint32_t pw, cons
     }
 }
 
-#if VFSMS_EXP & 64
-// ---- software-pipelined form (VFSMS_EXP & 64) ------------------------------------------------------------------------------------------
-// The gathers of round n + 1 are issued BEFORE the arithmetic of round n: a wave always has four gathers in flight while it computes, instead
-// of issuing four, waiting for them and only then computing (the compiler orders a round as written; it does not rotate loops).  A round is
-// always four samples of a lane (8 columns apart); rounds are drawn from the wave's units one after the other -- across unit and strip
-// boundaries -- into two register sets used in turn.  The last round of a row clamps its columns to the window (lanes past it repeat the
-// last column: same position, same byte).
-struct StageRound { uint32_t top[4]; float a[4], b[4]; uint8_t *drc; int jl; };
-
-template <bool CLAMP>
-__device__ __forceinline__ void round_issue(StageRound &S, g_cu8 ubase, const uint32_t pw, const double c, const double sn, const double sxc,
-                                            const double syc, const int jl, uint8_t *drc, const int win)
-{
-    S.drc = drc; S.jl = jl;
-    double px[4], py[4];
-    if (!CLAMP) {
-        const double jd = (double)jl;
-        px[0] = __builtin_fma(jd, c, sxc); py[0] = __builtin_fma(jd, -sn, syc);
-#pragma unroll
-        for (int u = 1; u < 4; u++) { px[u] = px[0] + (double)(8 * u) * c; py[u] = py[0] - (double)(8 * u) * sn; }
-    } else {
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const double jd = (double)min(jl + 8 * u, win - 1);
-            px[u] = __builtin_fma(jd, c, sxc); py[u] = __builtin_fma(jd, -sn, syc);
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const uint32_t off = ((uint32_t)__umul24((uint32_t)(int)py[u], pw) + (uint32_t)(int)px[u]) << 1;
-        S.top[u] = *(GAS const uint32_t *)(ubase + off);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) { S.a[u] = (float)__builtin_amdgcn_fract(px[u]); S.b[u] = (float)__builtin_amdgcn_fract(py[u]); }
-}
-template <bool CLAMP>
-__device__ __forceinline__ void round_finish(const StageRound &S, const int win)
-{
-    uint8_t *w = S.drc + S.jl;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const uint8_t v = round_u8_pos(bilinear_pk(S.top[u], S.a[u], S.b[u]));
-        if (!CLAMP) w[8 * u] = v; else S.drc[min(S.jl + 8 * u, win - 1)] = v;
-    }
-}
-
-template <int NW>
-__device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row, const float *sy_row,
-                                           int r0, int nrows, uint8_t *dst, uint8_t *strip_in)
-{
-    const int win = __builtin_amdgcn_readfirstlane(G.win);
-    r0 = __builtin_amdgcn_readfirstlane(r0); nrows = __builtin_amdgcn_readfirstlane(nrows);
-    const int lane = threadIdx.x & 63, wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int li = lane >> 3, lj = lane & 7;
-    const int strips = (nrows + 7) >> 3;
-    const double c = (double)G.cos_dir, sn = (double)G.sin_dir;
-    const int ncols1 = __builtin_amdgcn_readfirstlane(G.w) - 1, nrows1 = __builtin_amdgcn_readfirstlane(G.h) - 1;
-    const uint64_t bp = (uint64_t)G.pair;
-    g_cu8 ubase = (g_cu8)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32)) << 32) |
-                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)bp));
-    const uint32_t pw = (uint32_t)(ncols1 + 1);
-    const int rounds = (win + 31) >> 5;                          // rounds of 4 groups (32 columns) per row; the last one clamps if win % 32
-    const int nb = (rounds + 1) >> 1;                            // units of two rounds (64 columns)
-    const bool ragged = (win & 31) != 0;
-    const int total = strips * nb;
-    if (!G.upright) {
-        const int tid = NW == 1 ? lane : (int)threadIdx.x;
-        if (tid < strips) {
-            const int ia = min(r0 + tid * 8, VFSMS_MAX_WIN - 1), ib = min(min(r0 + tid * 8 + 7, r0 + nrows - 1), VFSMS_MAX_WIN - 1);
-            const double xa = (double)sx_row[ia], xb = (double)sx_row[ib], ya = (double)sy_row[ia], yb = (double)sy_row[ib];
-            const double jb = (double)(win - 1);
-            const double jxb = jb * c, jyb = -(jb * sn);
-            const double xmin = fmin(xa, xb) + fmin(0.0, jxb), xmax = fmax(xa, xb) + fmax(0.0, jxb);
-            const double ymin = fmin(ya, yb) + fmin(0.0, jyb), ymax = fmax(ya, yb) + fmax(0.0, jyb);
-            strip_in[tid] = xmin >= 0.0 && ymin >= 0.0 && xmax < (double)(ncols1 - 2) && ymax < (double)nrows1;
-        }
-        if (NW == 1) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-        else __syncthreads();
-    }
-    int ty = 0, cbi = wv;
-    while (cbi >= nb) { cbi -= nb; ty++; }
-    const int last_row = r0 + nrows - 1;
-    const int liw = li * win;
-    const int last_off = (nrows - 1) * win;
-    float nsx = 0.f, nsy = 0.f; int nflag = 0;
-    if (wv < total) {
-        const int ic0 = min(r0 + ty * 8 + li, last_row);
-        nsx = sx_row[ic0]; nsy = sy_row[ic0]; nflag = strip_in[ty];
-    }
-    // the round stream of this wave: (unit, round inside the unit)
-    int unit = wv;
-    int left = 0;                                                // rounds left in the current (interior) unit
-    int rnd = 0;                                                 // index of the next round in its row
-    double sxc = 0.0, syc = 0.0;
-    uint8_t *drc = dst;
-    StageRound A, B;
-    int pend = 0;                                                // 0: nothing in flight, 1: A, 2: B
-    bool clampA = false, clampB = false;
-    for (;;) {
-        if (left == 0) {
-            if (unit >= total) break;
-            // ---- next unit: bookkeeping, border / upright units are done here as a whole
-            const int r_lo = cbi * 2, r_hi = min(r_lo + 2, rounds);
-            const int cb0 = r_lo * 32, cb1 = min(r_hi * 32, win);
-            sxc = (double)nsx; syc = (double)nsy;
-            const int flag_cur = nflag;
-            const int ty_cur = ty;
-            drc = dst + min(ty * 8 * win + liw, last_off);
-            cbi += NW;
-            while (cbi >= nb) { cbi -= nb; ty++; }
-            unit += NW;
-            if (unit < total) {
-                const int icn = min(r0 + ty * 8 + li, last_row);
-                nsx = sx_row[icn]; nsy = sy_row[icn]; nflag = strip_in[ty];
-            }
-            if (G.upright) {
-                for (int j = cb0 + lj; j < cb1; j += 8) drc[j] = (uint8_t)win_sample_upright(G, min(r0 + ty_cur * 8 + li, last_row), j);
-                continue;
-            }
-            bool unit_in = __builtin_amdgcn_readfirstlane(flag_cur) != 0;
-            if (!unit_in) {
-                const int ia = min(r0 + ty_cur * 8, VFSMS_MAX_WIN - 1), ib = min(min(r0 + ty_cur * 8 + 7, last_row), VFSMS_MAX_WIN - 1);
-                const double xa = (double)sx_row[ia], xb = (double)sx_row[ib], ya = (double)sy_row[ia], yb = (double)sy_row[ib];
-                const double ja = (double)cb0, jb = (double)(cb1 - 1);
-                const double jxa = ja * c, jxb = jb * c, jya = -(ja * sn), jyb = -(jb * sn);
-                const double xmin = fmin(xa, xb) + fmin(jxa, jxb), xmax = fmax(xa, xb) + fmax(jxa, jxb);
-                const double ymin = fmin(ya, yb) + fmin(jya, jyb), ymax = fmax(ya, yb) + fmax(jya, jyb);
-                unit_in = xmin >= 0.0 && ymin >= 0.0 && xmax < (double)(ncols1 - 2) && ymax < (double)nrows1;
-            }
-            if (unit_in) { left = r_hi - r_lo; rnd = r_lo; continue; }
-            // the unit crosses the image border: clamped coordinates, select at the end (no branch per sample)
-            for (int jb = cb0; jb < cb1; jb += 8 * BORDER_ILP) {
-                double px[BORDER_ILP], py[BORDER_ILP];
-                int jc[BORDER_ILP];
-                uint32_t q0[BORDER_ILP], q1[BORDER_ILP];
-                bool inside[BORDER_ILP];
-#pragma unroll
-                for (int u = 0; u < BORDER_ILP; u++) {
-                    jc[u] = min(jb + u * 8 + lj, cb1 - 1);
-                    px[u] = sxc + (double)jc[u] * c;
-                    py[u] = syc - (double)jc[u] * sn;
-                    const int ix = (int)px[u], iy = (int)py[u];
-                    inside[u] = px[u] >= 0.0 && py[u] >= 0.0 && ix < ncols1 && iy < nrows1;
-                    const int rx = min(max(cv_round_d(px[u]), 0), ncols1), ry = min(max(cv_round_d(py[u]), 0), nrows1);
-                    const int cx = inside[u] ? ix : rx, cy = inside[u] ? iy : ry;
-                    const int cx1 = min(cx + 1, ncols1);
-                    const uint32_t o0 = (uint32_t)__umul24((uint32_t)cy, pw);
-                    q0[u] = *(GAS const uint16_t *)(ubase + ((o0 + (uint32_t)cx) << 1));
-                    q1[u] = *(GAS const uint16_t *)(ubase + ((o0 + (uint32_t)cx1) << 1));
-                }
-#pragma unroll
-                for (int u = 0; u < BORDER_ILP; u++) {
-                    const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
-                    const float v = (uint8_t)(q0[u] & 0xff) * (1.f - a) * (1.f - b) + (uint8_t)(q1[u] & 0xff) * a * (1.f - b) +
-                                    (uint8_t)(q0[u] >> 8) * (1.f - a) * b + (uint8_t)(q1[u] >> 8) * a * b;
-                    drc[jc[u]] = inside[u] ? (uint8_t)cv_round_f(v) : (uint8_t)(q0[u] & 0xff);
-                }
-            }
-            continue;
-        }
-        // ---- one round of the current unit: issue it, then finish the round issued before it
-        const int jl = rnd * 32 + lj;
-        const bool clamp = ragged && rnd == rounds - 1;
-        rnd++; left--;
-        if (pend != 1) {
-            if (clamp) round_issue<true>(A, ubase, pw, c, sn, sxc, syc, jl, drc, win); else round_issue<false>(A, ubase, pw, c, sn, sxc, syc, jl, drc, win);
-            clampA = clamp;
-            if (pend == 2) { if (clampB) round_finish<true>(B, win); else round_finish<false>(B, win); }
-            pend = 1;
-        } else {
-            if (clamp) round_issue<true>(B, ubase, pw, c, sn, sxc, syc, jl, drc, win); else round_issue<false>(B, ubase, pw, c, sn, sxc, syc, jl, drc, win);
-            clampB = clamp;
-            if (clampA) round_finish<true>(A, win); else round_finish<false>(A, win);
-            pend = 2;
-        }
-    }
-    if (pend == 1) { if (clampA) round_finish<true>(A, win); else round_finish<false>(A, win); }
-    else if (pend == 2) { if (clampB) round_finish<true>(B, win); else round_finish<false>(B, win); }
-}
-#else
 // Balanced form (round 5).  A work unit is (strip of 8 rows) x (a run of 8-column GROUPS): the G8 = ceil(win / 8) groups of a row are cut
 // into nb runs of floor / ceil(G8 / nb) groups -- at most 8 (64 columns) --, so that no unit is padded: the round-4 form cut 32-column
 // blocks from the left, and a 140-px window cost five of them (160 columns), a 42-px one two (64).  A unit samples its groups in rounds of
@@ -1348,186 +1167,6 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
     }
 #endif
 }
-#endif      // pipelined / balanced
-#else
-// ---- round-4 form (VFSMS_EXP & 4: kept for A/B timing against the balanced form) ------------------------------------------------
-template <int NW>                                              // NW waves share the strips (4: the workgroup; 1: one wave on its own)
-__device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row, const float *sy_row,
-                                           int r0, int nrows, uint8_t *dst, uint8_t *strip_in)
-{
-    // everything that is the same for the whole wave is pinned to SGPRs (the compiler cannot know that a keypoint read through a
-    // ticket index, or threadIdx.x >> 6, is wave-uniform): the unit bookkeeping below then runs on the scalar unit, not on the VALU
-    // that bounds this kernel
-    const int win = __builtin_amdgcn_readfirstlane(G.win);
-    r0 = __builtin_amdgcn_readfirstlane(r0); nrows = __builtin_amdgcn_readfirstlane(nrows);
-    const int lane = threadIdx.x & 63, wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int li = lane >> 3, lj = lane & 7;
-    const int strips = (nrows + 7) >> 3;
-    const double c = (double)G.cos_dir, sn = (double)G.sin_dir;
-    const int ncols1 = __builtin_amdgcn_readfirstlane(G.w) - 1, nrows1 = __builtin_amdgcn_readfirstlane(G.h) - 1;
-    // Samples read the ROW-PAIR image (k_pair_rows): element (y, x) = pixel (y, x) | pixel (y + 1, x) << 8, so the four taps of a
-    // bilinear sample are ONE dword at element (iy, ix) -- bytes t00, t10, t01, t11.  The descriptor kernels are bound by the
-    // texture-address path (PMC: TA busy 73 % of the launch, ~24 cycles per 64-lane gather whatever its width), so one gather per
-    // sample instead of two (rows y and y + 1 of the byte image) is what counts.  Its base is the same for the whole workgroup: pinned
-    // to SGPRs so gathers use scalar-base + 32-bit-offset addressing.
-    const uint64_t bp = (uint64_t)G.pair;
-    // (readfirstlane returns int: widen through uint32_t, or a low half with bit 31 set sign-extends into the high half)
-    g_cu8 ubase = (g_cu8)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32)) << 32) |
-                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)bp));
-    const uint32_t pw = (uint32_t)(ncols1 + 1);                  // pitch of the pair image in elements
-    // Work unit = (strip of 8 rows, block of 32 columns), dealt to the waves ROUND-ROBIN: units that cross the image border cost
-    // several times an interior unit, and they come in runs (the last strips of a window that hangs over the edge) -- contiguous runs
-    // per wave left three waves of the workgroup waiting at the barrier for the one that had drawn the border strips.
-    const int ncb = (win + UNIT_W - 1) / UNIT_W;
-    const int total = strips * ncb;
-    // Which strips lie inside the image as a whole (all `win` columns)?  One lane per strip answers once for everybody (the same
-    // separable extremes as the unit test below, over the full width); units of such strips skip their own test -- it was a sixth of
-    // the instructions of an interior unit.
-    if (!G.upright) {
-        const int tid = NW == 1 ? lane : (int)threadIdx.x;
-        if (tid < strips) {
-            const int ia = min(r0 + tid * 8, VFSMS_MAX_WIN - 1), ib = min(min(r0 + tid * 8 + 7, r0 + nrows - 1), VFSMS_MAX_WIN - 1);
-            const double xa = (double)sx_row[ia], xb = (double)sx_row[ib], ya = (double)sy_row[ia], yb = (double)sy_row[ib];
-            const double jb = (double)(win - 1);
-            const double jxb = jb * c, jyb = -(jb * sn);
-            const double xmin = fmin(xa, xb) + fmin(0.0, jxb), xmax = fmax(xa, xb) + fmax(0.0, jxb);
-            const double ymin = fmin(ya, yb) + fmin(0.0, jyb), ymax = fmax(ya, yb) + fmax(0.0, jyb);
-            strip_in[tid] = xmin >= 0.0 && ymin >= 0.0 && xmax < (double)(ncols1 - 2) && ymax < (double)nrows1;
-        }
-        if (NW == 1) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-        else __syncthreads();
-    }
-    int ty = 0, cbi = wv;                                        // (strip, column block) of the wave's current unit; stepped, not divided
-    while (cbi >= ncb) { cbi -= ncb; ty++; }
-#ifdef VFSMS_DESC_TIMING
-    unsigned long long _s0 = clock64(), _uacc[2] = {0, 0}, _ucnt[2] = {0, 0};
-#endif
-    // The row origins and the strip flag of a unit sit at the head of its dependency chain (LDS read -> f64 position -> address ->
-    // gather): they are fetched ONE UNIT AHEAD, so the chain of a unit starts with values that are already in registers.
-    float nsx = 0.f, nsy = 0.f; int nflag = 0;
-    if (wv < total) {
-        const int ic0 = min(r0 + min(ty * 8 + li, nrows - 1), VFSMS_MAX_WIN - 1);
-        nsx = sx_row[ic0]; nsy = sy_row[ic0]; nflag = strip_in[ty];
-    }
-    for (int unit = wv; unit < total; unit += NW) {
-        DT_UNIT_BEGIN;
-        const int cb0 = cbi * UNIT_W;
-        const int cb1 = min(win, cb0 + UNIT_W);
-        const int r = ty * 8 + li;
-        // a lane past the strip's last row repeats that row: same position, same value, same LDS byte
-        const int rc = min(r, nrows - 1);
-        const double sxc = (double)nsx, syc = (double)nsy;
-        const int flag_cur = nflag;
-        uint8_t *drc = dst + rc * win;
-        const int ty_cur = ty;
-        cbi += NW;
-        while (cbi >= ncb) { cbi -= ncb; ty++; }
-        if (unit + NW < total) {
-            const int icn = min(r0 + min(ty * 8 + li, nrows - 1), VFSMS_MAX_WIN - 1);
-            nsx = sx_row[icn]; nsy = sy_row[icn]; nflag = strip_in[ty];
-        }
-        if (G.upright) {
-            for (int j = cb0 + lj; j < cb1; j += 8) drc[j] = (uint8_t)win_sample_upright(G, r0 + rc, j);
-            continue;
-        }
-        // Unit-level interior test: x = origin(row) + j * c is separable, rows are monotone, so the extremes of the unit's samples are
-        // (extreme row origin) + (extreme of j * c).  A unit inside the image (with the 2 px of slack the dword taps need) runs
-        // without any per-sample bounds logic.
-        bool unit_in = __builtin_amdgcn_readfirstlane(flag_cur) != 0;
-        if (!unit_in) {
-            const int ia = min(r0 + ty_cur * 8, VFSMS_MAX_WIN - 1), ib = min(min(r0 + ty_cur * 8 + 7, r0 + nrows - 1), VFSMS_MAX_WIN - 1);
-            const double xa = (double)sx_row[ia], xb = (double)sx_row[ib], ya = (double)sy_row[ia], yb = (double)sy_row[ib];
-            const double ja = (double)cb0, jb = (double)(cb1 - 1);
-            const double jxa = ja * c, jxb = jb * c, jya = -(ja * sn), jyb = -(jb * sn);
-            const double xmin = fmin(xa, xb) + fmin(jxa, jxb), xmax = fmax(xa, xb) + fmax(jxa, jxb);
-            const double ymin = fmin(ya, yb) + fmin(jya, jyb), ymax = fmax(ya, yb) + fmax(jya, jyb);
-            unit_in = xmin >= 0.0 && ymin >= 0.0 && xmax < (double)(ncols1 - 2) && ymax < (double)nrows1;
-        }
-        if (unit_in) {
-            // No predicates here: a lane past the window's last column repeats that column, so every lane gathers from inside the
-            // tested unit, the loads keep the scalar-base form and there is no exec-mask bookkeeping around them.
-            uint32_t top[STAGE_ILP];
-            double px[STAGE_ILP], py[STAGE_ILP];
-            int jc[STAGE_ILP];
-            DT_TRIP(0);
-            if (cb0 + 8 * STAGE_ILP <= win) {
-                // a full block: the lane's four columns are 8 apart; 8 c, 16 c, 24 c are exact doubles, so px0 + 8 u c rounds like
-                // start + j * step whenever that is exact (the same argument as for the fused form)
-                const double jd = (double)(cb0 + lj);
-                px[0] = __builtin_fma(jd, c, sxc); py[0] = __builtin_fma(jd, -sn, syc);
-#pragma unroll
-                for (int u = 1; u < STAGE_ILP; u++) { px[u] = px[0] + (double)(8 * u) * c; py[u] = py[0] - (double)(8 * u) * sn; }
-#pragma unroll
-                for (int u = 0; u < STAGE_ILP; u++) jc[u] = cb0 + u * 8 + lj;
-            } else {
-#pragma unroll
-                for (int u = 0; u < STAGE_ILP; u++) {
-                    jc[u] = min(cb0 + u * 8 + lj, win - 1);
-                    const double jd = (double)jc[u];
-                    px[u] = __builtin_fma(jd, c, sxc);             // start + j * step: the product is exact in double
-                    py[u] = __builtin_fma(jd, -sn, syc);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < STAGE_ILP; u++) {
-                const uint32_t off = ((uint32_t)__umul24((uint32_t)(int)py[u], pw) + (uint32_t)(int)px[u]) << 1;
-                top[u] = *(GAS const uint32_t *)(ubase + off);      // 2-byte-aligned dword gather, uniform base + 32-bit offset
-            }
-#pragma unroll
-            for (int u = 0; u < STAGE_ILP; u++) {
-                const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
-#if VFSMS_EXP & 2
-                drc[jc[u]] = (uint8_t)cv_round_f(bilinear_pk(top[u], a, b));
-#else
-                drc[jc[u]] = round_u8_pos(bilinear_pk(top[u], a, b));
-#endif
-            }
-            DT_UNIT_END(0);
-            continue;
-        }
-        // The unit crosses the image border.  No branch per sample: every lane gathers at clamped coordinates -- the bilinear taps
-        // when (ix, iy) is interior, the nearest pixel clamp(cvRound(px), cvRound(py)) otherwise -- and selects at the end.
-        DT_TRIP(2);
-        for (int jb = cb0; jb < cb1; jb += 8 * BORDER_ILP) {
-            double px[BORDER_ILP], py[BORDER_ILP];
-            int jc[BORDER_ILP];
-            uint32_t q0[BORDER_ILP], q1[BORDER_ILP];          // pair elements (cy, cx) and (cy, cx1): two 16-bit gathers, not four bytes
-            bool inside[BORDER_ILP];
-#pragma unroll
-            for (int u = 0; u < BORDER_ILP; u++) {
-                jc[u] = min(jb + u * 8 + lj, win - 1);
-                px[u] = sxc + (double)jc[u] * c;
-                py[u] = syc - (double)jc[u] * sn;
-                const int ix = (int)px[u], iy = (int)py[u];                       // trunc == floor wherever `inside` holds
-                inside[u] = px[u] >= 0.0 && py[u] >= 0.0 && ix < ncols1 && iy < nrows1;
-                const int rx = min(max(cv_round_d(px[u]), 0), ncols1), ry = min(max(cv_round_d(py[u]), 0), nrows1);
-                const int cx = inside[u] ? ix : rx, cy = inside[u] ? iy : ry;
-                const int cx1 = min(cx + 1, ncols1);
-                const uint32_t o0 = (uint32_t)__umul24((uint32_t)cy, pw);
-                q0[u] = *(GAS const uint16_t *)(ubase + ((o0 + (uint32_t)cx) << 1));
-                q1[u] = *(GAS const uint16_t *)(ubase + ((o0 + (uint32_t)cx1) << 1));
-            }
-#pragma unroll
-            for (int u = 0; u < BORDER_ILP; u++) {
-                const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
-                // the high bytes are row min(cy + 1, h - 1): the clamped lower taps
-                const float v = (uint8_t)(q0[u] & 0xff) * (1.f - a) * (1.f - b) + (uint8_t)(q1[u] & 0xff) * a * (1.f - b) +
-                                (uint8_t)(q0[u] >> 8) * (1.f - a) * b + (uint8_t)(q1[u] >> 8) * a * b;
-                drc[jc[u]] = inside[u] ? (uint8_t)cv_round_f(v) : (uint8_t)(q0[u] & 0xff);
-            }
-        }
-        DT_UNIT_END(1);
-    }
-#ifdef VFSMS_DESC_TIMING
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&g_desc_unit_cycles[2], clock64() - _s0);
-        atomicAdd(&g_desc_unit_cycles[0], _uacc[0]); atomicAdd(&g_desc_unit_cycles[1], _uacc[1]);
-        atomicAdd(&g_desc_trips[0], _ucnt[0]); atomicAdd(&g_desc_trips[2], _ucnt[1]);
-    }
-#endif
-}
-
-#endif
 
 __device__ __forceinline__ uint8_t sat_u8(float v)
 {
@@ -1564,71 +1203,10 @@ __device__ __forceinline__ uint8_t area_col_tab(const float *rb, const AreaRec &
 }
 
 // band >= 0: only row `band` of the 21 x 21 patch (tickets of the largest windows are split by output row, see k_desc_plan)
-#define DESC_HEADS DESC_PLAN_HEADS
-#define DESC_HEAD_STRIDE 64          // ints between the ticket heads of a kernel
-// What thread 0 carries through a keypoint for the NEXT one (k_describe): the ticket it drew at the start -- an atomic whose return nobody
-// waits for --, then, once the window is staged, the record that ticket leads to.  Both trips to memory run beside the sampling; at the end
-// the record is handed to the workgroup through LDS.  (Before: atomic -> record, two dependent trips with four waves waiting, per keypoint.)
-struct DescNext {
-    int t, drawn;                 // the ticket (valid once the atomic has returned) / was one drawn?
-    int n, n0, start, split;      // the slice of the head it was drawn from (DescPlan)
-    int slot, band;               // resolved: record index (< 0: none yet) and output row of a split ticket
-    int r[8];                     // the record, in flight
-    int head, info_head;          // heads this workgroup has found exhausted / the head n, n0, start belong to
-};
-__device__ __forceinline__ void next_resolve(DescNext &N)
-{
-    // the head's class-0 records come first; with split > 1 each of them is `split` tickets, one per output row
-    N.band = -1;
-    if (N.t < N.n0 * N.split) { N.slot = N.start + N.t / N.split; N.band = N.split > 1 ? N.t % N.split : -1; }
-    else N.slot = N.start + N.n0 + (N.t - N.n0 * N.split);
-}
-__device__ __forceinline__ void next_draw(DescNext &N, const DescPlan *plan, int *counter)     // thread 0: issue the atomic of the next ticket
-{
-    N.drawn = 0; N.slot = -1; N.t = 0;
-    if (N.head < DESC_HEADS) {
-        const int q = (blockIdx.x + N.head) & (DESC_HEADS - 1);
-        if (N.info_head != N.head) {                         // the head's slice: read once per head, not once per keypoint (a trip to memory in front of the atomic)
-            N.n = plan->big_tickets[q]; N.n0 = plan->big_n0[q]; N.start = plan->big_start[q]; N.split = plan->split;
-            N.info_head = N.head;
-        }
-        if (N.n > 0) { N.t = atomicAdd(counter + q * DESC_HEAD_STRIDE, 1); N.drawn = 1; }
-    }
-}
-__device__ __forceinline__ void next_fetch(DescNext &N, const DescRec *recs)                    // thread 0: the ticket is back -- request its record
-{
-    if (N.drawn && N.t < N.n) {
-        next_resolve(N);
-        const int *q = (const int *)(recs + N.slot);
-#pragma unroll
-        for (int i = 0; i < 8; i++) N.r[i] = q[i];
-    }
-}
-// thread 0: hand the next keypoint to the workgroup (slot < 0: the launch is exhausted).  A ticket beyond its head's slice means that head
-// ran dry: the following heads are tried one after the other, this time waiting for every answer.
-__device__ __forceinline__ void next_publish(DescNext &N, const DescPlan *plan, const DescRec *recs, int *counter, int *s_next)
-{
-    if (N.slot < 0) {
-        if (N.drawn || (N.head < DESC_HEADS && N.n <= 0)) N.head++;
-        while (N.head < DESC_HEADS) {
-            next_draw(N, plan, counter);
-            if (N.drawn && N.t < N.n) { next_fetch(N, recs); break; }
-            N.head++;
-        }
-    }
-    s_next[0] = N.slot; s_next[1] = N.band;
-    if (N.slot >= 0) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) s_next[2 + i] = N.r[i];
-    }
-}
-
-__device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec *area_tab, const DescRec &rec, int extended, int upright, const int band,
-                             DescNext &N, const DescPlan *plan, const DescRec *recs, int *counter, int *s_next)
+__device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec *area_tab, const DescRec &rec, int extended, int upright, const int band)
 {
     DT_START;
     const int k = rec.k;
-    if (threadIdx.x == 0) next_draw(N, plan, counter);     // the next keypoint's ticket: on its way while this one is worked on
     __shared__ float sx_row[VFSMS_MAX_WIN], sy_row[VFSMS_MAX_WIN];
     __shared__ uint8_t PATCH[21][21 + 3];
     __shared__ AreaRec REC[AREA_RECS];                     // computeResizeAreaTab of this window size: same records for x and y
@@ -1641,21 +1219,11 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
     G.upright = upright; G.usx = 0; G.usy = 0; G.sin_dir = rec.sin_dir; G.cos_dir = rec.cos_dir;
     const int win = G.win;
     const int dsz = 21;
-    // computeResizeAreaTab of this window size (host-built table): requested now.  A window that is staged whole (win <= 128, not a band
-    // ticket) needs it only for the reduction -- its words go to LDS behind the sampling, their trip to memory beside it; the band forms
-    // cut their staging calls from it and wait here.
-    const bool whole = win * win <= DESC_WBUF && band < 0;
-    int rec_word = 0;
-    if (threadIdx.x < AREA_RECS * 8) rec_word = ((const int *)(area_tab + (size_t)win * AREA_RECS))[threadIdx.x];
-    int nmin = 0, nmax = 0, mode = 0; float inv_area = 0.f;
-    auto rec_arrived = [&]() {
-        if (threadIdx.x < AREA_RECS * 8) ((int *)REC)[threadIdx.x] = rec_word;
-        __syncthreads();
-        nmin = __builtin_amdgcn_readfirstlane(REC[21].j0); nmax = __builtin_amdgcn_readfirstlane(REC[21].n);
-        mode = __builtin_amdgcn_readfirstlane(REC[21].mode);
-        inv_area = REC[21].a0;
-    };
-    if (!whole) rec_arrived();
+    if (threadIdx.x < AREA_RECS * 8) ((int *)REC)[threadIdx.x] = ((const int *)(area_tab + (size_t)win * AREA_RECS))[threadIdx.x];
+    __syncthreads();
+    const int nmin = __builtin_amdgcn_readfirstlane(REC[21].j0), nmax = __builtin_amdgcn_readfirstlane(REC[21].n);
+    const int mode = __builtin_amdgcn_readfirstlane(REC[21].mode);
+    const float inv_area = REC[21].a0;
     if (!upright) {
         // Row origins are running float sums in the reference (start_x += sin_dir per row): inherently sequential, so one lane of wave 0
         // walks x while one lane of wave 1 walks y (both chains in lanes 0 / 1 of ONE wave -- half the issue slots -- measured 0.7 %
@@ -1701,12 +1269,9 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
             dyA = dyB;
         }
     };
-    bool fetched = false;                                  // has thread 0 asked for the next keypoint's record?
-    if (whole) {
+    if (win * win <= DESC_WBUF) {
         stage_rows<4>(G, sx_row, sy_row, 0, win, WINBUF, STRIP_IN);
-        rec_arrived();                                     // (its barrier is the one behind the staging)
-        if (threadIdx.x == 0) next_fetch(N, recs);
-        fetched = true;
+        __syncthreads();
         DT_MARK(1);
         reduce_rows(0, 0, dsz);
         DT_MARK(2);
@@ -1724,7 +1289,6 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
                 const int end = REC[d_stop - 1].j0 + REC[d_stop - 1].n - 1;
                 stage_rows<4>(G, sx_row, sy_row, rlo, end - rlo + 1, WINBUF, STRIP_IN);
                 __syncthreads();
-                if (!fetched) { if (threadIdx.x == 0) next_fetch(N, recs); fetched = true; }
                 DT_MARK(3);
                 reduce_rows(rlo, dy, d_stop);
                 DT_MARK(4);
@@ -1735,7 +1299,6 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
                     const int cn = min(crows, nrows - c0);
                     stage_rows<4>(G, sx_row, sy_row, rlo + c0, cn, WINBUF, STRIP_IN);
                     __syncthreads();
-                    if (!fetched) { if (threadIdx.x == 0) next_fetch(N, recs); fetched = true; }
                     DT_MARK(3);
                     for (int e = threadIdx.x; e < cn * 21; e += 256) {
                         const int r = (int)(((uint32_t)e * 3121u) >> 16), dx = e - 21 * r;
@@ -1751,10 +1314,6 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        if (!fetched) next_fetch(N, recs);
-        next_publish(N, plan, recs, counter, s_next);
-    }
     // hand the 21 x 21 patch to k_desc_tail (gradients, cell sums, normalisation run there, 16 keypoints per workgroup)
     if (band >= 0) {
         if (threadIdx.x < 21) R.patch[(size_t)k * VFSMS_PATCH_ROW + band * 21 + threadIdx.x] = PATCH[band][threadIdx.x];
@@ -1836,6 +1395,8 @@ __global__ __launch_bounds__(1024) void k_desc_order(const RoiDev *rois)
 // What a ticket leads to is ONE 32-byte record (DescRec) at a position that follows from the ticket alone: k_desc_plan lays the heads'
 // slices out, k_desc_recs fills them.
 // ---------------------------------------------------------------------------------------------------
+#define DESC_HEADS DESC_PLAN_HEADS
+#define DESC_HEAD_STRIDE 64          // ints between heads
 
 // one workgroup: the layout of the record arrays from the class counts of all ROIs (counters[12..15], k_desc_order)
 __global__ __launch_bounds__(256) void k_desc_plan(const RoiDev *rois, int nrois, DescPlan *plan, int big_grid)
@@ -2045,29 +1606,40 @@ __global__ __launch_bounds__(256) void k_pair_rows(const RoiDev *rois)
 __global__ __launch_bounds__(256, DESC_WGS) void k_describe(const RoiDev *rois, const DescPlan *plan, const DescRec *recs, int *counter, const SurfTables *T,
                                                   const AreaRec *area_tab, int extended, int upright)
 {
-    __shared__ int s_next[2][10];                            // [slot, band, record] of the keypoint to do next, double-buffered (written while the current one is read)
-    DescNext N;
-    N.head = 0; N.info_head = -1; N.slot = -1; N.drawn = 0; N.n = 1; N.band = -1; N.t = 0; N.n0 = 0; N.start = 0; N.split = 1;
-    if (threadIdx.x == 0) next_publish(N, plan, recs, counter, s_next[0]);      // the first keypoint: drawn and fetched with the workgroup waiting
-    int cur = 0;
+    __shared__ int s_slot, s_band;
+    int head = 0;                                            // thread 0's
 #ifdef VFSMS_DESC_TIMING
     unsigned long long tq = clock64();
 #endif
     for (;;) {
         __syncthreads();
-        const int slot = __builtin_amdgcn_readfirstlane(s_next[cur][0]), band = __builtin_amdgcn_readfirstlane(s_next[cur][1]);
+        if (threadIdx.x == 0) {
+            int slot = -1, band = -1;
+            const int split = plan->split;
+            while (head < DESC_HEADS) {
+                const int q = (blockIdx.x + head) & (DESC_HEADS - 1);
+                const int n = plan->big_tickets[q];
+                const int t = n > 0 ? atomicAdd(counter + q * DESC_HEAD_STRIDE, 1) : 0;
+                if (t < n) {
+                    // the head's class-0 records come first; with split > 1 each of them is `split` tickets, one per output row
+                    const int n0 = plan->big_n0[q];
+                    if (t < n0 * split) { slot = plan->big_start[q] + t / split; band = split > 1 ? t % split : -1; }
+                    else slot = plan->big_start[q] + n0 + (t - n0 * split);
+                    break;
+                }
+                head++;                                      // this head is exhausted (it stays exhausted): steal from the next
+            }
+            s_slot = slot; s_band = band;
+        }
+        __syncthreads();
+        const int slot = __builtin_amdgcn_readfirstlane(s_slot), band = __builtin_amdgcn_readfirstlane(s_band);
         if (slot < 0) break;
 #ifdef VFSMS_DESC_TIMING
         if (threadIdx.x == 0) atomicAdd(&g_desc_cycles[6], clock64() - tq);
 #endif
-        // the record and the ROI it names are the same for the whole workgroup: scalar registers, and everything derived from them stays off the VALU
-        DescRec rec;
-        rec.roi = __builtin_amdgcn_readfirstlane(s_next[cur][2]); rec.k = __builtin_amdgcn_readfirstlane(s_next[cur][3]);
-        rec.win = __builtin_amdgcn_readfirstlane(s_next[cur][4]); rec.pad = 0;
-        rec.sin_dir = __int_as_float(__builtin_amdgcn_readfirstlane(s_next[cur][6])); rec.cos_dir = __int_as_float(__builtin_amdgcn_readfirstlane(s_next[cur][7]));
-        rec.x = __int_as_float(__builtin_amdgcn_readfirstlane(s_next[cur][8])); rec.y = __int_as_float(__builtin_amdgcn_readfirstlane(s_next[cur][9]));
-        describe_one(rois[rec.roi], T, area_tab, rec, extended, upright, band, N, plan, recs, counter, s_next[cur ^ 1]);
-        cur ^= 1;
+        // the record and the ROI it names are the same for the whole workgroup: scalar loads, and everything derived from them stays off the VALU
+        const DescRec rec = load_rec_uniform(recs + slot);
+        describe_one(rois[rec.roi], T, area_tab, rec, extended, upright, band);
 #ifdef VFSMS_DESC_TIMING
         tq = clock64();
 #endif
