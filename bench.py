@@ -768,6 +768,7 @@ def main():
     max_err = int(err[ok].max()) if ok.any() else -1
     n_failed = int((~ok).sum())
 
+    untimed = dict(reg.stats)                                # what the process registered before the timed steps (prior instance, warm-up)
     for k in reg.stats:
         reg.stats[k] = 0
     eng.profile_enable(True)
@@ -978,6 +979,8 @@ def main():
             "h2d_ms_rank0_blocking": round(t_up * 1e3, 2), "tile_synthesis_s": round(t_gen, 1),
             "attempts_per_step": st["attempts"] / max(args.steps, 1), "batches_per_step": st["batches"] / max(args.steps, 1),
             "keypoints_per_roi": round(st["sum_nq_plus_nt"] / max(2 * st["attempts"], 1), 1) if args.method == "surf" else None,
+            # everything this process registered up to the end of the timed steps (rank 0): what a PMC pass over the whole run has counted
+            "process_totals_through_timed_steps": dict(attempts=untimed["attempts"] + st["attempts"], keypoints=untimed["sum_nq_plus_nt"] + st["sum_nq_plus_nt"]),
             "capacity_retries": getattr(reg, "capacity_retries", 0),
             "roofline": roofline,
             "pmc": pmc_info,

@@ -1037,7 +1037,7 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
     // runs of at most 8 groups.  (Measured, fixed 16-pair batch: shorter runs -- at most 4 groups, the round-4 unit size without its padding --
     // +2.5 %; a per-call choice of the run count by a cost model of the busiest wave +4 %: its scalar divisions cost more than the even
     // finish buys.)
-    int nb = (gfull + 7) >> 3;
+    int nb = NW == 1 ? 1 : (gfull + 7) >> 3;                     // (the one-wave form stages windows of at most 64 px: one run per strip, known at compile time)
 #if VFSMS_EXP & 16
     nb = (gfull + 3) >> 2;
 #endif
@@ -1192,6 +1192,27 @@ __device__ __forceinline__ float area_row_tab(const uint8_t *S, const AreaRec &c
     for (; t < nmax; t++) buf += (float)p[t] * (t < c.n - 1 ? c.af : (t == c.n - 1 ? c.al : 0.f));
     return buf;
 }
+// The same sum with the weights of the taps behind the common part -- taps max(1, nmin - 1) .. nmax - 1: af, al or 0 depending on the cell's own
+// count -- formed ONCE per cell (area_tail_weights) instead of by two compares and two selects per tap and row: the products and their order
+// are unchanged.  At most AREA_TAIL taps lie there (cell counts of a window differ by at most 2); callers fall back to area_row_tab otherwise.
+#define AREA_TAIL 4
+__device__ __forceinline__ void area_tail_weights(const AreaRec &c, const int nmin, float (&w)[AREA_TAIL])
+{
+    const int t0 = max(nmin - 1, 1);
+#pragma unroll
+    for (int i = 0; i < AREA_TAIL; i++) w[i] = t0 + i < c.n - 1 ? c.af : (t0 + i == c.n - 1 ? c.al : 0.f);
+}
+__device__ __forceinline__ float area_row_tab_w(const uint8_t *S, const AreaRec &c, const int nmin, const int nmax, const float (&w)[AREA_TAIL])
+{
+    const uint8_t *p = S + c.j0;
+    float buf = (float)p[0] * c.a0;
+    int t = 1;
+    for (; t < nmin - 1; t++) buf += (float)p[t] * c.af;
+#pragma unroll
+    for (int i = 0; i < AREA_TAIL; i++)
+        if (t + i < nmax) buf += (float)p[t + i] * w[i];
+    return buf;
+}
 // one output pixel from the row sums rb[0], rb[21], ... of its n source rows (sum = beta * buf, then sum += beta * buf)
 __device__ __forceinline__ uint8_t area_col_tab(const float *rb, const AreaRec &c, const int mode, const float inv_area)
 {
@@ -1249,6 +1270,7 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
     // table-driven passes in cv::resize's accumulation order: buf[dx] of every staged source row (one (row, cell) per lane, uniform
     // trip counts), then the output pixels from those row sums -- in chunks of whole output rows whose source rows fit `rowsum`.
     // rows_lo .. rows_hi of WINBUF row index 0 hold window rows st_lo ..; reduce the output rows [dyA, dyB_end)
+    const bool tail_ok = nmax - max(nmin - 1, 1) <= AREA_TAIL;     // (always, for the tables computeResizeAreaTab makes; wave-uniform)
     auto reduce_rows = [&](const int st_lo, int dyA, const int dy_stop) {
         while (dyA < dy_stop) {
             const int lo = REC[dyA].j0;
@@ -1257,7 +1279,13 @@ __device__ void describe_one(const RoiDev &R, const SurfTables *T, const AreaRec
             const int nr = REC[dyB - 1].j0 + REC[dyB - 1].n - lo;
             for (int e = threadIdx.x; e < nr * 21; e += 256) {
                 const int r = (int)(((uint32_t)e * 3121u) >> 16), dx = e - 21 * r;      // e / 21, exact for e < 43690
-                rowsum[e] = area_row_tab(WINBUF + (lo - st_lo + r) * win, REC[dx], nmin, nmax);
+                if (tail_ok) {
+                    const AreaRec cx = REC[dx];
+                    float w[AREA_TAIL];
+                    area_tail_weights(cx, nmin, w);
+                    rowsum[e] = area_row_tab_w(WINBUF + (lo - st_lo + r) * win, cx, nmin, nmax, w);
+                } else
+                    rowsum[e] = area_row_tab(WINBUF + (lo - st_lo + r) * win, REC[dx], nmin, nmax);
             }
             __syncthreads();
             for (int o = threadIdx.x; o < (dyB - dyA) * 21; o += 256) {
@@ -1521,6 +1549,7 @@ __device__ void describe_small(const RoiDev &R, const AreaRec *area_tab, const D
     const int nmin = __builtin_amdgcn_readfirstlane(L.rec[21].j0), nmax = __builtin_amdgcn_readfirstlane(L.rec[21].n);
     const int mode = __builtin_amdgcn_readfirstlane(L.rec[21].mode);
     const float inv_area = L.rec[21].a0;
+    const bool tail_ok = nmax - max(nmin - 1, 1) <= AREA_TAIL;
     uint8_t *prow = R.patch + (size_t)k * VFSMS_PATCH_ROW;
     // one output pixel per lane: sum over its source rows of beta * (row sum of its cell), uniform trip counts (surplus rows / pixels
     // weigh 0; they read at most nmax bytes past the window, inside L.win's padding or the row origins behind it)
@@ -1528,10 +1557,21 @@ __device__ void describe_small(const RoiDev &R, const AreaRec *area_tab, const D
         const int dy = (int)(((uint32_t)o * 3121u) >> 16), dx = o - dsz * dy;
         const AreaRec ry = L.rec[dy], rx = L.rec[dx];
         const uint8_t *S = L.win + ry.j0 * win;
-        float sum = ry.a0 * area_row_tab(S, rx, nmin, nmax);
-        for (int ty = 1; ty < nmax; ty++) {
-            const float beta = ty < ry.n - 1 ? ry.af : (ty == ry.n - 1 ? ry.al : 0.f);
-            sum += beta * area_row_tab(S + ty * win, rx, nmin, nmax);
+        float sum;
+        if (tail_ok) {                                     // the cell's tail weights once for all of its rows
+            float w[AREA_TAIL];
+            area_tail_weights(rx, nmin, w);
+            sum = ry.a0 * area_row_tab_w(S, rx, nmin, nmax, w);
+            for (int ty = 1; ty < nmax; ty++) {
+                const float beta = ty < ry.n - 1 ? ry.af : (ty == ry.n - 1 ? ry.al : 0.f);
+                sum += beta * area_row_tab_w(S + ty * win, rx, nmin, nmax, w);
+            }
+        } else {
+            sum = ry.a0 * area_row_tab(S, rx, nmin, nmax);
+            for (int ty = 1; ty < nmax; ty++) {
+                const float beta = ty < ry.n - 1 ? ry.af : (ty == ry.n - 1 ? ry.al : 0.f);
+                sum += beta * area_row_tab(S + ty * win, rx, nmin, nmax);
+            }
         }
         uint8_t outv;
         if (mode == 2) outv = (uint8_t)(((int)sum + 2) >> 2);

@@ -84,9 +84,13 @@ import json
 try:
     b=json.loads(open('$OUT/pmc_sq_bench.json').read().strip().splitlines()[-1])
     steps=b['steps']+max(b['warmup'],1)
-    kps=2.0*b['attempts_per_step']*b['keypoints_per_roi']*steps+b['keypoints_per_roi']
+    pt=b.get('process_totals_through_timed_steps')
+    if pt:      # counted by the run itself (incl. the registration of the prior instance): + the one-ROI samples-per-keypoint probe
+        kps=pt['keypoints']+b['keypoints_per_roi']; att=pt['attempts']
+    else:
+        kps=2.0*b['attempts_per_step']*b['keypoints_per_roi']*steps+b['keypoints_per_roi']; att=b['attempts_per_step']*steps
     out.write('\n# the SQ pass as a whole (for ratios of counter totals to algorithmic counts)\n')
-    out.write('pmc_run steps=%d attempts=%.0f keypoints=%.0f samples_per_keypoint=%.1f\n' % (steps, b['attempts_per_step']*steps, kps, b['roofline']['samples_per_keypoint']))
+    out.write('pmc_run steps=%d attempts=%.0f keypoints=%.0f samples_per_keypoint=%.1f\n' % (steps, att, kps, b['roofline']['samples_per_keypoint']))
 except Exception as e:
     out.write('# pmc_run: %s\n' % e)
 out.close()
