@@ -1518,3 +1518,35 @@ def test_mode_vote_beyond_one_hash_table_equals_the_oracle(engine, oracle):
             got = engine.mode_offset(ka, kb, pairs, ev)
             want = oracle.mode_offset(ka, kb, pairs, ev)
             assert (bool(got[0]), list(got[1]), int(got[2])) == (bool(want[0]), [int(want[1][0]), int(want[1][1])], int(want[2])), (ci, ev, got, want)
+
+
+@pytest.mark.gpu
+def test_descriptor_work_list_one_ticket_per_keypoint_regime(engine, oracle):
+    """The descriptor kernels draw their keypoints from k_desc_plan's work list in two regimes: small launches split every window > 256 px
+    into 21 tickets (one per output row of the patch), launches with more than 48 large-window keypoints per resident workgroup
+    (1280 x 48 = 61440) keep one ticket per keypoint.  The single-ROI entry points the other parity tests use are all in the first
+    regime; here 16 whole tiles of 1024 x 1280 go through vfsms_features_surf_batch in ONE fused launch sequence (78 k windows > 64 px: the
+    second regime, XCD-affine heads over 16 ROIs, every head owning two of them) and every tile's keypoints and descriptors must be
+    bit-identical to the tile described on its own -- and two of them to the oracle."""
+    from imagestitch_amd.synthetic import line_scan
+    tiles, _truth = line_scan(n=16)
+    hs = [engine.tile_upload(t) for t in tiles]
+    engine.set_keypoint_capacity(0)
+    feats, counts = engine.features_surf_batch(hs)
+    try:
+        big = 0
+        for k, (t, f, n) in enumerate(zip(tiles, feats, counts)):
+            kxy, desc = engine.features_download(f, n)
+            sxy, sdesc, kf = engine.surf_detect_describe(t, full=True)
+            assert n == len(sxy) and np.array_equal(kxy, sxy) and np.array_equal(desc, sdesc), k
+            win = np.minimum((21 * (kf["size"] * np.float32(1.2) / np.float32(9.0))).astype(np.int64), 739)
+            big += int((win > 64).sum())
+            if k in (0, 9):
+                ok, od = oracle.surf_detect_describe(t)
+                assert len(ok) == n and np.array_equal(desc, od), k
+        assert big >= 1280 * 48, big                       # the launch really was in the one-ticket-per-keypoint regime
+    finally:
+        for f in feats:
+            engine.features_free(f)
+        for h in hs:
+            engine.tile_free(h)
