@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvfsms.so")
+# VFSMS_LIB: another build of the library (A/B timing of kernel variants: tools/microbench.py, bench.py); the product is the in-tree one
+LIB_PATH = os.path.abspath(os.environ["VFSMS_LIB"]) if os.environ.get("VFSMS_LIB") else os.path.join(_HERE, "lib", "libvfsms.so")
 
 VFSMS_OK = 0
 VFSMS_ERR_BAD_ARG, VFSMS_ERR_CAPACITY, VFSMS_ERR_UNSUPPORTED = -1, -2, -6
