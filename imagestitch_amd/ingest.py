@@ -190,3 +190,168 @@ def _list_images(folder, extension):
     ext = "." + extension.lower()
     names = [n for n in os.listdir(folder) if n.lower().endswith(ext)] if os.path.isdir(folder) else []
     return [os.path.join(folder, n) for n in sorted(names)]
+
+
+class TileIngest:
+    """The ingest pipeline of one file list (Stitcher._registerBatched).  The reference decodes the whole file list before the first pair is
+    looked at, and each tile three times (Stitcher.py:68-69, 382-403).  Here every tile gets its device handle(s) up front
+    (vfsms_tile_reserve) and a pool of decoder threads (the library's own JPEG decoder, or Pillow with the GIL released) fills them in path
+    order; the native registrar starts at once and waits only for the tiles of the batch it is about to launch, so registration overlaps
+    decoding and the decoded arrays never pile up on the host (a thread holds one tile at a time).  Tiles a previous segment of this file
+    list decoded but did not use (they lay behind its registration break, flowStitchWithMutiple) are taken over as they are -- a file is
+    decoded once even when the path breaks (the reference decodes the remaining list again after every break, Stitcher.py:96-127).
+
+        job = TileIngest(stitcher, files, shapes, color, keep);  handles = job.start();  ...register...;  job.finish(table)
+
+    `finish` always runs (the caller's `finally`; `failed = True` first when the registration raised): decodes that have not started are
+    cancelled, running ones are waited for, every handle is released, handed to getStitchByOffset (`keep`: stitcher._resident) or parked for
+    the next segment (stitcher._ingestCache); the decoder's error is raised unless the file lies behind the registration break."""
+
+    def __init__(self, stitcher, fileList, shapes, color, keep):
+        self.st, self.eng = stitcher, stitcher.engine
+        self.fileList, self.shapes, self.color, self.keep = fileList, shapes, color, keep
+        self.handles, self.chandles, self.futures, self.todo = [], [], [], []
+        self.failed = False
+        self._blocks = None
+
+    def start(self):
+        """reserve (or take over) a device tile per file and hand the files to the decoder pool -> gray tile handles, in file order"""
+        import threading
+        import time
+        from . import stitcher as ST                      # (the decode helpers are looked up there at call time: tests swap them)
+        st, eng, fileList, shapes, color = self.st, self.eng, self.fileList, self.shapes, self.color
+        handles, chandles = self.handles, self.chandles
+        if not hasattr(eng, "tile_reserve"):
+            handles.extend(eng.tile_upload(ST._imread(f, False)) for f in fileList)
+            return handles
+        cache = st.__dict__.get("_ingestCache") or {}
+        have = []
+        for s, f in zip(shapes, fileList):                # one by one: a reserve that fails midway leaves nothing behind (finish)
+            ent = cache.get(f)
+            if ent is not None and tuple(ent[2]) == tuple(s) and (bool(ent[1]) or not color):
+                del cache[f]
+                handles.append(ent[0])
+                if color:
+                    chandles.append(ent[1])
+                elif ent[1]:
+                    eng.tile_free(ent[1])
+                have.append(True)
+                continue
+            handles.append(eng.tile_reserve(s[0], s[1]))
+            if color:
+                chandles.append(eng.tile_reserve_color(s[0], s[1], 3))
+            have.append(False)
+        nthreads = st._decoderThreads(len(fileList))
+        self._blocks = ST._PillowBlocks(color)
+        self._blocks.__enter__()
+        istats = st._ingestStats = dict(tiles=0, decode_s=0.0, fill_s=0.0, threads=nthreads)   # summed over the decoder threads
+        istats_mu = threading.Lock()
+
+        def ingest(k):
+            hc = chandles[k] if color else 0
+            try:
+                t0 = time.perf_counter()
+                if ST._fill_from_jpeg(eng, fileList[k], handles[k], hc):
+                    with istats_mu:
+                        istats["tiles"] += 1; istats["native"] = istats.get("native", 0) + 1; istats["decode_s"] += time.perf_counter() - t0
+                    return
+                owner, shape, parts = ST._decode_once(fileList[k], color)
+                t1 = time.perf_counter()
+                if tuple(shape) != tuple(shapes[k]):
+                    raise ValueError("decoded size %s of %s differs from its header %s" % (shape, fileList[k], shapes[k]))
+                if parts[0] == "src":
+                    if hc or parts[3] != 0:
+                        eng.tile_fill_pair(handles[k], hc, parts[1], parts[2], parts[3])
+                    else:
+                        eng.tile_fill_ptr(handles[k], parts[1], parts[2])
+                else:
+                    eng.tile_fill(handles[k], parts[1])
+                    if hc:
+                        eng.tile_fill(hc, parts[2])
+                del owner
+                with istats_mu:
+                    istats["tiles"] += 1; istats["decode_s"] += t1 - t0; istats["fill_s"] += time.perf_counter() - t1
+            except BaseException:
+                for h in (handles[k], hc):                # the batch waiting for this tile fails instead of hanging
+                    if h:
+                        try:
+                            eng.tile_fill(h, None)
+                        except Exception:                 # already filled (the second fill of an "arrays" pair failed)
+                            pass
+                raise
+        pool = ST._decoder_pool(nthreads)
+        self.todo = [k for k in range(len(fileList)) if not have[k]]
+        self.futures = [pool.submit(ingest, k) for k in self.todo]
+        return handles
+
+    def finish(self, table):
+        """flowStitch discards everything behind a break (Stitcher.py:74-76) and the reference never opens those files: decodes that have not
+        started are cancelled (their handles are given up so that they can be freed), and a file behind the last registered pair that fails
+        to decode is not an error of this call"""
+        st, eng, fileList, shapes, color = self.st, self.eng, self.fileList, self.shapes, self.color
+        handles, chandles, failed = self.handles, self.chandles, self.failed
+        keep = self.keep and not failed
+        # tiles of this segment: 0 .. (leading registered pairs); the rest lies behind the break
+        n_used = len(fileList)
+        if table is not None and not failed:
+            n_used = 1
+            for row in table:
+                if not row[0]:
+                    break
+                n_used += 1
+            n_used = min(n_used, len(fileList))
+        # (the incremental registrars return a FULL-length table with zero rows behind the break, so len(table) says nothing: what the
+        #  registration looked at are the tiles of the leading registered pairs plus the B tile of the pair that failed)
+        needed = len(fileList) if (failed or table is None) else min(n_used + 1, len(fileList))
+        err, unfilled = None, set()
+        for k, fu in zip(self.todo, self.futures):
+            if fu.cancel():
+                unfilled.add(k)
+                for h in ([handles[k]] + ([chandles[k]] if color else [])):
+                    try:
+                        eng.tile_fill(h, None)
+                    except Exception:
+                        pass
+        for k, fu in zip(self.todo, self.futures):        # every running decoder has finished with its handles before any is freed
+            if fu.cancelled():
+                continue
+            try:
+                fu.result()
+            except BaseException as e:                     # noqa: PERF203
+                unfilled.add(k)
+                if k < needed:
+                    err = err or e
+        if self._blocks is not None:
+            self._blocks.__exit__(None, None, None)
+        stash = st.__dict__.get("_ingestCache") if (not failed and err is None) else None
+        mine = list(range(len(handles)))
+
+        def release(k):
+            for h in ([handles[k]] + ([chandles[k]] if k < len(chandles) else [])):
+                try:
+                    eng.tile_free(h)
+                except Exception:
+                    # still reserved: its decoder never ran (a reserve further down the list failed before the pool started) -- give it
+                    # up first, a reserved tile cannot be freed
+                    try:
+                        eng.tile_fill(h, None)
+                        eng.tile_free(h)
+                    except Exception:
+                        if not failed and err is None:
+                            raise
+        if keep and err is None:
+            # the mosaic is assembled from these very tiles: getStitchByOffset takes them over (and frees them)
+            kept = chandles if color else handles
+            st._resident = {fileList[k]: (kept[k], (shapes[k][0], shapes[k][1], 3) if color else shapes[k]) for k in range(n_used)}
+            for k in range(n_used):
+                if color:
+                    eng.tile_free(handles[k])
+            mine = list(range(n_used, len(handles)))
+        for k in mine:
+            if stash is not None and k >= n_used and k not in unfilled and fileList[k] not in stash and k < len(handles) and \
+                    (not color or k < len(chandles)):
+                stash[fileList[k]] = (handles[k], chandles[k] if color else 0, shapes[k])      # decoded, unused: the next segment takes it over
+            else:
+                release(k)
+        if err is not None and not failed:
+            raise err

@@ -9,7 +9,6 @@ in HBM; see imagestitch_amd/csrc.
 """
 import copy
 import os
-import threading
 import time
 
 import numpy as np
@@ -61,7 +60,7 @@ class ResidentFeatures:
 
 
 from .ingest import (_imread, _imread_gray_pointer, _PillowBlocks, _decoder_pool, _decode_once, _fill_from_jpeg, _ycc_to_bgr, _imshape,  # noqa: F401
-                     _list_images)
+                     _list_images, TileIngest)
 from .io import (_imwrite, _imwrite_jpeg_stripes, NpyBandWriter, PngBandWriter, JpegBandWriter, TiffBandWriter, _NoNativeJpeg,  # noqa: F401
                  _native_jpeg_encoder, band_writer_for)
 
@@ -172,124 +171,64 @@ class Stitcher(Utility.Method):
         native = getattr(self.engine, "tile_fill_jpeg", None) is not None and os.environ.get("VFSMS_NATIVE_JPEG", "1") != "0"
         return max(1, min(int(self.decodeThreads or min(os.cpu_count() or 4, 32 if native else 16)), n_files, 64))
 
+    def _batchedMethod(self, caculateOffsetMethod, n_files):
+        """which fused path serves `caculateOffsetMethod` ("surf" / "orb" / "phase": incremental ROI search; "surf_full" / "orb_full": whole-tile
+        features, the line scans of Main.py:29-51), or None: a custom method or operators, the switch off, fewer than two files"""
+        fn, owner = getattr(caculateOffsetMethod, "__func__", None), getattr(caculateOffsetMethod, "__self__", None)
+        if not self.batchRegistration or owner is not self or n_files < 2:
+            return None
+        if fn is Stitcher.calculateOffsetForFeatureSearchIncre and self._usesStockOperators():
+            return self.featureMethod
+        if fn is Stitcher.calculateOffsetForPhaseCorrleateIncre and not self.phaseSignFix:
+            return "phase"
+        if fn is Stitcher.calculateOffsetForFeatureSearch and self._usesStockOperators() and self.offsetCaculate == "mode":
+            if self.featureMethod == "surf" and hasattr(self.engine, "features_surf_batch"):
+                return "surf_full"
+            if self.featureMethod == "orb" and not self.isEnhance and hasattr(self.engine, "attempt_orb_batch"):
+                return "orb_full"
+        return None
+
+    def _makeRegistrar(self, method, n_files):
+        """the GridRegistrar of one file list, primed with what the previous dataset taught this stitcher (accepted directions, same number of
+        tiles: GridRegistrar.path_memory; Main.py runs its datasets through ONE Stitcher with one setting) or with the operator's pathHint"""
+        from .grid import GridRegistrar
+        params = None if method == "phase" else (self._orbParams() if method in ("orb", "orb_full") else self._surfParams())
+        reg = GridRegistrar(self.engine, method="surf" if method == "surf_full" else "orb" if method == "orb_full" else method, roiRatio=self.roiRatio,
+                            searchRatio=self.searchRatio, offsetEvaluate=self.offsetEvaluate, directIncre=self.directIncre, surfParams=params,
+                            phaseResponseThreshold=self.phaseResponseThreshold, window=48,
+                            enhance=self._enhanceSpec() if method in ("surf", "surf_full") else (0, 0.0, 0))
+        reg.orbMaxDistance = self.orbMaxDistance if self.isGPUAvailable else -1
+        reg.path_memory = self.__dict__.get("_pathMemory")
+        reg.path_suspect = bool(self.__dict__.get("_pathSuspect", False))
+        if reg.path_memory is None and self.pathHint is not None and len(self.pathHint) == n_files - 1:
+            reg.path_memory = [int(d) for d in self.pathHint]
+        return reg
+
     def _registerBatched(self, fileList, caculateOffsetMethod):
         """The pair loop of flowStitch (Stitcher.py:64-79) through grid.GridRegistrar when `caculateOffsetMethod` is this
         object's own calculateOffsetForFeatureSearchIncre / calculateOffsetForPhaseCorrleateIncre with the stock operators:
-        all tiles go to the GPU once and the pairs are registered in speculative fused batches whose selected results equal
-        the pair-by-pair search (same offsets, same self.direction threading, same log lines).  Returns None when the
-        sequential loop has to run (custom method or operators, tiles of different sizes, switch off)
-        else (status, endfileIndex, offsetList, description of the break)."""
-        fn, owner = getattr(caculateOffsetMethod, "__func__", None), getattr(caculateOffsetMethod, "__self__", None)
-        if not self.batchRegistration or owner is not self or len(fileList) < 2:
-            return None
-        if fn is Stitcher.calculateOffsetForFeatureSearchIncre and self._usesStockOperators():
-            method = self.featureMethod
-        elif fn is Stitcher.calculateOffsetForPhaseCorrleateIncre and not self.phaseSignFix:
-            method = "phase"
-        elif (fn is Stitcher.calculateOffsetForFeatureSearch and self._usesStockOperators() and self.featureMethod == "surf"
-              and self.offsetCaculate == "mode" and hasattr(self.engine, "features_surf_batch")):
-            method = "surf_full"                              # the line scans of Main.py:29-51: whole-tile features, no ROI search
-        elif (fn is Stitcher.calculateOffsetForFeatureSearch and self._usesStockOperators() and self.featureMethod == "orb"
-              and self.offsetCaculate == "mode" and not self.isEnhance and hasattr(self.engine, "attempt_orb_batch")):
-            method = "orb_full"                               # the same scans with featureMethod = "orb"
-        else:
+        all tiles go to the GPU once (ingest.TileIngest: reserved handles filled by a pool of decoder threads while the registrar already
+        works) and the pairs are registered in speculative fused batches whose selected results equal the pair-by-pair search (same
+        offsets, same self.direction threading, same log lines).  Returns None when the sequential loop has to run (custom method or
+        operators, tiles of different sizes, switch off) else (status, endfileIndex, offsetList, description of the break)."""
+        method = self._batchedMethod(caculateOffsetMethod, len(fileList))
+        if method is None:
             return None
         eng = self.engine
         shapes = [_imshape(f) for f in fileList]             # from the file headers: nothing is decoded yet
         if any(s != shapes[0] for s in shapes):
             return None
-        from .grid import GridRegistrar
-        params = None if method == "phase" else (self._orbParams() if method in ("orb", "orb_full") else self._surfParams())
-        reg = GridRegistrar(eng, method="surf" if method == "surf_full" else "orb" if method == "orb_full" else method, roiRatio=self.roiRatio, searchRatio=self.searchRatio, offsetEvaluate=self.offsetEvaluate,
-                            directIncre=self.directIncre, surfParams=params,
-                            phaseResponseThreshold=self.phaseResponseThreshold, window=48,
-                            enhance=self._enhanceSpec() if method in ("surf", "surf_full") else (0, 0.0, 0))
-        reg.orbMaxDistance = self.orbMaxDistance if self.isGPUAvailable else -1
-        # the scan pattern the previous dataset taught this stitcher (accepted directions, same number of tiles): the speculation prior of
-        # this one (GridRegistrar.path_memory; Main.py runs its datasets through ONE Stitcher with one setting)
-        reg.path_memory = self.__dict__.get("_pathMemory")
-        reg.path_suspect = bool(self.__dict__.get("_pathSuspect", False))
-        if reg.path_memory is None and self.pathHint is not None and len(self.pathHint) == len(fileList) - 1:
-            reg.path_memory = [int(d) for d in self.pathHint]
+        reg = self._makeRegistrar(method, len(fileList))
         device_fuse = (self.fuseMethod in ("notFuse", "fadeInAndFadeOut", "trigonometric") and hasattr(eng, "canvas_fuse_tile_resident")) or \
                       (self.fuseMethod in ("average", "maximum", "minimum") and hasattr(eng, "canvas_blend_tile_resident"))
         # the tiles the mosaic is assembled from stay in HBM: the registration planes themselves for gray mosaics, and for colour mosaics
         # (Main.py:14's default) the B G R tiles the SAME decode produced -- every file is decoded exactly once (Stitcher.py:68-69, 382-403)
         color = bool(self.isColorMode) and device_fuse and hasattr(eng, "tile_fill_pair")
         keep = device_fuse and (color or not self.isColorMode) and len(set(fileList)) == len(fileList)
-        handles, chandles, pool, futures, failed, table, todo = [], [], None, [], False, None, []
-        block_alloc = None
+        job = TileIngest(self, fileList, shapes, color, keep)
+        table = None
         try:
-            if hasattr(eng, "tile_reserve"):
-                # Ingest pipeline.  The reference decodes the whole file list before the first pair is looked at, and each tile three
-                # times (Stitcher.py:68-69, 382-403).  Here every tile gets its device handle(s) up front (vfsms_tile_reserve) and a pool
-                # of decoder threads (Pillow releases the GIL while it decodes) fills them in path order; the native registrar starts
-                # at once and waits only for the tiles of the batch it is about to launch, so registration overlaps decoding and the
-                # decoded arrays never pile up on the host (a thread holds one tile at a time).
-                # Tiles a previous segment of this file list decoded but did not use (they lay behind its registration break,
-                # flowStitchWithMutiple): taken over as they are -- a file is decoded once even when the path breaks (the reference
-                # decodes the remaining list again after every break, Stitcher.py:96-127).
-                cache = self.__dict__.get("_ingestCache") or {}
-                have = []
-                for s, f in zip(shapes, fileList):            # one by one: a reserve that fails midway leaves nothing behind (finally)
-                    ent = cache.get(f)
-                    if ent is not None and tuple(ent[2]) == tuple(s) and (bool(ent[1]) or not color):
-                        del cache[f]
-                        handles.append(ent[0])
-                        if color:
-                            chandles.append(ent[1])
-                        elif ent[1]:
-                            eng.tile_free(ent[1])
-                        have.append(True)
-                        continue
-                    handles.append(eng.tile_reserve(s[0], s[1]))
-                    if color:
-                        chandles.append(eng.tile_reserve_color(s[0], s[1], 3))
-                    have.append(False)
-                nthreads = self._decoderThreads(len(fileList))
-                block_alloc = _PillowBlocks(color)
-                block_alloc.__enter__()
-
-                istats = self._ingestStats = dict(tiles=0, decode_s=0.0, fill_s=0.0, threads=nthreads)   # summed over the decoder threads
-                istats_mu = threading.Lock()
-
-                def ingest(k):
-                    hc = chandles[k] if color else 0
-                    try:
-                        t0 = time.perf_counter()
-                        if _fill_from_jpeg(eng, fileList[k], handles[k], hc):
-                            with istats_mu:
-                                istats["tiles"] += 1; istats["native"] = istats.get("native", 0) + 1; istats["decode_s"] += time.perf_counter() - t0
-                            return
-                        owner, shape, parts = _decode_once(fileList[k], color)
-                        t1 = time.perf_counter()
-                        if tuple(shape) != tuple(shapes[k]):
-                            raise ValueError("decoded size %s of %s differs from its header %s" % (shape, fileList[k], shapes[k]))
-                        if parts[0] == "src":
-                            if hc or parts[3] != 0:
-                                eng.tile_fill_pair(handles[k], hc, parts[1], parts[2], parts[3])
-                            else:
-                                eng.tile_fill_ptr(handles[k], parts[1], parts[2])
-                        else:
-                            eng.tile_fill(handles[k], parts[1])
-                            if hc:
-                                eng.tile_fill(hc, parts[2])
-                        del owner
-                        with istats_mu:
-                            istats["tiles"] += 1; istats["decode_s"] += t1 - t0; istats["fill_s"] += time.perf_counter() - t1
-                    except BaseException:
-                        for h in (handles[k], hc):            # the batch waiting for this tile fails instead of hanging
-                            if h:
-                                try:
-                                    eng.tile_fill(h, None)
-                                except Exception:             # already filled (the second fill of an "arrays" pair failed)
-                                    pass
-                        raise
-                pool = _decoder_pool(nthreads)
-                todo = [k for k in range(len(fileList)) if not have[k]]
-                futures = [pool.submit(ingest, k) for k in todo]
-            else:
-                handles = [eng.tile_upload(_imread(f, False)) for f in fileList]
+            handles = job.start()
             if method == "surf_full":
                 table = self._fullImageTable(handles)
             elif method == "orb_full":
@@ -299,76 +238,10 @@ class Stitcher(Utility.Method):
                 # (what this path taught, incl. "nothing": a memory that mispredicted twice in a row is dropped, GridRegistrar._learn)
                 self._pathMemory, self._pathSuspect = reg.path_memory, reg.path_suspect
         except BaseException:
-            keep, failed = False, True
+            job.failed = True
             raise
         finally:
-            # flowStitch discards everything behind a break (Stitcher.py:74-76) and the reference never opens those files: decodes that have
-            # not started are cancelled (their handles are given up so that they can be freed), and a file behind the last registered pair
-            # that fails to decode is not an error of this call
-            # tiles of this segment: 0 .. (leading registered pairs); the rest lies behind the break
-            n_used = len(fileList)
-            if table is not None and not failed:
-                n_used = 1
-                for row in table:
-                    if not row[0]:
-                        break
-                    n_used += 1
-                n_used = min(n_used, len(fileList))
-            # (the incremental registrars return a FULL-length table with zero rows behind the break, so len(table) says nothing: what the
-            #  registration looked at are the tiles of the leading registered pairs plus the B tile of the pair that failed)
-            needed = len(fileList) if (failed or table is None) else min(n_used + 1, len(fileList))
-            err, unfilled = None, set()
-            for k, fu in zip(todo, futures):
-                if fu.cancel():
-                    unfilled.add(k)
-                    for h in ([handles[k]] + ([chandles[k]] if color else [])):
-                        try:
-                            eng.tile_fill(h, None)
-                        except Exception:
-                            pass
-            for k, fu in zip(todo, futures):                  # every running decoder has finished with its handles before any is freed
-                if fu.cancelled():
-                    continue
-                try:
-                    fu.result()
-                except BaseException as e:                     # noqa: PERF203
-                    unfilled.add(k)
-                    if k < needed:
-                        err = err or e
-            if block_alloc is not None:
-                block_alloc.__exit__(None, None, None)
-            stash = self.__dict__.get("_ingestCache") if (not failed and err is None) else None
-            mine = list(range(len(handles)))
-
-            def release(k):
-                for h in ([handles[k]] + ([chandles[k]] if k < len(chandles) else [])):
-                    try:
-                        eng.tile_free(h)
-                    except Exception:
-                        # still reserved: its decoder never ran (a reserve further down the list failed before the pool started) -- give it
-                        # up first, a reserved tile cannot be freed
-                        try:
-                            eng.tile_fill(h, None)
-                            eng.tile_free(h)
-                        except Exception:
-                            if not failed and err is None:
-                                raise
-            if keep and err is None:
-                # the mosaic is assembled from these very tiles: getStitchByOffset takes them over (and frees them)
-                kept = chandles if color else handles
-                self._resident = {fileList[k]: (kept[k], (shapes[k][0], shapes[k][1], 3) if color else shapes[k]) for k in range(n_used)}
-                for k in range(n_used):
-                    if color:
-                        eng.tile_free(handles[k])
-                mine = list(range(n_used, len(handles)))
-            for k in mine:
-                if stash is not None and k >= n_used and k not in unfilled and fileList[k] not in stash and k < len(handles) and \
-                        (not color or k < len(chandles)):
-                    stash[fileList[k]] = (handles[k], chandles[k] if color else 0, shapes[k])      # decoded, unused: the next segment takes it over
-                else:
-                    release(k)
-            if err is not None and not failed:
-                raise err
+            job.finish(table)
         offsetList, endfileIndex, status, describtion = [], 0, True, ""
         for k, row in enumerate(table):
             self.printAndWrite("stitching " + str(fileList[k]) + " and " + str(fileList[k + 1]))

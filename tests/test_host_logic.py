@@ -971,3 +971,29 @@ def test_a_registration_break_does_not_decode_a_file_twice(oracle, tmp_path):
                     assert np.array_equal(results[1], ST._imread(sub[3], color))
     finally:
         isa.Stitcher.direction, isa.Stitcher.isColorMode, isa.Stitcher.featureMethod, isa.Stitcher.fuseMethod = old
+
+
+def test_bench_says_when_its_pmc_evidence_is_of_another_build(tmp_path, monkeypatch):
+    """bench.py reads the PMC-derived roofline fields from the newest profiles/*_pmc_summary.txt; tools/profile_round.sh stamps that file with
+    the content hash of the kernel sources it profiled (tools/build_id.py) and bench.pmc_build() compares: the same hash -> pmc_stale False,
+    another hash or a summary without a stamp -> True.  (What keeps `traffic`, `valu_busy_frac_pmc`, ... from silently describing an older
+    kernel.)"""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    from tools.build_id import build_id, src_sha256
+    mine = build_id()
+    assert mine["src_sha256"] == src_sha256() and len(mine["src_sha256"]) == 16
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (prof / "r97_pmc_summary.txt").write_text("# build: head=abc lib_sha256=%s src_sha256=%s\nk_describe launches=1 INSTS_VALU=1e9\n" % (mine["lib_sha256"], mine["src_sha256"]))
+    info = bench.pmc_build()
+    assert info["pmc_stale"] is False and info["pmc_build"]["src_sha256"] == mine["src_sha256"] and info["pmc_summary"].endswith("r97_pmc_summary.txt")
+    (prof / "r98_pmc_summary.txt").write_text("# build: head=abc lib_sha256=0 src_sha256=0000000000000000\nk_describe launches=1 INSTS_VALU=1e9\n")
+    assert bench.pmc_build()["pmc_stale"] is True                       # the newest summary is of other sources
+    (prof / "r99_pmc_summary.txt").write_text("k_describe launches=1 INSTS_VALU=1e9\n")
+    assert bench.pmc_build()["pmc_stale"] is True                       # no stamp at all (summaries of rounds 1-4)
