@@ -23,8 +23,19 @@ results never depend on it).  The warm-up step teaches it the grid's scan patter
 of 13, one primed chain per rank at N > 1.  `value_cold_path` (N = 1) is the same K steps by a registrar without memory -- the
 configuration of rounds 1-3; --no-path-memory makes it the headline.
 
+The prior of the timed steps is learned on ANOTHER instance of the scan pattern (--prior other, the default since round 5: same geometry,
+seed + 1 -- other texture, jitter and offsets --, registered once, cold, before the warm-up: what the second dataset of a session has;
+--prior same: only the warm-up steps of the timed grid teach it, round 4's headline).
+
+The surf roofline counts the REFERENCE's 26 lane-operations per bilinear sample (DESC_OPS_LOWER_BOUND) over the live HIP-event duration of the
+descriptor stage, against the calibrated VALU peak at 2.4 GHz (`frac`) and at the clock the kernel runs at (`frac_at_effective_clock`); its
+PMC-derived fields come from the newest profiles/*_pmc_summary.txt, and `pmc.pmc_stale` says whether that summary was taken of the kernel
+sources this run loaded (tools/build_id.py).
+
 --method orb | phase | fuse time the other paths of the scope table on the same grid (each with its own roofline object);
-the default, surf, is the BASELINE metric.
+the default, surf, is the BASELINE metric.  --rows 32 --cols 32 --tile 4096 [--also-fuse] is BASELINE configs[4] on one GPU (tiles synthesised
+by worker processes; --also-fuse prints the mosaic-assembly line of the same resident tiles as a second JSON line).  --force-dist (N = 1):
+the step's all-gather through torch.distributed "nccl" (RCCL) at world size 1.
 --workload dendritic25 (N = 1): the 25 committed pairs of the reference's dendriticCrystal set (tests/golden/real_path_strips.*), a second
 SURF line on real texture.  --from-files (N = 1): the same grid as JPEG files through Stitcher's ingest pipeline, decode inclusive.
 """
