@@ -447,3 +447,51 @@ def test_a_path_memory_that_mispredicts_is_not_kept_on_trust():
         # a caller's hint is never put on trial (it is the caller's to correct)
         reg.register(list(range(P + 1)), [SHAPE] * (P + 1), 1, hint=[1] * P)
         assert reg.mispredictions == 3
+
+
+def test_sharded_ranks_put_a_memory_on_probation_alike():
+    """The probation of a path memory (GridRegistrar._learn) is decided from the gathered table alone, so the ranks of the sharded form --
+    each with a registrar of its own that lives from path to path -- must stay in step: same memory, same suspicion, same count of
+    mispredictions after every path of the sequence A, A, B, A, B, A (10 x 9 and 9 x 10 serpentines: the same 89 pairs, turns elsewhere),
+    and every path's table equals its sequential search whatever the memory said (repair rounds included).  Four ranks on threads with an
+    in-process all-gather, Python twin and native chains."""
+    import threading
+    A, B = _serpentine_accept(10, 9), _serpentine_accept(9, 10)
+    P, world = len(A), 4
+    seqs = {id(A): sequential(A, 0.2, 1, 1), id(B): sequential(B, 0.2, 1, 1)}
+    for native in (False, True):
+        engs = [ScriptedAttemptEngine(SHAPE, 0.2, A) for _ in range(world)]
+        regs = [GridRegistrar(e, roiRatio=0.2, directIncre=1, window=48) for e in engs]
+        for r, e in zip(regs, engs):
+            r.native = native and hasattr(e, "pairs_offsets")
+        want_mis = 0
+        for step, acc in enumerate((A, A, B, A, B, A)):
+            bar = threading.Barrier(world)
+            slots, outs, errs = [None] * world, [None] * world, []
+
+            def work(rank):
+                try:
+                    engs[rank].accept = acc
+
+                    def all_gather(payload):
+                        slots[rank] = np.asarray(payload, np.int32)
+                        bar.wait()
+                        g = np.stack(slots)
+                        bar.wait()
+                        return g
+                    outs[rank] = regs[rank].register_sharded(list(range(P + 1)), [SHAPE] * (P + 1), 1, rank, world, all_gather)
+                except BaseException as e:                        # noqa: BLE001
+                    errs.append(e); bar.abort()
+            ths = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+            [t.start() for t in ths]; [t.join() for t in ths]
+            if errs:
+                raise errs[0]
+            seq, d_end, _n = seqs[id(acc)]
+            for full, d in outs:
+                assert d == d_end and [list(r[:4]) for r in full.tolist()] == seq, (native, step)
+            states = {(tuple(r.path_memory) if r.path_memory is not None else None, r.path_suspect, r.mispredictions) for r in regs}
+            assert len(states) == 1, (native, step, states)              # every rank decided alike
+            want_mis += 1 if step in (2, 3, 5) else 0                   # B on A's memory, A on B's (dropped), [B cold], A on B's
+            assert regs[0].mispredictions == want_mis, (native, step, regs[0].mispredictions)
+        # A, A: primed.  B: mispredicted, adopted on probation.  A: mispredicted again -> dropped.  B: cold, learned.  A: mispredicted, on probation.
+        assert regs[0].path_suspect and regs[0].path_memory is not None
