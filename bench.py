@@ -275,7 +275,8 @@ def bench_fuse(args, eng, grid, tiles, handles, torch, close=True):
                                % (args.rows, args.cols, args.tile, args.tile, rows, cols), "tiles": n, "tiles_resident_in_hbm": True,
                    "canvas_download_ms": round(dl * 1e3, 1), "canvas_download_is": "the first %d rows" % min(rows, grid.th) if big else "the whole mosaic",
                    "ms_per_step_with_host_tiles": round(dt_host * 1e3, 1) if dt_host is not None else None},
-        "roofline": roof, "cpu_baseline": None, "stages": {k: dict(ms=round(v[0], 3), launches=v[1]) for k, v in prof.items()},
+        "roofline": roof, "cpu_baseline": (cpu_baseline_fuse(args, grid, tiles, offsetList, rois, offs, rows, cols) if args.cpu_sample > 0 else None),
+        "stages": {k: dict(ms=round(v[0], 3), launches=v[1]) for k, v in prof.items()},
         "tile_Mpx_per_s": round(n * grid.th * grid.tw / 1e6 / dt, 2), "mosaic_nonzero_fraction": round(float((out > 0).mean()), 4),
         "mosaic_Mpx_per_s_of_the_fuse_kernels": round(mpx / (f_ms / args.steps * 1e-3), 2) if f_n else None,
         "note": "value = mosaic pixels / wall clock of one assembly INCLUDING the canvas allocation + clear and its release (at configs[4]'s 13.9 GB canvas "
@@ -585,6 +586,87 @@ def cpu_baseline_surf(args, grid, tiles, isa):
                 sample="%d pairs of the same grid, one pair per host thread (%d threads of %d), one ROI attempt each at the true direction (oracle "
                        "SURF+BF-L2+mode built -O3 -march=native here), %.1f s" % (len(pair_ids), min(cores, len(pair_ids)), cores, dt_all),
                 single_thread=dict(value=round(S1 / dt_one, 4), cores=1, sample="first %d pair(s), %.1f s" % (S1, dt_one)),
+                build=O.build_kind())
+
+
+def cpu_baseline_pairs(args, grid, tiles, isa, method):
+    """cpu_baseline of the ORB / phase lines: the oracle's chain for ONE ROI attempt per pair at the true direction (ImageUtility.py:260-262 +
+    297-302 + 139-178 for orb, Stitcher.py:230 for phase), one pair per host thread and a single-thread row, as cpu_baseline_surf does."""
+    from oracle import oracle as O
+    O.build()
+    try:
+        O.use_native()
+    except Exception as e:
+        print("cpu_baseline: native oracle build unavailable (%s)" % e, file=sys.stderr)
+    cores = os.cpu_count() or 1
+    dirs = grid.true_directions()
+
+    def one(k):
+        A, B = tiles[k], tiles[k + 1]
+        ra = isa.roi_rect(A.shape, dirs[k], "first", 0.2); rb = isa.roi_rect(B.shape, dirs[k], "second", 0.2)
+        roiA = np.ascontiguousarray(A[ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]]); roiB = np.ascontiguousarray(B[rb[0]:rb[0] + rb[2], rb[1]:rb[1] + rb[3]])
+        if method == "phase":
+            O.phase_correlate(roiA, roiB)
+            return
+        ka, da = O.orb_detect_describe(roiA); kb, db = O.orb_detect_describe(roiB)
+        pr, _dist = O.bf_hamming_matches(da, db)
+        O.mode_offset(np.stack([ka["x"], ka["y"]], 1), np.stack([kb["x"], kb["y"]], 1), pr, args.offset_evaluate)
+    from concurrent.futures import ThreadPoolExecutor
+    pair_ids = [k for k in sorted(tiles) if k + 1 in tiles][:min(grid.n_pairs, cores)]
+    t1 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=min(cores, len(pair_ids))) as ex:
+        list(ex.map(one, pair_ids))
+    dt_all = time.perf_counter() - t1
+    S1 = max(1, min(args.cpu_sample, 6, len(pair_ids)))
+    t1 = time.perf_counter()
+    for k in pair_ids[:S1]:
+        one(k)
+    dt_one = time.perf_counter() - t1
+    what = "oracle cv2.phaseCorrelate restatement (FP64, own mixed-radix FFT)" if method == "phase" else "oracle ORB(5000,1.2,8)+BF-Hamming 1-NN+mode"
+    return dict(value=round(len(pair_ids) / dt_all, 4), unit="image-pairs/s", cores=min(cores, len(pair_ids)), kind="port",
+                sample="%d pairs of the same grid, one pair per host thread (%d threads of %d), one ROI attempt each at the true direction (%s, built "
+                       "-O3 -march=native here), %.1f s" % (len(pair_ids), min(cores, len(pair_ids)), cores, what, dt_all),
+                single_thread=dict(value=round(S1 / dt_one, 4), cores=1, sample="first %d pair(s), %.1f s" % (S1, dt_one)), build=O.build_kind())
+
+
+def cpu_baseline_fuse(args, grid, tiles, offsetList, rois, offs, rows, cols):
+    """cpu_baseline of the fuse line: the reference's walk (Stitcher.py:434-486: int64 canvas with -1 for empty, every tile pasted, its
+    overlap with the canvas blended by ImageFusion.fuseByFadeInAndFadeOut -- the oracle's C restatement) over the FIRST tiles of the same
+    mosaic, bounded to ~20 s on one host thread (the walk is a chain: tile i blends against what tiles 0..i-1 left).  Mpx/s of the mosaic
+    area those tiles cover."""
+    from oracle import oracle as O
+    O.build()
+    try:
+        O.use_native()
+    except Exception as e:
+        print("cpu_baseline: native oracle build unavailable (%s)" % e, file=sys.stderr)
+    n = min(grid.n_tiles, max(2, int(os.environ.get("VFSMS_BENCH_FUSE_CPU_TILES", "24"))))
+    r1 = max(offsetList[i][0] + grid.th for i in range(n)); c1 = max(offsetList[i][1] + grid.tw for i in range(n))
+    r0 = min(offsetList[i][0] for i in range(n)); c0 = min(offsetList[i][1] for i in range(n))
+    t1 = time.perf_counter()
+    canvas = np.full((r1 - r0, c1 - c0), -1, np.int64)
+    done = 0
+    for i in range(n):
+        oy, ox = offsetList[i][0] - r0, offsetList[i][1] - c0
+        T = np.asarray(tiles[i]).astype(np.int64)
+        if i > 0:
+            y0, x0, y1, x1 = rois[i - 1]
+            y0 -= r0; y1 -= r0; x0 -= c0; x1 -= c0
+            A = canvas[y0:y1, x0:x1].copy()
+            B = T[y0 - oy:y1 - oy, x0 - ox:x1 - ox]
+            fused = O.fuse_fade(A, B, offs[i][0], offs[i][1])
+            canvas[oy:oy + grid.th, ox:ox + grid.tw] = T
+            canvas[y0:y1, x0:x1] = fused
+        else:
+            canvas[oy:oy + grid.th, ox:ox + grid.tw] = T
+        done = i + 1
+        if time.perf_counter() - t1 > 25.0:
+            break
+    dt = time.perf_counter() - t1
+    area = float((canvas >= 0).sum()) / 1e6
+    return dict(value=round(area / dt, 2), unit="Mpx/s", cores=1, kind="port",
+                sample="the reference walk (int64 / -1 canvas, paste + oracle fuseByFadeInAndFadeOut per overlap) over the first %d of %d tiles of "
+                       "the same mosaic: %.1f Mpx in %.1f s on one host thread (the walk is a dependency chain)" % (done, grid.n_tiles, area, dt),
                 build=O.build_kind())
 
 
@@ -961,13 +1043,15 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0 and args.method == "surf":
         cpu = cpu_baseline_surf(args, grid, tiles, isa)
+    elif rank == 0 and world == 1 and args.cpu_sample > 0 and args.method in ("orb", "phase"):
+        cpu = cpu_baseline_pairs(args, grid, tiles, isa, args.method)
 
     if rank == 0:
         pmc_info = pmc_build()
         if roofline is not None:
             roofline["pmc_stale"] = pmc_info["pmc_stale"]
         out = {
-            "metric": "image-pairs/sec (2048x2048 grayscale, SURF+BF)" if args.method == "surf" else "image-pairs/sec (%s)" % args.method,
+            "metric": "image-pairs/sec (%dx%d grayscale, SURF+BF)" % (args.tile, args.tile) if args.method == "surf" else "image-pairs/sec (%s)" % args.method,
             "value": round(P * args.steps / elapsed, 3),
             "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_extra_steps_until_1p5s": warm_extra,

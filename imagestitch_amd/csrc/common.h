@@ -43,6 +43,17 @@ constexpr int vfsms_haar_corner(int size, int k, int c)
                                  {1, 1, 4, 4}, {5, 1, 8, 4}, {1, 5, 4, 8}, {5, 5, 8, 8} };
     return (2 * size * src[k][c] + 9) / 18;
 }
+// the 9 x 9 pattern coordinate (0..9) behind corner c of box k: the integral ROW of a tap depends on it alone, which is what the
+// row-staged coarse Hessian (k_hessian_rows2) indexes its LDS row slots with
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+constexpr int vfsms_haar_src(int k, int c)
+{
+    constexpr int src[10][4] = { {0, 2, 3, 7}, {3, 2, 6, 7}, {6, 2, 9, 7}, {2, 0, 7, 3}, {2, 3, 7, 6}, {2, 6, 7, 9},
+                                 {1, 1, 4, 4}, {5, 1, 8, 4}, {1, 5, 4, 8}, {5, 5, 8, 8} };
+    return src[k][c];
+}
 struct LayerPat {
     int size, step, margin, octave;   // margin = (size/2)/step
     int box[10][4];                   // dx1, dy1, dx2, dy2 for Dx[3], Dy[3], Dxy[4]  (resizeHaarPattern)

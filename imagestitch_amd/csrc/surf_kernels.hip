@@ -316,12 +316,41 @@ __global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const L
     if (j0 * STEP >= R.w || i0 * STEP >= R.h) return;
     g_ci32 S = (g_ci32)R.sum;
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    for (int t = tid; t < LH * LW; t += 256) {
-        const int ty = t / LW, tx = t - ty * LW;
-        const int gy = min(i0 * STEP + ty, sh - 1), gx = min(j0 * STEP + tx, sw - 1);
-        const int32_t v = S[(size_t)gy * sw + gx];
-        if (STEP == 2) tile[(tx & 1) * PLANE + ty * LWH + (tx >> 1)] = v;
-        else tile[t] = v;
+    {
+        // Round 6: a wave stages whole window rows (the row address is scalar), its lanes the columns lane, lane + 64, ...: two VALU
+        // instructions per element (the load and the LDS store at a lane-constant offset) where the flat loop over LH * LW elements
+        // spent ~20 on div / mod, clamps, 64-bit addresses and plane offsets -- half of octave 1's instructions, whose 129 x 97 window
+        // feeds 512 samples.
+        constexpr int NK = (LW + 63) / 64;
+        const int lane = threadIdx.x, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
+        const int x0 = j0 * STEP, y0 = i0 * STEP;
+        uint32_t gxo[NK]; int lo[NK];
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            const int tx = lane + 64 * k;
+            gxo[k] = (uint32_t)min(x0 + tx, sw - 1);
+            lo[k] = STEP == 2 ? (tx & 1) * PLANE + (tx >> 1) : tx;
+        }
+        constexpr int RB = 4;                                     // rows in flight per wave: RB * NK loads are issued before the first store
+        for (int tb = wave; tb < LH; tb += 4 * RB) {
+            int32_t v[RB][NK];
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                g_ci32 row = S + (size_t)min(y0 + min(tb + 4 * r, LH - 1), sh - 1) * sw;
+#pragma unroll
+                for (int k = 0; k < NK; k++) v[r][k] = row[gxo[k]];
+            }
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                const int ty = tb + 4 * r;
+                if (ty < LH) {
+                    int32_t *trow = tile + ty * LWH;
+#pragma unroll
+                    for (int k = 0; k < NK; k++)
+                        if (NK * 64 == LW || k + 1 < NK || lane + 64 * k < LW) trow[lo[k]] = v[r][k];
+                }
+            }
+        }
     }
     __syncthreads();
     const int lcols = R.w / STEP;
@@ -428,6 +457,106 @@ __global__ __launch_bounds__(256) void k_hessian_coarse(const RoiDev *rois, cons
     if (o == 2) { switch (l) { case 0: HC(2, 0); break; case 1: HC(2, 1); break; case 2: HC(2, 2); break; case 3: HC(2, 3); break; default: HC(2, 4); } }
     else { switch (l) { case 0: HC(3, 0); break; case 1: HC(3, 1); break; case 2: HC(3, 2); break; case 3: HC(3, 3); break; default: HC(3, 4); } }
 #undef HC
+}
+
+// Octave 2 (step 4), round 6: ROW-STAGED.  The gather kernel above is bound by the texture-address path (TA busy 0.95): the 64 lanes of a
+// wave sample columns 16 bytes apart, so every one of its 32 distinct taps per (sample, layer) pulls 1 KB of cache lines through the
+// L1 for 256 useful bytes, and a (tile + wavelet) window of the octave does not fit LDS (120-200 KB).  But a layer's taps touch only
+// TEN integral rows per sample row (4 i + corner(v), v = 0..9: Dx uses rows 2, 7, Dy 0, 3, 6, 9, Dxy 1, 4, 5, 8 of the scaled
+// pattern), and every column of those rows inside the tile's span is used by some sample.  So one workgroup = (layer, 2 sample
+// rows, 128 samples): it stages the 20 row segments [4 j0, 4 (j0 + 127) + size] with coalesced 16-byte loads (51 KB for
+// the 132-px layer, three workgroups per CU), each row as four column planes (x & 3), and every tap is one conflict-free
+// ds_read_b32 at an immediate offset: lane jl needs column 4 jl + dx = element jl + (dx >> 2) of plane dx & 3 -- unit stride
+// across the lanes (a linear row would be read with a stride of four dwords: four lanes per bank).  Loaded bytes per sample drop from 32 x 16 (scattered) to ~40 x 4 (coalesced).  Arithmetic and its order
+// are those of k_hessian.
+template <int L>
+__device__ __forceinline__ void hessian_rows2_body(const RoiDev &R, const LayerPat *pats, int layers_per_octave, int ti, int tj, int32_t *lds)
+{
+    constexpr int STEP = 4;
+    constexpr int size = (9 + 6 * L) << 2;
+    constexpr int W4 = 128 + size / 4;                              // 16-byte chunks per staged row (size is a multiple of 4)
+    constexpr int RP = 4 * W4;                                      // ints per row slot: four column planes of W4
+    if (size > R.h || size > R.w) return;
+    const int samples_i = 1 + (R.h - size) / STEP, samples_j = 1 + (R.w - size) / STEP;
+    const int i0 = ti * 2, j0 = tj * 128;
+    if (i0 >= samples_i || j0 >= samples_j) return;                 // (whole workgroup)
+    const int sw = R.w + 1, sh = R.h + 1;
+    const int lane = threadIdx.x, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
+    const GAS char *S = (const GAS char *)R.sum;
+    const int x0 = j0 * STEP;
+    {
+        constexpr int NC = (W4 + 63) / 64;
+        uint32_t xo[NC]; bool ok[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int cc = lane + 64 * c, x = x0 + 4 * cc;
+            ok[c] = cc < W4 && x <= sw - 1;                         // a chunk that starts beyond the row holds nothing a valid sample reads
+            xo[c] = (uint32_t)min(x, sw - 1) * 4u;
+        }
+        // 20 row slots, 5 per wave: slot = si * 10 + v
+        int4u t[5][NC];
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const int slot = wave + 4 * r;
+            const int si = slot >= 10 ? 1 : 0, v = slot - 10 * si;
+            const int y = min(STEP * (i0 + si) + (2 * size * v + 9) / 18, sh - 1);
+            const GAS char *row = S + (size_t)y * sw * 4u;
+#pragma unroll
+            for (int c = 0; c < NC; c++) t[r][c] = *(const GAS int4u *)(row + xo[c]);
+        }
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            int32_t *dst = lds + (wave + 4 * r) * RP + lane;
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                if (ok[c]) { dst[64 * c] = t[r][c].x; dst[W4 + 64 * c] = t[r][c].y; dst[2 * W4 + 64 * c] = t[r][c].z; dst[3 * W4 + 64 * c] = t[r][c].w; }
+        }
+    }
+    __syncthreads();
+    const int si = wave >> 1, jl = (wave & 1) * 64 + lane;
+    const int i = i0 + si, j = j0 + jl;
+    if (i >= samples_i || j >= samples_j) return;
+    const int li = 2 * layers_per_octave + L;
+    const LayerPat &P = pats[li];
+    const int32_t *base = lds + si * 10 * RP + jl;
+#define HR_TAP(VY, DX) base[(VY) * RP + ((DX) & 3) * W4 + ((DX) >> 2)]
+    float d3[3];
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        const int k0 = g == 0 ? 0 : g == 1 ? 3 : 6, n = g == 2 ? 4 : 3;
+        double d = 0;
+#pragma unroll
+        for (int k = k0; k < k0 + n; k++) {
+            const int dx1 = vfsms_haar_corner(size, k, 0), dx2 = vfsms_haar_corner(size, k, 2);
+            const int vy1 = vfsms_haar_src(k, 1), vy2 = vfsms_haar_src(k, 3);
+            const int v = HR_TAP(vy1, dx1) + HR_TAP(vy2, dx2) - HR_TAP(vy2, dx1) - HR_TAP(vy1, dx2);
+            d += (double)((float)v * P.w[k]);
+        }
+        d3[g] = (float)d;
+    }
+#undef HR_TAP
+    const int margin = (size / 2) / STEP;
+    const int lcols = R.w / STEP;
+    ((g_f32)R.det[li])[(size_t)(i + margin) * lcols + (j + margin)] = d3[0] * d3[1] - 0.81f * d3[2] * d3[2];
+}
+
+#define HESS_ROWS2_LDS_INTS (20 * 4 * (128 + 33))
+__global__ __launch_bounds__(256) void k_hessian_rows2(const RoiDev *rois, const LayerPat *pats, int layers_per_octave, int tiles_i, int tiles_j, int nrois)
+{
+    __shared__ int32_t lds[HESS_ROWS2_LDS_INTS];
+    unsigned roi, inner;
+    xcd_roi_map(blockIdx.x, (unsigned)(tiles_i * tiles_j * 5), (unsigned)nrois, roi, inner);
+    const int l = (int)(inner % 5u);
+    const int t = (int)(inner / 5u);
+    const int tj = t % tiles_j, ti = t / tiles_j;
+    const RoiDev &R = rois[roi];
+    switch (l) {
+    case 0: hessian_rows2_body<0>(R, pats, layers_per_octave, ti, tj, lds); break;
+    case 1: hessian_rows2_body<1>(R, pats, layers_per_octave, ti, tj, lds); break;
+    case 2: hessian_rows2_body<2>(R, pats, layers_per_octave, ti, tj, lds); break;
+    case 3: hessian_rows2_body<3>(R, pats, layers_per_octave, ti, tj, lds); break;
+    default: hessian_rows2_body<4>(R, pats, layers_per_octave, ti, tj, lds);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -751,35 +880,26 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)   // core atan
     return a;
 }
 
-// resizeHaarPattern for the 4-unit gradient wavelets + calcHaarPattern (2 boxes)
-__device__ __forceinline__ float grad_haar(g_ci32 ptr, int sw, int gws, bool is_dx)
-{
-    // dx_s = {{0,0,2,4,-1},{2,0,4,4,1}}, dy_s = {{0,0,4,2,1},{0,2,4,4,-1}}
-    const float ratio = (float)gws / 4;
-    const int r2 = cv_round_f(ratio * 2), r4 = cv_round_f(ratio * 4);
-    double d = 0;
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        int dx1, dy1, dx2, dy2, sgn;
-        if (is_dx) { dx1 = k ? r2 : 0; dy1 = 0; dx2 = k ? r4 : r2; dy2 = r4; sgn = k ? 1 : -1; }
-        else       { dx1 = 0; dy1 = k ? r2 : 0; dx2 = r4; dy2 = k ? r4 : r2; sgn = k ? -1 : 1; }
-        float w = sgn / ((float)(dx2 - dx1) * (dy2 - dy1));
-        int v = ptr[dy1 * sw + dx1] + ptr[dy2 * sw + dx2] - ptr[dy2 * sw + dx1] - ptr[dy1 * sw + dx2];
-        d += (double)((float)v * w);
-    }
-    return (float)d;
-}
-
 // K4 dominant orientation, EIGHT keypoints per 1024-thread workgroup.  The three phases have different widths -- 113 gradient
 // samples, 72 sliding windows, one argmax per keypoint -- and a workgroup per keypoint left most lanes of its second wave idle in the
 // window phase (72 windows = one wave + 8 lanes) and one lane walking the 72 moduli.  Here phase 1 gives every keypoint 128 lanes
 // (sample = lane), phase 2 packs the 8 x 72 windows into nine full waves, phase 3 reduces each keypoint's 72 moduli in one wave
 // (first maximum in window order, as the reference's strict `>` scan keeps it).  The sums visit the samples in index order.
+//
+// Round 6.  Phase 1: the two gradient wavelets of resizeHaarPattern (dx_s = {{0,0,2,4,-1},{2,0,4,4,1}}, dy_s = {{0,0,4,2,1},{0,2,4,4,-1}})
+// share a 3 x 3 corner lattice (x, y in {0, r2, r4}): eight distinct integral taps, and their four weights are +-1 / (r2 * r4) and
+// +-1 / ((r4 - r2) * r4) -- the float product is commutative and IEEE division is sign-symmetric, so TWO divisions per sample give the
+// reference's four quotients bit for bit.  Phase 2: a sample's 72-bit window membership is kept as NINE BYTES (byte g = windows 8 g ..
+// 8 g + 7), sample-minor, so the lane of window w reads the bytes of four consecutive samples as one dword, isolates its bit in all four
+// with one shift and one mask, and each byte becomes the float 0 / 1 by v_cvt_f32_ubyteN; the masked accumulation of (x, y) is one packed
+// fma per sample -- fma(v, 1, s) = s + v and fma(v, 0, s) = s exactly (s is never -0: it starts at +0 and x + (-x) rounds to +0) -- 2.5
+// instructions per (sample, window) instead of 6.
 #define ORI_KP 8
+typedef float ori_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void orientation_block(const RoiDev &R, const SurfTables *T, const int k0, const int n, int upright)
 {
     __shared__ __attribute__((aligned(16))) float2 XY[ORI_KP][128];      // weighted gradient (x, y) of every sample, interleaved: phase 2 reads pairs
-    __shared__ __attribute__((aligned(16))) uint32_t M[ORI_KP][3][128];   // window membership of every sample (SurfTables::oriMask rows)
+    __shared__ __attribute__((aligned(16))) uint8_t Zb[ORI_KP][9][128];   // byte g of the window membership of every sample (SurfTables::oriMask rows)
     __shared__ float mod_s[ORI_KP][72], sx_s[ORI_KP][72], sy_s[ORI_KP][72];
     __shared__ int nvalid[ORI_KP], state[ORI_KP];              // state: 0 compute, 1 done (deleted / upright / beyond n)
     const int tid = threadIdx.x;
@@ -789,6 +909,8 @@ __device__ __forceinline__ void orientation_block(const RoiDev &R, const SurfTab
     {
         const int k = k0 + kq;
         int valid = 0;
+        uint32_t m0 = 0, m1 = 0, m2 = 0;
+        float2 xy = make_float2(0.f, 0.f);
         if (k < n) {
             const vfsms_keypoint kp = R.kps[k];
             const float s = kp.size * 1.2f / 9.0f;
@@ -802,20 +924,35 @@ __device__ __forceinline__ void orientation_block(const RoiDev &R, const SurfTab
                 int x = cv_round_f(kp.x + T->aptx[t] * s - (float)(gws - 1) / 2);
                 int y = cv_round_f(kp.y + T->apty[t] * s - (float)(gws - 1) / 2);
                 if (!(y < 0 || y >= srows - gws || x < 0 || x >= scols - gws)) {
-                    g_ci32 ptr = (g_ci32)R.sum + (size_t)y * sw + x;
-                    float vx = grad_haar(ptr, sw, gws, true);
-                    float vy = grad_haar(ptr, sw, gws, false);
-                    float xx = vx * T->aptw[t], yy = vy * T->aptw[t];
-                    XY[kq][t] = make_float2(xx, yy);
+                    // resizeHaarPattern for the 4-unit gradient wavelets + calcHaarPattern (2 boxes each)
+                    const float ratio = (float)gws / 4;
+                    const int r2 = cv_round_f(ratio * 2), r4 = cv_round_f(ratio * 4);
+                    g_ci32 p0 = (g_ci32)R.sum + (size_t)y * sw + x;
+                    g_ci32 p2 = p0 + (size_t)r2 * sw, p4 = p0 + (size_t)r4 * sw;
+                    const int a00 = p0[0], a02 = p0[r2], a04 = p0[r4];          // a<row><column> of the corner lattice
+                    const int a20 = p2[0], a24 = p2[r4];
+                    const int a40 = p4[0], a42 = p4[r2], a44 = p4[r4];
+                    const float wA = 1.f / ((float)r2 * (float)r4), wB = 1.f / ((float)(r4 - r2) * (float)r4);
+                    const int vx0 = a00 + a42 - a40 - a02, vx1 = a02 + a44 - a42 - a04;     // dx: {0,0,r2,r4} weight -wA, {r2,0,r4,r4} weight +wB
+                    const int vy0 = a00 + a24 - a20 - a04, vy1 = a20 + a44 - a40 - a24;     // dy: {0,0,r4,r2} weight +wA, {0,r2,r4,r4} weight -wB
+                    double dxd = 0; dxd += (double)(-((float)vx0 * wA)); dxd += (double)((float)vx1 * wB);
+                    double dyd = 0; dyd += (double)((float)vy0 * wA); dyd += (double)(-((float)vy1 * wB));
+                    const float vx = (float)dxd, vy = (float)dyd;
+                    const float aw = T->aptw[t];
+                    const float xx = vx * aw, yy = vy * aw;
+                    xy = make_float2(xx, yy);
                     const int ang = cv_round_f(fast_atan2_deg(yy, xx));     // cv::phase(X, Y, angle, true) then cvRound
                     const uint32_t *mrow = T->oriMask[min(max(ang, 0), 360)];
-                    M[kq][0][t] = mrow[0]; M[kq][1][t] = mrow[1]; M[kq][2][t] = mrow[2];
+                    m0 = mrow[0]; m1 = mrow[1]; m2 = mrow[2];
                     valid = 1;
                 }
             }
         } else if (t == 0) state[kq] = 1;
         // a sample outside the image (or past nOriSamples) belongs to no window and carries a zero gradient
-        if (!valid) { XY[kq][t] = make_float2(0.f, 0.f); M[kq][0][t] = 0; M[kq][1][t] = 0; M[kq][2][t] = 0; }
+        XY[kq][t] = xy;
+        Zb[kq][0][t] = (uint8_t)m0; Zb[kq][1][t] = (uint8_t)(m0 >> 8); Zb[kq][2][t] = (uint8_t)(m0 >> 16); Zb[kq][3][t] = (uint8_t)(m0 >> 24);
+        Zb[kq][4][t] = (uint8_t)m1; Zb[kq][5][t] = (uint8_t)(m1 >> 8); Zb[kq][6][t] = (uint8_t)(m1 >> 16); Zb[kq][7][t] = (uint8_t)(m1 >> 24);
+        Zb[kq][8][t] = (uint8_t)m2;
         const unsigned long long m = __ballot(valid);
         if ((tid & 63) == 0 && m) atomicAdd(&nvalid[kq], __popcll(m));
     }
@@ -823,26 +960,22 @@ __device__ __forceinline__ void orientation_block(const RoiDev &R, const SurfTab
     if (tid < ORI_KP * 72) {
         const int q = tid / 72, w = tid - q * 72;
         if (state[q] == 0 && nvalid[q] > 0) {
-            const int nori = T->nOriSamples;
-            // sum += m ? v : 0 written as sum += v * (float)m: v * 1 is v, v * 0 is a signed zero, and adding a zero of either sign
-            // leaves the running sum as it is (the sum is never -0: it starts at +0 and x + (-x) rounds to +0) -- so the membership
-            // bit costs one bit-field extract and one convert instead of the angle arithmetic and two selects per sample.
-            // Four samples per LDS read; the sums still visit the samples in index order.
-            const uint32_t *mw = M[q][w >> 5];
-            const int bit = w & 31;
-            float sumx = 0, sumy = 0;
-            for (int j = 0; j < nori; j += 4) {
-                const uint4 m4 = *reinterpret_cast<const uint4 *>(&mw[j]);
+            const int nori = T->nOriSamples;                  // <= 113: the groups of eight below cover 120 samples, the slots past nori are zero
+            const uint8_t *zrow = Zb[q][w >> 3];
+            const int bit = w & 7;
+            ori_f2 acc = {0.f, 0.f};
+            for (int j = 0; j < nori; j += 8) {
+                const uint2 z8 = *reinterpret_cast<const uint2 *>(&zrow[j]);
+                const uint32_t za = (z8.x >> bit) & 0x01010101u, zb = (z8.y >> bit) & 0x01010101u;
                 const float4 p01 = *reinterpret_cast<const float4 *>(&XY[q][j]), p23 = *reinterpret_cast<const float4 *>(&XY[q][j + 2]);
-                const uint32_t mm[4] = {m4.x, m4.y, m4.z, m4.w};
-                const float xx[4] = {p01.x, p01.z, p23.x, p23.z}, yy[4] = {p01.y, p01.w, p23.y, p23.w};
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const float mf = (float)((mm[u] >> bit) & 1u);
-                    sumx += xx[u] * mf;
-                    sumy += yy[u] * mf;
-                }
+                const float4 p45 = *reinterpret_cast<const float4 *>(&XY[q][j + 4]), p67 = *reinterpret_cast<const float4 *>(&XY[q][j + 6]);
+#define ORI_ACC(Z, N, P, XC, YC) do { float mf; asm("v_cvt_f32_ubyte" #N " %0, %1" : "=v"(mf) : "v"(Z)); \
+                                           acc = __builtin_elementwise_fma((ori_f2){P.XC, P.YC}, (ori_f2){mf, mf}, acc); } while (0)
+                ORI_ACC(za, 0, p01, x, y); ORI_ACC(za, 1, p01, z, w); ORI_ACC(za, 2, p23, x, y); ORI_ACC(za, 3, p23, z, w);
+                ORI_ACC(zb, 0, p45, x, y); ORI_ACC(zb, 1, p45, z, w); ORI_ACC(zb, 2, p67, x, y); ORI_ACC(zb, 3, p67, z, w);
+#undef ORI_ACC
             }
+            const float sumx = acc.x, sumy = acc.y;
             mod_s[q][w] = sumx * sumx + sumy * sumy;
             sx_s[q][w] = sumx; sy_s[q][w] = sumy;
         }
@@ -1870,6 +2003,16 @@ int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_roi
                     step *= 2;
                 }
             }
+            static const bool rows2 = !(getenv("VFSMS_HESSIAN_ROWS2") && atoi(getenv("VFSMS_HESSIAN_ROWS2")) == 0);
+            if (lpo == 5 && o == 2 && o < p->n_octaves && rows2 && !generic) {      // octave 2: row-staged (k_hessian_rows2)
+                const int s0 = 36;                                           // the octave's smallest layer has the most samples
+                if (q.h >= s0 && q.w >= s0) {
+                    const int tiles_i = ((q.h - s0) / 4 + 1 + 1) / 2, tiles_j = ((q.w - s0) / 4 + 1 + 127) / 128;
+                    hipLaunchKernelGGL(k_hessian_rows2, dim3((unsigned)(tiles_i * tiles_j * 5 * q.count)), dim3(64, 4), 0, ctx->stream, dq, ctx->d_layers, lpo,
+                                       tiles_i, tiles_j, q.count);
+                }
+                o++; step *= 2;
+            }
             HessPlan plan; plan.o0 = o; plan.noct = 0; plan.first[0] = 0;
             for (; o < p->n_octaves && plan.noct < VFSMS_MAX_OCTAVES; o++) {
                 const int lrows = q.h / step, lcols = q.w / step;
@@ -1880,7 +2023,7 @@ int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_roi
                 step *= 2;
             }
             if (plan.noct > 0 && plan.first[plan.noct] > 0) {
-                if (lpo == 5 && plan.o0 == 2 && plan.o0 + plan.noct <= 4 && !generic)       // the stock pyramid: constant-offset taps
+                if (lpo == 5 && plan.o0 >= 2 && plan.o0 + plan.noct <= 4 && !generic)       // the stock pyramid: constant-offset taps
                     hipLaunchKernelGGL(k_hessian_coarse, dim3((unsigned)plan.first[plan.noct] * lpo * q.count), dim3(64, 4), 0, ctx->stream, dq, ctx->d_layers, lpo, plan, q.count);
                 else
                     hipLaunchKernelGGL(k_hessian, dim3((unsigned)plan.first[plan.noct] * lpo * q.count), dim3(64, 4), 0, ctx->stream, dq, ctx->d_layers, lpo, plan, q.count);

@@ -330,7 +330,7 @@ class GridRegistrar:
 
     MISPREDICT_EXTRA = 0.25     # a prediction is "wrong" when it cost more than this fraction of the attempts it had promised
 
-    def _learn(self, table, predicted=None):
+    def _learn(self, table, predicted=None, direction_in=1):
         """The path just registered becomes the prediction of the next one of its length -- unless the prediction it was registered WITH
         (`predicted`: the memory, never a caller's hint) turned out wrong.  Wrong = the extra attempts it caused, estimated from the table
         every rank holds (per pair whose accepted direction differs from the predicted one: the rotation steps between the two, at least
@@ -350,7 +350,7 @@ class GridRegistrar:
                     while c != a and steps < 4 and self.directIncre != 0:
                         c = _rotate(c, self.directIncre); steps += 1
                     extra += max(steps, 1)
-            promised = sum(self.path_weights(predicted, int(predicted[0])))
+            promised = sum(self.path_weights(predicted, int(direction_in)))
             if extra > self.MISPREDICT_EXTRA * promised:
                 self.mispredictions += 1
                 if self.path_suspect:
@@ -359,6 +359,8 @@ class GridRegistrar:
                 self.path_suspect = True
             else:
                 self.path_suspect = False
+        else:
+            self.path_suspect = False             # no memory was on trial (first path, another length, a caller's hint): what is learned now starts clean
         self.path_memory = new
 
     def _memory_prediction(self, P, hint):
@@ -379,7 +381,7 @@ class GridRegistrar:
         else:
             out, d = self.chain(handles, shapes, 0, P, direction, stop_on_fail=stop_on_fail, hint=hint)
         if not stop_on_fail or bool(np.all(out[:, 0] == 1)):
-            self._learn(out, mem)
+            self._learn(out, mem, direction)
         return out, d
 
     # -- pair-sharded ---------------------------------------------------------------------------------------------------
@@ -533,12 +535,12 @@ class GridRegistrar:
             raise RuntimeError("all_gather returned %d payloads for a world of %d ranks" % (len(gathered), world))
         if hint is None:
             full, d = self.assemble(gathered, P, world, direction, weights)
-            self._learn(full, mem)
+            self._learn(full, mem, direction)
             return full, d
         missing = []
         full, d = self.assemble(gathered, P, world, direction, weights, missing, hint)
         if not missing:
-            self._learn(full, mem)
+            self._learn(full, mem, direction)
             return full, d
         # repair: every rank that followed a single hinted chain is a suspect (a wrong direction upstream changes what enters the ranks
         # behind it); those whose assumption is not confirmed by the first walk redo their chunk blind.  One extra collective.
@@ -551,8 +553,62 @@ class GridRegistrar:
             mine = self.shard_payload(handles, shapes, direction, rank, world, weights, hint, blind=True)
         gathered = all_gather(mine)
         full, d = self.assemble(gathered, P, world, direction, weights, None, hint)
-        self._learn(full, mem)
+        self._learn(full, mem, direction)
         return full, d
+
+    def register_projected(self, handles, shapes, direction, world, probe=None, all_gather=None):
+        """The sharded form of `world` ranks on ONE device, one rank AFTER the other, through the code the ranks run (shard_payload with
+        the rank's chunk, hinted start and plan; assemble; the repair round; _learn) -- what a development box with one GPU can measure of
+        an N-GPU step: every emulated rank has the device to itself, as it would on its own GPU.
+        probe(): called after every rank's part -> anything (bench.py: the HIP-event milliseconds since the last call); all_gather: run on
+        the stacked payloads once per round (bench.py: the RCCL gather of a world of one, for its latency), default none.
+        -> (table, final direction, per_rank [dict(pairs, wall_s, attempts, batches, probe, repair_wall_s)], tail_s): a rank's step is its
+        wall_s (+ repair_wall_s) + tail_s (gather + assemble + learn, common to all ranks)."""
+        import time
+        P = len(shapes) - 1
+        mem = self._memory_prediction(P, hint=None)
+        hint = self._prediction(P, None)
+        bounds = self._bounds(P, world, None, hint, direction)
+        per_rank, payloads = [], []
+        for r in range(world):
+            a0, b0 = self.stats["attempts"], self.stats["batches"]
+            t0 = time.perf_counter()
+            payloads.append(self.shard_payload(handles, shapes, direction, r, world, None, hint))
+            wall = time.perf_counter() - t0
+            per_rank.append(dict(rank=r, pairs=bounds[r][1] - bounds[r][0], wall_s=wall, attempts=self.stats["attempts"] - a0,
+                                 batches=self.stats["batches"] - b0, probe=probe() if probe else None, repair_wall_s=0.0))
+        t0 = time.perf_counter()
+        gathered = np.stack(payloads)
+        if all_gather is not None:
+            all_gather(payloads[0])
+        missing = []
+        if hint is None:
+            full, d = self.assemble(gathered, P, world, direction, None)
+        else:
+            full, d = self.assemble(gathered, P, world, direction, None, missing, hint)
+        tail = time.perf_counter() - t0
+        if missing:
+            self.hint_repairs = getattr(self, "hint_repairs", 0) + 1
+            confirmed = set(range(missing[0]))
+            for r in range(1, world):
+                if r in confirmed:
+                    continue
+                a0, b0 = self.stats["attempts"], self.stats["batches"]
+                t0 = time.perf_counter()
+                payloads[r] = self.shard_payload(handles, shapes, direction, r, world, None, hint, blind=True)
+                per_rank[r]["repair_wall_s"] = time.perf_counter() - t0
+                per_rank[r]["attempts"] += self.stats["attempts"] - a0; per_rank[r]["batches"] += self.stats["batches"] - b0
+                if probe:
+                    per_rank[r]["probe_repair"] = probe()
+            t0 = time.perf_counter()
+            if all_gather is not None:
+                all_gather(payloads[0])
+            full, d = self.assemble(np.stack(payloads), P, world, direction, None, None, hint)
+            tail += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        self._learn(full, mem, direction)
+        tail += time.perf_counter() - t0
+        return full, d, per_rank, tail
 
 
 def serpentine_directions(rows, cols, first=1, across=2):

@@ -146,6 +146,8 @@ class Stitcher(Utility.Method):
     def _streamTo(self, paths, pattern=None):
         """install a mosaicSink that opens one streaming encoder per mosaic: `paths` names the files (pattern is None) or collects the
         part files made from `pattern % n`; returns None (and installs nothing) when the format has no band encoder"""
+        if "mosaicSink" in self.__dict__:                    # the user streams the mosaics somewhere else (stitcher.mosaicSink = NpyBandWriter(...)): leave it alone
+            return None
         probe = pattern % 0 if pattern else paths[0]
         if band_writer_for(probe) is None:
             return None
@@ -200,9 +202,19 @@ class Stitcher(Utility.Method):
         reg.orbMaxDistance = self.orbMaxDistance if self.isGPUAvailable else -1
         reg.path_memory = self.__dict__.get("_pathMemory")
         reg.path_suspect = bool(self.__dict__.get("_pathSuspect", False))
-        if reg.path_memory is None and self.pathHint is not None and len(self.pathHint) == n_files - 1:
-            reg.path_memory = [int(d) for d in self.pathHint]
         return reg
+
+    def _operatorHint(self, reg, n_pairs):
+        """the operator's pathHint as a CALLER'S hint of register() -- never installed as the registrar's memory, so it is not put on trial
+        (GridRegistrar._learn tries memories only) -- and only while the registrar has no memory of its own for this path length; once a
+        learned memory was dropped for mispredicting twice in a row, the next path runs cold as _learn promises (the hint is not slipped
+        back in its place)."""
+        m = reg.path_memory
+        if (m is not None and len(m) == n_pairs) or self.pathHint is None or len(self.pathHint) != n_pairs:
+            return None
+        if self.__dict__.get("_pathMemoryDropped", False):
+            return None
+        return [int(d) for d in self.pathHint]
 
     def _registerBatched(self, fileList, caculateOffsetMethod):
         """The pair loop of flowStitch (Stitcher.py:64-79) through grid.GridRegistrar when `caculateOffsetMethod` is this
@@ -234,9 +246,11 @@ class Stitcher(Utility.Method):
             elif method == "orb_full":
                 table = self._fullImageTableOrb(handles, shapes)
             else:
-                table, _d = reg.register(handles, shapes, self.direction, stop_on_fail=True)
+                had_memory = reg.path_memory is not None
+                table, _d = reg.register(handles, shapes, self.direction, stop_on_fail=True, hint=self._operatorHint(reg, len(shapes) - 1))
                 # (what this path taught, incl. "nothing": a memory that mispredicted twice in a row is dropped, GridRegistrar._learn)
                 self._pathMemory, self._pathSuspect = reg.path_memory, reg.path_suspect
+                self._pathMemoryDropped = had_memory and reg.path_memory is None
         except BaseException:
             job.failed = True
             raise
@@ -347,14 +361,26 @@ class Stitcher(Utility.Method):
                 os.makedirs(outDir)
             Stitcher.outputAddress = outDir if outDir.endswith(os.sep) else outDir + os.sep
             outPath = os.path.join(outDir, "stitching_result_" + str(i) + "." + outputfileExtension)
-            streamed = self._streamTo([outPath]) if self.streamOutput else None
+            # streamed results are encoded under a hidden name and renamed when the mosaic is complete: an exception in the middle of
+            # an assembly must not leave a truncated file under the result's name
+            partPath = os.path.join(outDir, ".stitching_part_" + str(i) + "." + outputfileExtension)
+            streamed = self._streamTo([partPath]) if self.streamOutput else None
+            done = False
             try:
                 (status, result) = self.flowStitch(fileList, caculateOffsetMethod)
+                done = True
             finally:
                 if streamed is not None:
                     self.__dict__.pop("mosaicSink", None)
+                    if not done and os.path.exists(partPath):
+                        os.remove(partPath)
             self.tempImageFeature.isBreak = True
-            _imwrite(outPath, result)
+            if result is None and streamed is not None:
+                os.replace(partPath, outPath)
+            else:
+                if streamed is not None and os.path.exists(partPath):
+                    os.remove(partPath)
+                _imwrite(outPath, result)
             if status == False:
                 self.printAndWrite("stitching Failed")
 
@@ -370,11 +396,17 @@ class Stitcher(Utility.Method):
             Stitcher.outputAddress = outDir if outDir.endswith(os.sep) else outDir + os.sep   # printAndWrite appends the file name
             parts = []
             streamed = self._streamTo(parts, os.path.join(outDir, ".stitching_part_" + str(i) + "_%d." + outputfileExtension)) if self.streamOutput else None
+            done = False
             try:
                 result = self.flowStitchWithMutiple(fileList, caculateOffsetMethod)
+                done = True
             finally:
                 if streamed is not None:
                     self.__dict__.pop("mosaicSink", None)
+                    if not done:                              # no part file outlives a failed dataset
+                        for q in parts:
+                            if os.path.exists(q):
+                                os.remove(q)
             self.tempImageFeature.isBreak = True
             names = ([os.path.join(outDir, "stitching_result_" + str(i) + "." + outputfileExtension)] if len(result) == 1 else
                      [os.path.join(outDir, "stitching_result_" + str(i) + "_" + str(j + 1) + "." + outputfileExtension) for j in range(len(result))])
