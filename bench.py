@@ -640,7 +640,7 @@ def cpu_baseline_fuse(args, grid, tiles, offsetList, rois, offs, rows, cols):
         O.use_native()
     except Exception as e:
         print("cpu_baseline: native oracle build unavailable (%s)" % e, file=sys.stderr)
-    n = min(grid.n_tiles, max(2, int(os.environ.get("VFSMS_BENCH_FUSE_CPU_TILES", "24"))))
+    n = min(grid.n_tiles, max(2, int(os.environ.get("VFSMS_BENCH_FUSE_CPU_TILES", "128"))))     # (the 25-s bound below cuts larger mosaics)
     r1 = max(offsetList[i][0] + grid.th for i in range(n)); c1 = max(offsetList[i][1] + grid.tw for i in range(n))
     r0 = min(offsetList[i][0] for i in range(n)); c0 = min(offsetList[i][1] for i in range(n))
     t1 = time.perf_counter()
@@ -668,6 +668,55 @@ def cpu_baseline_fuse(args, grid, tiles, offsetList, rois, offs, rows, cols):
                 sample="the reference walk (int64 / -1 canvas, paste + oracle fuseByFadeInAndFadeOut per overlap) over the first %d of %d tiles of "
                        "the same mosaic: %.1f Mpx in %.1f s on one host thread (the walk is a dependency chain)" % (done, grid.n_tiles, area, dt),
                 build=O.build_kind())
+
+
+def project_shards(args, eng, reg, handles, shapes, res, P, ms1_s, fence, gather, progress):
+    """--project-shards: the pair-sharded step of N ranks on ONE GPU, rank after rank (GridRegistrar.register_projected), K steps per N.
+    What it shows: the work split, the launch chain, readback and interpreter time of a rank whose chunk is 1 / N of the path -- the fixed
+    cost per rank that decides the efficiency at N = 8 -- on the real kernels.  What it cannot show: RCCL at N ranks (the gather is run at
+    world size 1 when --force-dist is given, else left out and said so), xGMI, N host processes sharing the box's cores."""
+    from imagestitch_amd.grid import GridRegistrar
+    out = {}
+    K = max(args.steps, 1)
+    for N in [int(v) for v in args.project_shards.split(",") if v.strip()]:
+        rp = GridRegistrar(eng, method=args.method, roiRatio=0.2, searchRatio=0.75, offsetEvaluate=args.offset_evaluate, directIncre=1,
+                           surfParams=reg.params, window=args.window)
+        rp.path_memory = list(reg.path_memory) if reg.path_memory is not None else None      # what the session has learned (as on every rank)
+        rp._kp_cap = getattr(reg, "_kp_cap", 0)
+        eng.profile_enable(True); eng.profile_read(reset=True)
+
+        def probe():
+            eng.sync()
+            return sum(v[0] for v in eng.profile_read(reset=True).values())
+        full, _d, pr, tail = rp.register_projected(handles, shapes, 1, N, probe, gather)      # warm (arena sizes of the small batches)
+        assert np.array_equal(full, res), "the projected sharded form does not reproduce the one-GPU table"
+        acc = [dict(wall=0.0, gpu=0.0, attempts=0, batches=0, repair=0.0) for _ in range(N)]
+        tails = 0.0
+        fence()
+        for _ in range(K):
+            full, _d, pr, tail = rp.register_projected(handles, shapes, 1, N, probe, gather)
+            tails += tail
+            for r, q in enumerate(pr):
+                acc[r]["wall"] += q["wall_s"]; acc[r]["gpu"] += q["probe"] or 0.0; acc[r]["attempts"] += q["attempts"]; acc[r]["batches"] += q["batches"]
+                acc[r]["repair"] += q["repair_wall_s"]; acc[r]["pairs"] = q["pairs"]
+        eng.profile_enable(False)
+        ranks = [dict(rank=r, pairs=a["pairs"], attempts_per_step=a["attempts"] / K, batches_per_step=a["batches"] / K,
+                      wall_ms=round(a["wall"] / K * 1e3, 3), gpu_ms=round(a["gpu"] / K, 3), host_ms=round((a["wall"] / K * 1e3) - a["gpu"] / K, 3),
+                      repair_ms=round(a["repair"] / K * 1e3, 3)) for r, a in enumerate(acc)]
+        slowest = max(q["wall_ms"] + q["repair_ms"] for q in ranks)
+        tail_ms = tails / K * 1e3
+        step_ms = slowest + tail_ms
+        out["N=%d" % N] = dict(
+            ranks=ranks, tail_ms_gather_assemble_learn=round(tail_ms, 3), slowest_rank_ms=round(slowest, 3), projected_ms_per_step=round(step_ms, 3),
+            projected_pairs_per_s=round(P / (step_ms * 1e-3), 1), projected_efficiency_vs_this_run_at_1=round((ms1_s * 1e3) / (N * step_ms), 3),
+            attempts_all_ranks=sum(q["attempts_per_step"] for q in ranks), repair_rounds=getattr(rp, "hint_repairs", 0),
+            gather=("RCCL all_gather at world size 1 inside the tail (--force-dist)" if gather is not None else "not run (single process): add ~0.25 ms, "
+                    "profiles/r05_bench_force_dist_rccl_world1.json"))
+        progress("projected N=%d: slowest rank %.2f ms + tail %.2f ms -> %.0f pairs/s (efficiency %.2f)" % (N, slowest, tail_ms, P / (step_ms * 1e-3),
+                                                                                                     (ms1_s * 1e3) / (N * step_ms)))
+    out["note"] = ("PROJECTED from one GPU, not measured on N: every emulated rank runs its chunk alone on this device through the ranks' own code "
+                   "(shard_payload / assemble / _learn), tiles resident; per-rank wall = host + launch chain + kernels + readback of its chunk")
+    return out
 
 
 def main():
@@ -702,6 +751,12 @@ def main():
     ap.add_argument("--color", action="store_true", help="--from-files with colour JPEGs and isColorMode = True (Main.py:14's default)")
     ap.add_argument("--force-dist", action="store_true", help="N = 1: initialise the process group (nccl = RCCL) and run the step's all_gather through it "
                     "anyway -- the line then carries a non-null `collective` (RCCL start-up and the device-tensor all_gather exercised on one GPU)")
+    ap.add_argument("--project-shards", default="", help="N = 1: after the timed steps, run the pair-sharded form of these rank counts (e.g. 2,4,8) "
+                    "on THIS GPU, one emulated rank after the other (GridRegistrar.register_projected: the ranks' own code, each with the device to "
+                    "itself), and add `projected_scaling` to the line: per-rank wall / GPU milliseconds, the fixed cost per step and the projected "
+                    "pairs/s = pairs / (slowest rank + gather + assembly).  A projection from one GPU, not a measurement of N.")
+    ap.add_argument("--all-tiles-on-every-rank", action="store_true", help="N > 1: keep the whole grid resident on every rank (rounds 1-5); default: a rank "
+                    "synthesises, uploads and holds only the tiles of its chunk + one halo tile and re-fetches when the learned work split moves")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -758,8 +813,11 @@ def main():
     # truth, every attempt is still evaluated, results never depend on it; --no-path-memory measures every step cold.
     bounds = GridRegistrar.chunk_bounds(P, world)
     lo, hi = bounds[rank]
-    # (N > 1: the learned pattern moves the chunk boundaries after the first step, so every rank keeps all tiles resident)
-    need = list(range(grid.n_tiles)) if world > 1 else (list(range(lo, hi + 1)) if hi > lo else [])
+    # a rank holds only the tiles of its chunk + one halo tile.  The chunk of the first (cold) step is cut by pair count; the
+    # learned pattern moves the boundaries afterwards (chunks by predicted attempts), so the set is re-checked before every step
+    # (ensure_tiles below) and the missing tiles are synthesised + uploaded then -- inside the timed region if it happens there.
+    shard_local = world > 1 and not args.all_tiles_on_every_rank
+    need = list(range(grid.n_tiles)) if (world > 1 and not shard_local) else (list(range(lo, hi + 1)) if hi > lo else [])
     # tiles live in pinned host memory (what a decoder feeding this engine would write into): uploads from it are asynchronous DMA
     tiles = {}
     # (grids beyond 128 tiles -- configs[4]: 1024 tiles of 4096^2, two core-hours of texture synthesis -- are generated by worker processes)
@@ -796,7 +854,34 @@ def main():
         reg.path_memory = [int(d) for d in grid.true_directions()]
     gather = make_all_gather(coll_device) if dist is not None else single_process_all_gather
 
-    def step(hs=handles):
+    refetch = dict(events=0, tiles=0, seconds=0.0, dropped=0)
+
+    def ensure_tiles(g=None, hs=None, store=None):
+        """shard-local: make the tiles of THIS rank's current chunk (+ halo) resident, release the ones the moved boundaries took away"""
+        if not shard_local:
+            return
+        g = grid if g is None else g; hs = handles if hs is None else hs; store = tiles if store is None else store
+        a, b = reg._bounds(P, world, None, reg._prediction(P, None), 1)[rank]
+        want = set(range(a, b + 1)) if b > a else set()
+        missing = sorted(k for k in want if hs[k] is None)
+        if missing:
+            t_f = time.perf_counter()
+            for k, t in zip(missing, g.tiles(missing, threads=min(8, os.cpu_count() or 1), processes=gen_procs if len(missing) > 16 else 0)):
+                if store is not None:
+                    buf = eng.pinned_empty(t.shape); buf[...] = t; store[k] = buf
+                hs[k] = eng.tile_upload(t)
+            refetch["events"] += 1; refetch["tiles"] += len(missing); refetch["seconds"] += time.perf_counter() - t_f
+        for k in range(len(hs)):
+            if hs[k] is not None and k not in want:
+                eng.tile_free(hs[k]); hs[k] = None
+                if store is not None:
+                    store.pop(k, None)
+                refetch["dropped"] += 1
+
+    def step(hs=None):
+        if hs is None:
+            ensure_tiles()
+            hs = handles
         return reg.register_sharded(hs, shapes, 1, rank, world, gather)
 
     # The prior of the timed steps comes from ANOTHER dataset of the same scan pattern (what a session has: Main.py runs dataset after
@@ -804,17 +889,19 @@ def main():
     # registered once, cold, and teaches the registrar the pattern; its tiles are released before the warm-up.  (--prior same: only the
     # warm-up steps of the timed grid teach it.)
     prior_note = "the warm-up steps of the timed grid itself (--prior same)"
+    refetch_prior = dict(refetch)
     if args.prior == "other" and not args.no_path_memory and args.method in ("surf", "orb", "phase") and need:
         g2 = SyntheticGrid(args.rows, args.cols, args.tile, overlap=args.overlap, seed=grid.seed + 1)
         hs2 = [None] * grid.n_tiles
         for k, t in zip(need, g2.tiles(need, threads=min(8, os.cpu_count() or 1), processes=gen_procs)):
             hs2[k] = eng.tile_upload(t)
-        res2, _d2 = step(hs2)
+        res2, _d2 = step(hs2)                    # (cold: the chunks are those `need` was cut for)
         if args.method == "surf":
             t2 = np.array(g2.true_offsets(), np.int64)
             assert (res2[:, 0] == 1).all() and int(np.abs(res2[:, 1:3].astype(np.int64) - t2).max()) <= 1, "prior instance not registered"
         for k in need:
             eng.tile_free(hs2[k])
+        refetch_prior = dict(refetch)
         assert reg.path_memory is not None and len(reg.path_memory) == P
         prior_note = ("a DIFFERENT instance of the scan pattern (same %d x %d x %d geometry, seed + 1: other texture, jitter and offsets), registered "
                       "once cold before the warm-up -- the previous dataset of a session" % (args.rows, args.cols, args.tile))
@@ -827,6 +914,7 @@ def main():
         """the same step with the tiles in host memory at its start: asynchronous uploads in path order on the copy stream (the
         first batch waits only for the tiles it names), registration, release of the device copies"""
         hs = [None] * grid.n_tiles
+        ensure_tiles()                           # (shard-local: the pinned host copies of this rank's chunk)
         mine = my_tiles()
         for k in mine:
             hs[k] = eng.tile_upload_async(tiles[k])
@@ -867,6 +955,10 @@ def main():
     err = np.abs(res[:, 1:3].astype(np.int64) - truth)
     max_err = int(err[ok].max()) if ok.any() else -1
     n_failed = int((~ok).sum())
+    tol = 1 if args.method == "surf" else 0                  # SURF within 1 px, ORB exactly the ground truth
+    # (phase: the reference as written adds cv2.phaseCorrelate's shift with the sign of the feature path, Stitcher.py:244-251 -- its offsets are
+    #  not the ground truth by construction, see the line's note; not counted)
+    off_truth = [int(k) for k in np.nonzero(ok & (err.max(axis=1) > tol))[0]] if args.method in ("surf", "orb") else None
 
     untimed = dict(reg.stats)                                # what the process registered before the timed steps (prior instance, warm-up)
     for k in reg.stats:
@@ -874,6 +966,7 @@ def main():
     eng.profile_enable(True)
     eng.profile_read(reset=True)
     fence()
+    refetch_at_t0 = dict(refetch)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -908,11 +1001,17 @@ def main():
         fence()
         elapsed_cold = time.perf_counter() - t0
         cold_stats = dict(reg_c.stats)
+    projected = None
+    if world == 1 and args.project_shards and args.method in ("surf", "orb", "phase"):
+        projected = project_shards(args, eng, reg, handles, shapes, res, P, elapsed / args.steps, fence, gather if dist is not None else None, progress)
     per_rank = None
     if dist is not None:
         lo_t, hi_t = reg._bounds(P, world, None, reg._prediction(P, None), 1)[rank]      # the chunk of the timed steps (cut by the predicted attempts)
         mine = dict(rank=rank, pairs=hi_t - lo_t, attempts_per_step=st["attempts"] / max(args.steps, 1), batches_per_step=st["batches"] / max(args.steps, 1),
-                    gpu_ms_per_step=round(sum(v[0] for v in prof.values()) / max(args.steps, 1), 3), wall_ms_per_step=round(elapsed / args.steps * 1e3, 3))
+                    gpu_ms_per_step=round(sum(v[0] for v in prof.values()) / max(args.steps, 1), 3), wall_ms_per_step=round(elapsed / args.steps * 1e3, 3),
+                    tiles_resident=sum(1 for h in handles if h is not None), tiles_synthesised_first=len(need),
+                    tiles_refetched_after_the_split_moved=refetch["tiles"] - refetch_prior["tiles"], refetch_s=round(refetch["seconds"] - refetch_prior["seconds"], 3),
+                    refetches_inside_timed_steps=refetch["events"] - refetch_at_t0["events"])
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         t = torch.tensor([elapsed, elapsed_host or 0.0], dtype=torch.float64, device=coll_device)
@@ -930,8 +1029,12 @@ def main():
     # enqueued twice per batch and the stages of the second stream carry "@s2": times are summed per stage, divided by the batches.
     groups = int(st["batches"])
 
+    second_stream = any(k.endswith("@s2") for k in prof)
+
     def stage(name):
         a, b = prof.get(name, (0.0, 0)), prof.get(name + "@s2", (0.0, 0))
+        if not second_stream:
+            return (a[0], a[1])                       # the profiled launch groups themselves (a capacity retry is a group of its own)
         return (a[0] + b[0], groups if (a[1] + b[1]) else 0)
     de_ms, de_n = stage("describe")
     if de_n and args.method == "surf":
@@ -941,7 +1044,7 @@ def main():
         # cent of what 8 TB/s would move in that time.
         # Algorithmic work per launch = bilinear samples (win x win per keypoint, win = int(21 * size * 1.2 / 9)) x the VALU
         # instructions one sample takes in the kernel's own inner loop; samples/keypoint is measured outside the timed region.
-        k0 = need[0]
+        k0 = min(tiles) if isinstance(tiles, dict) and tiles else need[0]
         ra = isa.roi_rect((grid.th, grid.tw), 1, "first", 0.2)
         _k, _d, kf = eng.surf_detect_describe(np.ascontiguousarray(tiles[k0][ra[0]:ra[0] + ra[2], ra[1]:ra[1] + ra[3]]), full=True)
         win = np.minimum((21 * (kf["size"] * np.float32(1.2) / np.float32(9.0))).astype(np.int64), 739)
@@ -950,11 +1053,18 @@ def main():
         dur = de_ms / de_n * 1e-3
         laneops = kps * spk * DESC_OPS_LOWER_BOUND
         traffic, traffic_src = pmc_traffic_scaled("k_describe", st["attempts"] / de_n)
+        traffic_small, _src_s = pmc_traffic_scaled("k_describe_small", st["attempts"] / de_n)
+        traffic = (traffic + traffic_small) if (traffic is not None and traffic_small is not None) else None     # the same kernels as compulsory_bytes
         valu_insts, _src = pmc_value("k_describe", "INSTS_VALU")
         busy, _src2 = pmc_value("k_describe", "BUSY_CYCLES")            # summed over the 32 shader engines: / 32 = cycles of the launch
         valu_busy = round(valu_insts * 4.0 / (busy / 32.0 * 1024.0), 3) if valu_insts and busy else None
         roofline = dict(kernel="k_describe+k_describe_small", bound="valu", achieved=round(laneops / dur / 1e12, 3), peak=round(VALU_PEAK_TLANEOPS, 2),
                         unit="Tlane-op/s", frac=round(laneops / dur / 1e12 / VALU_PEAK_TLANEOPS, 4), traffic=traffic, traffic_source=traffic_src,
+                        # the other reading of the VALU roof: MI355X_MICROARCH.md's "wave64 VALU instruction over 2 cycles" / two elements per packed
+                        # f32 instruction = 78.6 T lane-ops/s; only plain VOP2 instructions get near it here (profiles/r05_valu_peak.txt: v_mul_f32
+                        # 64.9, v_add_u32 54 T), the kernel's f64 / conversion / VOP3 mix issues in the 4-cycle class.  Both are printed.
+                        peak_2cycle_or_packed=round(2 * VALU_PEAK_TLANEOPS, 2), frac_of_2cycle_or_packed_peak=round(laneops / dur / 1e12 / (2 * VALU_PEAK_TLANEOPS), 4),
+                        traffic_over_compulsory=(round(traffic / max(kps / max(len(kf), 1) * (2.0 * roi_h * roi_w) + kps * 441.0, 1.0), 3) if traffic else None),
                         compulsory_bytes_per_launch=round(kps / max(len(kf), 1) * (2.0 * roi_h * roi_w) + kps * 441.0), avg_launch_ms=round(dur * 1e3, 4),
                         lane_ops_per_launch=laneops, kernel_valu_insts_per_sample_inner_loop=DESC_VALU_PER_SAMPLE, keypoints_per_launch=kps,
                         samples_per_keypoint=round(spk, 1), launches=de_n,
@@ -1070,6 +1180,10 @@ def main():
                                            "path memory: the accepted directions of the previous registration of this scan pattern drive the speculation plan "
                                            "of the timed steps; nothing from the ground truth, every attempt evaluated; first learned from " + prior_note)},
             "max_abs_offset_error_px": max_err, "pairs_failed": n_failed,
+            "pairs_off_truth": len(off_truth) if off_truth is not None else None, "pairs_off_truth_indices": off_truth[:40] if off_truth is not None else None,
+            "pairs_off_truth_note": ("%d of %d pairs accepted off truth (tolerance %d px)%s" % (
+                len(off_truth), P, tol, "; reference behaviour at %d votes: every ORB query votes, ImageUtility.py:297-302" % args.offset_evaluate
+                if args.method == "orb" and off_truth else "")) if off_truth is not None else None,
             "path_memory_primed_for_profiling": os.environ.get("VFSMS_BENCH_PRIME", "0") not in ("", "0"),
             "value_cold_path": round(P * args.steps / elapsed_cold, 3) if elapsed_cold else None,
             "cold_path": (dict(ms_per_step=round(elapsed_cold / args.steps * 1e3, 3), attempts_per_step=cold_stats["attempts"] / (args.steps + 1),
@@ -1090,9 +1204,12 @@ def main():
             "stages": stages,
             "stages_sum_ms_per_step": round(sum(v[0] for v in prof.values()) / max(args.steps, 1), 3),
             "stages_second_stream_ms_per_step": round(sum(v[0] for k, v in prof.items() if k.endswith("@s2")) / max(args.steps, 1), 3),
-            "overlap_note": "stages named @s2 were enqueued on the second compute stream (2-NN search + vote of the first part of a batch beside the detect "
-                            "stage of the second part): ms_per_step < stages_sum_ms_per_step by what the two pipes hid of each other",
+            "overlap_note": ("stages named @s2 were enqueued on the second compute stream (2-NN search + vote of the first part of a batch beside the detect "
+                             "stage of the second part): ms_per_step < stages_sum_ms_per_step by what the two pipes hid of each other") if second_stream else None,
             "per_rank": per_rank,
+            "tiles_per_rank": ("shard-local: chunk + one halo tile, re-fetched when the learned split moves (per_rank[].tiles_*)" if shard_local else
+                               "all tiles on every rank" if world > 1 else "one rank"),
+            "projected_scaling": projected,
             "collective": (dict(backend=dist.get_backend(), world_size=dist.get_world_size(), device=str(coll_device), rank_devices=devs,
                                 prediction_repair_rounds=getattr(reg, "hint_repairs", 0),
                                 op="one all_gather of the int32 offset tables per step") if dist is not None else None),

@@ -291,17 +291,88 @@ __global__ __launch_bounds__(256) void k_hessian(const RoiDev *rois, const Layer
     ((g_f32)R.det[li])[o] = dx * dy - 0.81f * dxy * dxy;     // (the trace is recomputed for the candidates: cand_class_id)
 }
 
+// ---- the determinant of one sample from its 32 distinct integral taps (round 6; shared by the LDS, row-staged and gather kernels) --------------
+// A tap is named by the PATTERN coordinates (vy, vx), 0..9, of the 9 x 9 box filters; its offset in a layer of `SIZE` px is
+// hcorner<SIZE>(v) = cvRound(SIZE / 9.f * v) (vfsms_haar_corner).  What changed against the box-by-box form (3 integer operations per
+// box, 30 per sample): the three Dx boxes share their two rows and the three Dy boxes their two columns, so the differences across the
+// pair of rows (columns) are formed once -- V(c) = S(r7, c) - S(r2, c) for the four Dx columns, then box k = V(c_k+1) - V(c_k): 7
+// operations instead of 9, two's-complement arithmetic is associative, so every box sum is the same int -- and the first addend of a
+// wavelet is not added to 0.0 any more: its weight is positive and box sums of an integral image of bytes are non-negative, so the
+// product is never -0 and 0.0 + p == p bit for bit.  Float products and their double accumulation order are calcHaarPattern's.
+template <int SIZE> constexpr int hcorner(int v) { return (2 * SIZE * v + 9) / 18; }
+template <int SIZE, class Tap>
+__device__ __forceinline__ float hess_det(const Tap &T, const float (&w)[10])
+{
+    // Dx: boxes {0,2,3,7}, {3,2,6,7}, {6,2,9,7} as (x1, y1, x2, y2): rows 2 and 7, columns 0, 3, 6, 9
+    const int vx0 = T.template at<7, 0>() - T.template at<2, 0>(), vx3 = T.template at<7, 3>() - T.template at<2, 3>();
+    const int vx6 = T.template at<7, 6>() - T.template at<2, 6>(), vx9 = T.template at<7, 9>() - T.template at<2, 9>();
+    double d = (double)((float)(vx3 - vx0) * w[0]);
+    d += (double)((float)(vx6 - vx3) * w[1]);
+    d += (double)((float)(vx9 - vx6) * w[2]);
+    const float dx = (float)d;
+    // Dy: boxes {2,0,7,3}, {2,3,7,6}, {2,6,7,9}: columns 2 and 7, rows 0, 3, 6, 9
+    const int hy0 = T.template at<0, 7>() - T.template at<0, 2>(), hy3 = T.template at<3, 7>() - T.template at<3, 2>();
+    const int hy6 = T.template at<6, 7>() - T.template at<6, 2>(), hy9 = T.template at<9, 7>() - T.template at<9, 2>();
+    d = (double)((float)(hy3 - hy0) * w[3]);
+    d += (double)((float)(hy6 - hy3) * w[4]);
+    d += (double)((float)(hy9 - hy6) * w[5]);
+    const float dy = (float)d;
+    // Dxy: boxes {1,1,4,4}, {5,1,8,4}, {1,5,4,8}, {5,5,8,8}
+    const int b6 = T.template at<1, 1>() + T.template at<4, 4>() - T.template at<4, 1>() - T.template at<1, 4>();
+    const int b7 = T.template at<1, 5>() + T.template at<4, 8>() - T.template at<4, 5>() - T.template at<1, 8>();
+    const int b8 = T.template at<5, 1>() + T.template at<8, 4>() - T.template at<8, 1>() - T.template at<5, 4>();
+    const int b9 = T.template at<5, 5>() + T.template at<8, 8>() - T.template at<8, 5>() - T.template at<5, 8>();
+    d = (double)((float)b6 * w[6]);
+    d += (double)((float)b7 * w[7]);
+    d += (double)((float)b8 * w[8]);
+    d += (double)((float)b9 * w[9]);
+    const float dxy = (float)d;
+    return dx * dy - 0.81f * dxy * dxy;
+}
+
 // LDS-tiled variant for the fine octaves (0 and 1 hold 94 % of the samples): the five layers of an octave read the
 // same integral-image neighbourhood, so one workgroup stages the (tile + largest wavelet) window of the integral once
 // and evaluates all 5 x 40 taps of its TW x 16 samples from LDS -- 200 L2 gathers per sample become ~5 coalesced loads.
 // Arithmetic and its order are those of k_hessian.
 // The box corners of a layer depend on its size alone ((9 + 6 l) << octave; vfsms_haar_corner), so with the five layers and ten boxes
 // unrolled every LDS tap is `ds_read_b32 base offset:imm` -- no address arithmetic per tap; the weights stay the host's floats.
+template <int SIZE, int STEP, int LW, int LWH, int PLANE>
+struct HessLdsTap {
+    const int32_t *sp;
+    template <int VY, int VX> __device__ __forceinline__ int at() const
+    {
+        constexpr int dy = hcorner<SIZE>(VY), dx = hcorner<SIZE>(VX);
+        return STEP == 2 ? sp[(dx & 1) * PLANE + dy * LWH + (dx >> 1)] : sp[dy * LW + dx];
+    }
+};
+// one layer of a staged tile: TW x TH samples from the LDS window (k_hessian_lds)
+template <int STEP, int TW, int TH, int LW, int LWH, int PLANE, int L>
+__device__ __forceinline__ void hessian_lds_layer(const RoiDev &R, const LayerPat *pats, const int li, const int32_t *tile, const int i0, const int j0, const int tid)
+{
+    constexpr int OCT = STEP == 1 ? 0 : 1;
+    constexpr int size = (9 + 6 * L) << OCT;                      // == P.size (checked by ctx_prepare_surf)
+    if (size > R.h || size > R.w) return;
+    const LayerPat &P = pats[li];
+    const int samples_i = 1 + (R.h - size) / STEP, samples_j = 1 + (R.w - size) / STEP;
+    g_f32 det = (g_f32)R.det[li];
+    const int lcols = R.w / STEP;
+    constexpr int margin = (size / 2) / STEP;
+    float w[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) w[k] = P.w[k];
+    for (int e = tid; e < TW * TH; e += 256) {
+        const int ly = e / TW, lx = e - ly * TW;
+        const int i = i0 + ly, j = j0 + lx;
+        if (i >= samples_i || j >= samples_j) continue;
+        const int32_t *sp = STEP == 2 ? tile + (ly * STEP) * LWH + lx : tile + (ly * STEP) * LW + lx * STEP;
+        det[(size_t)(i + margin) * lcols + (j + margin)] = hess_det<size>(HessLdsTap<size, STEP, LW, LWH, PLANE>{sp}, w);
+    }
+}
+
 template <int STEP, int TW>
 __global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const LayerPat *pats, int layers_per_octave, int octave)
 {
     constexpr int TH = 16;
-    constexpr int OCT = STEP == 1 ? 0 : 1;
     constexpr int MAXSZ = 33 * STEP;                              // size of the octave's coarsest layer: (9 + 6*4) << o
     constexpr int LW = (TW - 1) * STEP + MAXSZ + 1, LH = (TH - 1) * STEP + MAXSZ + 1;
     // STEP 2: the lanes of a wave sample every second column, so a row-major window is read with a stride of two dwords -- two lanes per
@@ -353,47 +424,12 @@ __global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const L
         }
     }
     __syncthreads();
-    const int lcols = R.w / STEP;
-#pragma unroll
-    for (int l = 0; l < 5; l++) {
-        const int li = octave * layers_per_octave + l;
-        const LayerPat &P = pats[li];
-        const int size = (9 + 6 * l) << OCT;                      // == P.size (checked by ctx_prepare_surf)
-        if (size > R.h || size > R.w) continue;
-        const int samples_i = 1 + (R.h - size) / STEP, samples_j = 1 + (R.w - size) / STEP;
-        g_f32 det = (g_f32)R.det[li];
-        const int margin = (size / 2) / STEP;
-        float w[10];
-#pragma unroll
-        for (int k = 0; k < 10; k++) w[k] = P.w[k];
-        for (int e = tid; e < TW * TH; e += 256) {
-            const int ly = e / TW, lx = e - ly * TW;
-            const int i = i0 + ly, j = j0 + lx;
-            if (i >= samples_i || j >= samples_j) continue;
-            const int32_t *sp = STEP == 2 ? tile + (ly * STEP) * LWH + lx : tile + (ly * STEP) * LW + lx * STEP;
-            float d3[3];
-#pragma unroll
-            for (int g = 0; g < 3; g++) {
-                const int k0 = g == 0 ? 0 : g == 1 ? 3 : 6, n = g == 2 ? 4 : 3;
-                double d = 0;
-#pragma unroll
-                for (int k = k0; k < k0 + n; k++) {
-                    const int dx1 = vfsms_haar_corner(size, k, 0), dy1 = vfsms_haar_corner(size, k, 1);
-                    const int dx2 = vfsms_haar_corner(size, k, 2), dy2 = vfsms_haar_corner(size, k, 3);
-                    int v;
-                    if (STEP == 2)
-                        v = sp[(dx1 & 1) * PLANE + dy1 * LWH + (dx1 >> 1)] + sp[(dx2 & 1) * PLANE + dy2 * LWH + (dx2 >> 1)]
-                          - sp[(dx1 & 1) * PLANE + dy2 * LWH + (dx1 >> 1)] - sp[(dx2 & 1) * PLANE + dy1 * LWH + (dx2 >> 1)];
-                    else
-                        v = sp[dy1 * LW + dx1] + sp[dy2 * LW + dx2] - sp[dy2 * LW + dx1] - sp[dy1 * LW + dx2];
-                    d += (double)((float)v * w[k]);
-                }
-                d3[g] = (float)d;
-            }
-            const size_t o = (size_t)(i + margin) * lcols + (j + margin);
-            det[o] = d3[0] * d3[1] - 0.81f * d3[2] * d3[2];
-        }
-    }
+    const int lb = octave * layers_per_octave;
+    hessian_lds_layer<STEP, TW, TH, LW, LWH, PLANE, 0>(R, pats, lb + 0, tile, i0, j0, tid);
+    hessian_lds_layer<STEP, TW, TH, LW, LWH, PLANE, 1>(R, pats, lb + 1, tile, i0, j0, tid);
+    hessian_lds_layer<STEP, TW, TH, LW, LWH, PLANE, 2>(R, pats, lb + 2, tile, i0, j0, tid);
+    hessian_lds_layer<STEP, TW, TH, LW, LWH, PLANE, 3>(R, pats, lb + 3, tile, i0, j0, tid);
+    hessian_lds_layer<STEP, TW, TH, LW, LWH, PLANE, 4>(R, pats, lb + 4, tile, i0, j0, tid);
 }
 
 // Coarse octaves (2, 3) with the stock five layers: the (tile + wavelet) window of an octave-2 tile would be 120-200 KB of LDS, so the taps
@@ -402,6 +438,15 @@ __global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const L
 // -- the row base (y + dy) * pitch is one scalar multiply-add per corner ROW, the lane offset x * 4 is computed once per thread.  (The
 // generic k_hessian walks LayerPat tables: its scalar unit issued 3.4 instructions per VALU instruction, PMC round 3.)
 // 64 x 4 samples per workgroup; arithmetic and its order are those of k_hessian.
+template <int SIZE>
+struct HessGatherTap {
+    const GAS char *S; uint32_t sw, r0, voff;                      // integral image, its pitch, the sample's row (scalar) and column offset in bytes
+    template <int VY, int VX> __device__ __forceinline__ int at() const
+    {
+        const GAS char *row = S + (size_t)((r0 + (uint32_t)hcorner<SIZE>(VY)) * sw) * 4u;       // scalar: one row base per corner row
+        return ((const GAS int32_t *)(row + voff))[hcorner<SIZE>(VX)];
+    }
+};
 template <int OCT, int L>
 __device__ __forceinline__ void hessian_coarse_body(const RoiDev &R, const LayerPat *pats, int layers_per_octave, int ti, int tj)
 {
@@ -418,27 +463,12 @@ __device__ __forceinline__ void hessian_coarse_body(const RoiDev &R, const Layer
     const uint32_t voff = (uint32_t)(j * STEP) * 4u;                 // the lane's column, bytes
     const uint32_t row0 = (uint32_t)(i * STEP);                      // (threadIdx.y is not wave-uniform in general: blockDim = (64, 4) makes it so)
     const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0);
-    float d3[3];
+    float w[10];
 #pragma unroll
-    for (int g = 0; g < 3; g++) {
-        const int k0 = g == 0 ? 0 : g == 1 ? 3 : 6, n = g == 2 ? 4 : 3;
-        double d = 0;
-#pragma unroll
-        for (int k = k0; k < k0 + n; k++) {
-            constexpr int dummy = 0; (void)dummy;
-            const int dx1 = vfsms_haar_corner(size, k, 0), dy1 = vfsms_haar_corner(size, k, 1);
-            const int dx2 = vfsms_haar_corner(size, k, 2), dy2 = vfsms_haar_corner(size, k, 3);
-            const GAS char *ra = S + (size_t)((r0 + (uint32_t)dy1) * sw) * 4u;      // scalar: row bases of the two corner rows
-            const GAS char *rb = S + (size_t)((r0 + (uint32_t)dy2) * sw) * 4u;
-            const int v = ((const GAS int32_t *)(ra + voff))[dx1] + ((const GAS int32_t *)(rb + voff))[dx2]
-                        - ((const GAS int32_t *)(rb + voff))[dx1] - ((const GAS int32_t *)(ra + voff))[dx2];
-            d += (double)((float)v * P.w[k]);
-        }
-        d3[g] = (float)d;
-    }
+    for (int k = 0; k < 10; k++) w[k] = P.w[k];
     const int margin = (size / 2) / STEP;
     const int lcols = R.w / STEP;
-    ((g_f32)R.det[li])[(size_t)(i + margin) * lcols + (j + margin)] = d3[0] * d3[1] - 0.81f * d3[2] * d3[2];
+    ((g_f32)R.det[li])[(size_t)(i + margin) * lcols + (j + margin)] = hess_det<size>(HessGatherTap<size>{S, sw, r0, voff}, w);
 }
 
 __global__ __launch_bounds__(256) void k_hessian_coarse(const RoiDev *rois, const LayerPat *pats, int layers_per_octave, HessPlan plan, int nrois)
@@ -469,6 +499,15 @@ __global__ __launch_bounds__(256) void k_hessian_coarse(const RoiDev *rois, cons
 // ds_read_b32 at an immediate offset: lane jl needs column 4 jl + dx = element jl + (dx >> 2) of plane dx & 3 -- unit stride
 // across the lanes (a linear row would be read with a stride of four dwords: four lanes per bank).  Loaded bytes per sample drop from 32 x 16 (scattered) to ~40 x 4 (coalesced).  Arithmetic and its order
 // are those of k_hessian.
+template <int SIZE, int W4>
+struct HessRowsTap {
+    const int32_t *base;                                           // the lane's element of row slot 0 / plane 0
+    template <int VY, int VX> __device__ __forceinline__ int at() const
+    {
+        constexpr int dx = hcorner<SIZE>(VX);
+        return base[VY * (4 * W4) + (dx & 3) * W4 + (dx >> 2)];   // row slot = pattern row, plane = column phase
+    }
+};
 template <int L>
 __device__ __forceinline__ void hessian_rows2_body(const RoiDev &R, const LayerPat *pats, int layers_per_octave, int ti, int tj, int32_t *lds)
 {
@@ -519,25 +558,12 @@ __device__ __forceinline__ void hessian_rows2_body(const RoiDev &R, const LayerP
     const int li = 2 * layers_per_octave + L;
     const LayerPat &P = pats[li];
     const int32_t *base = lds + si * 10 * RP + jl;
-#define HR_TAP(VY, DX) base[(VY) * RP + ((DX) & 3) * W4 + ((DX) >> 2)]
-    float d3[3];
+    float w[10];
 #pragma unroll
-    for (int g = 0; g < 3; g++) {
-        const int k0 = g == 0 ? 0 : g == 1 ? 3 : 6, n = g == 2 ? 4 : 3;
-        double d = 0;
-#pragma unroll
-        for (int k = k0; k < k0 + n; k++) {
-            const int dx1 = vfsms_haar_corner(size, k, 0), dx2 = vfsms_haar_corner(size, k, 2);
-            const int vy1 = vfsms_haar_src(k, 1), vy2 = vfsms_haar_src(k, 3);
-            const int v = HR_TAP(vy1, dx1) + HR_TAP(vy2, dx2) - HR_TAP(vy2, dx1) - HR_TAP(vy1, dx2);
-            d += (double)((float)v * P.w[k]);
-        }
-        d3[g] = (float)d;
-    }
-#undef HR_TAP
+    for (int k = 0; k < 10; k++) w[k] = P.w[k];
     const int margin = (size / 2) / STEP;
     const int lcols = R.w / STEP;
-    ((g_f32)R.det[li])[(size_t)(i + margin) * lcols + (j + margin)] = d3[0] * d3[1] - 0.81f * d3[2] * d3[2];
+    ((g_f32)R.det[li])[(size_t)(i + margin) * lcols + (j + margin)] = hess_det<size>(HessRowsTap<size, W4>{base}, w);
 }
 
 #define HESS_ROWS2_LDS_INTS (20 * 4 * (128 + 33))
@@ -1265,7 +1291,7 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
         for (int jb = cb0; jb < cb1; jb += 8 * BORDER_ILP) {
             double px[BORDER_ILP], py[BORDER_ILP];
             int jc[BORDER_ILP];
-            uint32_t q0[BORDER_ILP], q1[BORDER_ILP];          // pair elements (cy, cx) and (cy, cx1): two 16-bit gathers, not four bytes
+            uint32_t top[BORDER_ILP];                         // pair elements (cy, cx) and (cy, cx + 1) as ONE dword (round 6; two 16-bit gathers before)
             bool inside[BORDER_ILP];
 #pragma unroll
             for (int u = 0; u < BORDER_ILP; u++) {
@@ -1276,18 +1302,18 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
                 inside[u] = px[u] >= 0.0 && py[u] >= 0.0 && ix < ncols1 && iy < nrows1;
                 const int rx = min(max(cv_round_d(px[u]), 0), ncols1), ry = min(max(cv_round_d(py[u]), 0), nrows1);
                 const int cx = inside[u] ? ix : rx, cy = inside[u] ? iy : ry;
-                const int cx1 = min(cx + 1, ncols1);
-                const uint32_t o0 = (uint32_t)__umul24((uint32_t)cy, pw);
-                q0[u] = *(GAS const uint16_t *)(ubase + ((o0 + (uint32_t)cx) << 1));
-                q1[u] = *(GAS const uint16_t *)(ubase + ((o0 + (uint32_t)cx1) << 1));
+                // An inside sample has ix + 1 <= w - 1: its dword is the four taps, as in the interior rounds.  An outside sample only uses
+                // the low byte, pixel (cy, cx); at cx = w - 1 the dword runs into the next row's first element -- or, on the last row, into
+                // the 8 bytes of slack behind the pair image (surf_roi_carve) -- whose bytes are never looked at.
+                top[u] = *(GAS const uint32_t *)(ubase + (((uint32_t)__umul24((uint32_t)cy, pw) + (uint32_t)cx) << 1));
             }
 #pragma unroll
             for (int u = 0; u < BORDER_ILP; u++) {
                 const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
-                // the high bytes are row min(cy + 1, h - 1): the clamped lower taps
-                const float v = (uint8_t)(q0[u] & 0xff) * (1.f - a) * (1.f - b) + (uint8_t)(q1[u] & 0xff) * a * (1.f - b) +
-                                (uint8_t)(q0[u] >> 8) * (1.f - a) * b + (uint8_t)(q1[u] >> 8) * a * b;
-                drc[jc[u]] = inside[u] ? (uint8_t)cv_round_f(v) : (uint8_t)(q0[u] & 0xff);
+                // bytes t00, t10, t01, t11 (the high byte of an element is row min(cy + 1, h - 1)); the reference's operation order
+                const float v = (float)(top[u] & 0xff) * (1.f - a) * (1.f - b) + (float)((top[u] >> 16) & 0xff) * a * (1.f - b) +
+                                (float)((top[u] >> 8) & 0xff) * (1.f - a) * b + (float)(top[u] >> 24) * a * b;
+                drc[jc[u]] = inside[u] ? (uint8_t)cv_round_f(v) : (uint8_t)(top[u] & 0xff);
             }
         }
         DT_UNIT_END(1);

@@ -495,3 +495,70 @@ def test_sharded_ranks_put_a_memory_on_probation_alike():
             assert regs[0].mispredictions == want_mis, (native, step, regs[0].mispredictions)
         # A, A: primed.  B: mispredicted, adopted on probation.  A: mispredicted again -> dropped.  B: cold, learned.  A: mispredicted, on probation.
         assert regs[0].path_suspect and regs[0].path_memory is not None
+
+
+def test_register_projected_runs_the_ranks_own_code_one_after_the_other():
+    """GridRegistrar.register_projected (bench.py --project-shards): the sharded form of N ranks in ONE process, rank after rank, through
+    shard_payload / assemble / the repair round / _learn.  Its table equals the sequential search and register_sharded's, cold and primed,
+    also when the memory mispredicts (paths A then B: one repair round); its per-rank attempt counts are those of ranks with registrars of
+    their own (the work split the projection reports is the one an N-GPU run would have)."""
+    A, B = _serpentine_accept(10, 9), _serpentine_accept(9, 10)
+    P = len(A)
+    seqs = {id(A): sequential(A, 0.2, 1, 1), id(B): sequential(B, 0.2, 1, 1)}
+    handles, shapes = list(range(P + 1)), [SHAPE] * (P + 1)
+    for world in (2, 4, 8):
+        eng = ScriptedAttemptEngine(SHAPE, 0.2, A)
+        reg = GridRegistrar(eng, roiRatio=0.2, directIncre=1, window=48)
+        calls = []
+        for acc in (A, A, B, B):
+            eng.accept = acc
+            primed = reg.path_memory is not None
+            full, d, per_rank, tail = reg.register_projected(handles, shapes, 1, world, probe=lambda: calls.append(1) or 7.0)
+            seq, d_end, n_seq = seqs[id(acc)]
+            assert [list(r[:4]) for r in full.tolist()] == seq and d == d_end
+            assert len(per_rank) == world and sum(q["pairs"] for q in per_rank) == P and tail >= 0.0
+            assert all(q["probe"] == 7.0 and q["wall_s"] >= 0.0 for q in per_rank)
+            # ranks with registrars (and engines) of their own, same memory: the same attempts per rank
+            want = []
+            for rank in range(world):
+                e2 = ScriptedAttemptEngine(SHAPE, 0.2, acc)
+                r2 = GridRegistrar(e2, roiRatio=0.2, directIncre=1, window=48)
+                r2.path_memory = None if not primed else list(mem_before)
+                r2.shard_payload(handles, shapes, 1, rank, world, None, r2._prediction(P, None))
+                want.append(r2.stats["attempts"])
+            got = [q["attempts"] for q in per_rank]
+            if acc is A or not primed or mem_before == reg.path_memory:
+                assert got == want, (world, got, want)
+            else:                                            # B under A's memory: the first round equals, the repair round adds to the unconfirmed ranks
+                assert all(g >= w for g, w in zip(got, want)) and sum(got) > sum(want) and reg.hint_repairs >= 1
+            mem_before = list(reg.path_memory) if reg.path_memory is not None else None
+        # primed A over 8 ranks: the sequential minimum of attempts, spread evenly
+        if world == 8:
+            eng.accept = A
+            reg.path_memory = [int(r[3]) for r in seqs[id(A)][0]]
+            full, d, per_rank, tail = reg.register_projected(handles, shapes, 1, world)
+            assert sum(q["attempts"] for q in per_rank) == seqs[id(A)][2] and max(q["attempts"] for q in per_rank) <= 18
+
+
+def test_probation_bookkeeping_round_6():
+    """(a) a memory replaced without a trial (another path length, a caller's hint) starts clean -- it must not inherit the
+    `suspect` mark of the memory it replaces; (b) the attempts a prediction promised are counted from the REAL incoming direction."""
+    A, B = _serpentine_accept(10, 9), _serpentine_accept(9, 10)
+    P = len(A)
+    eng = ScriptedAttemptEngine(SHAPE, 0.2, A)
+    reg = GridRegistrar(eng, roiRatio=0.2, directIncre=1, window=48)
+    reg.register(list(range(P + 1)), [SHAPE] * (P + 1), 1)
+    eng.accept = B
+    reg.register(list(range(P + 1)), [SHAPE] * (P + 1), 1)
+    assert reg.path_suspect                                   # B under A's memory: adopted on probation
+    short = _serpentine_accept(4, 3)
+    eng.accept = short
+    reg.register(list(range(len(short) + 1)), [SHAPE] * (len(short) + 1), 1)     # another length: no trial, learned clean
+    assert reg.path_memory is not None and len(reg.path_memory) == len(short) and not reg.path_suspect
+    # (b): a path entered with direction 3 whose memory says [3, 3, ...] promised one attempt per pair
+    up = [{(3, i): (3, 4) for i in range(1, 4)} for _ in range(6)]
+    eng.accept = up
+    reg2 = GridRegistrar(eng, roiRatio=0.2, directIncre=1, window=48)
+    reg2.register(list(range(7)), [SHAPE] * 7, 3)
+    reg2.register(list(range(7)), [SHAPE] * 7, 3)
+    assert reg2.mispredictions == 0 and not reg2.path_suspect
