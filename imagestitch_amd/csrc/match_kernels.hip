@@ -337,6 +337,9 @@ __global__ __launch_bounds__(256) void k_bf_split16(const MatchDev *jobs, float 
 // products; a train is listed when its score is <= thr(q) -- a handful per query instead of the ~2 ln(n) records per list that a
 // running threshold admits, so the append branch is almost never taken (one min3 tree + one ballot per accumulator decides) and
 // the verifier has a few distances to evaluate instead of ~200.
+#ifndef VFSMS_BF_SKIP
+#define VFSMS_BF_SKIP 1
+#endif
 #define BFM_HI_ERR 1.6e-2f           // >= 2 * ((1 + 2^-8)^2 - 1) * |q||t| = 1.57e-2 (bf16 keeps 8 significand bits: RNE unit roundoff 2^-8) + the split filter's own 3e-5
 #define GASM __attribute__((address_space(1)))
 typedef GASM const s8v *g_cs8v;
@@ -487,6 +490,56 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, 
             if (tl >= tile1) break;
             const s8v *st = stage[b][u];
             f16v acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+#if VFSMS_BF_SKIP
+            // Round 6 (pass 1): hi.hi + |t|^2 first -- the five k-steps of the bounds pass -- and the eight correction steps (hi.lo, lo.hi)
+            // only for an accumulator in which some query could still reach its threshold: the correction moves a score by at most
+            // BFM_HI_ERR, so a tile whose hi.hi scores all lie above thr + BFM_HI_ERR + BFM_MARGIN lists nothing.  Thresholds sit a hair
+            // above a query's second-best score: most 32 x 32 tiles hold no such train.  (The order of the k-steps changes the rounding of
+            // a listed score by ~1e-6, far inside BFM_MARGIN; what the verifier computes from the lists is exact either way.)
+            if (PASS == 1) {
+                s8v ah[4];
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    ah[s] = st[s * 64 + lane];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh0[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh1[s], acc1, 0, 0, 0);
+                }
+                const s8v na = st[(NFR - 1) * 64 + lane];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na, bn0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na, bn1, acc1, 0, 0, 0);
+                float pa = fminf(fminf(acc0[0], acc0[1]), fminf(acc0[2], acc0[3])), pb = fminf(fminf(acc1[0], acc1[1]), fminf(acc1[2], acc1[3]));
+#pragma unroll
+                for (int i = 4; i < 16; i += 3) {
+                    pa = fminf(pa, fminf(acc0[i], fminf(acc0[i + 1], acc0[i + 2])));
+                    pb = fminf(pb, fminf(acc1[i], fminf(acc1[i + 1], acc1[i + 2])));
+                }
+                const bool need0 = __any(pa <= thra + (BFM_HI_ERR + BFM_MARGIN)), need1 = __any(pb <= thrb + (BFM_HI_ERR + BFM_MARGIN));
+                if (!need0 && !need1) continue;
+                if (need0) {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        const s8v al = st[(4 + s) * 64 + lane];
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl0[s], acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0[s], acc0, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) acc0[i] = BFM_FAR;
+                }
+                if (need1) {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        const s8v al = st[(4 + s) * 64 + lane];
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl1[s], acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1[s], acc1, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) acc1[i] = BFM_FAR;
+                }
+            } else
+#endif
+            {
 #pragma unroll
             for (int s = 0; s < 4; s++) {            // fragment s = hi, 4 + s = lo of the lane's dims 8s .. 8s + 7
                 const s8v ah = st[s * 64 + lane];
@@ -503,6 +556,7 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, 
             const s8v na = st[(NFR - 1) * 64 + lane];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na, bn0, acc0, 0, 0, 0);      // + |t|^2 (hi + lo in both passes)
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(na, bn1, acc1, 0, 0, 0);
+            }
             if (tl * 32 + 31 >= nt) {                // train rows beyond nt never qualify
 #pragma unroll
                 for (int i = 0; i < 16; i++) {

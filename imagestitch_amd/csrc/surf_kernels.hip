@@ -628,6 +628,9 @@ __device__ __forceinline__ bool interpolate_keypoint(const float N9[3][9], int d
 // neighbours -- a fraction of a per cent of the cells -- is queued in the wave's LDS queue (ballot + prefix count); afterwards the
 // queue is examined one cell per lane against the layers below and above, so the 18 extra taps and the 3 x 3 solve run on full waves.
 #define NMS_RW 16
+#ifndef NMS_PF
+#define NMS_PF 3               // rows in flight ahead of the compared row
+#endif
 #define NMS_TH (4 * NMS_RW)
 #define NMS_LOCAL 192
 struct NmsPlan { int noct; int first[VFSMS_MAX_OCTAVES + 1]; int tiles_x[VFSMS_MAX_OCTAVES]; };
@@ -665,18 +668,22 @@ __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat 
         // evaluated cells have all 8 neighbours inside the layer; the clamps only keep the loads of the other lanes in bounds
         const int jl = min(j - 1, lcols - 1), jc = min(j, lcols - 1), jr = min(j + 1, lcols - 1);
         const bool jev = j < lcols - margin;
-        float up[3], mid[3], dn[3];
-        {
-            g_cf32 r0 = d2 + (size_t)min(ia - 1, lrows - 1) * st, r1 = d2 + (size_t)min(ia, lrows - 1) * st;
-            up[0] = r0[jl]; up[1] = r0[jc]; up[2] = r0[jr];
-            mid[0] = r1[jl]; mid[1] = r1[jc]; mid[2] = r1[jr];
-        }
+        // Round 6: the rows are requested NMS_PF rows AHEAD of the row they are compared in.  The scan was one dependent round trip per
+        // row (three loads, compare, next row): a workgroup needs 16 of them and a CU holds eight workgroups, which is what the launch
+        // lasted (PMC: the waves waited 82 % of their cycles).  rw[k] = row ia - 1 + k of the strip (18 rows: the 16 scanned + one above, one below).
+        float rw[NMS_RW + 2][3];
+        auto load_row = [&](int k) {
+            g_cf32 rp = d2 + (size_t)min(ia - 1 + k, lrows - 1) * st;
+            rw[k][0] = rp[jl]; rw[k][1] = rp[jc]; rw[k][2] = rp[jr];
+        };
+#pragma unroll
+        for (int k = 0; k < 2 + NMS_PF; k++) load_row(k);
         const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
         for (int r = 0; r < NMS_RW; r++) {
             const int i = ia + r;
-            g_cf32 r2 = d2 + (size_t)min(i + 1, lrows - 1) * st;
-            dn[0] = r2[jl]; dn[1] = r2[jc]; dn[2] = r2[jr];
+            if (r + 2 + NMS_PF < NMS_RW + 2) load_row(r + 2 + NMS_PF);
+            const float *up = rw[r], *mid = rw[r + 1], *dn = rw[r + 2];
             const float v = mid[1];
             const bool c2 = jev && i < lrows - margin && v > hessianThreshold &&
                             v > up[0] && v > up[1] && v > up[2] && v > mid[0] && v > mid[2] && v > dn[0] && v > dn[1] && v > dn[2];
@@ -685,8 +692,6 @@ __global__ __launch_bounds__(256) void k_nms(const RoiDev *rois, const LayerPat 
                 if (c2) queue[wave][nq + __popcll(m & below)] = (unsigned short)((r << 8) | lane);
                 nq += __popcll(m);
             }
-#pragma unroll
-            for (int k = 0; k < 3; k++) { up[k] = mid[k]; mid[k] = dn[k]; }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -958,7 +963,11 @@ __device__ __forceinline__ void orientation_block(const RoiDev &R, const SurfTab
                     const int a00 = p0[0], a02 = p0[r2], a04 = p0[r4];          // a<row><column> of the corner lattice
                     const int a20 = p2[0], a24 = p2[r4];
                     const int a40 = p4[0], a42 = p4[r2], a44 = p4[r4];
-                    const float wA = 1.f / ((float)r2 * (float)r4), wB = 1.f / ((float)(r4 - r2) * (float)r4);
+                    // gws is even, so r2 = gws / 2 and r4 = gws exactly and r4 - r2 = r2: the two boxes of a wavelet have ONE area -- one
+                    // division.  (A host-built table of the reciprocals measured 1.4 % SLOWER than the division: profiles/r06_ab_detect_stage.txt.)
+                    const float wA = 1.f / ((float)r2 * (float)r4);
+                    float wB = wA;
+                    if (r4 - r2 != r2) wB = 1.f / ((float)(r4 - r2) * (float)r4);
                     const int vx0 = a00 + a42 - a40 - a02, vx1 = a02 + a44 - a42 - a04;     // dx: {0,0,r2,r4} weight -wA, {r2,0,r4,r4} weight +wB
                     const int vy0 = a00 + a24 - a20 - a04, vy1 = a20 + a44 - a40 - a24;     // dy: {0,0,r4,r2} weight +wA, {0,r2,r4,r4} weight -wB
                     double dxd = 0; dxd += (double)(-((float)vx0 * wA)); dxd += (double)((float)vx1 * wB);

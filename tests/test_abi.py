@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -61,3 +62,16 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in src and "from oracle" not in src and "vfsms_oracle" not in src, f
+
+
+def test_reference_module_names_resolve_to_the_engine():
+    """with imagestitch_amd/compat on sys.path the reference's imports work unchanged (Main.py:1 `from Stitcher import Stitcher`,
+    Stitcher.py:10-11 `import ImageUtility as Utility`, `import ImageFusion`)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("from Stitcher import Stitcher; import ImageUtility as Utility; import ImageFusion; import imagestitch_amd as isa; "
+            "assert Stitcher is isa.Stitcher and Utility.Method is isa.Method and ImageFusion.ImageFusion is isa.ImageFusion; "
+            "assert issubclass(Stitcher, Utility.Method); print('ok')")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, os.path.join(root, "imagestitch_amd", "compat")]))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd="/tmp")
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr

@@ -511,3 +511,33 @@ def test_phase_oracle_against_the_reference_offset_vector(oracle, golden_dir):
         assert abs(x - r["phase_xy"][0]) < 1e-9 and abs(y - r["phase_xy"][1]) < 1e-9 and abs(resp - r["response"]) < 1e-12, r["a"]
         ry, rx = phase87_residual(r, (x, y))
         assert max(abs(ry), abs(rx)) <= 1.5
+
+
+def test_rbrief_table_second_transcription():
+    """Product and oracle read ONE file for ORB's learned rBRIEF table (imagestitch_amd/csrc/orb_pattern31.h), so a transcription slip in
+    it would pass every engine-vs-oracle comparison.  This is a SECOND, independent transcription of upstream's published
+    `bit_pattern_31_` (modules/features2d/src/orb.cpp; the same 256 tests are printed in ORB-SLAM's ORBextractor.cc): its first 64 tests
+    and its last 16, typed here from the published listing, not copied out of the header -- 320 of the 1024 coordinates, both ends of the
+    table, so a dropped or shifted row anywhere in between moves the tail -- held against the header's text, against what the oracle's
+    library hands out, and a digest of the whole table pins every other value against later edits."""
+    import hashlib
+    import re
+    head = [8, -3, 9, 5, 4, 2, 7, -12, -11, 9, -8, 2, 7, -12, 12, -13, 2, -13, 2, 12, 1, -7, 1, 6, -2, -10, -2, -4, -13, -13, -11, -8,
+            -13, -3, -12, -9, 10, 4, 11, 9, -13, -8, -8, -9, -11, 7, -9, 12, 7, 7, 12, 6, -4, -5, -3, 0, -13, 2, -12, -3, -9, 0, -7, 5,
+            12, -6, 12, -1, -3, 6, -2, 12, -6, -13, -4, -8, 11, -13, 12, -8, 4, 7, 5, 1, 5, -3, 10, -3, 3, -7, 6, 12, -8, -7, -6, -2,
+            -2, 11, -1, -10, -13, 12, -8, 10, -7, 3, -5, -3, -4, 2, -3, 7, -10, -12, -6, 11, 5, -12, 6, -7, 5, -6, 7, -1, 1, 0, 4, -5,
+            9, 11, 11, -13, 4, 7, 4, 12, 2, -1, 4, 4, -4, -12, -2, 7, -8, -5, -7, -10, 4, 11, 9, 12, 0, -8, 1, -13, -13, -2, -8, 2,
+            -3, -2, -2, 3, -6, 9, -4, -9, 8, 12, 10, 7, 0, 9, 1, 3, 7, -5, 11, -10, -13, -6, -11, 0, 10, 7, 12, 1, -6, -3, -6, 12,
+            10, -9, 12, -4, -13, 8, -8, -12, -13, 0, -8, -4, 3, 3, 7, 8, 5, 7, 10, -7, -1, 7, 1, -12, 3, -10, 5, 6, 2, -4, 3, -10,
+            -13, 0, -13, 5, -13, -7, -12, 12, -13, 3, -11, 8, -7, 12, -4, 7, 6, -10, 12, 8, -9, -1, -7, -6, -2, -5, 0, 12, -12, 5, -7, 5]
+    tail = [2, 7, 3, -9, -1, -6, -1, -1, 9, 5, 11, -2, 11, -3, 12, -8, 3, 0, 3, 5, -1, 4, 0, 10, 3, -6, 4, 5, -13, 0, -10, 5,
+            5, 8, 12, 11, 8, 9, 9, -6, 7, -4, 8, -12, -10, 4, -10, 9, 7, 3, 12, 4, 9, -7, 10, -2, 7, 0, 12, -2, -1, -6, 0, -11]
+    assert len(head) == 256 and len(tail) == 64
+    txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "imagestitch_amd", "csrc", "orb_pattern31.h")).read()
+    vals = [int(x) for x in re.findall(r"-?\d+", txt[txt.index("{") + 1:txt.rindex("}")])]
+    assert len(vals) == 1024
+    assert vals[:256] == head and vals[-64:] == tail
+    assert hashlib.sha256(bytes((x + 256) % 256 for x in vals)).hexdigest() == "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
+    from oracle import oracle as O
+    O.build()
+    assert O.orb_pattern().reshape(-1).tolist() == vals
