@@ -337,8 +337,11 @@ __global__ __launch_bounds__(256) void k_bf_split16(const MatchDev *jobs, float 
 // products; a train is listed when its score is <= thr(q) -- a handful per query instead of the ~2 ln(n) records per list that a
 // running threshold admits, so the append branch is almost never taken (one min3 tree + one ballot per accumulator decides) and
 // the verifier has a few distances to evaluate instead of ~200.
+// (measured, round 6: skipping the eight correction k-steps of tiles whose hi.hi scores all lie above the thresholds made pass 1 8 % SLOWER --
+//  0.652 -> 0.703 ms on the 16-pair batch, profiles/r06_ab_bf_skip.txt: the extra minimum tree and the wave-uniform branch break the MFMA
+//  chain, and the matrix pipe was only 0.54 busy to begin with; kept behind the switch)
 #ifndef VFSMS_BF_SKIP
-#define VFSMS_BF_SKIP 1
+#define VFSMS_BF_SKIP 0
 #endif
 #define BFM_HI_ERR 1.6e-2f           // >= 2 * ((1 + 2^-8)^2 - 1) * |q||t| = 1.57e-2 (bf16 keeps 8 significand bits: RNE unit roundoff 2^-8) + the split filter's own 3e-5
 #define GASM __attribute__((address_space(1)))

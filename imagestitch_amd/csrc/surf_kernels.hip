@@ -337,6 +337,9 @@ __device__ __forceinline__ float hess_det(const Tap &T, const float (&w)[10])
 // The box corners of a layer depend on its size alone ((9 + 6 l) << octave; vfsms_haar_corner), so with the five layers and ten boxes
 // unrolled every LDS tap is `ds_read_b32 base offset:imm` -- no address arithmetic per tap; the weights stay the host's floats.
 template <int SIZE, int STEP, int LW, int LWH, int PLANE>
+#ifndef HESS_O1_WAVES
+#define HESS_O1_WAVES 8
+#endif
 struct HessLdsTap {
     const int32_t *sp;
     template <int VY, int VX> __device__ __forceinline__ int at() const
@@ -346,7 +349,7 @@ struct HessLdsTap {
     }
 };
 // one layer of a staged tile: TW x TH samples from the LDS window (k_hessian_lds)
-template <int STEP, int TW, int TH, int LW, int LWH, int PLANE, int L>
+template <int STEP, int TW, int TH, int LW, int LWH, int PLANE, int NT, int L>
 __device__ __forceinline__ void hessian_lds_layer(const RoiDev &R, const LayerPat *pats, const int li, const int32_t *tile, const int i0, const int j0, const int tid)
 {
     constexpr int OCT = STEP == 1 ? 0 : 1;
@@ -360,7 +363,7 @@ __device__ __forceinline__ void hessian_lds_layer(const RoiDev &R, const LayerPa
     float w[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) w[k] = P.w[k];
-    for (int e = tid; e < TW * TH; e += 256) {
+    for (int e = tid; e < TW * TH; e += NT) {
         const int ly = e / TW, lx = e - ly * TW;
         const int i = i0 + ly, j = j0 + lx;
         if (i >= samples_i || j >= samples_j) continue;
@@ -369,8 +372,10 @@ __device__ __forceinline__ void hessian_lds_layer(const RoiDev &R, const LayerPa
     }
 }
 
-template <int STEP, int TW>
-__global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const LayerPat *pats, int layers_per_octave, int octave)
+// NW waves per workgroup (round 6: octave 1 runs EIGHT -- its 50 KB window admits three workgroups per CU whatever their size, and the kernel
+// waited 57 % of its wave cycles with twelve waves per CU; 24 hide more of the staging and tap latency for the same LDS)
+template <int STEP, int TW, int NW>
+__global__ __launch_bounds__(NW * 64) void k_hessian_lds(const RoiDev *rois, const LayerPat *pats, int layers_per_octave, int octave)
 {
     constexpr int TH = 16;
     constexpr int MAXSZ = 33 * STEP;                              // size of the octave's coarsest layer: (9 + 6*4) << o
@@ -403,17 +408,17 @@ __global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const L
             lo[k] = STEP == 2 ? (tx & 1) * PLANE + (tx >> 1) : tx;
         }
         constexpr int RB = 4;                                     // rows in flight per wave: RB * NK loads are issued before the first store
-        for (int tb = wave; tb < LH; tb += 4 * RB) {
+        for (int tb = wave; tb < LH; tb += NW * RB) {
             int32_t v[RB][NK];
 #pragma unroll
             for (int r = 0; r < RB; r++) {
-                g_ci32 row = S + (size_t)min(y0 + min(tb + 4 * r, LH - 1), sh - 1) * sw;
+                g_ci32 row = S + (size_t)min(y0 + min(tb + NW * r, LH - 1), sh - 1) * sw;
 #pragma unroll
                 for (int k = 0; k < NK; k++) v[r][k] = row[gxo[k]];
             }
 #pragma unroll
             for (int r = 0; r < RB; r++) {
-                const int ty = tb + 4 * r;
+                const int ty = tb + NW * r;
                 if (ty < LH) {
                     int32_t *trow = tile + ty * LWH;
 #pragma unroll
@@ -425,11 +430,11 @@ __global__ __launch_bounds__(256) void k_hessian_lds(const RoiDev *rois, const L
     }
     __syncthreads();
     const int lb = octave * layers_per_octave;
-    hessian_lds_layer<STEP, TW, TH, LW, LWH, PLANE, 0>(R, pats, lb + 0, tile, i0, j0, tid);
-    hessian_lds_layer<STEP, TW, TH, LW, LWH, PLANE, 1>(R, pats, lb + 1, tile, i0, j0, tid);
-    hessian_lds_layer<STEP, TW, TH, LW, LWH, PLANE, 2>(R, pats, lb + 2, tile, i0, j0, tid);
-    hessian_lds_layer<STEP, TW, TH, LW, LWH, PLANE, 3>(R, pats, lb + 3, tile, i0, j0, tid);
-    hessian_lds_layer<STEP, TW, TH, LW, LWH, PLANE, 4>(R, pats, lb + 4, tile, i0, j0, tid);
+    hessian_lds_layer<STEP, TW, TH, LW, LWH, PLANE, NW * 64, 0>(R, pats, lb + 0, tile, i0, j0, tid);
+    hessian_lds_layer<STEP, TW, TH, LW, LWH, PLANE, NW * 64, 1>(R, pats, lb + 1, tile, i0, j0, tid);
+    hessian_lds_layer<STEP, TW, TH, LW, LWH, PLANE, NW * 64, 2>(R, pats, lb + 2, tile, i0, j0, tid);
+    hessian_lds_layer<STEP, TW, TH, LW, LWH, PLANE, NW * 64, 3>(R, pats, lb + 3, tile, i0, j0, tid);
+    hessian_lds_layer<STEP, TW, TH, LW, LWH, PLANE, NW * 64, 4>(R, pats, lb + 4, tile, i0, j0, tid);
 }
 
 // Coarse octaves (2, 3) with the stock five layers: the (tile + wavelet) window of an octave-2 tile would be 120-200 KB of LDS, so the taps
@@ -925,7 +930,9 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)   // core atan
 // with one shift and one mask, and each byte becomes the float 0 / 1 by v_cvt_f32_ubyteN; the masked accumulation of (x, y) is one packed
 // fma per sample -- fma(v, 1, s) = s + v and fma(v, 0, s) = s exactly (s is never -0: it starts at +0 and x + (-x) rounds to +0) -- 2.5
 // instructions per (sample, window) instead of 6.
-#define ORI_KP 8
+#ifndef ORI_KP
+#define ORI_KP 2                // keypoints per workgroup (128 lanes each): 8 -> 0.571, 4 -> 0.539, 2 -> 0.534, 1 -> 0.547 ms on the 16-pair batch
+#endif
 typedef float ori_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void orientation_block(const RoiDev &R, const SurfTables *T, const int k0, const int n, int upright)
 {
@@ -1073,7 +1080,7 @@ extern "C" int vfsms_debug_desc_trips(unsigned long long *out) { return hipMemcp
 #define VFSMS_EXP 0
 #endif
 #ifndef DESC_WBUF
-#define DESC_WBUF 16384
+#define DESC_WBUF 15360       // (round 6: 16384 -> 15360 makes room for the sixth workgroup of a CU: 6 x 26.2 KB of LDS)
 #endif                            // LDS bytes for the staged descriptor window (win <= 128) / band chunk
 // start, start + d, (start + d) + d, ... : the reference's running float sum (one rounding per step, so the chain cannot be split), four
 // links per trip -- the trip overhead (counter, compare, branch, address) was four fifths of the instructions of this single-lane loop
@@ -1150,14 +1157,36 @@ __device__ __forceinline__ float bilinear_pk(uint32_t top, float a, float b)
 // N samples of one lane, 8 columns apart, starting at column j0 + lj of the lane's row: positions px0 + 8 u c (8 c, 16 c, 24 c are exact
 // doubles, so the sum rounds like start + j * step whenever that is exact), N gathers issued back to back, then the arithmetic; the LDS
 // bytes go to wrow + 8 u -- immediate offsets of ds_write_b8, no address arithmetic per sample.
+#ifndef STAGE_FRAC_FIRST
+#define STAGE_FRAC_FIRST 1
+#endif
+#ifndef STAGE_PIPE
+#define STAGE_PIPE 0
+#endif
 template <int N>
 __device__ __forceinline__ void stage_round(g_cu8 ubase, const uint32_t pw, const double c, const double sn, const double sxc, const double syc,
                                             const int jlane, uint8_t *wrow)
 {
     uint32_t top[N];
-    double px[N], py[N];
     const double jd = (double)jlane;
-    px[0] = __builtin_fma(jd, c, sxc); py[0] = __builtin_fma(jd, -sn, syc);     // start + j * step: the product is exact in double
+    const double px0 = __builtin_fma(jd, c, sxc), py0 = __builtin_fma(jd, -sn, syc);     // start + j * step: the product is exact in double
+#if STAGE_FRAC_FIRST
+    // Round 6: the fractions are taken BEFORE the gathers are issued, so what waits for the loads are 2 N floats, not 2 N doubles -- the
+    // positions were the kernel's widest live range (16 registers per round of four), and the kernel is bound by how many waves fit a SIMD
+    // (profiles/r06_ab_occupancy.txt: six workgroups per CU instead of five: -3.7 %).
+    float fa[N], fb[N];
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        const double px = u ? px0 + (double)(8 * u) * c : px0, py = u ? py0 - (double)(8 * u) * sn : py0;
+        const uint32_t off = ((uint32_t)__umul24((uint32_t)(int)py, pw) + (uint32_t)(int)px) << 1;
+        fa[u] = (float)__builtin_amdgcn_fract(px); fb[u] = (float)__builtin_amdgcn_fract(py);
+        top[u] = *(GAS const uint32_t *)(ubase + off);              // 2-byte-aligned dword gather, uniform base + 32-bit offset
+    }
+#pragma unroll
+    for (int u = 0; u < N; u++) wrow[8 * u] = round_u8_pos(bilinear_pk(top[u], fa[u], fb[u]));
+#else
+    double px[N], py[N];
+    px[0] = px0; py[0] = py0;
 #pragma unroll
     for (int u = 1; u < N; u++) { px[u] = px[0] + (double)(8 * u) * c; py[u] = py[0] - (double)(8 * u) * sn; }
 #pragma unroll
@@ -1170,6 +1199,32 @@ __device__ __forceinline__ void stage_round(g_cu8 ubase, const uint32_t pw, cons
         const float a = (float)__builtin_amdgcn_fract(px[u]), b = (float)__builtin_amdgcn_fract(py[u]);
         wrow[8 * u] = round_u8_pos(bilinear_pk(top[u], a, b));
     }
+#endif
+}
+
+// The two halves of a round (STAGE_PIPE): issue = positions, fractions, gathers; finish = bilinear arithmetic + LDS bytes.  A unit of 5..8
+// groups issues BOTH of its rounds before it finishes the first: the second round's gathers fly behind the first round's arithmetic.  With
+// the fractions taken at issue time a round in flight holds 12 registers (4 dwords + 8 floats), not 20.
+template <int N> struct RoundState { uint32_t top[N]; float fa[N], fb[N]; };
+template <int N>
+__device__ __forceinline__ void round_issue(RoundState<N> &R, g_cu8 ubase, const uint32_t pw, const double c, const double sn, const double sxc, const double syc,
+                                            const int jlane)
+{
+    const double jd = (double)jlane;
+    const double px0 = __builtin_fma(jd, c, sxc), py0 = __builtin_fma(jd, -sn, syc);
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        const double px = u ? px0 + (double)(8 * u) * c : px0, py = u ? py0 - (double)(8 * u) * sn : py0;
+        const uint32_t off = ((uint32_t)__umul24((uint32_t)(int)py, pw) + (uint32_t)(int)px) << 1;
+        R.fa[u] = (float)__builtin_amdgcn_fract(px); R.fb[u] = (float)__builtin_amdgcn_fract(py);
+        R.top[u] = *(GAS const uint32_t *)(ubase + off);
+    }
+}
+template <int N>
+__device__ __forceinline__ void round_finish(const RoundState<N> &R, uint8_t *wrow)
+{
+#pragma unroll
+    for (int u = 0; u < N; u++) wrow[8 * u] = round_u8_pos(bilinear_pk(R.top[u], R.fa[u], R.fb[u]));
 }
 
 // Balanced form (round 5).  A work unit is (strip of 8 rows) x (a run of 8-column GROUPS): the G8 = ceil(win / 8) groups of a row are cut
@@ -1282,6 +1337,17 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
             DT_TRIP(0);
             uint8_t *wrow = drc + cb0 + lj;
             int jl = cb0 + lj, left = gn;
+#if STAGE_PIPE
+            if (gn > 4) {                                  // 5..8 groups: both rounds issued, then both finished
+                RoundState<4> r0;
+                round_issue<4>(r0, ubase, pw, c, sn, sxc, syc, jl);
+                const int rest = gn - 4;
+#define PIPE2(NN) { RoundState<NN> r1; round_issue<NN>(r1, ubase, pw, c, sn, sxc, syc, jl + 32); round_finish<4>(r0, wrow); round_finish<NN>(r1, wrow + 32); }
+                if (rest == 4) PIPE2(4) else if (rest == 3) PIPE2(3) else if (rest == 2) PIPE2(2) else PIPE2(1)
+#undef PIPE2
+                left = 0;
+            }
+#endif
             while (left >= 4) { stage_round<4>(ubase, pw, c, sn, sxc, syc, jl, wrow); jl += 32; wrow += 32; left -= 4; }
             if (left == 3) stage_round<3>(ubase, pw, c, sn, sxc, syc, jl, wrow);
             else if (left == 2) stage_round<2>(ubase, pw, c, sn, sxc, syc, jl, wrow);
@@ -1657,7 +1723,7 @@ __global__ __launch_bounds__(256) void k_desc_recs(const RoiDev *rois, const Des
     (cls < 3 ? big : small)[plan->seg_base[roi][cls] + idx] = rec;
 }
 
-__global__ __launch_bounds__(1024, 8) void k_orientation(const RoiDev *rois, const SurfTables *T, int upright)
+__global__ __launch_bounds__(ORI_KP * 128, 8) void k_orientation(const RoiDev *rois, const SurfTables *T, int upright)
 {
     const RoiDev &R = rois[blockIdx.y];
     const int n = min(R.counters[0], R.cap);
@@ -1751,7 +1817,7 @@ __device__ void describe_small(const RoiDev &R, const AreaRec *area_tab, const D
 }
 
 #ifndef DESC_SMALL_WGS
-#define DESC_SMALL_WGS 6
+#define DESC_SMALL_WGS 7
 #endif
 // a wave-uniform record through the scalar unit: one s_load_dwordx8
 __device__ __forceinline__ DescRec load_rec_uniform(const DescRec *p)
@@ -1808,8 +1874,11 @@ __global__ __launch_bounds__(256) void k_pair_rows(const RoiDev *rois)
     }
 }
 
+// Round 6: SIX workgroups per CU (80 VGPRs instead of 96: a dozen cold spills at kernel entry).  The kernel is bound by how many waves
+// wait for gathers at a time, not by what it issues: 5 -> 6 workgroups -3.7 % (describe 3.70 -> 3.56 ms on the 16-pair batch), 7 (72
+// VGPRs, 11 KB window buffer) no further gain; k_describe_small 6 -> 7: -1.5 % (profiles/r06_ab_occupancy.txt).
 #ifndef DESC_WGS
-#define DESC_WGS 5
+#define DESC_WGS 6
 #endif
 __global__ __launch_bounds__(256, DESC_WGS) void k_describe(const RoiDev *rois, const DescPlan *plan, const DescRec *recs, int *counter, const SurfTables *T,
                                                   const AreaRec *area_tab, int extended, int upright)
@@ -2031,9 +2100,9 @@ int launch_surf_detect(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_roi
                     const int lrows = q.h / step, lcols = q.w / step;
                     if (lrows > 0 && lcols > 0) {
                         if (o == 0)
-                            hipLaunchKernelGGL((k_hessian_lds<1, 64>), dim3((lcols + 63) / 64, (lrows + 15) / 16, q.count), dim3(64, 4), 0, ctx->stream, dq, ctx->d_layers, lpo, o);
+                            hipLaunchKernelGGL((k_hessian_lds<1, 64, 4>), dim3((lcols + 63) / 64, (lrows + 15) / 16, q.count), dim3(64, 4), 0, ctx->stream, dq, ctx->d_layers, lpo, o);
                         else
-                            hipLaunchKernelGGL((k_hessian_lds<2, 32>), dim3((lcols + 31) / 32, (lrows + 15) / 16, q.count), dim3(64, 4), 0, ctx->stream, dq, ctx->d_layers, lpo, o);
+                            hipLaunchKernelGGL((k_hessian_lds<2, 32, HESS_O1_WAVES>), dim3((lcols + 31) / 32, (lrows + 15) / 16, q.count), dim3(64, HESS_O1_WAVES), 0, ctx->stream, dq, ctx->d_layers, lpo, o);
                     }
                     step *= 2;
                 }
@@ -2157,7 +2226,7 @@ int launch_surf_describe(vfsms_ctx *ctx, const RoiDev *d_rois, const RoiDev *h_r
     for (int r = 0; r < nrois; r++) maxcap = h_rois[r].cap > maxcap ? h_rois[r].cap : maxcap;
     {
         ProfScope ps(ctx, "orientation");
-        hipLaunchKernelGGL(k_orientation, dim3((maxcap + ORI_KP - 1) / ORI_KP, nrois), dim3(1024), 0, ctx->stream, d_rois, ctx->d_tables, p->upright);
+        hipLaunchKernelGGL(k_orientation, dim3((maxcap + ORI_KP - 1) / ORI_KP, nrois), dim3(ORI_KP * 128), 0, ctx->stream, d_rois, ctx->d_tables, p->upright);
     }
     {
         ProfScope ps(ctx, "compact");
