@@ -1026,6 +1026,13 @@ struct StreamSwap {
     StreamSwap(vfsms_ctx *ctx, hipStream_t s) : c(ctx), saved(ctx->stream) { ctx->stream = s; }
     ~StreamSwap() { c->stream = saved; }
 };
+// Joins the second stream on EVERY way out of the forked region of attempt_surf_impl: an error return behind the fork (e.g. a capacity
+// overflow of part 1's describe) would otherwise let the caller's retry reset and reuse the arena while part 0's search still runs on it.
+struct SecondStreamJoin {
+    vfsms_ctx *c; bool armed = false;
+    explicit SecondStreamJoin(vfsms_ctx *ctx) : c(ctx) {}
+    ~SecondStreamJoin() { if (armed && c->stream2) (void)hipStreamSynchronize(c->stream2); }
+};
 
 static int attempt_surf_impl(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, const vfsms_surf_params *params, double ratio,
                              int offset_evaluate, int enh_mode, double clip_limit, int tile_grid, int32_t *out)
@@ -1102,16 +1109,19 @@ static int attempt_surf_impl(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, 
     // profiles/r05_ab_overlap.txt): 52.03 ms per step on one stream, 52.85 with the overlap -- the second stream's 5.5 ms of stages do run
     // concurrently (stage sum 57.4 ms against 52.8 ms of wall clock), but Hessian and integral slow down by what the search takes from
     // them (8.95 vs 6.85 ms, 1.25 vs 0.38 ms) and the halved launches add their tails: these kernels fill the chip on their own, a second
-    // queue only re-divides it.  (Rounds 2-3 found the same for two half batches of the same mix.)
+    // queue only re-divides it.  (Rounds 2-3 found the same for two half batches of the same mix.)  Round 6: the search beside DESCRIBE
+    // instead cannot happen at all -- k_describe holds 6 x 80 of a SIMD's 512 VGPRs, a k_bf_mfma16_d64<1> wave needs 168.
     static const bool overlap_on = getenv("VFSMS_OVERLAP") && atoi(getenv("VFSMS_OVERLAP")) != 0;
     static const int overlap_pct = getenv("VFSMS_OVERLAP_PCT") ? atoi(getenv("VFSMS_OVERLAP_PCT")) : 70;
     const int n0 = (overlap_on && filtered && n >= 12) ? std::min(n - 2, std::max(2, n * overlap_pct / 100)) : n;
     if (n0 < n) TRY(ctx_second_stream(ctx));
     TRY(launch_surf_detect(ctx, dR, R.data(), 2 * n0, params));
     TRY(launch_surf_describe(ctx, dR, R.data(), 2 * n0, params));
+    SecondStreamJoin join_guard(ctx);
     if (n0 < n) {
         HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
         HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        join_guard.armed = true;
         {
             StreamSwap on_second(ctx, ctx->stream2);              // the launchers enqueue on ctx->stream (their profiling events too)
             TRY(launch_bf_l2_filtered(ctx, dM, n0, maxcap, maxcap, cns));
@@ -1123,6 +1133,7 @@ static int attempt_surf_impl(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, 
         TRY(launch_bf_l2_filtered(ctx, dM + n0, n - n0, maxcap, maxcap, cns));
         TRY(launch_ratio_mode(ctx, dM + n0, n - n0, maxcap, ratio, offset_evaluate));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        join_guard.armed = false;                        // joined in stream order: the synchronisation below covers both streams
     } else {
         if (filtered) { TRY(launch_bf_l2_filtered(ctx, dM, n, maxcap, maxcap, cns)); }
         else { TRY(launch_bf_l2(ctx, dM, n, maxcap, ns, dim)); }

@@ -916,7 +916,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)   // core atan
     return a;
 }
 
-// K4 dominant orientation, EIGHT keypoints per 1024-thread workgroup.  The three phases have different widths -- 113 gradient
+// K4 dominant orientation, ORI_KP keypoints per workgroup of 128 lanes each (eight per 1024 threads until round 6, now two).  The three phases have different widths -- 113 gradient
 // samples, 72 sliding windows, one argmax per keypoint -- and a workgroup per keypoint left most lanes of its second wave idle in the
 // window phase (72 windows = one wave + 8 lanes) and one lane walking the 72 moduli.  Here phase 1 gives every keypoint 128 lanes
 // (sample = lane), phase 2 packs the 8 x 72 windows into nine full waves, phase 3 reduces each keypoint's 72 moduli in one wave
@@ -1160,9 +1160,6 @@ __device__ __forceinline__ float bilinear_pk(uint32_t top, float a, float b)
 #ifndef STAGE_FRAC_FIRST
 #define STAGE_FRAC_FIRST 1
 #endif
-#ifndef STAGE_PIPE
-#define STAGE_PIPE 0
-#endif
 template <int N>
 __device__ __forceinline__ void stage_round(g_cu8 ubase, const uint32_t pw, const double c, const double sn, const double sxc, const double syc,
                                             const int jlane, uint8_t *wrow)
@@ -1202,31 +1199,9 @@ __device__ __forceinline__ void stage_round(g_cu8 ubase, const uint32_t pw, cons
 #endif
 }
 
-// The two halves of a round (STAGE_PIPE): issue = positions, fractions, gathers; finish = bilinear arithmetic + LDS bytes.  A unit of 5..8
-// groups issues BOTH of its rounds before it finishes the first: the second round's gathers fly behind the first round's arithmetic.  With
-// the fractions taken at issue time a round in flight holds 12 registers (4 dwords + 8 floats), not 20.
-template <int N> struct RoundState { uint32_t top[N]; float fa[N], fb[N]; };
-template <int N>
-__device__ __forceinline__ void round_issue(RoundState<N> &R, g_cu8 ubase, const uint32_t pw, const double c, const double sn, const double sxc, const double syc,
-                                            const int jlane)
-{
-    const double jd = (double)jlane;
-    const double px0 = __builtin_fma(jd, c, sxc), py0 = __builtin_fma(jd, -sn, syc);
-#pragma unroll
-    for (int u = 0; u < N; u++) {
-        const double px = u ? px0 + (double)(8 * u) * c : px0, py = u ? py0 - (double)(8 * u) * sn : py0;
-        const uint32_t off = ((uint32_t)__umul24((uint32_t)(int)py, pw) + (uint32_t)(int)px) << 1;
-        R.fa[u] = (float)__builtin_amdgcn_fract(px); R.fb[u] = (float)__builtin_amdgcn_fract(py);
-        R.top[u] = *(GAS const uint32_t *)(ubase + off);
-    }
-}
-template <int N>
-__device__ __forceinline__ void round_finish(const RoundState<N> &R, uint8_t *wrow)
-{
-#pragma unroll
-    for (int u = 0; u < N; u++) wrow[8 * u] = round_u8_pos(bilinear_pk(R.top[u], R.fa[u], R.fb[u]));
-}
-
+// (Round 6, measured and removed: issuing BOTH rounds of a 5..8-group unit before finishing the first -- the second round's gathers behind the
+// first round's arithmetic -- needs 24 more live registers: 41 spills at 80 VGPRs, 24 at 96, some inside the rounds: describe 3.50 -> 6.25 /
+// 5.80 ms on the 16-pair batch, profiles/r06_ab_stage_pipe.txt.)
 // Balanced form (round 5).  A work unit is (strip of 8 rows) x (a run of 8-column GROUPS): the G8 = ceil(win / 8) groups of a row are cut
 // into nb runs of floor / ceil(G8 / nb) groups -- at most 8 (64 columns) --, so that no unit is padded: the round-4 form cut 32-column
 // blocks from the left, and a 140-px window cost five of them (160 columns), a 42-px one two (64).  A unit samples its groups in rounds of
@@ -1337,17 +1312,6 @@ __device__ __forceinline__ void stage_rows(const WinGeom &G, const float *sx_row
             DT_TRIP(0);
             uint8_t *wrow = drc + cb0 + lj;
             int jl = cb0 + lj, left = gn;
-#if STAGE_PIPE
-            if (gn > 4) {                                  // 5..8 groups: both rounds issued, then both finished
-                RoundState<4> r0;
-                round_issue<4>(r0, ubase, pw, c, sn, sxc, syc, jl);
-                const int rest = gn - 4;
-#define PIPE2(NN) { RoundState<NN> r1; round_issue<NN>(r1, ubase, pw, c, sn, sxc, syc, jl + 32); round_finish<4>(r0, wrow); round_finish<NN>(r1, wrow + 32); }
-                if (rest == 4) PIPE2(4) else if (rest == 3) PIPE2(3) else if (rest == 2) PIPE2(2) else PIPE2(1)
-#undef PIPE2
-                left = 0;
-            }
-#endif
             while (left >= 4) { stage_round<4>(ubase, pw, c, sn, sxc, syc, jl, wrow); jl += 32; wrow += 32; left -= 4; }
             if (left == 3) stage_round<3>(ubase, pw, c, sn, sxc, syc, jl, wrow);
             else if (left == 2) stage_round<2>(ubase, pw, c, sn, sxc, syc, jl, wrow);
@@ -1679,9 +1643,12 @@ __global__ __launch_bounds__(256) void k_desc_plan(const RoiDev *rois, int nrois
             plan->big_tickets[q] = acc - plan->big_start[q];
         }
         total = acc;
-        // Small batches (fewer than ~48 keypoints per resident workgroup) are bounded by their few largest windows: those (class 0,
-        // win > 256) are then drawn as 21 tickets each, one per output row of the patch.  Large batches keep one ticket per keypoint
-        // (the split repeats the row-origin prologue 21 times).
+        // Small batches are bounded by their few largest windows: those (class 0, win > 256) are then drawn as 21 tickets each, one per
+        // output row of the patch.  Large batches keep one ticket per keypoint (the split repeats the row-origin prologue 21 times).
+        // "Small" = fewer than ~48 keypoints OF THIS KERNEL (classes 0-2: `total` does not count class 3, which k_describe_small serves
+        // from its own grid) per resident workgroup of this kernel -- since round 5; round 4 counted all four classes against the same
+        // bound, i.e. switched at a third of the batch size.  With six workgroups per CU the switch sits at ~74 k keypoints of classes
+        // 0-2 (~24 ROIs of 409 x 2048).
         const int split = total < big_grid * 48 ? 21 : 1;
         plan->split = split;
         for (int q = 0; q < DESC_HEADS; q++) plan->big_tickets[q] += (split - 1) * plan->big_n0[q];
