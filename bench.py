@@ -1126,12 +1126,15 @@ def main():
         # layers written, 4 x sum_o 5 (h/2^o)(w/2^o) = 26.6 B/px -- 42.6 B/px.  (SURVEY 8d's 69.1 B/px also counts the trace layers, which
         # have not been written since round 3: the sign of the Laplacian is recomputed for the few thousand candidates.)
         HESS_BYTES_PER_PX = 16.0 + 4.0 * 5.0 * (1 + 1 / 4.0 + 1 / 16.0 + 1 / 64.0)
-        extra["hessian_hbm"] = hbm_roofline("k_hessian_lds<1,64>+k_hessian_lds<2,32>+k_hessian_coarse(octaves 2, 3)", st["roi_px"] / he_n * HESS_BYTES_PER_PX, he_ms / he_n, he_n)
+        HK = ("void k_hessian_lds<1, 64, 4>", "void k_hessian_lds<2, 32, 8>", "k_hessian_rows2", "k_hessian_coarse")      # (names as the PMC summary cuts them: 28 characters)
+        extra["hessian_hbm"] = hbm_roofline("k_hessian_lds<1,64,4>+k_hessian_lds<2,32,8>+k_hessian_rows2(octave 2)+k_hessian_coarse(octave 3)",
+                                            st["roi_px"] / he_n * HESS_BYTES_PER_PX, he_ms / he_n, he_n)
         extra["hessian_hbm"]["bytes_per_px"] = round(HESS_BYTES_PER_PX, 2)
-        hv, _s = pmc_value("void k_hessian_lds<1, 64>", "INSTS_VALU"); hb, _s = pmc_value("void k_hessian_lds<1, 64>", "BUSY_CYCLES")
+        hv, _s = pmc_value(HK[0], "INSTS_VALU"); hb, _s = pmc_value(HK[0], "BUSY_CYCLES")
         extra["hessian_hbm"]["valu_insts_x4_over_simd_cycles_octave0"] = round(hv * 4.0 / (hb / 32.0 * 1024.0), 3) if hv and hb else None
-        htr = [pmc_traffic_scaled(k, st["attempts"] / he_n)[0] for k in ("void k_hessian_lds<1, 64>", "void k_hessian_lds<2, 32>", "k_hessian_coarse")]
-        extra["hessian_hbm"]["traffic"] = sum(htr) if all(v is not None for v in htr) else None
+        htr = [pmc_traffic_scaled(k, st["attempts"] / he_n) for k in HK]
+        extra["hessian_hbm"]["traffic"] = sum(v[0] for v in htr) if all(v[0] is not None for v in htr) else None
+        extra["hessian_hbm"]["traffic_source"] = htr[0][1]
         extra["hessian_hbm"]["note"] = ("bytes = what the stage moves (42.6 B/px: no trace layers; SURVEY 8d's 69.1 B/px counted them); the fine octaves are bound by VALU "
                                         "issue + LDS taps, not by HBM: SQ_INSTS_VALU x 4 cycles EXCEEDS the SIMD cycles of octave 0's launches "
                                         "(valu_insts_x4_over_simd_cycles_octave0 > 1) -- part of its instructions are plain VOP2 integer adds, which issue in "

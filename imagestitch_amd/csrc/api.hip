@@ -776,10 +776,19 @@ static int pick_nsplit(int nq, int nt, int njobs, int dim)
 
 // train splits of the MFMA filter: a wave holds 64 queries and two waves share a SIMD, so aim at >= 4 rounds of the
 // 2048 wave slots; more splits mean more candidate lists to verify, hence the cap
-static int pick_filter_nsplit(int nq, int njobs)
+// Round 6: and at least one split per BFM_SPLIT_TRAINS trains.  The candidate lists hold BFM_CAPL = 32 entries per (list, query); what a
+// list admits grows with the trains it covers (the threshold window of the bounds pass is an absolute 1.7e-2 in squared distance), and a
+// query whose list overflows is verified by an exhaustive scan of ALL trains.  configs[4]'s strips (37 k keypoints, large batches: the
+// wave count alone asked for ONE split) spent 11 ms per launch in k_bf_verify_d64 against 0.24 ms at the headline's 8.7 k; with the
+// train rule 4.1 ms (one split per 10240 trains; 5120: another 3 % off the search, profiles/r06_ab_bf_split_4096.txt).
+#ifndef BFM_SPLIT_TRAINS
+#define BFM_SPLIT_TRAINS 5120
+#endif
+static int pick_filter_nsplit(int nq, int njobs, int nt = 0)
 {
     const long long waves = (long long)((nq + 63) / 64) * njobs;
     int ns = (int)((8192 + waves - 1) / (waves > 0 ? waves : 1));
+    ns = std::max(ns, (nt + BFM_SPLIT_TRAINS - 1) / BFM_SPLIT_TRAINS);
     return std::max(1, std::min(ns, 8));
 }
 
@@ -793,7 +802,7 @@ static int bf_l2_host(vfsms_ctx *ctx, const float *q, int nq, const float *t, in
 {
     const int capq = std::max(nq, 1);
     const int ns_exact = pick_nsplit(nq, nt, 1, dim);
-    const int cns = pick_filter_nsplit(nq, 1);
+    const int cns = pick_filter_nsplit(nq, 1, nt);
     const bool try_filter = dim == 64 && nq > 0 && nt > 0 && !bf_force_exact();
     TRY(ctx_arena_reserve(ctx, sizeof(float) * ((size_t)nq + nt) * dim + match_bytes(capq, ns_exact) +
                                (try_filter ? match_filter_bytes(capq, std::max(nt, 1), cns) : 0) + 65536));
@@ -1051,7 +1060,7 @@ static int attempt_surf_impl(vfsms_ctx *ctx, const vfsms_roi_pair *jobs, int n, 
     // 64-d descriptors leave the descriptor kernel with norm <= 1: their 2-NN search runs as an MFMA candidate filter plus
     // exact verification (match_kernels.hip); other widths, or VFSMS_BF_EXACT=1, take the exhaustive VALU kernel.
     const bool filtered = dim == 64 && !bf_force_exact();
-    const int cns = pick_filter_nsplit(maxcap * 2 / 3, n);   // the registrar sizes the capacity at 1.5x the largest ROI seen
+    const int cns = pick_filter_nsplit(maxcap * 2 / 3, n, maxcap * 2 / 3);   // the registrar sizes the capacity at 1.5x the largest ROI seen
     const int ns = filtered ? 1 : pick_nsplit(maxcap / 3, maxcap / 3, n, dim);   // typical occupancy of the capacity
     for (int k = 0; k < n; k++)
         need += 2 * surf_roi_bytes(jobs[k].h, jobs[k].w, caps[k], ctx->n_layers, params->n_octaves, dim) + match_bytes(caps[k], ns) +
@@ -1371,7 +1380,7 @@ extern "C" int vfsms_features_match_offset_batch(vfsms_ctx *ctx, const int64_t *
     const int m = (int)live.size();
     if (m == 0) return VFSMS_OK;
     const bool filtered = dim == 64 && !bf_force_exact();
-    const int cns = pick_filter_nsplit(maxq, m);
+    const int cns = pick_filter_nsplit(maxq, m, maxt);
     const int ns = filtered ? 1 : pick_nsplit(maxq, maxt, m, dim);
     size_t need = 0;
     for (int j = 0; j < m; j++)
@@ -1457,7 +1466,7 @@ extern "C" int vfsms_features_match_offset(vfsms_ctx *ctx, int64_t feat_a, int64
     if (A.n == 0 || B.n == 0) return VFSMS_OK;
     const int dim = A.dim, capq = A.n;
     const bool filtered = dim == 64 && !bf_force_exact();          // SURF descriptors are L2-normalised by construction
-    const int cns = pick_filter_nsplit(A.n, 1);
+    const int cns = pick_filter_nsplit(A.n, 1, B.n);
     const int ns = filtered ? 1 : pick_nsplit(A.n, B.n, 1, dim);
     TRY(ctx_arena_reserve(ctx, match_bytes(capq, ns) + (filtered ? match_filter_bytes(capq, B.n, cns) : 0) + 65536));
     ctx->pinned_off = 0;
