@@ -730,6 +730,24 @@ def jpeg_decode(data, want_planes=False):
     return out[:, :, 0] if c.value == 1 else out
 
 
+def jpeg_decode_raw420(data):
+    """vfsms_jpeg_decode(want_planes = 2): the DOWNSAMPLED planes of a 4:2:0 Y Cb Cr file as the entropy decode + IDCT leave them (what
+    vfsms_tile_fill_jpeg stages for the device's upsampler) -> (Y u8 (ph, pw), Cb u8 (ph / 2, pw / 2), Cr, h, w) on the iMCU grid (pw, ph =
+    w, h rounded up to 16), or None when the file is not 4:2:0 / not taken."""
+    lib = load_library()
+    h, w, c = C.c_int(), C.c_int(), C.c_int()
+    rc = lib.vfsms_jpeg_decode(data, len(data), 2, None, 0, C.byref(h), C.byref(w), C.byref(c))
+    if rc != VFSMS_ERR_CAPACITY:
+        return None
+    pw, ph = (w.value + 15) & ~15, (h.value + 15) & ~15
+    out = np.empty(pw * ph * 3 // 2, np.uint8)
+    rc = lib.vfsms_jpeg_decode(data, len(data), 2, out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(h), C.byref(w), C.byref(c))
+    if rc != VFSMS_OK:
+        return None
+    n = pw * ph
+    return out[:n].reshape(ph, pw), out[n:n + n // 4].reshape(ph // 2, pw // 2), out[n + n // 4:].reshape(ph // 2, pw // 2), h.value, w.value
+
+
 def _last_error(lib):
     buf = C.create_string_buffer(512)
     lib.vfsms_last_error(buf, 512)

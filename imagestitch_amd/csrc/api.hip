@@ -505,11 +505,14 @@ static int fill_pair_lookup(vfsms_ctx *ctx, int64_t gray, int64_t color, bool gi
 }
 // `host` (h * w pixels of `format`, densely packed; pinned when `host_pinned`) -> the device staging buffer -> the split kernel -> both tiles
 // complete (or both given up, on an error) when this returns
+#define VFSMS_SRC_YCC420_RAW 100      // internal: the raw planes of a 4:2:0 JPEG on the iMCU grid (jpeg_decode_raw420_host) -> k_ingest_420
+int launch_ingest_420(hipStream_t stream, const uint8_t *src, int pw, int ph, int h, int w, uint8_t *gray, uint8_t *bgr);
 static int fill_pair_upload(vfsms_ctx *ctx, int64_t gray, int64_t color, const uint8_t *host, int h, int w, int format, hipEvent_t ev, uint8_t *dg, uint8_t *dc,
                             const char *who)
 {
     const int spx = ingest_source_pixel_bytes(format);
-    const size_t need = (size_t)h * w * spx;
+    const int pw = (w + 15) & ~15, ph = (h + 15) & ~15;
+    const size_t need = format == VFSMS_SRC_YCC420_RAW ? (size_t)pw * ph * 3 / 2 : (size_t)h * w * spx;
     hipError_t e = hipSuccess; int rc = VFSMS_OK;
     StageBuf sb{nullptr, 0};
     if (format == VFSMS_SRC_GRAY8 && !dc) e = hipMemcpyAsync(dg, host, need, hipMemcpyHostToDevice, ctx->copy_stream);      // nothing to convert
@@ -521,7 +524,8 @@ static int fill_pair_upload(vfsms_ctx *ctx, int64_t gray, int64_t color, const u
         }
         if (!sb.ptr) { e = hipMalloc((void **)&sb.ptr, need); sb.bytes = need; if (e != hipSuccess) sb.ptr = nullptr; }
         if (e == hipSuccess) e = hipMemcpyAsync(sb.ptr, host, need, hipMemcpyHostToDevice, ctx->copy_stream);
-        if (e == hipSuccess) rc = launch_ingest_split(ctx->copy_stream, sb.ptr, dg, dc, (long long)h * w, format);
+        if (e == hipSuccess) rc = format == VFSMS_SRC_YCC420_RAW ? launch_ingest_420(ctx->copy_stream, sb.ptr, pw, ph, h, w, dg, dc)
+                                                                 : launch_ingest_split(ctx->copy_stream, sb.ptr, dg, dc, (long long)h * w, format);
     }
     if (e == hipSuccess && rc == VFSMS_OK) e = hipEventRecord(ev, ctx->copy_stream);
     if (e == hipSuccess && rc == VFSMS_OK) e = hipEventSynchronize(ev);
@@ -571,24 +575,31 @@ extern "C" int vfsms_tile_fill_pair(vfsms_ctx *ctx, int64_t gray, int64_t color,
 // (VFSMS_ERR_UNSUPPORTED: no libjpeg.so.8 on the host, not a 1- / 3-component JPEG; VFSMS_ERR_BAD_ARG: a damaged file, or a file whose size
 // is not the tiles') BOTH TILES STAY RESERVED: the caller decodes some other way and fills them, or gives them up.
 int jpeg_decode_host(const unsigned char *jpeg, size_t nbytes, int want_planes, unsigned char *out, size_t cap, int *h_out, int *w_out, int *comp_out);
+int jpeg_decode_raw420_host(const unsigned char *jpeg, size_t nbytes, unsigned char *out, size_t cap, int *h_out, int *w_out);
 extern "C" int vfsms_tile_fill_jpeg(vfsms_ctx *ctx, int64_t gray, int64_t color, const uint8_t *jpeg, size_t nbytes)
 {
     CTX_ENTER(ctx);
     if (!jpeg || !nbytes) { vfsms_set_error("tile_fill_jpeg: no data"); return VFSMS_ERR_BAD_ARG; }
     hipEvent_t ev = nullptr; uint8_t *dg = nullptr, *dc = nullptr; int h = 0, w = 0;
     TRY(fill_pair_lookup(ctx, gray, color, false, "tile_fill_jpeg", &h, &w, &ev, &dg, &dc));
-    const size_t cap = (size_t)h * w * (dc ? 3 : 1);
+    // (the staging buffer is sized for either form: the interleaved planes are 3 bytes per pixel, the raw 4:2:0 planes 1.5 on the iMCU grid)
+    const size_t cap = std::max((size_t)h * w * (dc ? 3 : 1), dc ? (size_t)((w + 15) & ~15) * ((h + 15) & ~15) * 3 / 2 : (size_t)0);
     StageBuf pb{nullptr, 0};
     std::vector<uint8_t> pageable;
     uint8_t *host = nullptr;
     if (stage_pinned_get(ctx, cap, &pb) == VFSMS_OK) host = pb.ptr;
     else { pb.ptr = nullptr; pageable.resize(cap); host = pageable.data(); }
     int jh = 0, jw = 0, comp = 0;
-    int rc = jpeg_decode_host(jpeg, nbytes, dc != nullptr, host, cap, &jh, &jw, &comp);
+    // Colour wanted and a 4:2:0 file: the host stops behind the IDCT, the device upsamples the chroma and converts (k_ingest_420).
+    static const bool raw420 = !(getenv("VFSMS_JPEG_RAW420") && atoi(getenv("VFSMS_JPEG_RAW420")) == 0);
+    int rc = VFSMS_ERR_UNSUPPORTED;
+    if (dc && raw420) { rc = jpeg_decode_raw420_host(jpeg, nbytes, host, cap, &jh, &jw); comp = 420; }
+    if (rc == VFSMS_ERR_UNSUPPORTED) rc = jpeg_decode_host(jpeg, nbytes, dc != nullptr, host, cap, &jh, &jw, &comp);
     if (rc == VFSMS_ERR_CAPACITY || (rc == VFSMS_OK && (jh != h || jw != w))) {
         vfsms_set_error("tile_fill_jpeg: the file is %d x %d, the reserved tiles %d x %d", jh, jw, h, w); rc = VFSMS_ERR_BAD_ARG;
     }
-    if (rc == VFSMS_OK) rc = fill_pair_upload(ctx, gray, color, host, h, w, comp == 3 ? VFSMS_SRC_YCC24 : VFSMS_SRC_GRAY8, ev, dg, dc, "tile_fill_jpeg");
+    if (rc == VFSMS_OK)
+        rc = fill_pair_upload(ctx, gray, color, host, h, w, comp == 420 ? VFSMS_SRC_YCC420_RAW : comp == 3 ? VFSMS_SRC_YCC24 : VFSMS_SRC_GRAY8, ev, dg, dc, "tile_fill_jpeg");
     stage_pinned_put(ctx, pb);
     return rc;
 }

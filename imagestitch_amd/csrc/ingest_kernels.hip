@@ -89,3 +89,67 @@ int launch_ingest_split(hipStream_t stream, const uint8_t *src, uint8_t *gray, u
     HIP_TRY(hipGetLastError());
     return VFSMS_OK;
 }
+
+// ---- round 6: a device stage INSIDE the JPEG decode ----------------------------------------------------------------------------------------
+// The host stops behind the IDCT (jpeg_read_raw_data, csrc/jpeg_host.cpp): what arrives are the component planes of a 4:2:0 file as they are
+// coded -- Y at full size, Cb and Cr at half size in both directions, all on the iMCU grid (pitch pw = w rounded up to 16).  This kernel
+// is libjpeg's upsampler and colour converter in one pass:
+//   jdsample.c h2v2_fancy_upsample (the default, do_fancy_upsampling = TRUE; libjpeg-turbo's SIMD routines produce the same bytes): a
+//   triangle filter, 3/4 nearer + 1/4 further sample in each direction --
+//       colsum(c) = 3 * near_row[c] + far_row[c]            near = row y >> 1, far = the row above (y even) / below (y odd)
+//       out(2 c)     = (3 * colsum(c) + colsum(c - 1) + 8) >> 4
+//       out(2 c + 1) = (3 * colsum(c) + colsum(c + 1) + 7) >> 4
+//   with the image's first / last sample row and column standing in for the missing neighbour (jdmainct.c duplicates the edge rows; the
+//   first / last column forms (4 * colsum + 8) >> 4 and (4 * colsum + 7) >> 4 are the formulas above with c - 1, c + 1 clamped);
+//   then jdcolor.c's fixed-point conversion (ycc_to_bgr above) for the B G R tile, and Y as it is for the gray tile.
+// The restatement is held to the library's own upsampled planes on the CPU (tests/test_host_logic.py) and the kernel to Pillow's two decodes
+// on the GPU (test_tile_fill_jpeg_equals_the_two_decodes).  A lane converts four pixels of a row.
+__global__ void __launch_bounds__(256) k_ingest_420(const uint8_t *__restrict__ src, int pw, int ph, int h, int w, uint8_t *__restrict__ gray, uint8_t *__restrict__ bgr)
+{
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x0 >= w || y >= h) return;
+    const uint8_t *Yp = src, *Cb = src + (size_t)pw * ph, *Cr = Cb + (size_t)(pw >> 1) * (ph >> 1);
+    const int cp = pw >> 1, dh = (h + 1) >> 1, dw = (w + 1) >> 1;
+    const int rn = y >> 1, rf = (y & 1) ? min(rn + 1, dh - 1) : max(rn - 1, 0);
+    const int c0 = x0 >> 1;
+    const int ci[4] = { max(c0 - 1, 0), min(c0, dw - 1), min(c0 + 1, dw - 1), min(c0 + 2, dw - 1) };
+    int sb[4], sr[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        sb[k] = 3 * (int)Cb[(size_t)rn * cp + ci[k]] + (int)Cb[(size_t)rf * cp + ci[k]];
+        sr[k] = 3 * (int)Cr[(size_t)rn * cp + ci[k]] + (int)Cr[(size_t)rf * cp + ci[k]];
+    }
+    // pixels x0 .. x0 + 3 sit on chroma columns c0, c0, c0 + 1, c0 + 1 (sb / sr index 1, 1, 2, 2); even x look left, odd x look right
+    unsigned ub[4], ur[4];
+    ub[0] = (unsigned)(3 * sb[1] + sb[0] + 8) >> 4; ub[1] = (unsigned)(3 * sb[1] + sb[2] + 7) >> 4;
+    ub[2] = (unsigned)(3 * sb[2] + sb[1] + 8) >> 4; ub[3] = (unsigned)(3 * sb[2] + sb[3] + 7) >> 4;
+    ur[0] = (unsigned)(3 * sr[1] + sr[0] + 8) >> 4; ur[1] = (unsigned)(3 * sr[1] + sr[2] + 7) >> 4;
+    ur[2] = (unsigned)(3 * sr[2] + sr[1] + 8) >> 4; ur[3] = (unsigned)(3 * sr[2] + sr[3] + 7) >> 4;
+    const unsigned yv = *(const unsigned *)(Yp + (size_t)y * pw + x0);          // (pw is a multiple of 16, x0 of 4: aligned, and inside the padded row)
+    unsigned px[4];                                                             // B | G << 8 | R << 16 | Y << 24
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const unsigned yy = (yv >> (8 * k)) & 255u; px[k] = ycc_to_bgr(yy, ub[k], ur[k]) | (yy << 24); }
+    const size_t p0 = (size_t)y * w + x0;
+    if ((w & 3) == 0) {
+        if (gray) *(unsigned *)(gray + p0) = yv;
+        if (bgr) {
+            unsigned *o = (unsigned *)(bgr + p0 * 3);
+            o[0] = (px[0] & 0xffffffu) | (px[1] << 24);
+            o[1] = ((px[1] >> 8) & 0xffffu) | (px[2] << 16);
+            o[2] = ((px[2] >> 16) & 0xffu) | (px[3] << 8);
+        }
+        return;
+    }
+    for (int k = 0; k < 4 && x0 + k < w; k++) {                                 // widths that are not multiples of 4: byte stores
+        if (gray) gray[p0 + k] = (uint8_t)(px[k] >> 24);
+        if (bgr) { bgr[(p0 + k) * 3] = (uint8_t)px[k]; bgr[(p0 + k) * 3 + 1] = (uint8_t)(px[k] >> 8); bgr[(p0 + k) * 3 + 2] = (uint8_t)(px[k] >> 16); }
+    }
+}
+
+// stream-ordered; src: the raw planes of jpeg_decode_raw420_host on the device
+int launch_ingest_420(hipStream_t stream, const uint8_t *src, int pw, int ph, int h, int w, uint8_t *gray, uint8_t *bgr)
+{
+    hipLaunchKernelGGL(k_ingest_420, dim3((unsigned)((w + 1023) / 1024), (unsigned)h), dim3(256), 0, stream, src, pw, ph, h, w, gray, bgr);
+    HIP_TRY(hipGetLastError());
+    return VFSMS_OK;
+}

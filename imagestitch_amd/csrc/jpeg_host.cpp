@@ -81,6 +81,7 @@ struct JpegApi {
     int (*read_header)(void *, int);
     int (*start)(void *);
     unsigned (*read_scanlines)(void *, unsigned char **, unsigned);
+    unsigned (*read_raw)(void *, unsigned char ***, unsigned);          // jpeg_read_raw_data (may be absent: the raw 4:2:0 path is then off)
     int (*finish)(void *);
     void (*destroy)(void *);
     size_t cinfo_size;                  // as the library reports it
@@ -122,6 +123,7 @@ const JpegApi &api()
         a.read_header = (int (*)(void *, int))dlsym(h, "jpeg_read_header");
         a.start = (int (*)(void *))dlsym(h, "jpeg_start_decompress");
         a.read_scanlines = (unsigned (*)(void *, unsigned char **, unsigned))dlsym(h, "jpeg_read_scanlines");
+        a.read_raw = (unsigned (*)(void *, unsigned char ***, unsigned))dlsym(h, "jpeg_read_raw_data");
         a.finish = (int (*)(void *))dlsym(h, "jpeg_finish_decompress");
         a.destroy = (void (*)(void *))dlsym(h, "jpeg_destroy_decompress");
         if (!a.std_error || !a.create || !a.mem_src || !a.read_header || !a.start || !a.read_scanlines || !a.finish || !a.destroy) return a;
@@ -160,7 +162,7 @@ const JpegApi &api()
 }
 
 // (rows, cols, components) from the first SOFn marker: the independent witness for the struct offsets
-bool sof_size(const unsigned char *p, size_t n, int *h, int *w, int *nc)
+bool sof_size(const unsigned char *p, size_t n, int *h, int *w, int *nc, int *samp = nullptr)
 {
     if (n < 4 || p[0] != 0xFF || p[1] != 0xD8) return false;
     size_t q = 2;
@@ -172,6 +174,10 @@ bool sof_size(const unsigned char *p, size_t n, int *h, int *w, int *nc)
         const size_t seg = ((size_t)p[q + 2] << 8) | p[q + 3];
         if (m >= 0xC0 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
             *h = (p[q + 5] << 8) | p[q + 6]; *w = (p[q + 7] << 8) | p[q + 8]; *nc = p[q + 9];
+            if (samp) {                                       // (H << 4 | V) of up to three components
+                samp[0] = samp[1] = samp[2] = 0;
+                for (int k = 0; k < *nc && k < 3 && q + 10 + 3 * k + 2 < n; k++) samp[k] = p[q + 10 + 3 * k + 1];
+            }
             return *h > 0 && *w > 0;
         }
         q += 2 + seg;
@@ -245,10 +251,77 @@ int jpeg_decode_host(const unsigned char *jpeg, size_t nbytes, int want_planes, 
     return VFSMS_OK;
 }
 
+// Round 6: the DOWNSAMPLED planes of a 4:2:0 Y Cb Cr file (jpeg_read_raw_data: entropy decode + IDCT on the host, nothing else) --
+// chroma upsampling and the colour conversion run on the device (csrc/ingest_kernels.hip: k_ingest_420, libjpeg's h2v2 "fancy" triangle
+// filter restated).  The host writes 1.5 bytes per pixel into pinned staging instead of 3 and skips its upsampling and interleaving passes.
+// out: Y plane, pitch pw = w rounded up to 16, ph = h rounded up to 16 rows (the iMCU grid: the rows / columns beyond the image hold the
+// decoder's edge padding and are never looked at), then the Cb plane (pitch pw / 2, ph / 2 rows), then Cr.  VFSMS_ERR_UNSUPPORTED: not a
+// 3-component Y Cb Cr file sampled 2x2, 1x1, 1x1, or no jpeg_read_raw_data in the library -- the caller takes the full decode.
+int jpeg_decode_raw420_host(const unsigned char *jpeg, size_t nbytes, unsigned char *out, size_t cap, int *h_out, int *w_out)
+{
+    const JpegApi &A = api();
+    if (!A.ok || !A.read_raw) { vfsms_set_error("jpeg: no raw-data decode on this host"); return VFSMS_ERR_UNSUPPORTED; }
+    int sh = 0, sw = 0, snc = 0, samp[3] = {0, 0, 0};
+    if (!jpeg || !sof_size(jpeg, nbytes, &sh, &sw, &snc, samp) || snc != 3 || samp[0] != 0x22 || samp[1] != 0x11 || samp[2] != 0x11 || sw < 4 || sh < 2) {
+        vfsms_set_error("jpeg: not a 4:2:0 Y Cb Cr file"); return VFSMS_ERR_UNSUPPORTED;
+    }
+    const size_t pw = ((size_t)sw + 15) & ~(size_t)15, ph = ((size_t)sh + 15) & ~(size_t)15;
+    *h_out = sh; *w_out = sw;
+    if (!out || cap < pw * ph * 3 / 2) { vfsms_set_error("jpeg: output buffer too small"); return VFSMS_ERR_CAPACITY; }
+    alignas(16) unsigned char cinfo[JPEG_CINFO_BYTES]; memset(cinfo, 0, sizeof(cinfo));
+    jerr_abi err; memset(&err, 0, sizeof(err));
+    Guard g; memset(&g.code, 0, sizeof(g) - offsetof(Guard, code));
+    jdec_head_abi *c = (jdec_head_abi *)cinfo;
+    volatile bool created = false;
+    if (setjmp(g.jb)) {
+        if (created) A.destroy(cinfo);
+        vfsms_set_error("jpeg: %s", g.text[0] ? g.text : "decode error");
+        return VFSMS_ERR_BAD_ARG;
+    }
+    c->err = A.std_error(&err);
+    err.error_exit = on_error; err.output_message = on_message;
+    c->client_data = &g;
+    A.create(cinfo, JPEG_ABI_VERSION, A.cinfo_size);
+    created = true;
+    c->client_data = &g;
+    A.mem_src(cinfo, jpeg, (unsigned long)nbytes);
+    A.read_header(cinfo, 1);
+    if ((int)c->image_height != sh || (int)c->image_width != sw || c->num_components != 3 || c->jpeg_color_space != JCS_YCbCr_) {
+        A.destroy(cinfo);
+        vfsms_set_error("jpeg: not a Y Cb Cr file (or an unexpected struct layout)");
+        return VFSMS_ERR_UNSUPPORTED;
+    }
+    c->out_color_space = JCS_YCbCr_;
+    c->raw_data_out = 1;
+    A.start(cinfo);
+    if ((int)c->output_width != sw || (int)c->output_height != sh) { A.destroy(cinfo); vfsms_set_error("jpeg: unexpected output geometry"); return VFSMS_ERR_UNSUPPORTED; }
+    unsigned char *Y = out, *Cb = out + pw * ph, *Cr = Cb + (pw / 2) * (ph / 2);
+    bool ok = true;
+    while (c->output_scanline < c->output_height) {
+        const unsigned y0 = c->output_scanline;                  // a multiple of 16: one iMCU row per call
+        if (y0 % 16 || y0 + 16 > ph) { ok = false; break; }
+        unsigned char *yr[16], *br[8], *rr[8];
+        for (unsigned r = 0; r < 16; r++) yr[r] = Y + (size_t)(y0 + r) * pw;
+        for (unsigned r = 0; r < 8; r++) { br[r] = Cb + (size_t)(y0 / 2 + r) * (pw / 2); rr[r] = Cr + (size_t)(y0 / 2 + r) * (pw / 2); }
+        unsigned char **planes[3] = { yr, br, rr };
+        if (A.read_raw(cinfo, planes, 16) == 0) { ok = false; break; }
+    }
+    const bool complete = ok && c->output_scanline >= c->output_height;
+    if (complete) A.finish(cinfo);
+    const long warnings = err.num_warnings;
+    A.destroy(cinfo);
+    if (!complete || warnings) { vfsms_set_error("jpeg: truncated or damaged file (%ld decoder warnings)", warnings); return VFSMS_ERR_BAD_ARG; }
+    return VFSMS_OK;
+}
+
 // host-only entry (no context, no GPU): the decode of jpeg_decode_host, for tests and for callers that want the planes themselves
 extern "C" int vfsms_jpeg_decode(const uint8_t *jpeg, size_t nbytes, int want_planes, uint8_t *out, size_t cap, int *h, int *w, int *comp)
 {
     if (!h || !w || !comp) { vfsms_set_error("jpeg_decode: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    if (want_planes == 2) {                                  // the raw 4:2:0 planes (comp = 420): Y | Cb | Cr on the iMCU grid, see jpeg_decode_raw420_host
+        *comp = 420;
+        return jpeg_decode_raw420_host(jpeg, nbytes, out, cap, h, w);
+    }
     return jpeg_decode_host(jpeg, nbytes, want_planes, out, cap, h, w, comp);
 }
 

@@ -132,14 +132,19 @@ int vfsms_tile_reserve_ch(vfsms_ctx *ctx, int h, int w, int ch, int64_t *handle)
 int vfsms_tile_fill_pair(vfsms_ctx *ctx, int64_t gray, int64_t color, const uint8_t *src, int stride_bytes, int format);
 /* The decode itself, for JPEG files (what cv2.imread / cv2.imdecode do on the reference's host: Stitcher.py:68-69, 382-403): the FILE'S
  * BYTES in, both tiles out.  The system's libjpeg-turbo (libjpeg.so.8, loaded at first use) decodes straight into the library's pinned
- * staging memory -- the Y plane alone when only `gray` is given (IMREAD_GRAYSCALE), the upsampled Y Cb Cr planes when `color` is given --
- * and the device finishes as in vfsms_tile_fill_pair.  Any thread; returns when both tiles are complete.  VFSMS_ERR_UNSUPPORTED (no
+ * staging memory -- the Y plane alone when only `gray` is given (IMREAD_GRAYSCALE); when `color` is given, the DOWNSAMPLED Y Cb Cr planes of
+ * a 4:2:0 file (round 6: libjpeg's h2v2 fancy upsampling and jdcolor.c's conversion both run on the device, k_ingest_420;
+ * VFSMS_JPEG_RAW420=0 restores the host's upsampling), the upsampled planes of any other sampling -- and the device finishes as in
+ * vfsms_tile_fill_pair.  Any thread; returns when both tiles are complete.  VFSMS_ERR_UNSUPPORTED (no
  * libjpeg.so.8 on this host; not a 1- or 3-component YCbCr / gray JPEG) and VFSMS_ERR_BAD_ARG (a damaged file; a file that is not the
  * size of the reserved tiles) leave BOTH TILES RESERVED: decode some other way and fill them, or give them up.                          */
 int vfsms_tile_fill_jpeg(vfsms_ctx *ctx, int64_t gray, int64_t color, const uint8_t *jpeg, size_t nbytes);
 /* the same decode into the caller's memory, no context and no GPU: rows of *w * *comp bytes, comp = 3 (Y Cb Cr interleaved) when
  * want_planes != 0 and the file has three components, else 1 (the grayscale decode).  VFSMS_ERR_CAPACITY (with *h, *w, *comp set) when
- * `cap` bytes are too few -- call with out == NULL to ask for the size.                                                                 */
+ * `cap` bytes are too few -- call with out == NULL to ask for the size.  want_planes == 2 (round 6): the DOWNSAMPLED planes of a 4:2:0
+ * Y Cb Cr file as jpeg_read_raw_data hands them out (*comp = 420): Y with pitch pw = *w rounded up to 16 and ph = *h rounded up to 16 rows,
+ * then Cb and Cr (pitch pw / 2, ph / 2 rows) -- pw * ph * 3 / 2 bytes; what vfsms_tile_fill_jpeg stages when the device does the chroma
+ * upsampling (VFSMS_ERR_UNSUPPORTED for any other sampling).                                                                            */
 int vfsms_jpeg_decode(const uint8_t *jpeg, size_t nbytes, int want_planes, uint8_t *out, size_t cap, int *h, int *w, int *comp);
 /* The way out, for the mosaic: replaces cv2.imwrite(path, result) for .jpg results (Stitcher.py:149, 175-179; Main.py:21-51 writes every
  * result as jpg).  vfsms_jpeg_encode: n_rows x cols pixels of 1 or 3 channels (R G B, or B G R -- the canvas order -- with bgr != 0), rows

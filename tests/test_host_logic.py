@@ -512,6 +512,48 @@ def test_library_jpeg_decoder_equals_pillow_and_refuses_what_it_does_not_take(tm
     assert all(np.array_equal(o, ref[k % len(blobs)]) for k, o in enumerate(outs))
 
 
+def test_raw_420_planes_and_the_restated_fancy_upsampler_equal_the_library():
+    """Round 6: with a colour tile wanted and a 4:2:0 file, vfsms_tile_fill_jpeg stops the host behind the IDCT (jpeg_read_raw_data) and the
+    DEVICE upsamples the chroma (k_ingest_420 restates jdsample.c's h2v2 fancy upsampling).  The restatement is held here, on the CPU, to the
+    library's own upsampled planes: the raw Y plane == the Y of the full decode, and numpy's copy of the kernel's arithmetic --
+    colsum(c) = 3 near + far, out(2c) = (3 colsum(c) + colsum(c - 1) + 8) >> 4, out(2c + 1) = (3 colsum(c) + colsum(c + 1) + 7) >> 4,
+    neighbours clamped to the image's first / last sample row and column -- on the raw Cb / Cr planes == the library's, byte for byte: odd
+    sizes, one-iMCU-row images, progressive files, the bench's 2048 x 2048.  Other samplings are refused (the full decode takes them)."""
+    import io
+    from PIL import Image
+    from imagestitch_amd import _lib
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (41, 57, 3), dtype=np.uint8)
+    if _lib.jpeg_decode(_jpeg_bytes(base), False) is None:
+        pytest.skip("no libjpeg.so.8 on this host: the Stitcher decodes with Pillow")
+
+    def fancy(plane, H, W):
+        dh, dw = (H + 1) // 2, (W + 1) // 2
+        p = plane[:dh, :dw].astype(np.int32)
+        up = np.vstack([p[:1], p[:-1]]); dn = np.vstack([p[1:], p[-1:]])
+        rows = np.empty((2 * dh, dw), np.int32); rows[0::2] = 3 * p + up; rows[1::2] = 3 * p + dn
+        left = np.hstack([rows[:, :1], rows[:, :-1]]); right = np.hstack([rows[:, 1:], rows[:, -1:]])
+        out = np.empty((2 * dh, 2 * dw), np.int32)
+        out[:, 0::2] = (3 * rows + left + 8) >> 4; out[:, 1::2] = (3 * rows + right + 7) >> 4
+        return out[:H, :W].astype(np.uint8)
+    for (w, h), kw in (((613, 407), dict(quality=90)), ((333, 7), dict(quality=70)), ((1021, 767), dict(quality=85, progressive=True)),
+                       ((64, 48), dict(quality=95)), ((5, 3), dict(quality=90)), ((2048, 2048), dict(quality=90))):
+        img = np.asarray(Image.fromarray(base).resize((w, h), Image.BICUBIC))
+        b = io.BytesIO(); Image.fromarray(img).save(b, "JPEG", subsampling=2, **kw); data = b.getvalue()
+        full = _lib.jpeg_decode(data, True)
+        raw = _lib.jpeg_decode_raw420(data)
+        assert raw is not None and full is not None, (w, h)
+        Y, Cb, Cr, H, W = raw
+        assert (H, W) == (h, w) and Y.shape == ((h + 15) // 16 * 16, (w + 15) // 16 * 16)
+        assert np.array_equal(Y[:H, :W], full[:, :, 0]), (w, h)
+        assert np.array_equal(fancy(Cb, H, W), full[:, :, 1]) and np.array_equal(fancy(Cr, H, W), full[:, :, 2]), (w, h)
+    for ss in (0, 1):                                                          # 4:4:4 and 4:2:2: not this path's
+        assert _lib.jpeg_decode_raw420(_jpeg_bytes(np.asarray(Image.fromarray(base).resize((64, 48))), subsampling=ss)) is None
+    assert _lib.jpeg_decode_raw420(_jpeg_bytes(base[:, :, 0])) is None         # a grayscale file
+    b = _jpeg_bytes(np.asarray(Image.fromarray(base).resize((320, 200))), subsampling=2)
+    assert _lib.jpeg_decode_raw420(b[:len(b) // 2]) is None                     # truncated
+
+
 def test_library_jpeg_decoder_on_damaged_files():
     """Files are untrusted input to a C decoder running in the decoder threads: flipped bytes, cuts and splices in baseline / progressive /
     restart-marker files.  Every outcome is either a refusal (None: the caller's decoder takes over) or exactly Pillow's decode of the same
