@@ -1153,8 +1153,12 @@ def main():
         if fa_n:
             # fused FAST-9/16 + NMS over the 8-level pyramid of every ROI: each level read once (sum of level areas = 3.27 h w at
             # scale 1.2), 1 B/px; scores never leave LDS
+            longest = max(prof.items(), key=lambda kv: kv[1][0]) if prof else (None, (0.0, 0))
             roofline = hbm_roofline("k_orb_fast_nms", st["roi_px"] / fa_n * 3.27, fa_ms / fa_n, fa_n,
-                                    note="dominant ORB stage; bytes = pyramid levels read once")
+                                    note="the longest single KERNEL of the ORB path and its one streaming pass (bytes = pyramid levels read once); the "
+                                         "longest STAGE is `longest_stage` -- orb_select is six kernels of per-keypoint work (Harris, rank, angle), "
+                                         "latency-bound, with no bytes-per-pixel figure to hold against HBM",
+                                    longest_stage=longest[0], longest_stage_ms_per_launch=round(longest[1][0] / max(longest[1][1], 1), 4))
         py_ms, py_n = prof.get("orb_pyramid", (0.0, 0))
         if py_n:
             extra["orb_pyramid_hbm"] = hbm_roofline("k_orb_resize", st["roi_px"] / py_n * (3.27 + 2.27), py_ms / py_n, py_n)

@@ -343,6 +343,9 @@ __global__ __launch_bounds__(256) void k_bf_split16(const MatchDev *jobs, float 
 #ifndef VFSMS_BF_SKIP
 #define VFSMS_BF_SKIP 0
 #endif
+#ifndef BFM_GLDS
+#define BFM_GLDS 1                // round 6: train tiles reach LDS by LDS-DMA (global_load_lds_dwordx4), not through registers
+#endif
 #define BFM_HI_ERR 1.6e-2f           // >= 2 * ((1 + 2^-8)^2 - 1) * |q||t| = 1.57e-2 (bf16 keeps 8 significand bits: RNE unit roundoff 2^-8) + the split filter's own 3e-5
 #define GASM __attribute__((address_space(1)))
 typedef GASM const s8v *g_cs8v;
@@ -403,9 +406,36 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, 
     constexpr int BFM_UNIT = 2;                          // train tiles per meeting (four in pass 0 -- twice the bytes in flight -- changed nothing)
     __shared__ s8v stage[2][BFM_UNIT][NFR * 64];
     g_cs8v T = (g_cs8v)J.t16;                            // fragment order: tile * 9 fragments * 64 lanes (k_bf_split16)
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x; (void)tid;
     // Units are fetched BFM_SETS + 1 ahead of their MFMAs into BFM_SETS register sets (pass 0 has the registers for two: its iteration --
     // ten MFMAs per tile -- is shorter than a trip to memory, and half of its wave cycles were the wait in front of the put).
+#if BFM_GLDS
+    // Round 6: a tile's fragments are ONE lane-linear block in global memory (k_bf_split16 writes them in fragment order) and the same block
+    // in LDS, so the copy is LDS-DMA: wave w issues global_load_lds_dwordx4 for the 1 KB chunks w and 4 + w (wave 0 also the norm
+    // fragment) -- two or three instructions per tile and wave, no staging registers (24 VGPRs), no ds_write pass.  Unit u + 1 is
+    // requested right behind the barrier that frees its buffer and has the whole of unit u's MFMAs to land; the barrier's vmcnt(0)
+    // (hipcc drains the DMA in front of __syncthreads) is what makes it visible.  (profiles/r06_glds_probe.txt: the instruction takes
+    // 4-byte-aligned global addresses and partial EXEC.)
+    constexpr int NSET = 1;
+    const int wv_u = __builtin_amdgcn_readfirstlane(wave);
+    auto glds16 = [&](g_cs8v src, const s8v *dst) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+    auto fetch = [&](int unit, int b) {
+#pragma unroll
+        for (int u = 0; u < BFM_UNIT; u++) {
+            const int tl = min(tile0 + unit * BFM_UNIT + u, tile1 - 1);
+            g_cs8v pn = T + (size_t)tl * (BF16_FRAGS * 64);
+            glds16(pn + 64 * wv_u + lane, &stage[b][u][64 * wv_u]);
+            if (PASS == 1) {
+                glds16(pn + 256 + 64 * wv_u + lane, &stage[b][u][256 + 64 * wv_u]);
+                if (wv_u == 0) glds16(pn + 512 + lane, &stage[b][u][PASS == 1 ? 512 : 0]);
+            } else if (wv_u == 0) glds16(pn + 512 + lane, &stage[b][u][256]);
+        }
+    };
+    const int nunits = (tile1 - tile0 + BFM_UNIT - 1) / BFM_UNIT;
+    if (nunits > 0) fetch(0, 0);
+#else
     constexpr int NSET = PASS == 0 ? 2 : 1;
     s8v g0[NSET][BFM_UNIT], g1[NSET][BFM_UNIT], g2[NSET][BFM_UNIT];
 #pragma unroll
@@ -434,6 +464,7 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, 
         }
     };
     if (nunits > 0) fetch(0, 0);                     // under way while the query operands and the thresholds arrive
+#endif
     // Pin the query operands as "defined here": the compiler otherwise carries their load waits into the tile loop as in-order
     // vmcnt counts, which also drain the train prefetch issued at the top of every iteration (a full L2 round trip per tile).
 #pragma unroll
@@ -468,12 +499,15 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, 
         if (va) thra = a2 + (BFM_HI_ERR + BFM_MARGIN);
         if (vb) thrb = b2 + (BFM_HI_ERR + BFM_MARGIN);
     }
-    uint2 *lista = J.c_ent + (size_t)lst * BFM_CAPL * pitch + (q0 + col), *listb = lista + 32;
+    // (global address space: a generic pointer makes the append a flat_store, which the compiler orders behind every LDS-DMA in flight)
+    GASM unsigned long long *lista = (GASM unsigned long long *)J.c_ent + (size_t)lst * BFM_CAPL * pitch + (q0 + col), *listb = lista + 32;   // uint2 (score bits, train) as one 64-bit word
+#if !BFM_GLDS
     if (nunits > 0) {
         put(0, 0);
 #pragma unroll
         for (int k = 1; k <= NSET; k++) fetch(min(k, nunits - 1), k % NSET);
     }
+#endif
     BT_MARK(0);
     for (int unit0 = 0; unit0 < nunits; unit0 += NSET) {
 #pragma unroll
@@ -481,10 +515,19 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, 
         const int unit = unit0 + v;
         if (unit >= nunits) break;
         const int b = unit & 1;
+#if BFM_GLDS
+        // this wave's LDS-DMA of the unit has landed (hipcc 7.2 does NOT put this wait in front of the barrier by itself: the ISA showed
+        // `s_waitcnt lgkmcnt(0); s_barrier` only) -- behind the barrier every wave's has
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         __syncthreads();
         BT_MARK(1);
+#if BFM_GLDS
+        if (unit + 1 < nunits) fetch(unit + 1, b ^ 1);
+#else
         if (unit + 1 < nunits) put(b ^ 1, (v + 1) % NSET);
         fetch(min(unit + 1 + NSET, nunits - 1), (v + 1) % NSET);
+#endif
         BT_MARK(2);
         if (!live) continue;
 #pragma unroll
@@ -596,7 +639,7 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, 
                     const bool some = __any(mn <= thr);
                     BT_MARK(3);
                     if (some) {
-                        uint2 *list = h == 0 ? lista : listb;
+                        GASM unsigned long long *list = h == 0 ? lista : listb;
                         int cnt = h == 0 ? cnta : cntb;
 #pragma unroll
                         for (int g = 0; g < 5; g++) {
@@ -605,7 +648,7 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma16_d64(const MatchDev *jobs, 
                             for (int i = (g == 0 ? 0 : 3 * g + 1); i < (g == 0 ? 4 : 3 * g + 4); i++) {
                                 const float v = acc[i];
                                 if (v <= thr && v < 1e29f) {
-                                    if (cnt < BFM_CAPL) list[cnt * pitch] = make_uint2(__float_as_uint(v), (unsigned)(row0 + (i & 3) + 8 * (i >> 2)));
+                                    if (cnt < BFM_CAPL) list[cnt * pitch] = (unsigned long long)__float_as_uint(v) | ((unsigned long long)(unsigned)(row0 + (i & 3) + 8 * (i >> 2)) << 32);
                                     cnt++;
                                 }
                             }
