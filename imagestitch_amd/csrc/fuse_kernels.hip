@@ -246,15 +246,24 @@ __global__ __launch_bounds__(256) void k_i64_apply(I64View V, int r, int c, cons
 // patched to 1, Python's negative-index wrap, and the geometries where the reference itself raises reported in out[5].
 //   out: [0] corner mode, [1..4] info (mode, quadrant, rowIndex, colIndex), [5] error
 // ---------------------------------------------------------------------------------------------------
+// A record another workgroup of THIS launch produced (agent-scope atomic, or a write-through `sc1` store) is read with an agent-scope
+// relaxed load (`global_load ... sc1`: bypasses this CU's L1) -- what lets k_fuse_stats_weights hand its statistics to the last workgroup
+// without the two agent fences it had (round 6; MI355X_MICROARCH.md, "valid forms": sc1 stores + drained vmcnt + flag on the producing
+// side, sc1 loads on the consuming side).  The standalone ramp kernel (k_fuse_weights, its inputs come from earlier launches) reads the
+// same way; it costs it nothing.
+__device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int pywrap(int i, int n) { return i < 0 ? i + n : i; }
 
 // (first_encoded: the canvas path stores "first valid" positions as n - 1 - first so that every record starts at -1 and is a maximum;
 //  bit 0: columns' first valid row, bit 1: rows' first valid column)
 __device__ __forceinline__ void fuse_weights_body(int r, int c, int ch, int dx, int dy, int force_corner, const FuseStats *st,
-                                                  const int *rowFirstRaw, const int *rowLast, const int *colFirstRaw, const int *colLast,
+                                                  const int *rowFirstRaw, const int *rowLastRaw, const int *colFirstRaw, const int *colLastRaw,
                                                   float *wAr, float *wAc, float *wBr, float *wBc, int *out, int *sticky_err, int first_encoded)
 {
-    struct First { const int *p; int n, enc; __device__ int operator[](int j) const { const int v = p[j]; return (enc && v >= 0) ? n - 1 - v : v; } };
+    struct First { const int *p; int n, enc; __device__ int operator[](int j) const { const int v = ld_agent(p + j); return (enc && v >= 0) ? n - 1 - v : v; } };
+    struct Last { const int *p; __device__ int operator[](int j) const { return ld_agent(p + j); } };
+    const Last colLast = {colLastRaw}, rowLast = {rowLastRaw};
     const First colFirst = {colFirstRaw, r, first_encoded & 1};
     const First rowFirst = {rowFirstRaw, c, (first_encoded >> 1) & 1};
     const int t = threadIdx.x;
@@ -473,7 +482,7 @@ __device__ __forceinline__ void fuse_stats_block(const CanvasView &V, int r, int
     {
         unsigned x = 0;
         for (int w = 0; w < FUSE_NW; w++) x += s_cnt[threadIdx.x][w];
-        S.slots[(size_t)wg * 8 + threadIdx.x] = x;
+        __hip_atomic_store(&S.slots[(size_t)wg * 8 + threadIdx.x], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // write-through (sc1): visible to the last workgroup without a fence
     }
 }
 
@@ -489,7 +498,7 @@ __device__ __forceinline__ void fuse_ramps_tail(int r, int c, int ch, int dx, in
         unsigned long long sum5[5] = {0, 0, 0, 0, 0};
         for (unsigned w = threadIdx.x; w < nwg; w += 256)
 #pragma unroll
-            for (int q = 0; q < 5; q++) sum5[q] += __builtin_nontemporal_load(&S.slots[(size_t)w * 8 + q]);
+            for (int q = 0; q < 5; q++) sum5[q] += ld_agent(&S.slots[(size_t)w * 8 + q]);
 #pragma unroll
         for (int q = 0; q < 5; q++) {
             unsigned long long x = sum5[q];
@@ -511,13 +520,17 @@ __global__ __launch_bounds__(FUSE_NW * 64) void k_fuse_stats_weights(CanvasView 
 {
     __shared__ int s_last;
     fuse_stats_block<FUSE_SBT, FUSE_UR>(V, r, c, S, wx_n, blockIdx.x, blockIdx.y, gridDim.x);
-    // the last workgroup to arrive builds the ramps
-    __threadfence();
+    // The last workgroup to arrive builds the ramps.  Round 6: no agent fences (they were 20 % of a mosaic: ~11 us per tile,
+    // profiles/r06_ab_fuse_fences.txt).  Everything a statistics block publishes is either an agent-scope atomic (row / column records) or a
+    // write-through store (its slot); a thread's are complete when its vmcnt has drained, the barrier collects the workgroup's, and only
+    // then does thread 0 take the ticket -- so whoever draws the last ticket finds every block's records at the agent's coherence point and
+    // reads them with sc1 loads (ld_agent); no line of them is in this CU's L1 or this XCD's L2 (they are only ever touched by atomics and
+    // sc1 accesses inside this launch, and the ramps / resets the tail writes are for the NEXT launch: kernel boundary).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(S.done, 1u) == gridDim.x * gridDim.y - 1;
     __syncthreads();
     if (!s_last || threadIdx.x >= 256) return;          // the ramps are a 256-thread job (finished waves do not count at the barriers)
-    __threadfence();
     fuse_ramps_tail(r, c, V.ch, dx, dy, S, gridDim.x * gridDim.y, sticky_err);
 }
 
