@@ -1604,3 +1604,71 @@ def test_descriptor_work_list_one_ticket_per_keypoint_regime(engine, oracle):
             engine.features_free(f)
         for h in hs:
             engine.tile_free(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["surf", "orb", "phase"])
+def test_projected_shards_reproduce_the_one_gpu_table_on_the_device(engine, method):
+    """`bench.py --project-shards` (GridRegistrar.register_projected): the pair-sharded step of 2, 3 and 5 ranks run rank after rank on
+    the one device -- cold (no path memory: blind chunk starts + direction stitch-up in assemble) and warm (path memory as the prior:
+    hinted starts, speculation plan, repair round when a hint fails) -- gives the table and final direction of the one-GPU walk
+    (Stitcher.py:196-217's direction threading), row for row."""
+    from imagestitch_amd.grid import GridRegistrar
+    g = SyntheticGrid(3, 4, 1024, overlap=0.10)
+    tiles = g.tiles(threads=4)
+    shapes = [t.shape for t in tiles]
+    hs = [engine.tile_upload(t) for t in tiles]
+    try:
+        one = GridRegistrar(engine, method=method, roiRatio=0.2, offsetEvaluate=3, directIncre=1)
+        want, d_want = one.register(hs, shapes, 1)
+        assert int(want[:, 0].sum()) >= len(tiles) - 2, want
+        for world in (2, 3, 5):
+            rp = GridRegistrar(engine, method=method, roiRatio=0.2, offsetEvaluate=3, directIncre=1)
+            cold, d_cold, per_rank, _tail = rp.register_projected(hs, shapes, 1, world)
+            assert np.array_equal(cold, want) and d_cold == d_want, (method, world, "cold")
+            assert sum(q["pairs"] for q in per_rank) == len(tiles) - 1
+            warm, d_warm, per_rank, _tail = rp.register_projected(hs, shapes, 1, world)      # path memory of the cold step is the prior now
+            assert np.array_equal(warm, want) and d_warm == d_want, (method, world, "warm")
+            assert 0 < sum(q["attempts"] for q in per_rank) <= sum(int(r[4]) + 1 for r in want) + world * 8, per_rank
+    finally:
+        for h in hs:
+            engine.tile_free(h)
+
+
+@pytest.mark.gpu
+def test_mosaic_walk_hand_off_is_stable_over_repeated_assemblies(engine):
+    """The stats -> weights hand-off of the fuse kernels carries no agent-scope fence since round 6 (slots written and read with
+    agent-scope atomics, the ticket orders them): 24 assemblies of the same 3 x 3 mosaic of 2048 x 2048 tiles, alternating with a second
+    geometry so that the slots are rewritten with other values in between, give the same canvas bytes every time."""
+    import zlib
+    T = 2048
+    g = SyntheticGrid(3, 3, T)
+    tiles = g.tiles(threads=4)
+    n = len(tiles)
+    handles = [engine.tile_upload(t) for t in tiles]
+
+    def geometry(offs):
+        offsetList, rangeX, rangeY, rows, cols = isa.Stitcher._layout([t.shape for t in tiles], offs)
+        rois = [None] + [(max(offsetList[i][0], rangeX[i - 1][0]), max(offsetList[i][1], rangeY[i - 1][0]),
+                          min(offsetList[i][0] + T, rangeX[i - 1][1]), min(offsetList[i][1] + T, rangeY[i - 1][1])) for i in range(1, n)]
+        geom = [(offsetList[0][0], offsetList[0][1], 0, 0, 0, 0, 0, 0, -1)]
+        geom += [(offsetList[i][0], offsetList[i][1]) + tuple(rois[i]) + (offs[i][0], offs[i][1], 0) for i in range(1, n)]
+        return geom, rows, cols
+    offs_a = [[0, 0]] + [list(map(int, o)) for o in g.true_offsets()]
+    offs_b = [[0, 0]] + [[o[0] + (7 if o[0] > 0 else -7 if o[0] < 0 else 3), o[1] + (5 if k % 2 else -5)] for k, o in enumerate(offs_a[1:])]
+    seen = {}
+    try:
+        for rep in range(24):
+            tag, offs = ("a", offs_a) if rep % 2 == 0 else ("b", offs_b)
+            geom, rows, cols = geometry(offs)
+            cv = engine.canvas_create(rows, cols, 1)
+            try:
+                engine.canvas_assemble_resident(cv, handles, geom)
+                crc = zlib.crc32(engine.canvas_download(cv, rows, cols, 1).tobytes())
+            finally:
+                engine.canvas_free(cv)
+            assert seen.setdefault(tag, crc) == crc, (rep, tag)
+    finally:
+        for h in handles:
+            engine.tile_free(h)
+    assert len(seen) == 2 and seen["a"] != seen["b"]
