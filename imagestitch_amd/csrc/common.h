@@ -204,6 +204,7 @@ struct vfsms_ctx {
     std::unordered_map<int64_t, FeatBlock> feat_blocks;      // one allocation for the sets of a batch (vfsms_features_surf_batch), freed with its last set
     int64_t next_handle;
     std::list<FftPlan> plans;            // list: get_plan hands out stable pointers
+    std::vector<std::pair<int, void *>> fft_tabs;   // twiddle tables exp(-2 pi i q / L) of the LDS transforms of phase_kernels.hip, one per length
     // optional per-stage timing with HIP events on this context's stream (vfsms_profile_*)
     bool prof_on;
     std::vector<ProfRec> prof_recs;
