@@ -1144,10 +1144,39 @@ def main():
         if ph_n:
             M, N = optimal_dft_size(roi_h), optimal_dft_size(roi_w)
             per_attempt = 2 * roi_h * roi_w + 240 * M * (N // 2 + 1) + 8 * M * N
-            roofline = hbm_roofline("rocFFT r2c/c2r + k_pad_u8_f64 + k_cross_power + k_argmax_*", per_attempt * st["attempts"] / ph_n, ph_ms / ph_n, ph_n,
-                                    note="one 'launch' = one batched phase correlation (pad, 2 forward + 1 inverse FP64 transforms, cross power, "
-                                         "argmax, centroid) over all attempts of a batch; bytes per attempt = 2hw + 240 M (N/2+1) + 8 MN",
-                                    attempts_per_launch=st["attempts"] / ph_n, padded=[M, N])
+            plan = eng.phase_plan(roi_h, roi_w)
+            if plan["lds_transforms"]:
+                # since round 6 the transforms run in LDS: a strip's spectra cross HBM three times (rows -> columns -> rows), not the 2 x 2 x 3 passes
+                # + 3 cross-power streams SURVEY 8d's figure counts for a transform library -- `achieved` stays on SURVEY's bytes (the work done),
+                # `bytes_moved_by_this_design` is what these kernels read and write
+                Mc, Nr = plan["M"], plan["N"]
+                hh = roi_w if plan["transposed"] else roi_h
+                Ct = plan["columns_per_workgroup"]
+                ncp = ((Nr // 2 + 1 + Ct - 1) // Ct) * Ct
+                moved = (2 * roi_h * roi_w * (3 if plan["transposed"] else 1) + 2 * 2 * 16 * hh * (Nr // 2 + 1) + 2 * 16 * Mc * ncp + 8 * Mc * Nr)
+                roofline = hbm_roofline("k_phase_rows_fwd + k_phase_cols + k_phase_rows_inv + k_peak_centroid", per_attempt * st["attempts"] / ph_n, ph_ms / ph_n, ph_n,
+                                        note="one 'launch' = one batched phase correlation over all attempts of a batch: FP64 row transforms (packed real, LDS), "
+                                             "column transforms + cross power + inverse column transforms in ONE kernel (LDS), inverse rows + arg-max, centroid; "
+                                             "bytes per attempt = SURVEY 8d's 2hw + 240 M (N/2+1) + 8 MN (a transform library's passes); this design moves "
+                                             "bytes_moved_by_this_design per attempt, and its kernels are 50-70 % VALU-busy (FP64 butterflies + addressing: "
+                                             "profiles/r06_pmc_phase.txt) -- no unit of the chip is the single roof",
+                                        attempts_per_launch=st["attempts"] / ph_n, padded=[M, N], plan=plan,
+                                        bytes_moved_by_this_design=moved, frac_of_bytes_moved=round(moved * st["attempts"] / ph_n / (ph_ms / ph_n * 1e-3) / 8e12, 4))
+                # PMC traffic of the path's kernels (profiles/*_pmc_summary.txt, phase section: batches of 32 attempts) per attempt x this run's attempts per launch
+                parts = [pmc_total(kname, "total(x2 rule)")[0] for kname in ("k_phase_rows_fwd", "k_phase_cols", "k_phase_rows_inv", "k_peak_centroid")]
+                tot = sum(parts) + (pmc_total("k_phase_transpose_u8", "total(x2 rule)")[0] or 0.0) if all(v is not None for v in parts) else None
+                _t, n_cols = pmc_total("k_phase_cols", "total(x2 rule)")
+                apl, src = pmc_value("k_phase_cols", "attempts_per_launch")
+                if tot and n_cols and apl:
+                    roofline["traffic"] = tot / (n_cols * apl) * st["attempts"] / ph_n
+                    roofline["traffic_source"] = src
+                    roofline["traffic_over_bytes_moved"] = round(roofline["traffic"] / (moved * st["attempts"] / ph_n), 3)
+                    roofline["valu_busy_frac_pmc"] = {k: pmc_value(k, "valu_busy_frac")[0] for k in ("k_phase_rows_fwd", "k_phase_cols", "k_phase_rows_inv")}
+            else:
+                roofline = hbm_roofline("rocFFT r2c/c2r + k_pad_u8_f64 + k_cross_power + k_argmax_*", per_attempt * st["attempts"] / ph_n, ph_ms / ph_n, ph_n,
+                                        note="one 'launch' = one batched phase correlation (pad, 2 forward + 1 inverse FP64 transforms, cross power, "
+                                             "argmax, centroid) over all attempts of a batch; bytes per attempt = 2hw + 240 M (N/2+1) + 8 MN",
+                                        attempts_per_launch=st["attempts"] / ph_n, padded=[M, N], plan=plan)
     if args.method == "orb":
         fa_ms, fa_n = prof.get("orb_fast", (0.0, 0))
         if fa_n:

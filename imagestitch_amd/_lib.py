@@ -123,6 +123,7 @@ _SIGNATURES = {
     "vfsms_pairs_offsets_eval": (C.c_int, [ATTEMPT_EVAL, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.POINTER(GridParams), C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "vfsms_attempt_phase_batch": (C.c_int, [C.c_void_p, C.POINTER(RoiPair), C.c_int, C.c_void_p]),
+    "vfsms_phase_plan": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     "vfsms_canvas_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "vfsms_canvas_free": (C.c_int, [C.c_void_p, C.c_int64]),
     "vfsms_canvas_paste": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -448,6 +449,13 @@ class Engine:
         out = np.zeros(3, np.float64)
         self._check(self.lib.vfsms_phase_correlate_u8(self.ctx, _ptr(a), _ptr(b), a.shape[0], a.shape[1], a.strides[0], b.strides[0], _ptr(out)))
         return (float(out[0]), float(out[1])), float(out[2])
+
+    def phase_plan(self, h, w):
+        """-> dict: how a strip of h x w is correlated (vfsms_phase_plan): the LDS transforms or rocFFT, orientation, padded sizes, workgroup shapes"""
+        info = np.zeros(8, np.int32)
+        self._check(self.lib.vfsms_phase_plan(int(h), int(w), _ptr(info)))
+        keys = ("lds_transforms", "transposed", "M", "N", "columns_per_workgroup", "rows_per_workgroup", "row_threads", "column_threads")
+        return {k: int(v) for k, v in zip(keys, info)}
 
     def fuse_fade_i64(self, A, B, dx, dy, return_info=False):
         A = np.ascontiguousarray(A, np.int64); B = np.ascontiguousarray(B, np.int64)

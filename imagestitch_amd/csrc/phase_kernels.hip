@@ -187,6 +187,9 @@ __global__ __launch_bounds__(64) void k_argmax_centroid(const double *__restrict
 // arg-max / centroid index the surface through the original coordinates -- so that the long axis is always the contiguous one.
 // Lengths: every 2^a 3^b 5^c that fits (radix 4 / 2 / 3 / 5 passes, one LDS buffer: all inputs of a pass are in registers before a barrier,
 // all outputs written after it); an odd row length or a column too long for LDS takes the rocFFT path below.
+#ifndef PHASE_TW_LOAD
+#define PHASE_TW_LOAD 0  // 1: the R - 1 twiddles of a radix >= 8 butterfly are gathered from the (L1 / L2 resident) table instead of formed by squaring from one
+#endif
 struct FftPass { int R, Ls, m, twstride; unsigned magic_m, magic_Ls; };      // m = L / R butterflies per transform; Ls = length done so far
 struct FftSched { int n, L; unsigned magic_L, magic_L1; FftPass p[13]; };      // magic_L / magic_L1: x / L and x / (L + 1) by __umulhi
 
@@ -333,14 +336,33 @@ __device__ __forceinline__ void fft_pass(cplx *buf, const cplx *__restrict__ tw,
             const int f = P.magic_m ? (int)__umulhi((unsigned)id, P.magic_m) : id;       // id / m (magic 0: m == 1)
             const int j = id - f * P.m;
             const int k = P.magic_Ls ? j - (int)__umulhi((unsigned)j, P.magic_Ls) * P.Ls : 0;   // j % Ls (magic 0: Ls == 1)
+            const int kk = k * P.twstride;
             cplx w1; w1.x = 1.0; w1.y = 0.0;
-            if (P.Ls > 1) w1 = tw[k * P.twstride];
-            const cplx *src = buf + f * LP;
-#pragma unroll
-            for (int t = 0; t < R; t++) v[i][t] = src[pad_e(j + t * P.m)];
+            cplx wt[PHASE_TW_LOAD && R >= 8 ? R : 1];
             if (P.Ls > 1) {
-                w1.y = s > 0.0 ? -w1.y : w1.y;
-                apply_powers<R>(v[i], w1);
+                if (PHASE_TW_LOAD && R >= 8) {
+#pragma unroll
+                    for (int t = 1; t < R; t++) wt[PHASE_TW_LOAD && R >= 8 ? t : 0] = tw[t * kk];
+                } else {
+                    w1 = tw[kk];
+                }
+            }
+            const cplx *src = buf + f * LP;
+            int e = j;
+#pragma unroll
+            for (int t = 0; t < R; t++) { v[i][t] = src[pad_e(e)]; e += P.m; }
+            if (P.Ls > 1) {
+                if (PHASE_TW_LOAD && R >= 8) {
+#pragma unroll
+                    for (int t = 1; t < R; t++) {
+                        cplx w = wt[PHASE_TW_LOAD && R >= 8 ? t : 0];
+                        w.y = s > 0.0 ? -w.y : w.y;
+                        v[i][t] = c_mul(v[i][t], w);
+                    }
+                } else {
+                    w1.y = s > 0.0 ? -w1.y : w1.y;
+                    apply_powers<R>(v[i], w1);
+                }
             }
             bfly<R>(v[i], s);
             ob[i] = (j - k) * R + k + (f << 16);
@@ -351,9 +373,9 @@ __device__ __forceinline__ void fft_pass(cplx *buf, const cplx *__restrict__ tw,
     for (int i = 0; i < NB; i++)
         if (ob[i] >= 0) {
             cplx *dst = buf + (ob[i] >> 16) * LP;
-            const int e0 = ob[i] & 0xffff;
+            int e = ob[i] & 0xffff;
 #pragma unroll
-            for (int t = 0; t < R; t++) dst[pad_e(e0 + t * P.Ls)] = v[i][t];
+            for (int t = 0; t < R; t++) { dst[pad_e(e)] = v[i][t]; e += P.Ls; }
         }
     __syncthreads();
 }
@@ -397,11 +419,14 @@ __device__ __forceinline__ int div_magic(int x, unsigned magic) { return magic ?
 
 // The global loads of a workgroup's prologue are issued TOGETHER (fixed, unrolled trip counts; clamped addresses instead of branches): with the
 // plain strided loops a thread waited out one HBM round trip per iteration, eight times in a row, with a handful of waves per CU to hide it.
+#ifndef PHASE_DBG
+#define PHASE_DBG 0      // timing experiments only (tools/job_r06_*.sh): 1 no forward column passes, 2 no inverse ones, 4 no cross power
+#endif
 #define PHASE_NI 8          // points of a workgroup per thread, at most (host: nfft * L <= 8 T)
 
 // Forward row transforms: workgroup = RPW rows of one image (blockIdx.y = 2 * job + image), rows [0, hh) of length ww padded to N = 2 H.
 // LDS: RPW transforms of H points (padded layout).  FQ: [2 nb][M][H + 1].
-__global__ __launch_bounds__(512) void k_phase_rows_fwd(const PhaseJob *__restrict__ jobs, int hh, int ww, int M, int RPW, const FftSched S,
+__global__ __launch_bounds__(512) void k_phase_rows_fwd(const PhaseJob *__restrict__ jobs, int hh, int ww, int M, int RPW, int lc, const FftSched S,
                                                          const cplx *__restrict__ tabN, cplx *__restrict__ FQ)
 {
     extern __shared__ __align__(16) unsigned char phase_lds[];
@@ -438,7 +463,8 @@ __global__ __launch_bounds__(512) void k_phase_rows_fwd(const PhaseJob *__restri
     __syncthreads();
     fft_lds(buf, tabN, S, LP, rows, -1.0, tid, T);
     // X[k] = ((Z[k] + conj Z[H-k]) - i e^(-2 pi i k / N) (Z[k] - conj Z[H-k])) / 2,  k = 0 .. H, Z[H] = Z[0]
-    const int Nc = H + 1, nout = rows * Nc;
+    const int Nc = H + 1, nout = rows * Nc, C = 1 << lc;
+    const size_t plane = (size_t)M * (((Nc + C - 1) >> lc) << lc);            // spectra are stored in column tiles of C: [tile][row][C]
     cplx wk[PHASE_NI + 1];
 #pragma unroll
     for (int i = 0; i < PHASE_NI + 1; i++) {
@@ -456,7 +482,7 @@ __global__ __launch_bounds__(512) void k_phase_rows_fwd(const PhaseJob *__restri
             zc.y = -zc.y;
             const cplx e = c_add(zk, zc), o = c_mul(c_sub(zk, zc), wk[i]);
             cplx x; x.x = 0.5 * (e.x + o.y); x.y = 0.5 * (e.y - o.x);             // e - i o
-            FQ[((size_t)blockIdx.y * M + y0 + r) * Nc + k] = x;
+            FQ[(size_t)blockIdx.y * plane + ((size_t)(k >> lc) * M + y0 + r) * C + (k & (C - 1))] = x;
         }
     }
 }
@@ -471,21 +497,21 @@ __global__ __launch_bounds__(512) void k_phase_cols(const cplx *__restrict__ FQ,
     cplx *buf = (cplx *)phase_lds;
     const int v0 = blockIdx.x * C;
     const int cols = min(C, Nc - v0);
-    const size_t plane = (size_t)M * Nc;
-    const cplx *A = FQ + (size_t)(2 * blockIdx.y) * plane;
+    const size_t plane = (size_t)M * gridDim.x * C;                           // [tile][row][C]: this workgroup's tile is CONTIGUOUS
+    const cplx *A = FQ + (size_t)(2 * blockIdx.y) * plane + (size_t)blockIdx.x * M * C;
     {
         cplx z[PHASE_NI];
 #pragma unroll
         for (int i = 0; i < PHASE_NI; i++) {
-            const int p = tid + i * T;                                           // p = (u * 2 + img) * C + c
-            const int c = min(p & (C - 1), cols - 1), t = p >> lc, img = t & 1, u = min(t >> 1, hh - 1);
-            z[i] = A[(size_t)img * plane + (size_t)u * Nc + v0 + c];
+            const int p = tid + i * T;                                           // p = (img * M + u) * C + c
+            const int t = p >> lc, img = t >= M ? 1 : 0, u = min(t - img * M, hh - 1);
+            z[i] = A[(size_t)img * plane + (size_t)u * C + (p & (C - 1))];
         }
 #pragma unroll
         for (int i = 0; i < PHASE_NI; i++) {
             const int p = tid + i * T;
-            const int c = p & (C - 1), t = p >> lc, img = t & 1, u = t >> 1;
-            if (u < M) {
+            const int c = p & (C - 1), t = p >> lc, img = t >= M ? 1 : 0, u = t - img * M;
+            if (t < 2 * M) {
                 cplx o = z[i];
                 if (u >= hh || c >= cols) { o.x = 0.0; o.y = 0.0; }
                 buf[(img * C + c) * LP + pad_e(u)] = o;
@@ -493,8 +519,11 @@ __global__ __launch_bounds__(512) void k_phase_cols(const cplx *__restrict__ FQ,
         }
     }
     __syncthreads();
+#if !(PHASE_DBG & 1)
     fft_lds(buf, tabM, S, LP, 2 * C, -1.0, tid, T);
+#endif
     const double eps = DBL_EPSILON;
+#if !(PHASE_DBG & 4)
     for (int p = tid; p < M * C; p += T) {
         const int c = div_magic(p, S.magic_L), u = p - c * M, v = v0 + c;
         const cplx f1 = buf[c * LP + pad_e(u)], f2 = buf[(C + c) * LP + pad_e(u)];
@@ -515,17 +544,17 @@ __global__ __launch_bounds__(512) void k_phase_cols(const cplx *__restrict__ FQ,
         buf[c * LP + pad_e(u)] = o;
     }
     __syncthreads();
+#endif
+#if !(PHASE_DBG & 2)
     fft_lds(buf, tabM, S, LP, C, 1.0, tid, T);
-    cplx *O = CP + (size_t)blockIdx.y * plane;
-    for (int p = tid; p < M * C; p += T) {
-        const int c = p & (C - 1), u = p >> lc;
-        if (c < cols) O[(size_t)u * Nc + v0 + c] = buf[c * LP + pad_e(u)];
-    }
+#endif
+    cplx *O = CP + (size_t)blockIdx.y * plane + (size_t)blockIdx.x * M * C;   // the same tiled layout: one contiguous run
+    for (int p = tid; p < M * C; p += T) O[p] = buf[(p & (C - 1)) * LP + pad_e(p >> lc)];
 }
 
 // Inverse row transforms + the arg-max of the row block: workgroup = RPW rows of one job (blockIdx.y).  CP: [nb][M][H + 1] -> RE: [nb][M][2 H].
 // tr: the planes hold the TRANSPOSED problem (stored row = original column); the arg-max index is over the original, shifted surface.
-__global__ __launch_bounds__(512) void k_phase_rows_inv(const cplx *__restrict__ CP, double *__restrict__ RE, int M, int RPW, const FftSched S,
+__global__ __launch_bounds__(512) void k_phase_rows_inv(const cplx *__restrict__ CP, double *__restrict__ RE, int M, int RPW, int lc, const FftSched S,
                                                          const cplx *__restrict__ tabN, int tr, ArgMax *__restrict__ partial)
 {
     extern __shared__ __align__(16) unsigned char phase_lds[];
@@ -534,7 +563,8 @@ __global__ __launch_bounds__(512) void k_phase_rows_inv(const cplx *__restrict__
     const int y0 = blockIdx.x * RPW;
     const int rows = min(RPW, M - y0);
     const int npts = rows * H;
-    const cplx *G = CP + ((size_t)blockIdx.y * M + y0) * Nc;
+    const int C = 1 << lc;
+    const cplx *G = CP + (size_t)blockIdx.y * M * (((Nc + C - 1) >> lc) << lc) + (size_t)y0 * C;      // [tile][row][C]
     // Z[k] = (G[k] + conj G[H-k]) + i e^(+2 pi i k / N) (G[k] - conj G[H-k]),  k = 0 .. H-1; the imaginary parts of the DC and Nyquist bins do
     // not exist in the packed format of the reference (and rocFFT's real inverse ignores them): dropped
     {
@@ -543,7 +573,8 @@ __global__ __launch_bounds__(512) void k_phase_rows_inv(const cplx *__restrict__
         for (int i = 0; i < PHASE_NI; i++) {
             const int p = min(tid + i * T, npts - 1);
             const int r = div_magic(p, S.magic_L), k = p - r * H;
-            gk[i] = G[(size_t)r * Nc + k]; gc[i] = G[(size_t)r * Nc + H - k]; w[i] = tabN[k];
+            const int kc = H - k;
+            gk[i] = G[((size_t)(k >> lc) * M + r) * C + (k & (C - 1))]; gc[i] = G[((size_t)(kc >> lc) * M + r) * C + (kc & (C - 1))]; w[i] = tabN[k];
         }
 #pragma unroll
         for (int i = 0; i < PHASE_NI; i++) {
@@ -606,21 +637,29 @@ __global__ __launch_bounds__(64) void k_peak_centroid(const double *__restrict__
         o.v = __shfl_down(best.v, d); o.idx = __shfl_down(best.idx, d);
         best = better(best, o);
     }
-    if (threadIdx.x != 0) return;
+    best.v = __shfl(best.v, 0); best.idx = __shfl(best.idx, 0);
     const int py = (int)(best.idx / N), px = (int)(best.idx % N);
     int minr = py - 2, maxr = py + 2, minc = px - 2, maxc = px + 2;
     if (minr < 0) minr = 0;
     if (minc < 0) minc = 0;
     if (maxr > M - 1) maxr = M - 1;
     if (maxc > N - 1) maxc = N - 1;
+    // the (at most) 25 window elements are fetched by 25 lanes at once; lane 0 then accumulates them in the reference's row-major order
+    const int wc = maxc - minc + 1, cnt = (maxr - minr + 1) * wc;
+    double mine = 0.0;
+    if ((int)threadIdx.x < cnt) {
+        const int y = minr + (int)threadIdx.x / wc, x = minc + (int)threadIdx.x % wc;
+        int uy, ux;
+        unshift2(y, x, M, N, uy, ux);
+        mine = R[(size_t)uy * sy + (size_t)ux * sx];
+    }
     double cx = 0, cy = 0, s = 0;
-    for (int y = minr; y <= maxr; y++)
-        for (int x = minc; x <= maxc; x++) {
-            int uy, ux;
-            unshift2(y, x, M, N, uy, ux);
-            const double v = R[(size_t)uy * sy + (size_t)ux * sx];
-            cx += (double)x * v; cy += (double)y * v; s += v;
-        }
+    for (int q = 0; q < cnt; q++) {
+        const double v = __shfl(mine, q);
+        const int y = minr + q / wc, x = minc + q % wc;
+        cx += (double)x * v; cy += (double)y * v; s += v;
+    }
+    if (threadIdx.x != 0) return;
     double response = s;
     s += DBL_EPSILON;
     cx /= s; cy /= s;
@@ -711,7 +750,7 @@ static bool phase_own_shape(int h, int w, OwnShape *S)
         if ((N & 1) || N < 4 || M < 2) continue;
         const int H = N / 2;
         if (H > 4096) continue;
-        const int RPW = std::max(1, std::min(16, 2048 / H));
+        const int RPW = std::max(1, std::min(16, std::max(1, env_int("VFSMS_PHASE_ROWPTS", 2048)) / H));      // rows of a workgroup: ~2048 points
         const int tdiv = std::max(1, env_int("VFSMS_PHASE_TDIV", 8));                    // points of a workgroup per thread
         const int Trow = round64((RPW * H + tdiv - 1) / tdiv);
         const size_t lds_row = sizeof(cplx) * (size_t)RPW * fft_lp(H);
@@ -789,10 +828,24 @@ static int get_tab(vfsms_ctx *ctx, int L, const cplx **out)
     return VFSMS_OK;
 }
 
+extern "C" int vfsms_phase_plan(int h, int w, int32_t *info8)
+{
+    if (h <= 0 || w <= 0 || !info8) { vfsms_set_error("phase_plan: bad arguments"); return VFSMS_ERR_BAD_ARG; }
+    OwnShape S;
+    memset(info8, 0, sizeof(int32_t) * 8);
+    if (phase_own_shape(h, w, &S)) {
+        const int32_t v[8] = {1, S.tr, S.M, S.N, S.C, S.RPW, S.Trow, S.Tcol};
+        memcpy(info8, v, sizeof(v));
+    } else {
+        info8[2] = optimal_dft_size(h); info8[3] = optimal_dft_size(w);
+    }
+    return VFSMS_OK;
+}
+
 static size_t own_bytes(const OwnShape &S, int h, int w, int nb)
 {
     const size_t c = (size_t)std::min(nb, PHASE_MAX_CHUNK);
-    const size_t cpl = sizeof(cplx) * (size_t)S.M * (S.H + 1);
+    const size_t cpl = sizeof(cplx) * (size_t)S.M * (((S.H + 1 + S.C - 1) / S.C) * S.C);
     return al256(c * sizeof(double) * S.M * S.N) + al256(2 * c * cpl) + al256(c * cpl) + al256(2 * c * (size_t)h * w) + al256(sizeof(PhaseJob) * 2 * nb) +
            al256(sizeof(ArgMax) * c * S.M) + 65536;
 }
@@ -808,7 +861,7 @@ static int phase_own_batch(vfsms_ctx *ctx, const OwnShape &S, const PhaseJobHost
     }
     const int M = S.M, N = S.N, Nc = S.H + 1;
     const int cmax = std::min(nb, std::max(1, std::min(PHASE_MAX_CHUNK, env_int("VFSMS_PHASE_CHUNK", PHASE_MAX_CHUNK))));
-    const size_t real = (size_t)M * N, cpl = (size_t)M * Nc;
+    const size_t real = (size_t)M * N, cpl = (size_t)M * (((Nc + S.C - 1) / S.C) * S.C);          // spectra in column tiles of C
     const int nparts = (M + S.RPW - 1) / S.RPW;
     double *RE = (double *)ctx_arena_alloc(ctx, sizeof(double) * cmax * real);
     cplx *FQ = (cplx *)ctx_arena_alloc(ctx, sizeof(cplx) * 2 * cmax * cpl);
@@ -836,10 +889,10 @@ static int phase_own_batch(vfsms_ctx *ctx, const OwnShape &S, const PhaseJobHost
             hipLaunchKernelGGL(k_phase_transpose_u8, dim3((w + 63) / 64, (h + 63) / 64, 2 * c), dim3(256), 0, ctx->stream, dj + done, h, w, TB);
             rowjobs = dj + nb;
         }
-        hipLaunchKernelGGL(k_phase_rows_fwd, dim3((S.hh + S.RPW - 1) / S.RPW, 2 * c), dim3(S.Trow), S.lds_row, ctx->stream, rowjobs, S.hh, S.ww, M, S.RPW, SR,
-                           tabN, FQ);
+        hipLaunchKernelGGL(k_phase_rows_fwd, dim3((S.hh + S.RPW - 1) / S.RPW, 2 * c), dim3(S.Trow), S.lds_row, ctx->stream, rowjobs, S.hh, S.ww, M, S.RPW, S.lc,
+                           SR, tabN, FQ);
         hipLaunchKernelGGL(k_phase_cols, dim3((Nc + S.C - 1) / S.C, c), dim3(S.Tcol), S.lds_col, ctx->stream, (const cplx *)FQ, CP, S.hh, Nc, N, S.lc, SC, tabM);
-        hipLaunchKernelGGL(k_phase_rows_inv, dim3(nparts, c), dim3(S.Trow), S.lds_row, ctx->stream, (const cplx *)CP, RE, M, S.RPW, SR, tabN, S.tr, partial);
+        hipLaunchKernelGGL(k_phase_rows_inv, dim3(nparts, c), dim3(S.Trow), S.lds_row, ctx->stream, (const cplx *)CP, RE, M, S.RPW, S.lc, SR, tabN, S.tr, partial);
         // the surface as the reference indexes it: oM x oN (the original padded size)
         const int oM = S.tr ? N : M, oN = S.tr ? M : N;
         hipLaunchKernelGGL(k_peak_centroid, dim3(c), dim3(64), 0, ctx->stream, (const double *)RE, oM, oN, (long long)(S.tr ? 1 : N), (long long)(S.tr ? N : 1),

@@ -210,6 +210,11 @@ int vfsms_mode_offset(vfsms_ctx *ctx, const float *kpsA, int nA, const float *kp
 /* cv2.phaseCorrelate(np.float64(a), np.float64(b)) (Stitcher.py:230): out3 = {x, y, response}     */
 int vfsms_phase_correlate_u8(vfsms_ctx *ctx, const uint8_t *a, const uint8_t *b, int h, int w,
                              int stride_a, int stride_b, double *out3);
+/* How a strip of h x w is correlated (no reference counterpart: what bench.py / the tests report about the path that ran).
+ * info8 = {1 = the transforms run in LDS (csrc/phase_kernels.hip) | 0 = rocFFT plans, 1 = correlated as its byte transpose,
+ *          column length M, row length N (the padded sizes in the orientation used), columns per workgroup, rows per workgroup,
+ *          threads of a row workgroup, threads of a column workgroup}; no device work                                           */
+int vfsms_phase_plan(int h, int w, int32_t *info8);
 
 /* ImageFusion.fuseByFadeInAndFadeOut([A,B],dx,dy) (ImageFusion.py:192-244) on the reference's own
  * representation: int64 [r][c][ch] with -1 = empty (Stitcher.py:434-436).  out: uint8 [r][c][ch].

@@ -1,19 +1,14 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/r06z
-for ch in 32 16 8 4; do
-  echo "== CHUNK=$ch"
-  VFSMS_PHASE_CHUNK=$ch timeout 300 python tools/phase_ab.py 32 20 t 2>&1 | grep "LDS transforms"
+cd /tmp && export TMPDIR=/tmp
+for v in base twload; do
+  lib=$R/build_ab/$v.so; [ $v = base ] && lib=$R/imagestitch_amd/lib/libvfsms.so
+  rm -rf $R/gpurun_out/r06z/prof
+  VFSMS_LIB=$lib timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r06z/prof -o ph -- python $R/tools/phase_ab.py 32 10 t > $R/gpurun_out/r06z/ab_$v.log 2>&1
+  grep "LDS transforms" $R/gpurun_out/r06z/ab_$v.log | cut -c1-100
+  db=$(ls $R/gpurun_out/r06z/prof/*results.db 2>/dev/null | head -1)
+  [ -n "$db" ] && python $R/tools/rocpd_summary.py $db $R/gpurun_out/r06z/ks_$v.csv > /dev/null && echo "$v:" && grep "k_phase\|k_peak" $R/gpurun_out/r06z/ks_$v.csv | awk -F, '{print "   ", $1, $(NF-1)}' | cut -c1-60
 done
-timeout 600 python bench.py --method phase > $R/gpurun_out/r06z/bench_phase.json 2> $R/gpurun_out/r06z/bench_phase.err
-python - <<'PY'
-import json
-d = json.loads(open("gpurun_out/r06z/bench_phase.json").read().strip().splitlines()[-1])
-print(d["value"], d["unit"], d["ms_per_step"], d.get("roofline"))
-PY
-VFSMS_PHASE_LDS_FFT=0 timeout 600 python bench.py --method phase --cpu-sample 0 > $R/gpurun_out/r06z/bench_phase_rocfft.json 2> $R/gpurun_out/r06z/bench_phase_rocfft.err
-python - <<'PY'
-import json
-d = json.loads(open("gpurun_out/r06z/bench_phase_rocfft.json").read().strip().splitlines()[-1])
-print("rocfft:", d["value"], d["unit"], d["ms_per_step"])
-PY
+rm -rf $R/gpurun_out/r06z/prof
+cd $R; VFSMS_LIB=$R/build_ab/twload.so timeout 300 python tools/phase_ab.py 4 2 2>&1 | grep "worst"

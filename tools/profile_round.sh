@@ -96,4 +96,32 @@ except Exception as e:
 out.close()
 print(open('$OUT/pmc_summary.txt').read())
 PY
-rm -rf $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_ta $OUT/pmc_mfma
+# ---- the phase path's own kernels (csrc/phase_kernels.hip, LDS transforms): batches of 32 attempts of the bench's two strip shapes ----
+PHCMD="python tools/phase_ab.py 32 2 t"
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES -d $OUT/pmc_ph_sq -o pmc --output-format csv -- $PHCMD > $OUT/pmc_ph_sq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_ph_fetch -o pmc --output-format csv -- $PHCMD > $OUT/pmc_ph_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_ph_write -o pmc --output-format csv -- $PHCMD > $OUT/pmc_ph_write.log 2>&1
+python - <<PY
+import csv, glob, collections
+def agg(pat):
+    a=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(set)
+    f=glob.glob(pat, recursive=True)
+    if not f: return a, {}
+    for row in csv.DictReader(open(f[0])):
+        k=row['Kernel_Name'].split('(')[0]
+        a[k][row['Counter_Name']]+=float(row['Counter_Value']); n[k].add(row.get('Dispatch_Id'))
+    return a, {k: len(v) for k, v in n.items()}
+sq,nsq=agg('$OUT/pmc_ph_sq/**/*counter_collection.csv'); f,nf=agg('$OUT/pmc_ph_fetch/**/*counter_collection.csv'); w,nw=agg('$OUT/pmc_ph_write/**/*counter_collection.csv')
+out=open('$OUT/pmc_summary.txt','a')
+out.write('\n# the phase path (separate passes of `tools/phase_ab.py 32 2 t`: batches of 32 attempts, 409 x 2048 strips and 2048 x 409 strips (transposed first)):\n# per launch; valu_busy_frac = INSTS_VALU x 4 cycles / (BUSY_CYCLES / 32 x 1024 SIMDs); traffic by the same x2 rule as above\n')
+for k in sorted(sq):
+    if 'k_phase' in k or 'k_peak' in k:
+        n=max(nsq.get(k,1),1); v=sq[k]
+        busy=v.get('SQ_BUSY_CYCLES',0)/n/32.0
+        fb=f.get(k,{}).get('FETCH_SIZE',0)*1024/max(nf.get(k,n),1); wb=w.get(k,{}).get('WRITE_SIZE',0)*1024/max(nw.get(k,n),1)
+        out.write('%-24s launches=%d attempts_per_launch=32 '%(k[:24],n)+' '.join('%s=%.4g'%(c.replace('SQ_',''),x/n) for c,x in sorted(v.items()))+
+                  ' valu_busy_frac=%.3f fetch_x2=%.4g B/launch write=%.4g B/launch total(x2 rule)=%.4g B/launch\n' % ((v.get('SQ_INSTS_VALU',0)/n*4.0)/(busy*1024.0) if busy else 0.0, 2*fb, wb, 2*fb+wb))
+out.close()
+print(open('$OUT/pmc_summary.txt').read()[-2500:])
+PY
+rm -rf $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_ta $OUT/pmc_mfma $OUT/pmc_ph_sq $OUT/pmc_ph_fetch $OUT/pmc_ph_write
