@@ -113,7 +113,7 @@ def agg(pat):
     return a, {k: len(v) for k, v in n.items()}
 sq,nsq=agg('$OUT/pmc_ph_sq/**/*counter_collection.csv'); f,nf=agg('$OUT/pmc_ph_fetch/**/*counter_collection.csv'); w,nw=agg('$OUT/pmc_ph_write/**/*counter_collection.csv')
 out=open('$OUT/pmc_summary.txt','a')
-out.write('\n# the phase path (separate passes of `tools/phase_ab.py 32 2 t`: batches of 32 attempts, 409 x 2048 strips and 2048 x 409 strips (transposed first)):\n# per launch; valu_busy_frac = INSTS_VALU x 4 cycles / (BUSY_CYCLES / 32 x 1024 SIMDs); traffic by the same x2 rule as above\n')
+out.write('\n# the phase path (separate passes of tools/phase_ab.py 32 2 t: batches of 32 attempts, 409 x 2048 strips and 2048 x 409 strips (transposed first)):\n# per launch; valu_busy_frac = INSTS_VALU x 4 cycles / (BUSY_CYCLES / 32 x 1024 SIMDs); traffic by the same x2 rule as above\n')
 for k in sorted(sq):
     if 'k_phase' in k or 'k_peak' in k:
         n=max(nsq.get(k,1),1); v=sq[k]
