@@ -75,3 +75,26 @@ def test_reference_module_names_resolve_to_the_engine():
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, os.path.join(root, "imagestitch_amd", "compat")]))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd="/tmp")
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_phase_plan_picks_the_lds_transforms_for_the_strips_of_the_path():
+    """vfsms_phase_plan does no device work: which strips the hand-written LDS transforms take (csrc/phase_kernels.hip), in which orientation, and
+    which stay with rocFFT.  The column axis is the SHORTER padded one (a tall strip is correlated as its transpose), the row length must be even,
+    the padded sizes are cv2.getOptimalDFTSize's (409 -> 432, 819 -> 864, 387 -> 400, 2584 -> 2592)."""
+    import numpy as np
+    lib = isa.load_library()
+
+    def plan(h, w):
+        info = np.zeros(8, np.int32)
+        assert lib.vfsms_phase_plan(h, w, info.ctypes.data_as(ctypes.c_void_p)) == 0
+        return [int(v) for v in info]
+    assert plan(409, 2048)[:4] == [1, 0, 432, 2048]               # strip above / below at 2048^2 tiles, roiRatio 0.2
+    assert plan(2048, 409)[:4] == [1, 1, 432, 2048]               # strip left / right: transposed first
+    assert plan(819, 4096)[:4] == [1, 0, 864, 4096]               # configs[4]
+    assert plan(387, 2584)[:4] == [1, 0, 400, 2592]               # the dendriticCrystal tiles (1936 x 2584)
+    assert plan(97, 131)[:4] == [1, 1, 135, 100]                  # 131 pads to the odd 135: only the other axis can be the packed real one
+    assert plan(625, 625)[0] == 0 and plan(625, 625)[2:4] == [625, 625]      # odd both ways: rocFFT
+    assert plan(3000, 3000)[0] == 0                               # a 3000-point column does not fit LDS twice over: rocFFT
+    p = plan(409, 2048)
+    assert p[4] in (2, 4, 8) and p[5] >= 1 and p[6] % 64 == 0 and p[7] % 64 == 0 and 2 * p[4] * p[2] <= 8 * p[7] and p[5] * p[3] // 2 <= 8 * p[6]
+    assert lib.vfsms_phase_plan(0, 5, np.zeros(8, np.int32).ctypes.data_as(ctypes.c_void_p)) != 0
