@@ -1706,3 +1706,39 @@ def test_phase_peak_on_the_odd_last_row_or_column(engine, oracle):
             for q in row:
                 assert abs(q[0] - ox) < 1e-6 and abs(q[1] - oy) < 1e-6 and abs(q[2] - orr) < 1e-9, (shp, seed, q, (ox, oy, orr))
     assert touched >= 20, touched
+
+
+@pytest.mark.gpu
+def test_phase_lds_transforms_equal_the_rocfft_path_and_the_oracle_over_strip_shapes(engine, oracle):
+    """The hand-written FP64 transforms (csrc/phase_kernels.hip: packed real rows, column kernel with cross power, radix 16 / 9 / 8 / 6 / 10 / 4 /
+    3 / 5 / 2 passes) against the rocFFT plans of rounds 2-5 (VFSMS_PHASE_LDS_FFT=0, same process) and the CPU oracle on the strip shapes of the
+    datasets and then some: both orientations (tall strips run transposed), 3- and 5-smooth paddings, an odd column length (614 -> 625), tiny
+    strips, the config sizes.  1e-9 px between the two device paths, 1e-6 px / 1e-9 response against the oracle (Stitcher.py:230)."""
+    shapes = [(409, 2048), (2048, 409), (387, 2584), (2584, 387), (614, 1280), (1280, 614), (204, 1024), (1024, 256), (128, 640), (97, 131), (131, 97),
+              (625, 64), (64, 625), (80, 96), (16, 16), (6, 10), (37, 64), (300, 1000), (100, 100), (2, 2), (243, 250), (50, 54), (27, 20), (3, 4)]
+    keep = os.environ.get("VFSMS_PHASE_LDS_FFT")
+    took_lds = 0
+    try:
+        for k, shp in enumerate(shapes):
+            a = _rand_img(300 + k, shp)
+            dy, dx = min(5, shp[0] // 3), -min(9, shp[1] // 3)
+            b = np.roll(np.roll(a, dy, 0), dx, 1)
+            b = (b.astype(np.int32) + (_rand_img(400 + k, shp) >> 3)).clip(0, 255).astype(np.uint8)
+            os.environ["VFSMS_PHASE_LDS_FFT"] = "1"
+            took_lds += engine.phase_plan(*shp)["lds_transforms"]
+            (x1, y1), r1 = engine.phase_correlate(a, b)
+            os.environ["VFSMS_PHASE_LDS_FFT"] = "0"
+            assert engine.phase_plan(*shp)["lds_transforms"] == 0
+            (x0, y0), r0 = engine.phase_correlate(a, b)
+            # relative where the centroid's weight sum is next to zero (a few-pixel strip: the quotient is in the millions of pixels)
+            sx, sy = max(1.0, abs(x0)), max(1.0, abs(y0))
+            assert abs(x1 - x0) < 1e-8 * sx and abs(y1 - y0) < 1e-8 * sy and abs(r1 - r0) < 1e-12, (shp, (x1, y1, r1), (x0, y0, r0))
+            if shp[0] * shp[1] <= 1 << 20:
+                (ox, oy), orr = oracle.phase_correlate(np.ascontiguousarray(a), np.ascontiguousarray(b))
+                assert abs(x1 - ox) < 1e-6 * sx and abs(y1 - oy) < 1e-6 * sy and abs(r1 - orr) < 1e-9, (shp, (x1, y1, r1), (ox, oy, orr))
+    finally:
+        if keep is None:
+            os.environ.pop("VFSMS_PHASE_LDS_FFT", None)
+        else:
+            os.environ["VFSMS_PHASE_LDS_FFT"] = keep
+    assert took_lds >= len(shapes) - 2, took_lds               # (2, 2) pads to a 2-point row (rocFFT); everything else runs in LDS

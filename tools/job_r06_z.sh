@@ -1,14 +1,13 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/r06z
-cd /tmp && export TMPDIR=/tmp
-for v in nopre pre128 pre153; do
-  lib=$R/build_ab/$v.so
-  rm -rf $R/gpurun_out/r06z/prof
-  VFSMS_LIB=$lib timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r06z/prof -o ph -- python $R/tools/phase_ab.py 32 10 t > $R/gpurun_out/r06z/ab_$v.log 2>&1
-  grep "LDS transforms" $R/gpurun_out/r06z/ab_$v.log | cut -c1-100
-  db=$(ls $R/gpurun_out/r06z/prof/*results.db 2>/dev/null | head -1)
-  [ -n "$db" ] && python $R/tools/rocpd_summary.py $db $R/gpurun_out/r06z/ks_$v.csv > /dev/null && echo "$v:" && grep "k_phase\|k_peak" $R/gpurun_out/r06z/ks_$v.csv | awk -F, '{print "   ", $1, $(NF-1)}' | cut -c1-60
+# configs[4] on one GPU with smaller speculation windows (batch working set against the 256 MB infinity cache)
+mkdir -p gpurun_out/r06z
+O=gpurun_out/r06z
+for W in 16 24; do
+  timeout 700 python bench.py --rows 32 --cols 32 --tile 4096 --steps 2 --warmup 1 --cpu-sample 0 --no-host-leg --no-cold-leg --prior same --window $W > $O/bench_config4_w$W.json 2> $O/bench_config4_w$W.err
+  tail -1 $O/bench_config4_w$W.err
+  python - $O/bench_config4_w$W.json <<'PY'
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+print(d["value"], d["ms_per_step"], d.get("attempts_per_step"), d.get("batches_per_step"), {k: v["ms_per_launch"] for k, v in d["stages"].items() if k in ("describe", "bf_mfma", "hessian", "orientation", "bf_verify")})
+PY
 done
-rm -rf $R/gpurun_out/r06z/prof
-cd $R; for v in pre128 pre153; do VFSMS_LIB=$R/build_ab/$v.so timeout 300 python tools/phase_ab.py 4 2 2>&1 | grep "worst"; done
