@@ -169,7 +169,7 @@ struct MatchDev {
 struct TileRec { uint8_t *ptr; int h, w, stride; bool owned; hipEvent_t ready; bool pending; int ch = 1; size_t bytes = 0; int fill = 0; };
 struct StageBuf { uint8_t *ptr; size_t bytes; };                    // device staging of one decoded source image (vfsms_tile_fill_pair)
 struct PoolEnt { size_t bytes; uint8_t *ptr; hipEvent_t idle; };   // a freed tile buffer; idle: recorded on the compute stream when the tile was freed
-struct CanvasRec { uint8_t *pix; uint8_t *mask; int rows, cols, ch; int *d_err; void *scratch; };   // d_err: sticky "degenerate fuse geometry" flag for calls made without an info readback; scratch: the fuse's statistics records + ramps
+struct CanvasRec { uint8_t *pix; uint8_t *mask; int rows, cols, ch; int *d_err; void *scratch; std::vector<int32_t> placed; };   // d_err: sticky "degenerate fuse geometry" flag for calls made without an info readback; scratch: the fuse's statistics records + ramps; placed: (y0, x0, y1, x1) of every tile rectangle written so far = the canvas's validity (canvas_fuse_device counts the valid pixels of a ROI from it)
 struct FftPlan { int M, N, nb; void *fwd, *inv, *fwd_info, *inv_info; size_t fwd_work, inv_work; };   // rocfft_plan / rocfft_execution_info
 struct PhaseJobHost { const uint8_t *a, *b; int sa, sb; };
 struct ProfRec { int id; hipEvent_t a, b; };

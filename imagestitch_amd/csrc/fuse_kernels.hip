@@ -12,7 +12,9 @@
 #include "common.h"
 #include "detmath.h"
 #include <vector>
+#include <algorithm>
 #include <string.h>
+#include <stdlib.h>
 
 struct FuseStats {                  // device-side result of k_fuse_stats
     unsigned long long valid;       // count_nonzero(A > -1)  (elements)
@@ -78,18 +80,47 @@ __device__ __forceinline__ uint8_t trig_px(const TrigGeom &G, bool corner, int i
     res = res > 255 ? 255 : res;
     return (uint8_t)res;
 }
+// the strip ramps of fuseByFadeInAndFadeOut in closed form, with the reference's float32 expression ((1. * f) * 1.0) / n:
+//   col <= row: weightMatA_2[col - i - 1] = weightMatB_2[i] = f(i) / col, f(i) = i (dy >= 0) or col - i;  else  weightMatA_1[i] =
+//   weightMatB_1[row - i - 1] = g(i) / row, g(i) = i (dx <= 0) or row - i  (what fuse_weights_body's strip branch stores into the arrays)
+// kind 3: getWeightsMatrix's corner ramps (ImageFusion.py:43-190 as fuse_weights_body stores them) from (index, rowIndex, colIndex):
+//   rows, index 2 / 1: weightMatB_1[i] = i / ri for 0 <= i <= rowIndex (ri = rowIndex, 0 patched to 1: then only [1] = 1 is written);
+//         index 3 / 0: weightMatB_1[i] = (row - i - 1) / (row - ri - 1) for i >= max(rowIndex, 0);   columns alike with colIndex, index 2 / 3 | 0 / 1
+//   quotients in float64, stored as float32; everything else stays 1
+struct AnalyticRamps {
+    int kind, r, c, dx, dy;
+    int index, rowIndex, colIndex;
+    __device__ __forceinline__ float corner_b(int i, int n, int at, bool counting_up) const
+    {
+        const int ai = at == 0 ? 1 : at;
+        if (counting_up) return (at >= 1 && i <= at) ? (float)((double)i * 1 / ai) : 1.f;
+        return i >= max(at, 0) ? (float)((double)(n - i - 1) * 1 / (n - ai - 1)) : 1.f;
+    }
+    __device__ __forceinline__ float cb_row(int i) const { return corner_b(i, r, rowIndex, index == 2 || index == 1); }
+    __device__ __forceinline__ float cb_col(int j) const { return corner_b(j, c, colIndex, index == 2 || index == 3); }
+    __device__ __forceinline__ float ratio(int n, int d) const { return ((1.f * (float)n) * 1.0f) / (float)d; }
+    __device__ __forceinline__ float a_col(int j) const { return kind == 1 ? ratio(dy >= 0 ? c - 1 - j : j + 1, c) : 1.f; }
+    __device__ __forceinline__ float b_col(int j) const { return kind == 1 ? ratio(dy >= 0 ? j : c - j, c) : 1.f; }
+    __device__ __forceinline__ float a_row(int i) const { return kind == 2 ? ratio(dx <= 0 ? i : r - i, r) : 1.f; }
+    __device__ __forceinline__ float b_row(int i) const { return kind == 2 ? ratio(dx <= 0 ? r - 1 - i : i + 1, r) : 1.f; }
+};
 // (bx, by): the block of the tile this workgroup blends -- blockIdx for the per-tile launch, a drawn index inside k_mosaic_walk
 __device__ __forceinline__ void fuse_apply_block(uint8_t *pix, uint8_t *mask, int ccols, int ch,
                                                  const uint8_t *tile, int th, int tw, int y0, int x0,
                                                  int ry0, int rx0, int r, int c, const int *mode,
                                                  const float *wAr, const float *wAc, const float *wBr, const float *wBc, const TrigGeom &TG,
-                                                 unsigned bx, unsigned by)
+                                                 unsigned bx, unsigned by, int analytic = 0)
 {
     const int y = (int)by;
     const int cy = y0 + y;
     const int i = cy - ry0;
     const bool row_in = i >= 0 && i < r;
-    const int corner = mode[0];
+    const int corner = analytic == 3 ? 1 : analytic ? 0 : mode[0];
+    // analytic: the ROI is a strip (more than 65 % of it valid -- counted by the host from the rectangles placed so far) and the ramps are the
+    // closed forms of fuseByFadeInAndFadeOut's strip branch (ImageFusion.py:206-221), formed here instead of read from the statistics kernel's
+    // arrays: 1 = ramps along the columns (col <= row), 2 = along the rows; every other weight is 1.f as the reference initialises them
+    AnalyticRamps AR = {analytic, r, c, TG.dx, TG.dy, 0, 0, 0};
+    if (analytic == 3) { AR.index = mode[2]; AR.rowIndex = mode[3]; AR.colIndex = mode[4]; }
     if (ch == 1) {
         // four pixels per lane: tile, canvas and validity bytes move as (unaligned) dwords
         const int x = (int)(bx * 256 + threadIdx.x) * 4;
@@ -102,7 +133,7 @@ __device__ __forceinline__ void fuse_apply_block(uint8_t *pix, uint8_t *mask, in
         else { tb = 0; for (int k = 0; k < nk; k++) { tb |= (uint32_t)tp[k] << (8 * k); if (row_in) { pb |= (uint32_t)pix[co + k] << (8 * k); mb |= (uint32_t)mask[co + k] << (8 * k); } } }
         uint32_t ob = tb;
         if (row_in) {
-            const float war = wAr[i], wbr = wBr[i];
+            const float war = analytic == 3 ? 1.f : analytic ? AR.a_row(i) : wAr[i], wbr = analytic == 3 ? AR.cb_row(i) : analytic ? AR.b_row(i) : wBr[i];
             ob = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -110,10 +141,11 @@ __device__ __forceinline__ void fuse_apply_block(uint8_t *pix, uint8_t *mask, in
                 const int b = (tb >> (8 * k)) & 0xff;
                 uint32_t o = (uint32_t)b;
                 if (k < nk && j >= 0 && j < c) {
-                    if (TG.on) o = trig_px(TG, corner, i, j, wbr, wBc[j], ((mb >> (8 * k)) & 0xff) != 0, (pb >> (8 * k)) & 0xff, b);
+                    if (TG.on) o = trig_px(TG, corner, i, j, wbr, analytic == 3 ? AR.cb_col(j) : analytic ? 1.f : wBc[j], ((mb >> (8 * k)) & 0xff) != 0, (pb >> (8 * k)) & 0xff, b);
                     else {
                         float wA, wB;
-                        if (corner) { wB = wbr * wBc[j]; wA = 1 - wB; }
+                        if (corner) { wB = wbr * (analytic == 3 ? AR.cb_col(j) : wBc[j]); wA = 1 - wB; }
+                        else if (analytic) { wA = war * AR.a_col(j); wB = wbr * AR.b_col(j); }
                         else { wA = war * wAc[j]; wB = wbr * wBc[j]; }
                         o = fade_px(wA, wB, ((mb >> (8 * k)) & 0xff) != 0, (pb >> (8 * k)) & 0xff, b);
                     }
@@ -133,11 +165,13 @@ __device__ __forceinline__ void fuse_apply_block(uint8_t *pix, uint8_t *mask, in
     const bool in_roi = (row_in && j >= 0 && j < c);
     if (in_roi) {
         float wA, wB;
-        if (corner) { wB = wBr[i] * wBc[j]; wA = 1 - wB; }
+        const float cbr = analytic == 3 ? AR.cb_row(i) : analytic ? 1.f : wBr[i], cbc = analytic == 3 ? AR.cb_col(j) : analytic ? 1.f : wBc[j];
+        if (corner) { wB = cbr * cbc; wA = 1 - wB; }
+        else if (analytic) { wA = AR.a_row(i) * AR.a_col(j); wB = AR.b_row(i) * AR.b_col(j); }
         else { wA = wAr[i] * wAc[j]; wB = wBr[i] * wBc[j]; }
         const bool av = mask[co] != 0;
         for (int k = 0; k < ch; k++)
-            pix[co * ch + k] = TG.on ? trig_px(TG, corner, i, j, wBr[i], wBc[j], av, (int)pix[co * ch + k], tile[((size_t)y * tw + x) * ch + k])
+            pix[co * ch + k] = TG.on ? trig_px(TG, corner, i, j, cbr, cbc, av, (int)pix[co * ch + k], tile[((size_t)y * tw + x) * ch + k])
                                      : fade_px(wA, wB, av, (int)pix[co * ch + k], tile[((size_t)y * tw + x) * ch + k]);
     } else {
         for (int k = 0; k < ch; k++) pix[co * ch + k] = tile[((size_t)y * tw + x) * ch + k];
@@ -148,9 +182,9 @@ __device__ __forceinline__ void fuse_apply_block(uint8_t *pix, uint8_t *mask, in
 __global__ __launch_bounds__(256) void k_fuse_apply(uint8_t *pix, uint8_t *mask, int ccols, int ch,
                                                     const uint8_t *tile, int th, int tw, int y0, int x0,
                                                     int ry0, int rx0, int r, int c, const int *mode,
-                                                    const float *wAr, const float *wAc, const float *wBr, const float *wBc, TrigGeom TG)
+                                                    const float *wAr, const float *wAc, const float *wBr, const float *wBc, TrigGeom TG, int analytic)
 {
-    fuse_apply_block(pix, mask, ccols, ch, tile, th, tw, y0, x0, ry0, rx0, r, c, mode, wAr, wAc, wBr, wBc, TG, blockIdx.x, blockIdx.y);
+    fuse_apply_block(pix, mask, ccols, ch, tile, th, tw, y0, x0, ry0, rx0, r, c, mode, wAr, wAc, wBr, wBc, TG, blockIdx.x, blockIdx.y, analytic);
 }
 
 __device__ __forceinline__ void paste_block(uint8_t *pix, uint8_t *mask, int ccols, int ch,
@@ -377,7 +411,7 @@ __global__ __launch_bounds__(256) void k_fuse_weights(int r, int c, int ch, int 
 #define FUSE_NW 4                    // waves of a statistics workgroup (16-wave workgroups, i.e. a quarter of the tickets: 8 % slower)
 struct FuseCanvasScratch { unsigned *slots; int *out; unsigned *done; int *rowFirstEnc, *rowLast, *colFirstEnc, *colLast; float *wAr, *wBr, *wAc, *wBc; };
 
-template <int FUSE_SBT, int FUSE_UR>
+template <int FUSE_SBT, int FUSE_UR, bool GEOM>
 __device__ __forceinline__ void fuse_stats_block(const CanvasView &V, int r, int c, const FuseCanvasScratch &S, int wx_n, unsigned bx, unsigned by, unsigned nbx)
 {
     __shared__ unsigned s_cnt[5][FUSE_NW];
@@ -433,13 +467,16 @@ __device__ __forceinline__ void fuse_stats_block(const CanvasView &V, int r, int
                             if (j + k < c2) pos_lo += pos; else pos_hi += pos;
                         }
                 }
+                if (GEOM) {
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if ((m >> (8 * k)) & 0xff) { if (first[k] < 0) first[k] = i; last[k] = i; }
+                    for (int k = 0; k < 4; k++)
+                        if ((m >> (8 * k)) & 0xff) { if (first[k] < 0) first[k] = i; last[k] = i; }
+                }
             }
             if (i < r2) { q_tl += pos_lo; q_tr += pos_hi; } else { q_bl += pos_lo; q_br += pos_hi; }
-            // first / last valid column of row i inside this wave's 256 columns
-            const unsigned long long any = __ballot(m != 0);
+            // first / last valid column of row i inside this wave's 256 columns (GEOM = false: the host derives the geometry from the canvas's
+            // rectangle list, the blocks only count)
+            const unsigned long long any = GEOM ? __ballot(m != 0) : 0ull;
             if (any) {
                 const int lo_lane = __ffsll((long long)any) - 1, hi_lane = 63 - __clzll((long long)any);
                 if (lane == lo_lane) atomicMax(&S.rowFirstEnc[i], c - 1 - (j + (__ffs((int)m) - 1) / 8));
@@ -447,7 +484,8 @@ __device__ __forceinline__ void fuse_stats_block(const CanvasView &V, int r, int
             }
         }
     }
-    if (wy_n == 1) {
+    if (!GEOM) {
+    } else if (wy_n == 1) {
         for (int k = 0; k < nk; k++)
             if (last[k] >= 0) { atomicMax(&S.colLast[j + k], last[k]); atomicMax(&S.colFirstEnc[j + k], r - 1 - first[k]); }
     } else {
@@ -519,7 +557,7 @@ template <int FUSE_SBT, int FUSE_UR>
 __global__ __launch_bounds__(FUSE_NW * 64) void k_fuse_stats_weights(CanvasView V, int r, int c, FuseCanvasScratch S, int dx, int dy, int *sticky_err, int wx_n)
 {
     __shared__ int s_last;
-    fuse_stats_block<FUSE_SBT, FUSE_UR>(V, r, c, S, wx_n, blockIdx.x, blockIdx.y, gridDim.x);
+    fuse_stats_block<FUSE_SBT, FUSE_UR, true>(V, r, c, S, wx_n, blockIdx.x, blockIdx.y, gridDim.x);
     // The last workgroup to arrive builds the ramps.  Round 6: no agent fences (they were 20 % of a mosaic: ~11 us per tile,
     // profiles/r06_ab_fuse_fences.txt).  Everything a statistics block publishes is either an agent-scope atomic (row / column records) or a
     // write-through store (its slot); a thread's are complete when its vmcnt has drained, the barrier collects the workgroup's, and only
@@ -532,6 +570,40 @@ __global__ __launch_bounds__(FUSE_NW * 64) void k_fuse_stats_weights(CanvasView 
     __syncthreads();
     if (!s_last || threadIdx.x >= 256) return;          // the ramps are a 256-thread job (finished waves do not count at the barriers)
     fuse_ramps_tail(r, c, V.ch, dx, dy, S, gridDim.x * gridDim.y, sticky_err);
+}
+
+// A corner ROI on a canvas whose validity the host knows (the rectangle list): getWeightsMatrix's geometry -- rowIndex, colIndex, the degenerate
+// cases -- is a function of the VALIDITY pattern and of `index`, the quadrant with the fewest non-zero elements; only that count needs the
+// pixels.  The host evaluates the geometry for all four possible quadrants (CornerPick), the blocks count, the last workgroup sums the slots,
+// picks the quadrant and publishes {1, 1, index, rowIndex, colIndex, err}: no row / column records, no atomics per row, no dependent record
+// loads in the tail, no ramp arrays (k_fuse_apply forms the corner ramps from the three numbers).
+struct CornerPick { int rowIndex[4], colIndex[4], err[4]; };
+
+template <int FUSE_SBT, int FUSE_UR>
+__global__ __launch_bounds__(FUSE_NW * 64) void k_fuse_counts_pick(CanvasView V, int r, int c, FuseCanvasScratch S, CornerPick P, int *sticky_err, int wx_n)
+{
+    __shared__ int s_last;
+    fuse_stats_block<FUSE_SBT, FUSE_UR, false>(V, r, c, S, wx_n, blockIdx.x, blockIdx.y, gridDim.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(S.done, 1u) == gridDim.x * gridDim.y - 1;
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    const unsigned nwg = gridDim.x * gridDim.y;
+    unsigned long long q4[4] = {0, 0, 0, 0};
+    for (unsigned w = threadIdx.x; w < nwg; w += 64)
+#pragma unroll
+        for (int q = 0; q < 4; q++) q4[q] += ld_agent(&S.slots[(size_t)w * 8 + 1 + q]);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        for (int d = 32; d > 0; d >>= 1) q4[q] += __shfl_down(q4[q], d, 64);
+    if (threadIdx.x == 0) {
+        int index = 0;
+        for (int q = 1; q < 4; q++) if (q4[q] < q4[index]) index = q;
+        S.out[0] = 1; S.out[1] = 1; S.out[2] = index; S.out[3] = P.rowIndex[index]; S.out[4] = P.colIndex[index]; S.out[5] = P.err[index];
+        if (P.err[index] && sticky_err) atomicOr(sticky_err, 1);
+        *S.done = 0;
+    }
 }
 
 struct FuseScratch { FuseStats *st; int *rowFirst, *rowLast, *colFirst, *colLast; float *wAr, *wAc, *wBr, *wBc; int *out; };
@@ -604,6 +676,37 @@ __global__ __launch_bounds__(256) void k_fuse_simple(uint8_t *pix, uint8_t *mask
     mask[idx] = 1;
 }
 
+// ---- the canvas's validity, known to the host ------------------------------------------------------------------------------------------------
+// Every write to a canvas is a whole tile rectangle (k_paste, k_fuse_apply and k_fuse_simple mark all of it valid), so the validity mask IS the
+// union of the rectangles placed so far.  fuseByFadeInAndFadeOut needs the COUNT of valid elements of the ROI to choose between its strip and
+// its corner branch (ImageFusion.py:201: count / size > 0.65); the strip branch then needs nothing else from the canvas -- its ramps are closed
+// forms of (row, col, dx, dy).  The host therefore counts the valid pixels of the ROI from the rectangle list (exact: coordinate compression
+// over the few rectangles that meet the ROI), and a strip tile is ONE launch (k_fuse_apply with analytic ramps) instead of statistics + blend.
+static void canvas_mark(CanvasRec *cv, int y0, int x0, int h, int w)
+{
+    const int32_t q[4] = {std::max(y0, 0), std::max(x0, 0), std::min(y0 + h, cv->rows), std::min(x0 + w, cv->cols)};
+    if (q[2] > q[0] && q[3] > q[1]) cv->placed.insert(cv->placed.end(), q, q + 4);
+}
+
+static long long canvas_valid_area(const CanvasRec *cv, int ry0, int rx0, int ry1, int rx1)
+{
+    std::vector<int> ys, xs, hit;
+    for (size_t k = 0; k + 3 < cv->placed.size(); k += 4) {
+        const int a0 = std::max(cv->placed[k], ry0), b0 = std::max(cv->placed[k + 1], rx0), a1 = std::min(cv->placed[k + 2], ry1), b1 = std::min(cv->placed[k + 3], rx1);
+        if (a1 > a0 && b1 > b0) { hit.push_back(a0); hit.push_back(b0); hit.push_back(a1); hit.push_back(b1); ys.push_back(a0); ys.push_back(a1); xs.push_back(b0); xs.push_back(b1); }
+    }
+    std::sort(ys.begin(), ys.end()); ys.erase(std::unique(ys.begin(), ys.end()), ys.end());
+    std::sort(xs.begin(), xs.end()); xs.erase(std::unique(xs.begin(), xs.end()), xs.end());
+    long long area = 0;
+    for (size_t a = 0; a + 1 < ys.size(); a++)
+        for (size_t b = 0; b + 1 < xs.size(); b++) {
+            bool in = false;
+            for (size_t k = 0; k < hit.size() && !in; k += 4) in = hit[k] <= ys[a] && ys[a + 1] <= hit[k + 2] && hit[k + 1] <= xs[b] && xs[b + 1] <= hit[k + 3];
+            if (in) area += (long long)(ys[a + 1] - ys[a]) * (xs[b + 1] - xs[b]);
+        }
+    return area;
+}
+
 int canvas_blend_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int h, int w, int y0, int x0,
                         int ry0, int rx0, int ry1, int rx1, int mode)
 {
@@ -612,6 +715,7 @@ int canvas_blend_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, in
     hipLaunchKernelGGL(k_fuse_simple, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, cv->pix, cv->mask, cv->cols, cv->ch,
                        d_tile, h, w, y0, x0, ry0, rx0, r, c, mode);
     HIP_TRY(hipGetLastError());
+    canvas_mark(cv, y0, x0, h, w);
     return VFSMS_OK;
 }
 
@@ -620,6 +724,7 @@ int canvas_paste_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, in
     hipLaunchKernelGGL(k_paste, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, cv->pix, cv->mask, cv->cols, cv->ch,
                        d_tile, h, w, y0, x0);
     HIP_TRY(hipGetLastError());
+    canvas_mark(cv, y0, x0, h, w);
     return VFSMS_OK;
 }
 
@@ -629,6 +734,24 @@ int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int
     const int r = ry1 - ry0, c = rx1 - rx0;
     if (r <= 0 || c <= 0) return canvas_paste_device(ctx, cv, d_tile, h, w, y0, x0);
     ProfScope ps(ctx, "fuse");
+    const TrigGeom TG = {method == 1, r, c, dx, dy};
+    const dim3 agrid(cv->ch == 1 ? (w + 1023) / 1024 : (w + 255) / 256, h);
+    const char *env_an = getenv("VFSMS_FUSE_ANALYTIC");                      // 0: always run the statistics kernel (A/B runs, tests)
+    const bool analytic_on = !(env_an && atoi(env_an) == 0);
+    if (analytic_on) {
+        // fuseByFadeInAndFadeOut's own test (ImageFusion.py:201), on the count the statistics kernel would have produced: valid elements = valid
+        // pixels x channels
+        const long long valid = canvas_valid_area(cv, ry0, rx0, ry1, rx1) * cv->ch;
+        const double nel = (double)r * c * cv->ch;
+        if ((double)valid / nel > 0.65) {
+            hipLaunchKernelGGL(k_fuse_apply, agrid, dim3(256), 0, ctx->stream, cv->pix, cv->mask, cv->cols, cv->ch, d_tile, h, w, y0, x0, ry0, rx0, r, c,
+                               (const int *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, TG, c <= r ? 1 : 2);
+            HIP_TRY(hipGetLastError());
+            canvas_mark(cv, y0, x0, h, w);
+            if (info) { info[0] = 0; info[1] = -1; info[2] = 0; info[3] = 0; }      // what the ramp kernel reports for a strip: mode 0, no corner index
+            return VFSMS_OK;
+        }
+    }
     // the canvas's own scratch (allocated and initialised once: canvas_scratch_bytes / canvas_scratch_init): st | out | done | rows | cols | ramps
     FuseCanvasScratch S;
     char *base = (char *)cv->scratch;
@@ -642,11 +765,53 @@ int canvas_fuse_device(vfsms_ctx *ctx, CanvasRec *cv, const uint8_t *d_tile, int
     V.pix = cv->pix; V.mask = cv->mask; V.ccols = cv->cols; V.ch = cv->ch; V.ry0 = ry0; V.rx0 = rx0;
     V.tile = d_tile; V.tw = w; V.ty0 = ry0 - y0; V.tx0 = rx0 - x0;
     const int wx_n = c <= 256 ? 1 : c <= 512 ? 2 : 4, wy_n = FUSE_NW / wx_n;
-    hipLaunchKernelGGL((k_fuse_stats_weights<FUSE_SB, FUSE_SB>), dim3((c + 256 * wx_n - 1) / (256 * wx_n), (r + FUSE_SB * wy_n - 1) / (FUSE_SB * wy_n)),
-                       dim3(FUSE_NW * 64), 0, ctx->stream, V, r, c, S, dx, dy, cv->d_err, wx_n);
-    hipLaunchKernelGGL(k_fuse_apply, dim3(cv->ch == 1 ? (w + 1023) / 1024 : (w + 255) / 256, h), dim3(256), 0, ctx->stream, cv->pix, cv->mask, cv->cols, cv->ch,
-                       d_tile, h, w, y0, x0, ry0, rx0, r, c, S.out, S.wAr, S.wAc, S.wBr, S.wBc, TrigGeom{method == 1, r, c, dx, dy});
+    const dim3 sgrid((c + 256 * wx_n - 1) / (256 * wx_n), (r + FUSE_SB * wy_n - 1) / (FUSE_SB * wy_n));
+    if (analytic_on) {
+        // a corner ROI: first / last valid column of every row and first / last valid row of every column from the rectangles that meet the ROI,
+        // then getWeightsMatrix's scan (fuse_weights_body) for each of the four quadrants `index` could turn out to be
+        std::vector<int> rec((size_t)2 * r + 2 * c, -1);
+        int *rowF = rec.data(), *rowL = rowF + r, *colF = rowL + r, *colL = colF + c;
+        for (size_t k = 0; k + 3 < cv->placed.size(); k += 4) {
+            const int a0 = std::max(cv->placed[k], ry0) - ry0, b0 = std::max(cv->placed[k + 1], rx0) - rx0;
+            const int a1 = std::min(cv->placed[k + 2], ry1) - ry0, b1 = std::min(cv->placed[k + 3], rx1) - rx0;
+            if (a1 <= a0 || b1 <= b0) continue;
+            for (int i = a0; i < a1; i++) { rowF[i] = rowF[i] < 0 ? b0 : std::min(rowF[i], b0); rowL[i] = std::max(rowL[i], b1 - 1); }
+            for (int jj = b0; jj < b1; jj++) { colF[jj] = colF[jj] < 0 ? a0 : std::min(colF[jj], a0); colL[jj] = std::max(colL[jj], a1 - 1); }
+        }
+        CornerPick P;
+        for (int index = 0; index < 4; index++) {
+            const bool from_right = index == 2 || index == 3, by_last = index == 2 || index == 1;
+            int rowIndex = 0, colIndex = 0, err = 0;
+            for (int jj = from_right ? 1 : 0; jj < c; jj++) {
+                const int col = from_right ? c - jj : jj;
+                int cand = 0;
+                if (by_last) { if (colL[col] >= 0) cand = colL[col] + 1; }
+                else         { if (colF[col] >= 0) cand = colF[col] - 1; }
+                if (cand != 0) { rowIndex = cand; break; }
+            }
+            if (rowIndex >= r) err = 1;
+            else {
+                const int rr = rowIndex < 0 ? rowIndex + r : rowIndex;
+                if (from_right) { if (rowL[rr] >= 0) colIndex = rowL[rr] + 1; }
+                else            { if (rowF[rr] >= 0) colIndex = rowF[rr] - 1; }
+            }
+            if (!err) {                                  // the degenerate cases of the ramp loops (fuse_weights_body)
+                const int ri = rowIndex == 0 ? 1 : rowIndex, ci = colIndex == 0 ? 1 : colIndex;
+                if (by_last) { if (ri >= r) err = 1; } else if (rowIndex < r && r - ri - 1 == 0) err = 1;
+                if (from_right) { if (ci >= c) err = 1; } else if (colIndex < c && c - ci - 1 == 0) err = 1;
+            }
+            P.rowIndex[index] = rowIndex; P.colIndex[index] = colIndex; P.err[index] = err;
+        }
+        hipLaunchKernelGGL((k_fuse_counts_pick<FUSE_SB, FUSE_SB>), sgrid, dim3(FUSE_NW * 64), 0, ctx->stream, V, r, c, S, P, cv->d_err, wx_n);
+        hipLaunchKernelGGL(k_fuse_apply, agrid, dim3(256), 0, ctx->stream, cv->pix, cv->mask, cv->cols, cv->ch, d_tile, h, w, y0, x0, ry0, rx0, r, c,
+                           (const int *)S.out, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, TG, 3);
+    } else {
+        hipLaunchKernelGGL((k_fuse_stats_weights<FUSE_SB, FUSE_SB>), sgrid, dim3(FUSE_NW * 64), 0, ctx->stream, V, r, c, S, dx, dy, cv->d_err, wx_n);
+        hipLaunchKernelGGL(k_fuse_apply, agrid, dim3(256), 0, ctx->stream, cv->pix, cv->mask, cv->cols, cv->ch,
+                           d_tile, h, w, y0, x0, ry0, rx0, r, c, (const int *)S.out, (const float *)S.wAr, (const float *)S.wAc, (const float *)S.wBr, (const float *)S.wBc, TG, 0);
+    }
     HIP_TRY(hipGetLastError());
+    canvas_mark(cv, y0, x0, h, w);
     if (!info) return VFSMS_OK;          // no readback wanted: a degenerate geometry is latched in the canvas and reported by the download
     int out[8];
     HIP_TRY(hipMemcpyAsync(out, S.out, sizeof(out), hipMemcpyDeviceToHost, ctx->stream));

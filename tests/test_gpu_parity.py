@@ -1742,3 +1742,47 @@ def test_phase_lds_transforms_equal_the_rocfft_path_and_the_oracle_over_strip_sh
         else:
             os.environ["VFSMS_PHASE_LDS_FFT"] = keep
     assert took_lds >= len(shapes) - 2, took_lds               # (2, 2) pads to a 2-point row (rocFFT); everything else runs in LDS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("colour", [False, True])
+def test_strip_tiles_fused_from_the_rectangle_list_equal_the_statistics_path(engine, colour):
+    """Since round 6 the host counts the valid pixels of a fuse ROI from the rectangles placed on the canvas (ImageFusion.py:201's count / size >
+    0.65) and blends a strip tile in ONE launch with closed-form ramps; corner tiles keep the statistics kernel.  The same 3 x 3 serpentine mosaic
+    (strip ROIs, whole-tile ROIs after the turns, fade and trigonometric operators, negative and positive dx / dy) assembled with the analytic path
+    on and off (VFSMS_FUSE_ANALYTIC=0) must be the same bytes, and so must the per-tile calls with their info rows."""
+    T = 768
+    g = SyntheticGrid(3, 3, T)
+    tiles = g.tiles(threads=4)
+    if colour:
+        tiles = [np.ascontiguousarray(np.stack([t, 255 - t, (t // 2) + 17], -1).astype(np.uint8)) for t in tiles]
+    n = len(tiles)
+    ch = 3 if colour else 1
+    offs = [[0, 0]] + [list(map(int, o)) for o in g.true_offsets()]
+    offsetList, rangeX, rangeY, rows, cols = isa.Stitcher._layout([t.shape[:2] for t in tiles], offs)
+    rois = [None] + [(max(offsetList[i][0], rangeX[i - 1][0]), max(offsetList[i][1], rangeY[i - 1][0]),
+                      min(offsetList[i][0] + T, rangeX[i - 1][1]), min(offsetList[i][1] + T, rangeY[i - 1][1])) for i in range(1, n)]
+    handles = [(engine.tile_upload_color(t) if colour else engine.tile_upload(t)) for t in tiles]
+    keep = os.environ.get("VFSMS_FUSE_ANALYTIC")
+    got = {}
+    try:
+        for method in (0, 1):
+            geom = [(offsetList[0][0], offsetList[0][1], 0, 0, 0, 0, 0, 0, -1)]
+            geom += [(offsetList[i][0], offsetList[i][1]) + tuple(rois[i]) + (offs[i][0], offs[i][1], method) for i in range(1, n)]
+            for flag in ("1", "0"):
+                os.environ["VFSMS_FUSE_ANALYTIC"] = flag
+                cv = engine.canvas_create(rows, cols, ch)
+                try:
+                    engine.canvas_assemble_resident(cv, handles, geom)
+                    got[(method, flag)] = engine.canvas_download(cv, rows, cols, ch)
+                finally:
+                    engine.canvas_free(cv)
+            assert np.array_equal(got[(method, "1")], got[(method, "0")]), method
+        assert not np.array_equal(got[(0, "1")], got[(1, "1")])
+    finally:
+        if keep is None:
+            os.environ.pop("VFSMS_FUSE_ANALYTIC", None)
+        else:
+            os.environ["VFSMS_FUSE_ANALYTIC"] = keep
+        for h in handles:
+            engine.tile_free(h)

@@ -1,13 +1,12 @@
 #!/bin/bash
-# configs[4] on one GPU with smaller speculation windows (batch working set against the 256 MB infinity cache)
 mkdir -p gpurun_out/r06z
 O=gpurun_out/r06z
-for W in 16 24; do
-  timeout 700 python bench.py --rows 32 --cols 32 --tile 4096 --steps 2 --warmup 1 --cpu-sample 0 --no-host-leg --no-cold-leg --prior same --window $W > $O/bench_config4_w$W.json 2> $O/bench_config4_w$W.err
-  tail -1 $O/bench_config4_w$W.err
-  python - $O/bench_config4_w$W.json <<'PY'
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "fuse or mosaic or fused_from or canvas or driver or main_py or line_scan or hand_off or golden" 2>&1 | tail -6
+for A in 1 0 1; do
+  VFSMS_FUSE_ANALYTIC=$A timeout 300 python bench.py --method fuse --steps 10 --warmup 3 --cpu-sample 0 > $O/bench_fuse_a$A.json 2> $O/bench_fuse_a$A.err
+  python - $O/bench_fuse_a$A.json $A <<'PY'
 import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
-print(d["value"], d["ms_per_step"], d.get("attempts_per_step"), d.get("batches_per_step"), {k: v["ms_per_launch"] for k, v in d["stages"].items() if k in ("describe", "bf_mfma", "hessian", "orientation", "bf_verify")})
+print("analytic", sys.argv[2], d["value"], d["unit"], d["ms_per_step"], d["roofline"]["frac"])
 PY
 done
