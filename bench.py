@@ -273,9 +273,11 @@ def bench_fuse(args, eng, grid, tiles, handles, torch, close=True):
     f_ms, f_n = prof.get("fuse", (0.0, 0))
     roof = None
     if f_n:
-        roof = hbm_roofline("k_fuse_stats_weights+k_fuse_apply", fuse_bytes, min(f_ms / args.steps, dt * 1e3), args.steps,
-                            note="one 'launch' = the whole mosaic (%d tiles: stats, weights, blend, paste per tile); bytes = 3 r c per fuse ROI + "
-                                 "2 B/px pasted outside it" % n, launch_groups=f_n)
+        roof = hbm_roofline("k_fuse_counts_pick+k_fuse_apply", fuse_bytes, min(f_ms / args.steps, dt * 1e3), args.steps,
+                            note="one 'launch' = the whole mosaic (%d tiles; per tile: the count of non-zero elements per quadrant + the pick of "
+                                 "getWeightsMatrix's geometry, then the blend -- a strip tile the blend alone; the validity of a ROI comes from the "
+                                 "canvas's rectangle list on the host); bytes = 3 r c per fuse ROI + 2 B/px pasted outside it; the walk is a chain of "
+                                 "dependent ~12 us launches, not a stream" % n, launch_groups=f_n)
     print(json.dumps({
         "metric": "fuse Mpx/sec (mosaic pixels, fadeInAndFadeOut)", "value": round(mpx / dt, 2), "unit": "Mpx/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "ms_per_step_with_stage_events": round(dt_prof * 1e3, 3),
