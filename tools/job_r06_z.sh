@@ -1,23 +1,12 @@
 #!/bin/bash
-# per-dispatch durations of the fuse kernels of one mosaic (rocprofv3 --kernel-trace, csv), analytic on / off
-R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/r06z
-cd /tmp && export TMPDIR=/tmp
-for A in 1 0; do
-  rm -rf $R/gpurun_out/r06z/prof
-  VFSMS_FUSE_ANALYTIC=$A timeout 200 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r06z/prof -o fz -- python $R/bench.py --method fuse --steps 1 --warmup 0 --cpu-sample 0 > $R/gpurun_out/r06z/fz_$A.json 2> $R/gpurun_out/r06z/fz_$A.err
-  f=$(find $R/gpurun_out/r06z/prof -name "*kernel_trace.csv" | head -1)
-  python - "$f" $A <<'PY'
-import csv, sys, collections
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_fuse" in r["Kernel_Name"] or "k_paste" in r["Kernel_Name"]]
-rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-by = collections.defaultdict(list)
-for r in rows:
-    by[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-print("analytic", sys.argv[2])
-for k, v in by.items():
-    v2 = sorted(v)
-    print("  %-40s n=%d sum=%.0f us min=%.1f med=%.1f p90=%.1f max=%.1f" % (k[:40], len(v), sum(v), v2[0], v2[len(v2)//2], v2[int(len(v2)*0.9)], v2[-1]))
+mkdir -p gpurun_out/r06z
+O=gpurun_out/r06z
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "fuse or mosaic or fused_from or canvas or driver or main_py or line_scan or hand_off or golden or colour or color" 2>&1 | tail -6
+for A in 1 0 1; do
+  VFSMS_FUSE_ANALYTIC=$A timeout 300 python bench.py --method fuse --steps 10 --warmup 3 --cpu-sample 0 > $O/bench_fuse_a$A.json 2> $O/bench_fuse_a$A.err
+  python - $O/bench_fuse_a$A.json $A <<'PY'
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+print("analytic", sys.argv[2], d["value"], d["unit"], d["ms_per_step"], d["roofline"]["frac"])
 PY
 done
-rm -rf $R/gpurun_out/r06z/prof
