@@ -1786,3 +1786,70 @@ def test_strip_tiles_fused_from_the_rectangle_list_equal_the_statistics_path(eng
             os.environ["VFSMS_FUSE_ANALYTIC"] = keep
         for h in handles:
             engine.tile_free(h)
+
+
+@pytest.mark.gpu
+def test_random_placements_fused_from_the_rectangle_list_equal_the_statistics_path(engine):
+    """The host-side geometry of round 6 (valid count, getWeightsMatrix's rowIndex / colIndex for the four quadrants, the degenerate cases) against
+    the statistics kernel on placements no serpentine produces: tiles dropped left of, above, below and across earlier ones (all four `index`
+    quadrants, scans from both sides, negative dx / dy), ROI = tile rectangle cut by the bounding box of what lies there (Stitcher.py:446-457)
+    or a random sub-rectangle of the tile.  Same bytes, and the same verdict on a degenerate geometry (both raise or neither)."""
+    rng = np.random.default_rng(20190158)
+    keep = os.environ.get("VFSMS_FUSE_ANALYTIC")
+    n_err = n_corner = 0
+    try:
+        for case in range(40):
+            rows, cols = int(rng.integers(500, 900)), int(rng.integers(500, 900))
+            ntile = int(rng.integers(3, 8))
+            tiles, geom = [], []
+            bbox = None
+            for k in range(ntile):
+                th, tw = int(rng.integers(90, 320)), int(rng.integers(90, 320))
+                y0, x0 = int(rng.integers(0, rows - th)), int(rng.integers(0, cols - tw))
+                t = rng.integers(0, 256, (th, tw), dtype=np.uint8)
+                if case % 5 == 0:
+                    t[rng.random((th, tw)) < 0.3] = 0                            # black pixels: the quadrant counts are not the valid areas
+                tiles.append(t)
+                if bbox is None:
+                    geom.append((y0, x0, 0, 0, 0, 0, 0, 0, -1))
+                    bbox = [y0, x0, y0 + th, x0 + tw]
+                    continue
+                if case % 3 == 2:                                                    # any sub-rectangle of the tile
+                    ry0 = y0 + int(rng.integers(0, th // 2)); rx0 = x0 + int(rng.integers(0, tw // 2))
+                    ry1 = int(rng.integers(ry0 + 2, y0 + th + 1)); rx1 = int(rng.integers(rx0 + 2, x0 + tw + 1))
+                else:
+                    ry0, rx0, ry1, rx1 = max(y0, bbox[0]), max(x0, bbox[1]), min(y0 + th, bbox[2]), min(x0 + tw, bbox[3])
+                if ry1 <= ry0 or rx1 <= rx0:
+                    geom.append((y0, x0, 0, 0, 0, 0, 0, 0, -1))
+                else:
+                    geom.append((y0, x0, ry0, rx0, ry1, rx1, int(rng.integers(-40, 41)), int(rng.integers(-40, 41)), int(rng.integers(0, 2))))
+                bbox = [min(bbox[0], y0), min(bbox[1], x0), max(bbox[2], y0 + th), max(bbox[3], x0 + tw)]
+            hs = [engine.tile_upload(t) for t in tiles]
+            res = {}
+            for flag in ("1", "0"):
+                os.environ["VFSMS_FUSE_ANALYTIC"] = flag
+                cv = engine.canvas_create(rows, cols, 1)
+                try:
+                    engine.canvas_assemble_resident(cv, hs, geom)
+                    try:
+                        res[flag] = engine.canvas_download(cv, rows, cols, 1)
+                    except isa.VfsmsError as e:
+                        assert "degenerate" in str(e)
+                        res[flag] = None
+                finally:
+                    engine.canvas_free(cv)
+            for h in hs:
+                engine.tile_free(h)
+            assert (res["1"] is None) == (res["0"] is None), (case, geom)
+            if res["1"] is None:
+                n_err += 1
+            else:
+                assert np.array_equal(res["1"], res["0"]), (case, geom)
+            n_corner += sum(1 for g in geom if g[8] >= 0)
+    finally:
+        if keep is None:
+            os.environ.pop("VFSMS_FUSE_ANALYTIC", None)
+        else:
+            os.environ["VFSMS_FUSE_ANALYTIC"] = keep
+    print("random placements: %d fused tiles, %d of 40 canvases with a degenerate geometry" % (n_corner, n_err))
+    assert n_corner > 100 and n_err < 30, (n_corner, n_err)
