@@ -278,6 +278,20 @@ def bench_fuse(args, eng, grid, tiles, handles, torch, close=True):
                                  "getWeightsMatrix's geometry, then the blend -- a strip tile the blend alone; the validity of a ROI comes from the "
                                  "canvas's rectangle list on the host); bytes = 3 r c per fuse ROI + 2 B/px pasted outside it; the walk is a chain of "
                                  "dependent ~12 us launches, not a stream" % n, launch_groups=f_n)
+        # PMC traffic of one mosaic: per-launch traffic x launches per mosaic of the walk's kernels (profiles/*_pmc_summary.txt, mosaic section)
+        tot, src = 0.0, None
+        for kname in ("k_fuse_apply", "k_fuse_counts_pick<16, 16>", "k_paste"):
+            t_k, n_k = pmc_total(kname, "total(x2 rule)")
+            m_k, src_k = pmc_value(kname, "mosaics")
+            if t_k is None or not m_k:
+                tot = None
+                break
+            tot += t_k / m_k
+            src = src_k
+        if tot:
+            roof["traffic"] = tot
+            roof["traffic_source"] = src
+            roof["traffic_over_algorithmic"] = round(tot / fuse_bytes, 3)
     print(json.dumps({
         "metric": "fuse Mpx/sec (mosaic pixels, fadeInAndFadeOut)", "value": round(mpx / dt, 2), "unit": "Mpx/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "ms_per_step_with_stage_events": round(dt_prof * 1e3, 3),

@@ -124,4 +124,5 @@ for k in sorted(sq):
 out.close()
 print(open('$OUT/pmc_summary.txt').read()[-2500:])
 PY
+bash tools/profile_mosaic_pmc.sh $OUT
 rm -rf $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_ta $OUT/pmc_mfma $OUT/pmc_ph_sq $OUT/pmc_ph_fetch $OUT/pmc_ph_write
