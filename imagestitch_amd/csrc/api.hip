@@ -247,6 +247,7 @@ extern "C" int vfsms_ctx_destroy(vfsms_ctx *ctx)
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     for (auto &kv : ctx->canvases) { hipFree(kv.second.pix); hipFree(kv.second.mask); hipFree(kv.second.d_err); hipFree(kv.second.scratch); }
+    if (ctx->has_spare_canvas) { hipFree(ctx->spare_canvas.pix); hipFree(ctx->spare_canvas.mask); hipFree(ctx->spare_canvas.d_err); hipFree(ctx->spare_canvas.scratch); ctx->has_spare_canvas = false; }
     for (auto &kv : ctx->feats) if (!kv.second.block) { if (kv.second.kps_xy) hipFree(kv.second.kps_xy); if (kv.second.desc) hipFree(kv.second.desc); }
     for (auto &kv : ctx->feat_blocks) hipFree(kv.second.base);
     if (ctx->arena) hipFree(ctx->arena);
@@ -1554,10 +1555,15 @@ extern "C" int vfsms_canvas_create(vfsms_ctx *ctx, int rows, int cols, int ch, i
     CTX_ENTER(ctx);
     if (!handle || rows <= 0 || cols <= 0 || ch < 1 || ch > 4) { vfsms_set_error("canvas_create: bad arguments"); return VFSMS_ERR_BAD_ARG; }
     CanvasRec cv; cv.rows = rows; cv.cols = cols; cv.ch = ch;
-    HIP_TRY(hipMalloc((void **)&cv.pix, (size_t)rows * cols * ch));
-    HIP_TRY(hipMalloc((void **)&cv.mask, (size_t)rows * cols));
-    HIP_TRY(hipMalloc((void **)&cv.d_err, sizeof(int)));
-    HIP_TRY(hipMalloc(&cv.scratch, canvas_scratch_bytes(rows, cols)));
+    if (ctx->has_spare_canvas && ctx->spare_canvas.rows == rows && ctx->spare_canvas.cols == cols && ctx->spare_canvas.ch == ch) {
+        cv = ctx->spare_canvas; cv.placed.clear();          // same size as the canvas freed last: its buffers, re-initialised below in stream order
+        ctx->has_spare_canvas = false;
+    } else {
+        HIP_TRY(hipMalloc((void **)&cv.pix, (size_t)rows * cols * ch));
+        HIP_TRY(hipMalloc((void **)&cv.mask, (size_t)rows * cols));
+        HIP_TRY(hipMalloc((void **)&cv.d_err, sizeof(int)));
+        HIP_TRY(hipMalloc(&cv.scratch, canvas_scratch_bytes(rows, cols)));
+    }
     TRY(canvas_scratch_init(ctx, &cv));
     HIP_TRY(hipMemsetAsync(cv.d_err, 0, sizeof(int), ctx->stream));
     HIP_TRY(hipMemsetAsync(cv.pix, 0, (size_t)rows * cols * ch, ctx->stream));
@@ -1571,8 +1577,12 @@ extern "C" int vfsms_canvas_free(vfsms_ctx *ctx, int64_t handle)
     CTX_ENTER(ctx);
     auto it = ctx->canvases.find(handle);
     if (it == ctx->canvases.end()) { vfsms_set_error("canvas_free: unknown handle"); return VFSMS_ERR_BAD_ARG; }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(it->second.pix)); HIP_TRY(hipFree(it->second.mask)); HIP_TRY(hipFree(it->second.d_err)); HIP_TRY(hipFree(it->second.scratch));
+    if (ctx->has_spare_canvas) {                               // one spare at a time: the older one goes back to the device
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        CanvasRec &o = ctx->spare_canvas;
+        HIP_TRY(hipFree(o.pix)); HIP_TRY(hipFree(o.mask)); HIP_TRY(hipFree(o.d_err)); HIP_TRY(hipFree(o.scratch));
+    }
+    ctx->spare_canvas = it->second; ctx->has_spare_canvas = true;      // kept for a canvas of the same size (stream order makes the reuse safe)
     ctx->canvases.erase(it);
     return VFSMS_OK;
 }

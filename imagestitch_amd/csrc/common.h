@@ -200,6 +200,7 @@ struct vfsms_ctx {
     size_t tile_pool_bytes = 0;
     std::vector<hipEvent_t> event_pool;
     std::unordered_map<int64_t, CanvasRec> canvases;
+    CanvasRec spare_canvas; bool has_spare_canvas = false;   // the buffers of the last canvas freed: a session's mosaics are of one size, and hipMalloc / hipFree of a canvas (28 GB at configs[4]) cost more than the walk
     std::unordered_map<int64_t, FeatRec> feats;
     std::unordered_map<int64_t, FeatBlock> feat_blocks;      // one allocation for the sets of a batch (vfsms_features_surf_batch), freed with its last set
     int64_t next_handle;

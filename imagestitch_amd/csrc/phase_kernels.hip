@@ -852,12 +852,10 @@ static size_t own_bytes(const OwnShape &S, int h, int w, int nb)
 
 static int phase_own_batch(vfsms_ctx *ctx, const OwnShape &S, const PhaseJobHost *jobs, int nb, int h, int w, double *d_out3)
 {
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (ctx->fft_tabs.empty()) {                               // first use on this context (= this device): > 64 KB of dynamic LDS must be asked for
         HIP_TRY(hipFuncSetAttribute((const void *)k_phase_rows_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, PHASE_LDS_MAX));
         HIP_TRY(hipFuncSetAttribute((const void *)k_phase_cols, hipFuncAttributeMaxDynamicSharedMemorySize, PHASE_LDS_MAX));
         HIP_TRY(hipFuncSetAttribute((const void *)k_phase_rows_inv, hipFuncAttributeMaxDynamicSharedMemorySize, PHASE_LDS_MAX));
-        attr_done = true;
     }
     const int M = S.M, N = S.N, Nc = S.H + 1;
     const int cmax = std::min(nb, std::max(1, std::min(PHASE_MAX_CHUNK, env_int("VFSMS_PHASE_CHUNK", PHASE_MAX_CHUNK))));

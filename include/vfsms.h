@@ -330,6 +330,8 @@ int vfsms_enhance_u8(vfsms_ctx *ctx, const uint8_t *img, int h, int w, int strid
 /* ---- device-resident mosaic canvas (Stitcher.getStitchByOffset, Stitcher.py:369-486) -------------- */
 /* u8 canvas + validity plane instead of the reference's int64 / -1 sentinel                         */
 int vfsms_canvas_create(vfsms_ctx *ctx, int rows, int cols, int ch, int64_t *handle);
+/* the buffers of the canvas freed last stay with the context for the next canvas of the same size (released by the next free of another
+ * canvas or with the context): a session's mosaics are of one size, and allocating 2 x rows x cols bytes costs more than assembling them      */
 int vfsms_canvas_free(vfsms_ctx *ctx, int64_t handle);
 /* plain paste of a host tile (u8 [h][w][ch]) at (y0, x0): Stitcher.py:444-451 ("notFuse" / tile 0)  */
 int vfsms_canvas_paste(vfsms_ctx *ctx, int64_t canvas, const uint8_t *tile, int h, int w, int y0, int x0);
